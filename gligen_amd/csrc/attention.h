@@ -1,0 +1,23 @@
+#pragma once
+#include "common.h"
+
+namespace gl {
+
+struct AttnParams {
+    const bf16* q;
+    const bf16* k;
+    const bf16* vt;
+    bf16* o;
+    int H, d;
+    int Nq, Nk;          // real query / key counts per (b,h)
+    int Tq_pad, Tk_pad;  // padded row counts of the q / k,vt buffers (128- / 64-multiples)
+    int ldo;             // O row stride in elements
+    int o_rows_per_b;    // rows per sample in O
+    float scale_log2e;   // d^-0.5 * log2(e)
+};
+
+// padded head dims used by the q/k (DP) and v^T (DPV) buffers for a real head dim d
+int attn_dims(int d, int* DP, int* DPV);
+int attn_launch(const AttnParams& P, int B, hipStream_t stream);
+
+}  // namespace gl

@@ -1,0 +1,255 @@
+// Fused (flash-style) multi-head attention forward for gfx950, bf16 in / fp32 softmax+accumulate.
+//
+// Replaces the materialised-softmax attention of the reference:
+//   SelfAttention.forward   ldm/modules/attention.py:167-186   (attn1 and the GLIGEN fuser)
+//   CrossAttention.forward  ldm/modules/attention.py:127-149   (attn2, 77 CLIP tokens)
+// sim = (q k^T) * d^-0.5 ; softmax over keys ; out = attn v.   No mask, no dropout.
+//
+// Layouts (written by the projection GEMM epilogues, gemm.hip EPI_QK_HEADS / EPI_VT_HEADS):
+//   q  [B*H][Tq_pad][DP]   head dim zero-padded to DP (48 / 80 / 160)
+//   k  [B*H][Tk_pad][DP]
+//   vt [B*H][DPV][Tk_pad]  V transposed, tokens permuted inside groups of 16 as
+//                          [0-3, 8-11, 4-7, 12-15]  (DPV = 64 / 96 / 160)
+//   o  [B][rows][ldo]      token-major, head h at columns [h*d, (h+1)*d)
+//
+// Per wave: 32 query rows, "swapped" products so the softmax axis is lane-local
+//   S^T = K Q^T  (v_mfma_f32_32x32x16_bf16: A = K rows, B = Q rows): lane (q = lane&31) holds
+//                16 keys per 32-key sub-tile; the other 16 sit in lane^32
+//   O^T = V^T P^T: the S^T accumulator registers, converted to bf16 8 at a time, ARE the B
+//                fragment (the key permutation above makes the matching V^T fragment one
+//                ds_read_b128); online-softmax rescale factors are per lane.
+// A 256-thread block (4 waves = 128 query rows) streams 64-key tiles of K and V^T through a
+// 2-stage LDS ring (register-staged: loads of tile t+1 are in flight during the MFMAs of tile t).
+#include "attention.h"
+
+namespace gl {
+
+template <int DP, int DPV>
+__global__ void __launch_bounds__(256) attn_kernel(AttnParams P) {
+    constexpr int KS = DP / 16;
+    constexpr int DT = DPV / 32;
+    constexpr int KROW = DP * 2 + 16;  // LDS row strides (bytes): +16 keeps b128 reads conflict-free
+    constexpr int VROW = 64 * 2 + 16;
+    constexpr int KBYTES = 64 * KROW;
+    constexpr int VBYTES = DPV * VROW;
+    constexpr int STAGE = KBYTES + VBYTES;
+    constexpr int KCH = 64 * DP / 8;  // 16-byte chunks per K tile
+    constexpr int NKC = (KCH + 255) / 256;
+    constexpr int NVC = DPV * 8 / 256;
+    static_assert(DPV * 8 % 256 == 0, "V tile must split evenly");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int lrow = lane & 31;
+    const int half = lane >> 5;
+    const int h = blockIdx.y;
+    const int b = blockIdx.z;
+    const size_t bh = (size_t)b * P.H + h;
+
+    const bf16* __restrict__ Qg = P.q + bh * P.Tq_pad * DP;
+    const bf16* __restrict__ Kg = P.k + bh * P.Tk_pad * DP;
+    const bf16* __restrict__ Vg = P.vt + bh * DPV * P.Tk_pad;
+
+    const int myq = blockIdx.x * 128 + wave * 32 + lrow;
+
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+        qf[s] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)myq * DP + 16 * s + 8 * half);
+
+    f32x16 ot[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
+    float m_run = -1e30f;  // running max, in scaled (log2) units
+    float l_run = 0.f;     // this lane's partial denominator (its 16+16 keys per tile)
+    const float c = P.scale_log2e;
+
+    const int nt = (P.Nk + 63) >> 6;
+
+    typedef uint32_t kvec_t __attribute__((ext_vector_type(4 * NKC)));
+    typedef uint32_t vvec_t __attribute__((ext_vector_type(4 * NVC)));
+    kvec_t kreg; vvec_t vreg;
+    auto load_tile = [&](int it, kvec_t& kreg, vvec_t& vreg) {
+        const int kv0 = it << 6;
+        const bf16* kp = Kg + (size_t)kv0 * DP;
+#pragma unroll
+        for (int i = 0; i < NKC; ++i) {
+            int id = t + i * 256;
+            if (id > KCH - 1) id = KCH - 1;  // tail threads re-read the last chunk (never stored)
+            uint4 v = *reinterpret_cast<const uint4*>(kp + id * 8);
+            kreg[4*i]=v.x; kreg[4*i+1]=v.y; kreg[4*i+2]=v.z; kreg[4*i+3]=v.w;
+        }
+#pragma unroll
+        for (int i = 0; i < NVC; ++i) {
+            int id = t + i * 256;
+            uint4 v = *reinterpret_cast<const uint4*>(Vg + (size_t)(id >> 3) * P.Tk_pad + kv0 + (id & 7) * 8);
+            vreg[4*i]=v.x; vreg[4*i+1]=v.y; vreg[4*i+2]=v.z; vreg[4*i+3]=v.w;
+        }
+    };
+    auto store_tile = [&](int buf, const kvec_t& kreg, const vvec_t& vreg) {
+        unsigned char* ks = smem + buf * STAGE;
+        unsigned char* vs = ks + KBYTES;
+#pragma unroll
+        for (int i = 0; i < NKC; ++i) {
+            int id = t + i * 256;
+            if (id < KCH) {
+                int row = id / (DP / 8);
+                int cch = id - row * (DP / 8);
+                *reinterpret_cast<uint4*>(ks + row * KROW + cch * 16) = make_uint4(kreg[4*i],kreg[4*i+1],kreg[4*i+2],kreg[4*i+3]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NVC; ++i) {
+            int id = t + i * 256;
+            *reinterpret_cast<uint4*>(vs + (id >> 3) * VROW + (id & 7) * 16) = make_uint4(vreg[4*i],vreg[4*i+1],vreg[4*i+2],vreg[4*i+3]);
+        }
+    };
+
+    load_tile(0, kreg, vreg);
+    store_tile(0, kreg, vreg);
+    __syncthreads();
+
+    for (int it = 0; it < nt; ++it) {
+        const int buf = it & 1;
+        const bool more = it + 1 < nt;
+        if (more) load_tile(it + 1, kreg, vreg);
+
+        const unsigned char* ks = smem + buf * STAGE;
+        const unsigned char* vs = ks + KBYTES;
+
+        // ---- S^T = K Q^T for two 32-key sub-tiles
+        f32x16 st[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[u][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + (32 * u + lrow) * KROW + (2 * s + half) * 16);
+                st[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[u], 0, 0, 0);
+            }
+        }
+
+        // ---- online softmax (per lane = per query row; keys split between lane and lane^32)
+        const int kv0 = it << 6;
+        if (kv0 + 64 > P.Nk) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int kv = kv0 + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (kv >= P.Nk) st[u][r] = -1e30f;
+                }
+        }
+        float mx = st[0][0];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[u][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * c);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        bf16x8 pb0, pb1, pb2, pb3;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = __builtin_amdgcn_exp2f(fmaf(st[u][r], c, -m_new));
+                psum += p;
+                st[u][r] = p;
+            }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            pb0[e] = f2bf(st[0][e]);
+            pb1[e] = f2bf(st[0][8 + e]);
+            pb2[e] = f2bf(st[1][e]);
+            pb3[e] = f2bf(st[1][8 + e]);
+        }
+        l_run = fmaf(l_run, alpha, psum);
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
+
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int i = 0; i < DT; ++i) {
+            const unsigned char* vrow = vs + (32 * i + lrow) * VROW + half * 16;
+            bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(vrow);
+            bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(vrow + 32);
+            bf16x8 vf2 = *reinterpret_cast<const bf16x8*>(vrow + 64);
+            bf16x8 vf3 = *reinterpret_cast<const bf16x8*>(vrow + 96);
+            ot[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, pb0, ot[i], 0, 0, 0);
+            ot[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, pb1, ot[i], 0, 0, 0);
+            ot[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf2, pb2, ot[i], 0, 0, 0);
+            ot[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf3, pb3, ot[i], 0, 0, 0);
+        }
+
+        if (more) store_tile(buf ^ 1, kreg, vreg);
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (myq < P.Nq) {
+        bf16* orow = P.o + ((size_t)b * P.o_rows_per_b + myq) * P.ldo + h * P.d;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                int dd0 = 32 * i + 8 * q4 + 4 * half;
+                if (dd0 < P.d) {
+                    U2BF4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o.e[e] = f2bf(ot[i][4 * q4 + e] * inv);
+                    *reinterpret_cast<uint2*>(orow + dd0) = o.u;
+                }
+            }
+    }
+}
+
+template <int DP, int DPV>
+static int launch_attn(const AttnParams& P, int B, hipStream_t stream) {
+    constexpr int KROW = DP * 2 + 16, VROW = 144;
+    size_t lds = 2 * (64 * KROW + DPV * VROW);
+    auto kfn = attn_kernel<DP, DPV>;
+    static bool attr_done = false;  // once per instantiation; never inside a stream capture
+    if (!attr_done && lds > 48 * 1024) {
+        GL_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    dim3 grid(cdiv(P.Nq, 128), P.H, B);
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, stream, P);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+int attn_dims(int d, int* DP, int* DPV) {
+    switch (d) {
+        case 40: *DP = 48; *DPV = 64; return GL_OK;
+        case 80: *DP = 80; *DPV = 96; return GL_OK;
+        case 160: *DP = 160; *DPV = 160; return GL_OK;
+        default: return set_error(GL_ERR_UNSUPPORTED, "attention: head dim %d not supported (40, 80, 160)", d);
+    }
+}
+
+int attn_launch(const AttnParams& P, int B, hipStream_t stream) {
+    if (P.Nq <= 0 || P.Nk <= 0) return set_error(GL_ERR_ARG, "attention: empty Nq=%d Nk=%d", P.Nq, P.Nk);
+    if (P.Tq_pad % 128 != 0 || P.Tk_pad % 64 != 0 || P.Tq_pad < P.Nq || P.Tk_pad < P.Nk)
+        return set_error(GL_ERR_ARG, "attention: bad padding Tq_pad=%d Tk_pad=%d (Nq=%d Nk=%d)", P.Tq_pad, P.Tk_pad, P.Nq, P.Nk);
+    switch (P.d) {
+        case 40: return launch_attn<48, 64>(P, B, stream);
+        case 80: return launch_attn<80, 96>(P, B, stream);
+        case 160: return launch_attn<160, 160>(P, B, stream);
+        default: return set_error(GL_ERR_UNSUPPORTED, "attention: head dim %d not supported (40, 80, 160)", P.d);
+    }
+}
+
+}  // namespace gl

@@ -1,0 +1,296 @@
+// extern "C" surface of libgligen_amd.so (see include/gligen_amd.h). Nothing throws across it.
+#include "engine.h"
+
+#include <cmath>
+
+using namespace gl;
+
+struct gl_ctx {
+    Engine* eng;
+};
+
+#define GL_API_BEGIN try {
+#define GL_API_END                                       \
+    }                                                    \
+    catch (const gl::GlError& e) {                       \
+        return gl::set_error(e.code, "%s", e.what());    \
+    }                                                    \
+    catch (const std::exception& e) {                    \
+        return gl::set_error(GL_ERR_STATE, "%s", e.what()); \
+    }                                                    \
+    return GL_OK;
+
+#define NEED(ctx)                                                         \
+    if (!(ctx) || !(ctx)->eng) return gl::set_error(GL_ERR_ARG, "null context");
+
+static inline hipStream_t S(gl_stream s) { return reinterpret_cast<hipStream_t>(s); }
+
+extern "C" {
+
+const char* gl_last_error(void) { return gl::last_error(); }
+
+int gl_ctx_create(int device, size_t arena_bytes, gl_ctx** out) {
+    if (!out) return gl::set_error(GL_ERR_ARG, "null out pointer");
+    GL_API_BEGIN
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        throw GlError(GL_ERR_HIP, "no HIP device available: libgligen_amd has no CPU path");
+    if (device < 0 || device >= ndev) throw GlError(GL_ERR_ARG, "device index out of range");
+    if (hipSetDevice(device) != hipSuccess) throw GlError(GL_ERR_HIP, "hipSetDevice failed");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) throw GlError(GL_ERR_HIP, "hipGetDeviceProperties failed");
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        throw GlError(GL_ERR_UNSUPPORTED, std::string("libgligen_amd is built for gfx950 (MI355X); device is ") + prop.gcnArchName);
+    gl_ctx* c = new gl_ctx{new Engine(device)};
+    try {
+        c->eng->arena().init(arena_bytes ? arena_bytes : (size_t(8) << 30));
+        c->eng->init_workspace();
+    } catch (...) {
+        delete c->eng;
+        delete c;
+        throw;
+    }
+    *out = c;
+    GL_API_END
+}
+
+int gl_ctx_destroy(gl_ctx* ctx) {
+    if (!ctx) return GL_OK;
+    GL_API_BEGIN
+    (void)hipDeviceSynchronize();
+    delete ctx->eng;
+    delete ctx;
+    GL_API_END
+}
+
+int gl_unet_configure(gl_ctx* ctx, const gl_unet_config* cfg) {
+    NEED(ctx);
+    if (!cfg) return gl::set_error(GL_ERR_ARG, "null config");
+    GL_API_BEGIN
+    ctx->eng->configure_unet(*cfg);
+    GL_API_END
+}
+
+int gl_vae_configure(gl_ctx* ctx, const gl_vae_config* cfg) {
+    NEED(ctx);
+    if (!cfg) return gl::set_error(GL_ERR_ARG, "null config");
+    GL_API_BEGIN
+    ctx->eng->configure_vae(*cfg);
+    GL_API_END
+}
+
+int gl_weight_upload(gl_ctx* ctx, const char* key, const void* data, int ndim, const int64_t* shape, int is_device) {
+    NEED(ctx);
+    if (!key || !data || ndim < 0 || (ndim > 0 && !shape)) return gl::set_error(GL_ERR_ARG, "bad weight upload arguments");
+    GL_API_BEGIN
+    ctx->eng->upload(key, data, ndim, shape, is_device != 0);
+    GL_API_END
+}
+
+int gl_finalize(gl_ctx* ctx) {
+    NEED(ctx);
+    GL_API_BEGIN
+    ctx->eng->finalize();
+    GL_API_END
+}
+
+int gl_unet_set_cond(gl_ctx* ctx, int Beff, const float* context, int n_ctx_tokens, const gl_grounding* g, gl_stream s) {
+    NEED(ctx);
+    if (!context || !g) return gl::set_error(GL_ERR_ARG, "null context/grounding");
+    GL_API_BEGIN
+    ctx->eng->set_cond(Beff, context, n_ctx_tokens, *g, S(s));
+    GL_API_END
+}
+
+int gl_unet_set_fuser_scale(gl_ctx* ctx, float scale, gl_stream s) {
+    NEED(ctx);
+    GL_API_BEGIN
+    ctx->eng->set_fuser_scale(scale, S(s));
+    GL_API_END
+}
+
+int gl_unet_forward(gl_ctx* ctx, int Beff, int h, int w, const float* x, int xB, const int64_t* timesteps,
+                    const float* inpaint_extra, int extraB, float* eps_out, gl_stream s) {
+    NEED(ctx);
+    if (!x || !timesteps || !eps_out || Beff <= 0 || h <= 0 || w <= 0) return gl::set_error(GL_ERR_ARG, "bad unet_forward arguments");
+    GL_API_BEGIN
+    ctx->eng->unet_forward(Beff, h, w, x, xB, timesteps, inpaint_extra, extraB, eps_out, S(s));
+    GL_API_END
+}
+
+int gl_vae_decode(gl_ctx* ctx, int B, int h, int w, const float* z, float* img, gl_stream s) {
+    NEED(ctx);
+    if (!z || !img || B <= 0 || h <= 0 || w <= 0) return gl::set_error(GL_ERR_ARG, "bad vae_decode arguments");
+    GL_API_BEGIN
+    ctx->eng->vae_decode(B, h, w, z, img, S(s));
+    GL_API_END
+}
+
+int gl_sample_plms(gl_ctx* ctx, const gl_plms_args* args, gl_stream s) {
+    NEED(ctx);
+    if (!args) return gl::set_error(GL_ERR_ARG, "null args");
+    GL_API_BEGIN
+    ctx->eng->sample_plms(*args, S(s));
+    GL_API_END
+}
+
+int gl_to_uint8(const float* img, uint8_t* out, int B, int C, int HW, gl_stream s) {
+    if (!img || !out) return gl::set_error(GL_ERR_ARG, "null pointer");
+    return to_uint8_launch(img, out, B, C, HW, S(s));
+}
+
+int gl_arena_high_water(gl_ctx* ctx, size_t* bytes) {
+    NEED(ctx);
+    *bytes = ctx->eng->arena().high_water();
+    return GL_OK;
+}
+
+int gl_launch_count(gl_ctx* ctx, int64_t* n) {
+    NEED(ctx);
+    *n = ctx->eng->n_launches;
+    return GL_OK;
+}
+
+// ------------------------------------------------------------------ single operators
+int gl_op_linear(gl_ctx* ctx, const void* x, const void* w, const float* bias, const void* res, void* y,
+                 int M, int N, int K, int act, int out_f32, gl_stream s) {
+    NEED(ctx);
+    GL_API_BEGIN
+    AOperand A;
+    aoperand_rows(A, (const bf16*)x, K, K);
+    Epilogue E;
+    epilogue_defaults(E);
+    E.out = y; E.ldo = N; E.out_f32 = out_f32; E.bias = bias; E.act = act; E.res = (const bf16*)res; E.ldres = N;
+    int r = gemm_launch(A, (const bf16*)w, M, N, K, E, ctx->eng->splitk_ws(), ctx->eng->splitk_ws_bytes(), S(s));
+    if (r != GL_OK) throw GlError(r, gl::last_error());
+    GL_API_END
+}
+
+int gl_op_geglu(gl_ctx* ctx, const void* x, const float* w_f32, const float* b_f32, void* y, int M, int inner, int K, gl_stream s) {
+    NEED(ctx);
+    GL_API_BEGIN
+    Arena& ar = ctx->eng->arena();
+    ar.reset();
+    bf16* wp = ar.get<bf16>((size_t)2 * inner * K);
+    float* bp = ar.get<float>((size_t)2 * inner);
+    int r = pack_geglu_launch(w_f32, b_f32, wp, bp, inner, K, S(s));
+    if (r != GL_OK) throw GlError(r, gl::last_error());
+    AOperand A;
+    aoperand_rows(A, (const bf16*)x, K, K);
+    Epilogue E;
+    epilogue_defaults(E);
+    E.act = ACT_GEGLU; E.out = y; E.ldo = inner; E.bias = bp;
+    r = gemm_launch(A, wp, M, 2 * inner, K, E, ctx->eng->splitk_ws(), ctx->eng->splitk_ws_bytes(), S(s));
+    if (r != GL_OK) throw GlError(r, gl::last_error());
+    GL_API_END
+}
+
+int gl_op_conv3x3(gl_ctx* ctx, const void* x0, int C0, const void* x1, int C1, int B, int H, int W,
+                  const float* w_oihw, const float* bias, int Cout, int stride, int ups, int pad_lo,
+                  const void* res, void* y, gl_stream s) {
+    NEED(ctx);
+    GL_API_BEGIN
+    Arena& ar = ctx->eng->arena();
+    ar.reset();
+    const int Cin = C0 + C1;
+    bf16* wp = ar.get<bf16>((size_t)Cout * 9 * Cin);
+    int r = pack_conv_weight_launch(w_oihw, wp, Cout, Cin, 3, 3, Cout, S(s));
+    if (r != GL_OK) throw GlError(r, gl::last_error());
+    const int Hup = H << ups, Wup = W << ups;
+    const int Ho = stride == 1 ? Hup : (pad_lo ? (Hup + 2 - 3) / 2 + 1 : (Hup + 1 - 3) / 2 + 1);
+    const int Wo = stride == 1 ? Wup : (pad_lo ? (Wup + 2 - 3) / 2 + 1 : (Wup + 1 - 3) / 2 + 1);
+    AOperand A{};
+    A.p0 = (const bf16*)x0; A.C0 = C0; A.ld0 = C0; A.p1 = (const bf16*)x1; A.C1 = C1; A.ld1 = C1;
+    A.mode = A_CONV3; A.Hin = H; A.Win = W; A.Ho = Ho; A.Wo = Wo; A.stride = stride; A.ups = ups; A.pad_lo = pad_lo;
+    Epilogue E;
+    epilogue_defaults(E);
+    E.out = y; E.ldo = Cout; E.bias = bias; E.res = (const bf16*)res; E.ldres = Cout; E.rows_per_b = Ho * Wo;
+    r = gemm_launch(A, wp, B * Ho * Wo, Cout, 9 * Cin, E, ctx->eng->splitk_ws(), ctx->eng->splitk_ws_bytes(), S(s));
+    if (r != GL_OK) throw GlError(r, gl::last_error());
+    GL_API_END
+}
+
+int gl_op_groupnorm(gl_ctx* ctx, const void* x0, int C0, const void* x1, int C1, int B, int HW,
+                    const float* gamma, const float* beta, float eps, int silu, void* y, gl_stream s) {
+    NEED(ctx);
+    GL_API_BEGIN
+    Arena& ar = ctx->eng->arena();
+    ar.reset();
+    GNParams P{};
+    P.x0 = (const bf16*)x0; P.C0 = C0; P.x1 = (const bf16*)x1; P.C1 = C1; P.B = B; P.HW = HW; P.eps = eps;
+    P.gamma = gamma; P.beta = beta; P.y = (bf16*)y; P.silu = silu;
+    P.partial = reinterpret_cast<float*>(ar.alloc(gn_partial_bytes(B, HW)));
+    int r = groupnorm_launch(P, S(s));
+    if (r != GL_OK) throw GlError(r, gl::last_error());
+    GL_API_END
+}
+
+int gl_op_layernorm(gl_ctx* ctx, const void* x, const void* x2, int B, int N1, int N2, int Tpad, int C,
+                    const float* gamma, const float* beta, float eps, void* y, gl_stream s) {
+    NEED(ctx);
+    GL_API_BEGIN
+    LNParams P{};
+    P.x = (const bf16*)x; P.x2 = (const bf16*)x2; P.B = B; P.N1 = N1; P.N2 = N2; P.Tpad = Tpad; P.C = C; P.eps = eps;
+    P.gamma = gamma; P.beta = beta; P.y = (bf16*)y;
+    int r = layernorm_launch(P, S(s));
+    if (r != GL_OK) throw GlError(r, gl::last_error());
+    GL_API_END
+}
+
+int gl_op_attention(gl_ctx* ctx, const void* xq, const void* xkv, int B, int Nq, int Nk, int C, int Ck, int H,
+                    const float* wq, const float* wk, const float* wv, void* o, gl_stream s) {
+    NEED(ctx);
+    GL_API_BEGIN
+    Engine& eng = *ctx->eng;
+    Arena& ar = eng.arena();
+    ar.reset();
+    if (C % H != 0) throw GlError(GL_ERR_ARG, "C must be divisible by H");
+    const int d = C / H;
+    int dp, dpv;
+    int r = attn_dims(d, &dp, &dpv);
+    if (r != GL_OK) throw GlError(r, gl::last_error());
+    const int Tq = round_up(Nq, 64), Tk = round_up(Nk, 64);
+    AttnBufs& bufs = eng.attn_bufs(B, H, d, Tq, Tk);
+    bf16* wqb = ar.get<bf16>((size_t)C * C);
+    bf16* wkb = ar.get<bf16>((size_t)C * Ck);
+    bf16* wvb = ar.get<bf16>((size_t)C * Ck);
+    bf16* xqp = ar.get<bf16>((size_t)B * Tq * C);
+    bf16* xkp = ar.get<bf16>((size_t)B * Tk * Ck);
+    auto ck = [&](int rc) { if (rc != GL_OK) throw GlError(rc, gl::last_error()); };
+    ck(cast_f32_bf16_launch(wq, wqb, (int64_t)C * C, S(s)));
+    ck(cast_f32_bf16_launch(wk, wkb, (int64_t)C * Ck, S(s)));
+    ck(cast_f32_bf16_launch(wv, wvb, (int64_t)C * Ck, S(s)));
+    ck(pad_rows_bf16_launch((const bf16*)xq, xqp, B, Nq, Tq, C, S(s)));
+    ck(pad_rows_bf16_launch((const bf16*)xkv, xkp, B, Nk, Tk, Ck, S(s)));
+    {
+        AOperand A;
+        aoperand_rows(A, xqp, C, C);
+        Epilogue E;
+        epilogue_defaults(E);
+        E.mode = EPI_QK_HEADS; E.q = bufs.q; E.C = C; E.H = H; E.d = d; E.DP = dp; E.T = Tq; E.Tpad_q = bufs.Tq_pad;
+        ck(gemm_launch(A, wqb, B * Tq, C, C, E, eng.splitk_ws(), eng.splitk_ws_bytes(), S(s)));
+    }
+    {
+        AOperand A;
+        aoperand_rows(A, xkp, Ck, Ck);
+        Epilogue E;
+        epilogue_defaults(E);
+        E.mode = EPI_QK_HEADS; E.q = bufs.k; E.C = C; E.H = H; E.d = d; E.DP = dp; E.T = Tk; E.Tpad_q = bufs.Tk_pad;
+        ck(gemm_launch(A, wkb, B * Tk, C, Ck, E, eng.splitk_ws(), eng.splitk_ws_bytes(), S(s)));
+    }
+    {
+        Epilogue E;
+        epilogue_defaults(E);
+        E.mode = EPI_VT_HEADS; E.out = bufs.vt; E.H = H; E.d = d; E.DPV = dpv; E.T = Tk; E.Tpad_k = bufs.Tk_pad;
+        ck(gemm_launch_t(wvb, C, xkp, B * Tk, Ck, E, S(s)));
+    }
+    AttnParams P{};
+    P.q = bufs.q; P.k = bufs.k; P.vt = bufs.vt; P.o = (bf16*)o; P.H = H; P.d = d; P.Nq = Nq; P.Nk = Nk;
+    P.Tq_pad = bufs.Tq_pad; P.Tk_pad = bufs.Tk_pad; P.ldo = C; P.o_rows_per_b = Nq;
+    P.scale_log2e = (float)(1.4426950408889634 / std::sqrt((double)d));
+    ck(attn_launch(P, B, S(s)));
+    GL_API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// gligen_amd — shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels.
+// wave = 64 lanes everywhere; no other architecture is targeted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GL_OK 0
+#define GL_ERR_HIP 1
+#define GL_ERR_ARG 2
+#define GL_ERR_STATE 3
+#define GL_ERR_MISSING 4
+#define GL_ERR_UNSUPPORTED 5
+
+namespace gl {
+
+int set_error(int code, const char* fmt, ...);
+const char* last_error();
+
+#define GL_HIP(expr)                                                               \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess)                                                      \
+            return gl::set_error(GL_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, \
+                                 #expr, hipGetErrorString(_e));                    \
+    } while (0)
+
+#define GL_TRY(expr)               \
+    do {                           \
+        int _r = (expr);           \
+        if (_r != GL_OK) return _r; \
+    } while (0)
+
+#define GL_LAUNCH_CHECK() GL_HIP(hipGetLastError())
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+// ---- device helpers -------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+__device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
+// exact (erf) GELU, as torch F.gelu default (reference ldm/modules/attention.py:44)
+__device__ __forceinline__ float gelu_erf_f(float v) {
+    return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+union U4BF8 {
+    uint4 u;
+    bf16x8 v;
+    bf16 e[8];
+};
+union U2BF4 {
+    uint2 u;
+    bf16x4 v;
+    bf16 e[4];
+};
+
+}  // namespace gl

@@ -1,0 +1,222 @@
+// gligen_amd engine: owns packed weights + workspace for one device and runs the GLIGEN
+// denoising path (UNet forward, CFG + PLMS loop, VAE decode) as sequences of HIP kernels.
+#pragma once
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "attention.h"
+#include "common.h"
+#include "gemm.h"
+#include "misc.h"
+#include "norm.h"
+#include "../../include/gligen_amd.h"
+
+namespace gl {
+
+struct GlError : std::runtime_error {
+    int code;
+    GlError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+struct RawTensor {
+    float* p = nullptr;  // device fp32
+    std::vector<int64_t> shape;
+    int64_t numel = 0;
+};
+
+// Bump allocator over one hipMalloc'd slab with stack-style scopes. Addresses are a pure
+// function of the allocation sequence, so a captured hipGraph replays against the same buffers.
+class Arena {
+   public:
+    void init(size_t bytes);
+    void destroy();
+    void* alloc(size_t bytes);
+    template <class T> T* get(size_t n) { return reinterpret_cast<T*>(alloc(n * sizeof(T))); }
+    size_t mark() const { return off_; }
+    void release(size_t m) { off_ = m; }
+    void reset() { off_ = 0; }
+    size_t capacity() const { return cap_; }
+    size_t high_water() const { return hw_; }
+
+   private:
+    char* base_ = nullptr;
+    size_t cap_ = 0, off_ = 0, hw_ = 0;
+};
+
+struct NormW { const float* g = nullptr; const float* b = nullptr; int C = 0; };
+struct LinW { const bf16* w = nullptr; const float* b = nullptr; int K = 0, N = 0; };
+struct ConvW { const bf16* w = nullptr; const float* b = nullptr; int Cin = 0, Cout = 0, Npad = 0; };
+
+struct ResW {
+    int Cin = 0, Cout = 0;
+    NormW n1, n2;
+    ConvW c1, c2;
+    int emb_off = -1;  // column offset into the concatenated emb_layers output (UNet only)
+    bool has_skip = false;
+    LinW skip;
+};
+struct SelfAttnW { const bf16* wqk = nullptr; const bf16* wv = nullptr; LinW out; };
+struct CrossAttnW { LinW q; const bf16* wk = nullptr; const bf16* wv = nullptr; LinW out; int ctx_dim = 0; };
+struct FFW { const bf16* w1 = nullptr; const float* b1 = nullptr; LinW w2; int C = 0; };
+struct STW {
+    int C = 0, d = 0, idx = 0;
+    NormW gn;
+    LinW proj_in, proj_out;
+    NormW ln1, ln2, ln3, fn1, fn2;
+    SelfAttnW a1, fa;
+    CrossAttnW a2;
+    FFW ff, fff;
+    LinW flin;  // fuser.linear (context_dim -> C)
+};
+
+enum LayerKind { L_CONV_IN, L_RES, L_ST, L_DOWN, L_UP };
+struct Layer {
+    LayerKind kind;
+    int idx;  // index into res_/st_/updown_ vectors
+};
+struct UNetBlock { std::vector<Layer> layers; };
+
+struct VaeAttnW { NormW gn; LinW q, k, v, proj; };
+
+struct AttnBufs {  // persistent, zero-initialised head-layout buffers for one attention shape
+    bf16* q = nullptr;
+    bf16* k = nullptr;
+    bf16* vt = nullptr;
+    int Tq_pad = 0, Tk_pad = 0;
+};
+
+// channel-concat view of up to two NHWC bf16 tensors
+struct TRef { const bf16* p0 = nullptr; int C0 = 0; const bf16* p1 = nullptr; int C1 = 0; int C() const { return C0 + C1; } };
+
+class Engine {
+   public:
+    explicit Engine(int device);
+    ~Engine();
+
+    void upload(const std::string& key, const void* src, int ndim, const int64_t* shape, bool is_device);
+    void configure_unet(const gl_unet_config& c);
+    void configure_vae(const gl_vae_config& c);
+    void finalize();
+    bool finalized() const { return finalized_; }
+
+    void set_cond(int Beff, const float* context, int n_ctx, const gl_grounding& g, hipStream_t s);
+    void set_fuser_scale(float v, hipStream_t s);
+    void unet_forward(int Beff, int h, int w, const float* x, int xB, const int64_t* t, const float* extra,
+                      int extraB, float* eps, hipStream_t s);
+    void vae_decode(int B, int h, int w, const float* z, float* out, hipStream_t s);
+    void sample_plms(const gl_plms_args& a, hipStream_t s);
+
+    // single-op entry points (tests / profiling)
+    Arena& arena() { return arena_; }
+    float* splitk_ws() { return ws_; }
+    size_t splitk_ws_bytes() const { return ws_bytes_; }
+    void* persist(size_t bytes, bool zero);
+    void init_workspace();
+    AttnBufs& attn_bufs(int B, int H, int d, int Tq, int Tk);
+
+    int device() const { return device_; }
+    int64_t n_launches = 0;
+
+   private:
+    const RawTensor& raw(const std::string& key) const;
+    bool has(const std::string& key) const { return raw_.count(key) != 0; }
+    const float* F(const std::string& key) const { return raw(key).p; }
+    NormW norm(const std::string& prefix);
+    LinW linear(const std::string& prefix, bool bias = true);
+    ConvW conv3(const std::string& prefix, int Npad = 0);
+    LinW conv1(const std::string& prefix);
+    const bf16* cast_rows(const std::vector<std::string>& weight_keys);
+    FFW ffw(const std::string& prefix, int C);
+    ResW resw(const std::string& prefix, int Cin, int Cout, bool unet);
+    void build_unet();
+    void build_vae();
+
+    // execution helpers
+    void gemm(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, hipStream_t s);
+    bf16* linear_rows(const bf16* x, int M, const LinW& L, int act, const bf16* res, const float* gate, hipStream_t s);
+    bf16* groupnorm(const TRef& x, int B, int HW, const NormW& n, float eps, bool silu, hipStream_t s);
+    bf16* layernorm(const bf16* x, int B, int N, int C, const NormW& n, bool pad64, hipStream_t s);
+    bf16* conv3x3(const TRef& x, int B, int Hin, int Win, const ConvW& c, int stride, int ups, int pad_lo,
+                  const float* bias2, int bias2_ld, const bf16* res, hipStream_t s);
+    bf16* resblock(const ResW& r, const TRef& x, int B, int H, int W, const float* embout, int emb_ld, float eps, hipStream_t s);
+    bf16* transformer(const STW& t, const bf16* x, int B, int H, int W, hipStream_t s);
+    bf16* feedforward(const FFW& f, const bf16* ln, int M, const bf16* res, const float* gate, hipStream_t s);
+    void self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, int Nq, int Nk, int C, int d, bf16* o, hipStream_t s);
+    bf16* vae_attn(const VaeAttnW& a, const bf16* x, int B, int HW, hipStream_t s);
+
+    int device_;
+    bool finalized_ = false;
+    std::unordered_map<std::string, RawTensor> raw_;
+    std::vector<void*> owned_;  // persistent device allocations
+    Arena arena_;
+    float* ws_ = nullptr;
+    size_t ws_bytes_ = 0;
+
+    // ---- UNet
+    bool has_unet_ = false;
+    gl_unet_config ucfg_{};
+    LinW te0_, te2_;
+    LinW embcat_;  // all ResBlock emb_layers concatenated: [sumCout][4*mc]
+    ConvW conv_in_small_;  // [mc][Kpad] via small im2col
+    int conv_in_kpad_ = 0;
+    std::vector<ResW> res_;
+    std::vector<STW> st_;
+    std::vector<ConvW> updown_;
+    std::vector<UNetBlock> in_blocks_, out_blocks_;
+    UNetBlock mid_block_;
+    NormW out_norm_;
+    ConvW out_conv_;
+    const float* const* alpha_ptrs_ = nullptr;  // device array [2*n_st]
+    float* gates_ = nullptr;                    // device [2*n_st]: (attn, dense) per transformer
+    float* fuser_scale_ = nullptr;              // device scalar
+    // grounding tokenizer
+    int gkind_ = 0;
+    LinW pn_[2][3];
+    const float* pn_null_feat_[2] = {nullptr, nullptr};
+    const float* pn_null_pos_ = nullptr;
+    const float* kp_table_ = nullptr;  // keypoint: person+keypoint embedding table [P*17][out]
+
+    // ---- conditioning cache
+    struct Cond {
+        int Beff = 0, Ng = 0, ctx_T = 0, ctx_Tpad = 0;
+        std::vector<bf16*> objs;    // per transformer: [Beff*Ng][C]
+        std::vector<bf16*> ctx_k;   // per transformer: [Beff*H][ctx_Tpad][DP]
+        std::vector<bf16*> ctx_vt;  // per transformer: [Beff*H][DPV][ctx_Tpad]
+        std::vector<void*> allocs;
+    } cond_;
+
+    std::unordered_map<uint64_t, AttnBufs> attn_bufs_;
+
+    // ---- VAE decoder
+    bool has_vae_ = false;
+    gl_vae_config vcfg_{};
+    const float* pq_w_ = nullptr;
+    const float* pq_b_ = nullptr;
+    ConvW vae_in_small_;
+    int vae_in_kpad_ = 0;
+    ResW vmid1_, vmid2_;
+    VaeAttnW vattn_;
+    struct VaeUp { std::vector<ResW> blocks; bool has_up = false; ConvW up; };
+    std::vector<VaeUp> vup_;  // index = level (0 = full resolution)
+    NormW vnorm_out_;
+    ConvW vconv_out_;
+
+    // ---- sampler state
+    struct Sampler {
+        int B = 0, h = 0, w = 0;
+        float* x2 = nullptr;
+        float* eps_pair = nullptr;
+        float* hist[4] = {nullptr, nullptr, nullptr, nullptr};
+        float* x_tmp = nullptr;
+        int64_t* t_dev = nullptr;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        bool has_extra = false;
+        const float* extra = nullptr;
+    } smp_;
+    void sampler_release_graph();
+};
+
+}  // namespace gl

@@ -1,0 +1,1164 @@
+// gligen_amd engine — weight packing and the kernel schedules of UNetModel.forward,
+// AutoencoderKL.decode and the CFG + PLMS sampling loop (see engine.h, include/gligen_amd.h).
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace gl {
+
+static thread_local char g_err[2048] = "";
+int set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+const char* last_error() { return g_err; }
+
+#define CK(expr)                                              \
+    do {                                                      \
+        int _r = (expr);                                      \
+        if (_r != GL_OK) throw GlError(_r, gl::last_error()); \
+    } while (0)
+#define HIPCK(expr)                                                                             \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            throw GlError(GL_ERR_HIP, std::string(#expr) + " -> " + hipGetErrorString(_e));     \
+    } while (0)
+
+static std::string fmt(const char* f, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, f);
+    vsnprintf(buf, sizeof(buf), f, ap);
+    va_end(ap);
+    return buf;
+}
+
+// ---------------------------------------------------------------- Arena
+void Arena::init(size_t bytes) {
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&base_), bytes));
+    cap_ = bytes;
+    off_ = hw_ = 0;
+}
+void Arena::destroy() {
+    if (base_) (void)hipFree(base_);
+    base_ = nullptr;
+}
+void* Arena::alloc(size_t bytes) {
+    size_t a = (off_ + 255) & ~size_t(255);
+    if (a + bytes > cap_)
+        throw GlError(GL_ERR_STATE, fmt("workspace arena exhausted: need %zu more bytes (capacity %zu); "
+                                        "create the context with a larger arena", bytes, cap_));
+    off_ = a + bytes;
+    hw_ = std::max(hw_, off_);
+    return base_ + a;
+}
+
+// ---------------------------------------------------------------- Engine basics
+Engine::Engine(int device) : device_(device) {}
+
+Engine::~Engine() {
+    sampler_release_graph();
+    for (auto& kv : raw_)
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    for (void* p : owned_) (void)hipFree(p);
+    for (void* p : cond_.allocs) (void)hipFree(p);
+    arena_.destroy();
+}
+
+void Engine::init_workspace() {
+    if (ws_) return;
+    ws_bytes_ = size_t(256) << 20;  // fp32 split-K slabs
+    ws_ = reinterpret_cast<float*>(persist(ws_bytes_, false));
+}
+
+void* Engine::persist(size_t bytes, bool zero) {
+    void* p = nullptr;
+    HIPCK(hipMalloc(&p, std::max<size_t>(bytes, 256)));
+    if (zero) HIPCK(hipMemset(p, 0, std::max<size_t>(bytes, 256)));
+    owned_.push_back(p);
+    return p;
+}
+
+void Engine::upload(const std::string& key, const void* src, int ndim, const int64_t* shape, bool is_device) {
+    if (finalized_) throw GlError(GL_ERR_STATE, "weights cannot be uploaded after gl_finalize");
+    RawTensor t;
+    t.numel = 1;
+    for (int i = 0; i < ndim; ++i) {
+        t.shape.push_back(shape[i]);
+        t.numel *= shape[i];
+    }
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&t.p), std::max<int64_t>(t.numel, 4) * sizeof(float)));
+    HIPCK(hipMemcpy(t.p, src, t.numel * sizeof(float), is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    auto it = raw_.find(key);
+    if (it != raw_.end()) (void)hipFree(it->second.p);
+    raw_[key] = t;
+}
+
+const RawTensor& Engine::raw(const std::string& key) const {
+    auto it = raw_.find(key);
+    if (it == raw_.end()) throw GlError(GL_ERR_MISSING, "missing weight '" + key + "'");
+    return it->second;
+}
+
+void Engine::configure_unet(const gl_unet_config& c) {
+    if (c.n_mult < 1 || c.n_mult > 8 || c.n_attn < 0 || c.n_attn > 8) throw GlError(GL_ERR_ARG, "bad unet config");
+    if (c.model_channels % 64 != 0) throw GlError(GL_ERR_UNSUPPORTED, "model_channels must be a multiple of 64");
+    ucfg_ = c;
+    has_unet_ = true;
+}
+void Engine::configure_vae(const gl_vae_config& c) {
+    if (c.n_mult < 1 || c.n_mult > 8) throw GlError(GL_ERR_ARG, "bad vae config");
+    vcfg_ = c;
+    has_vae_ = true;
+}
+
+// ---------------------------------------------------------------- weight packing
+NormW Engine::norm(const std::string& p) {
+    NormW n;
+    n.g = F(p + ".weight");
+    n.b = F(p + ".bias");
+    n.C = (int)raw(p + ".weight").numel;
+    return n;
+}
+
+const bf16* Engine::cast_rows(const std::vector<std::string>& keys) {
+    int64_t total = 0;
+    for (auto& k : keys) total += raw(k).numel;
+    bf16* dst = reinterpret_cast<bf16*>(persist(total * sizeof(bf16), false));
+    int64_t off = 0;
+    for (auto& k : keys) {
+        const RawTensor& t = raw(k);
+        CK(cast_f32_bf16_launch(t.p, dst + off, t.numel, 0));
+        off += t.numel;
+    }
+    return dst;
+}
+
+LinW Engine::linear(const std::string& p, bool bias) {
+    LinW l;
+    const RawTensor& w = raw(p + ".weight");
+    l.N = (int)w.shape[0];
+    l.K = (int)(w.numel / w.shape[0]);
+    if (l.K % 64 != 0) {  // zero-pad K (keypoint PositionNet: 768 + 32 -> 832)
+        int Kp = round_up(l.K, 64);
+        bf16* dst = reinterpret_cast<bf16*>(persist((size_t)l.N * Kp * sizeof(bf16), false));
+        CK(cast_pad_cols_launch(w.p, dst, l.N, l.K, Kp, 0));
+        l.w = dst;
+        l.K = Kp;
+    } else {
+        l.w = cast_rows({p + ".weight"});
+    }
+    l.b = bias ? F(p + ".bias") : nullptr;
+    return l;
+}
+
+LinW Engine::conv1(const std::string& p) { return linear(p, true); }
+
+ConvW Engine::conv3(const std::string& p, int Npad) {
+    ConvW c;
+    const RawTensor& w = raw(p + ".weight");
+    if (w.shape.size() != 4 || w.shape[2] != 3 || w.shape[3] != 3) throw GlError(GL_ERR_ARG, "'" + p + ".weight' is not a 3x3 conv");
+    c.Cout = (int)w.shape[0];
+    c.Cin = (int)w.shape[1];
+    c.Npad = Npad ? Npad : c.Cout;
+    bf16* dst = reinterpret_cast<bf16*>(persist((size_t)c.Npad * 9 * c.Cin * sizeof(bf16), false));
+    CK(pack_conv_weight_launch(w.p, dst, c.Cout, c.Cin, 3, 3, c.Npad, 0));
+    c.w = dst;
+    if (c.Npad != c.Cout) {
+        float* b = reinterpret_cast<float*>(persist(c.Npad * sizeof(float), true));
+        HIPCK(hipMemcpy(b, F(p + ".bias"), c.Cout * sizeof(float), hipMemcpyDeviceToDevice));
+        c.b = b;
+    } else {
+        c.b = F(p + ".bias");
+    }
+    return c;
+}
+
+FFW Engine::ffw(const std::string& p, int C) {
+    FFW f;
+    f.C = C;
+    const RawTensor& w = raw(p + ".net.0.proj.weight");
+    const int C8 = (int)w.shape[0], K = (int)w.shape[1];
+    if (C8 != 8 * C || K != C) throw GlError(GL_ERR_ARG, "'" + p + "' GEGLU projection has unexpected shape");
+    bf16* wp = reinterpret_cast<bf16*>(persist((size_t)C8 * K * sizeof(bf16), false));
+    float* bp = reinterpret_cast<float*>(persist(C8 * sizeof(float), false));
+    CK(pack_geglu_launch(w.p, F(p + ".net.0.proj.bias"), wp, bp, 4 * C, K, 0));
+    f.w1 = wp;
+    f.b1 = bp;
+    f.w2 = linear(p + ".net.2");
+    return f;
+}
+
+ResW Engine::resw(const std::string& p, int Cin, int Cout, bool unet) {
+    ResW r;
+    r.Cin = Cin;
+    r.Cout = Cout;
+    if (unet) {
+        r.n1 = norm(p + ".in_layers.0");
+        r.c1 = conv3(p + ".in_layers.2");
+        r.n2 = norm(p + ".out_layers.0");
+        r.c2 = conv3(p + ".out_layers.3");
+        r.has_skip = has(p + ".skip_connection.weight");
+        if (r.has_skip) r.skip = conv1(p + ".skip_connection");
+    } else {
+        r.n1 = norm(p + ".norm1");
+        r.c1 = conv3(p + ".conv1");
+        r.n2 = norm(p + ".norm2");
+        r.c2 = conv3(p + ".conv2");
+        r.has_skip = has(p + ".nin_shortcut.weight");
+        if (r.has_skip) r.skip = conv1(p + ".nin_shortcut");
+        if (has(p + ".conv_shortcut.weight")) throw GlError(GL_ERR_UNSUPPORTED, "'" + p + "': 3x3 conv_shortcut is not supported");
+    }
+    if (r.c1.Cin != Cin || r.c1.Cout != Cout || (Cin != Cout) != r.has_skip)
+        throw GlError(GL_ERR_ARG, fmt("'%s': weights do not match the configured topology (%d -> %d)", p.c_str(), Cin, Cout));
+    return r;
+}
+
+void Engine::build_unet() {
+    const gl_unet_config& c = ucfg_;
+    const int mc = c.model_channels;
+    const std::string U = "unet/";
+    auto in_attn = [&](int ds) {
+        for (int i = 0; i < c.n_attn; ++i)
+            if (c.attention_resolutions[i] == ds) return true;
+        return false;
+    };
+    te0_ = linear(U + "time_embed.0");
+    te2_ = linear(U + "time_embed.2");
+
+    // first conv through the small-channel im2col path (K = 9*in_c padded to 64)
+    {
+        const RawTensor& w = raw(U + "input_blocks.0.0.weight");
+        const int in_c = (int)w.shape[1];
+        const int expect = c.inpaint_mode ? 2 * c.in_channels + 1 : c.in_channels;
+        if (in_c != expect) throw GlError(GL_ERR_ARG, fmt("first conv has %d input channels, config implies %d", in_c, expect));
+        conv_in_kpad_ = round_up(9 * in_c, 64);
+        bf16* dst = reinterpret_cast<bf16*>(persist((size_t)mc * conv_in_kpad_ * sizeof(bf16), false));
+        CK(pack_conv_small_launch(w.p, dst, mc, in_c, conv_in_kpad_, 0));
+        conv_in_small_.w = dst;
+        conv_in_small_.b = F(U + "input_blocks.0.0.bias");
+        conv_in_small_.Cin = in_c;
+        conv_in_small_.Cout = mc;
+    }
+
+    std::vector<std::string> emb_keys;
+    std::vector<const float*> emb_bias;
+    std::vector<int> emb_n;
+    int emb_total = 0;
+    auto add_res = [&](const std::string& p, int Cin, int Cout) {
+        ResW r = resw(p, Cin, Cout, true);
+        r.emb_off = emb_total;
+        emb_keys.push_back(p + ".emb_layers.1.weight");
+        emb_bias.push_back(F(p + ".emb_layers.1.bias"));
+        emb_n.push_back(Cout);
+        emb_total += Cout;
+        res_.push_back(r);
+        return Layer{L_RES, (int)res_.size() - 1};
+    };
+    auto add_st = [&](const std::string& p, int C) {
+        STW t;
+        t.C = C;
+        t.d = C / c.num_heads;
+        t.idx = (int)st_.size();
+        int dp, dpv;
+        CK(attn_dims(t.d, &dp, &dpv));
+        const std::string tb = p + ".transformer_blocks.0";
+        t.gn = norm(p + ".norm");
+        t.proj_in = conv1(p + ".proj_in");
+        t.proj_out = conv1(p + ".proj_out");
+        t.ln1 = norm(tb + ".norm1");
+        t.ln2 = norm(tb + ".norm2");
+        t.ln3 = norm(tb + ".norm3");
+        t.a1.wqk = cast_rows({tb + ".attn1.to_q.weight", tb + ".attn1.to_k.weight"});
+        t.a1.wv = cast_rows({tb + ".attn1.to_v.weight"});
+        t.a1.out = linear(tb + ".attn1.to_out.0");
+        t.a2.q = linear(tb + ".attn2.to_q", false);
+        t.a2.wk = cast_rows({tb + ".attn2.to_k.weight"});
+        t.a2.wv = cast_rows({tb + ".attn2.to_v.weight"});
+        t.a2.ctx_dim = (int)raw(tb + ".attn2.to_k.weight").shape[1];
+        t.a2.out = linear(tb + ".attn2.to_out.0");
+        t.ff = ffw(tb + ".ff", C);
+        if (!has(tb + ".fuser.linear.weight"))
+            throw GlError(GL_ERR_UNSUPPORTED, "only fuser_type gatedSA (GatedSelfAttentionDense) is supported");
+        t.flin = linear(tb + ".fuser.linear");
+        t.fn1 = norm(tb + ".fuser.norm1");
+        t.fn2 = norm(tb + ".fuser.norm2");
+        t.fa.wqk = cast_rows({tb + ".fuser.attn.to_q.weight", tb + ".fuser.attn.to_k.weight"});
+        t.fa.wv = cast_rows({tb + ".fuser.attn.to_v.weight"});
+        t.fa.out = linear(tb + ".fuser.attn.to_out.0");
+        t.fff = ffw(tb + ".fuser.ff", C);
+        raw(tb + ".fuser.alpha_attn");
+        raw(tb + ".fuser.alpha_dense");
+        st_.push_back(t);
+        return Layer{L_ST, t.idx};
+    };
+
+    std::vector<std::string> st_prefix;  // for alpha pointer table
+    in_blocks_.clear();
+    in_blocks_.push_back(UNetBlock{{Layer{L_CONV_IN, 0}}});
+    std::vector<int> chans{mc};
+    int ch = mc, ds = 1, n = 1;
+    for (int level = 0; level < c.n_mult; ++level) {
+        const int mult = c.channel_mult[level];
+        for (int r = 0; r < c.num_res_blocks; ++r) {
+            UNetBlock b;
+            const std::string p = U + fmt("input_blocks.%d", n);
+            b.layers.push_back(add_res(p + ".0", ch, mult * mc));
+            ch = mult * mc;
+            if (in_attn(ds)) {
+                b.layers.push_back(add_st(p + ".1", ch));
+                st_prefix.push_back(p + ".1");
+            }
+            in_blocks_.push_back(b);
+            chans.push_back(ch);
+            ++n;
+        }
+        if (level != c.n_mult - 1) {
+            updown_.push_back(conv3(U + fmt("input_blocks.%d.0.op", n)));
+            in_blocks_.push_back(UNetBlock{{Layer{L_DOWN, (int)updown_.size() - 1}}});
+            chans.push_back(ch);
+            ds *= 2;
+            ++n;
+        }
+    }
+    mid_block_.layers.clear();
+    mid_block_.layers.push_back(add_res(U + "middle_block.0", ch, ch));
+    mid_block_.layers.push_back(add_st(U + "middle_block.1", ch));
+    st_prefix.push_back(U + "middle_block.1");
+    mid_block_.layers.push_back(add_res(U + "middle_block.2", ch, ch));
+
+    out_blocks_.clear();
+    n = 0;
+    for (int level = c.n_mult - 1; level >= 0; --level) {
+        const int mult = c.channel_mult[level];
+        for (int i = 0; i <= c.num_res_blocks; ++i) {
+            const int ich = chans.back();
+            chans.pop_back();
+            UNetBlock b;
+            const std::string p = U + fmt("output_blocks.%d", n);
+            b.layers.push_back(add_res(p + ".0", ch + ich, mc * mult));
+            ch = mc * mult;
+            int j = 1;
+            if (in_attn(ds)) {
+                b.layers.push_back(add_st(p + ".1", ch));
+                st_prefix.push_back(p + ".1");
+                j = 2;
+            }
+            if (level && i == c.num_res_blocks) {
+                updown_.push_back(conv3(p + fmt(".%d.conv", j)));
+                b.layers.push_back(Layer{L_UP, (int)updown_.size() - 1});
+                ds /= 2;
+            }
+            out_blocks_.push_back(b);
+            ++n;
+        }
+    }
+    out_norm_ = norm(U + "out.0");
+    out_conv_ = conv3(U + "out.2", 32);
+    if (out_conv_.Cout != c.out_channels) throw GlError(GL_ERR_ARG, "out conv channels do not match out_channels");
+
+    // all emb_layers in one GEMM
+    embcat_.w = cast_rows(emb_keys);
+    embcat_.K = 4 * mc;
+    embcat_.N = emb_total;
+    {
+        float* b = reinterpret_cast<float*>(persist(emb_total * sizeof(float), false));
+        int off = 0;
+        for (size_t i = 0; i < emb_bias.size(); ++i) {
+            HIPCK(hipMemcpy(b + off, emb_bias[i], emb_n[i] * sizeof(float), hipMemcpyDeviceToDevice));
+            off += emb_n[i];
+        }
+        embcat_.b = b;
+    }
+
+    // fuser gates
+    {
+        std::vector<const float*> ptrs;
+        for (auto& p : st_prefix) {
+            ptrs.push_back(F(p + ".transformer_blocks.0.fuser.alpha_attn"));
+            ptrs.push_back(F(p + ".transformer_blocks.0.fuser.alpha_dense"));
+        }
+        void* d = persist(ptrs.size() * sizeof(float*), false);
+        HIPCK(hipMemcpy(d, ptrs.data(), ptrs.size() * sizeof(float*), hipMemcpyHostToDevice));
+        alpha_ptrs_ = reinterpret_cast<const float* const*>(d);
+        gates_ = reinterpret_cast<float*>(persist(ptrs.size() * sizeof(float), true));
+        fuser_scale_ = reinterpret_cast<float*>(persist(sizeof(float), true));
+        const float one = 1.f;
+        HIPCK(hipMemcpy(fuser_scale_, &one, sizeof(float), hipMemcpyHostToDevice));
+    }
+
+    // grounding tokenizer (position_net)
+    gkind_ = c.grounding_kind;
+    const std::string PN = U + "position_net.";
+    if (gkind_ == 0) {
+        for (int i = 0; i < 3; ++i) pn_[0][i] = linear(PN + fmt("linears.%d", 2 * i));
+        pn_null_feat_[0] = F(PN + "null_positive_feature");
+        pn_null_pos_ = F(PN + "null_position_feature");
+    } else if (gkind_ == 1) {
+        for (int i = 0; i < 3; ++i) {
+            pn_[0][i] = linear(PN + fmt("linears_text.%d", 2 * i));
+            pn_[1][i] = linear(PN + fmt("linears_image.%d", 2 * i));
+        }
+        pn_null_feat_[0] = F(PN + "null_text_feature");
+        pn_null_feat_[1] = F(PN + "null_image_feature");
+        pn_null_pos_ = F(PN + "null_position_feature");
+    } else if (gkind_ == 2) {
+        for (int i = 0; i < 3; ++i) pn_[0][i] = linear(PN + fmt("linears.%d", 2 * i));
+        pn_null_feat_[0] = F(PN + "null_person_feature");
+        pn_null_pos_ = F(PN + "null_xy_feature");
+        // person_embeddings[p] + keypoint_embeddings[j] (keypoint_grounding_net.py:39-42)
+        const RawTensor& pe = raw(PN + "person_embeddings");
+        const RawTensor& ke = raw(PN + "keypoint_embeddings");
+        const int P = (int)pe.shape[0], D = (int)pe.shape[1];
+        std::vector<float> hp(pe.numel), hk(ke.numel), tab((size_t)P * 17 * D);
+        HIPCK(hipMemcpy(hp.data(), pe.p, pe.numel * sizeof(float), hipMemcpyDeviceToHost));
+        HIPCK(hipMemcpy(hk.data(), ke.p, ke.numel * sizeof(float), hipMemcpyDeviceToHost));
+        for (int p = 0; p < P; ++p)
+            for (int j = 0; j < 17; ++j)
+                for (int k = 0; k < D; ++k) tab[((size_t)p * 17 + j) * D + k] = hp[(size_t)p * D + k] + hk[(size_t)j * D + k];
+        float* d = reinterpret_cast<float*>(persist(tab.size() * sizeof(float), false));
+        HIPCK(hipMemcpy(d, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+        kp_table_ = d;
+    } else {
+        throw GlError(GL_ERR_UNSUPPORTED, "grounding_kind must be 0 (text), 1 (text+image) or 2 (keypoint)");
+    }
+}
+
+void Engine::build_vae() {
+    const gl_vae_config& c = vcfg_;
+    const std::string V = "vae/";
+    pq_w_ = F(V + "post_quant_conv.weight");
+    pq_b_ = F(V + "post_quant_conv.bias");
+    const int block_in0 = c.ch * c.ch_mult[c.n_mult - 1];
+    {
+        const RawTensor& w = raw(V + "decoder.conv_in.weight");
+        const int in_c = (int)w.shape[1];
+        vae_in_kpad_ = round_up(9 * in_c, 64);
+        bf16* dst = reinterpret_cast<bf16*>(persist((size_t)block_in0 * vae_in_kpad_ * sizeof(bf16), false));
+        CK(pack_conv_small_launch(w.p, dst, block_in0, in_c, vae_in_kpad_, 0));
+        vae_in_small_.w = dst;
+        vae_in_small_.b = F(V + "decoder.conv_in.bias");
+        vae_in_small_.Cin = in_c;
+        vae_in_small_.Cout = block_in0;
+    }
+    vmid1_ = resw(V + "decoder.mid.block_1", block_in0, block_in0, false);
+    vmid2_ = resw(V + "decoder.mid.block_2", block_in0, block_in0, false);
+    vattn_.gn = norm(V + "decoder.mid.attn_1.norm");
+    vattn_.q = conv1(V + "decoder.mid.attn_1.q");
+    vattn_.k = conv1(V + "decoder.mid.attn_1.k");
+    vattn_.v = conv1(V + "decoder.mid.attn_1.v");
+    vattn_.proj = conv1(V + "decoder.mid.attn_1.proj_out");
+    vup_.assign(c.n_mult, VaeUp{});
+    int block_in = block_in0;
+    for (int level = c.n_mult - 1; level >= 0; --level) {
+        const int block_out = c.ch * c.ch_mult[level];
+        for (int i = 0; i <= c.num_res_blocks; ++i) {
+            vup_[level].blocks.push_back(resw(V + fmt("decoder.up.%d.block.%d", level, i), block_in, block_out, false));
+            block_in = block_out;
+        }
+        if (level != 0) {
+            vup_[level].has_up = true;
+            vup_[level].up = conv3(V + fmt("decoder.up.%d.upsample.conv", level));
+        }
+    }
+    vnorm_out_ = norm(V + "decoder.norm_out");
+    vconv_out_ = conv3(V + "decoder.conv_out", 32);
+}
+
+void Engine::finalize() {
+    if (finalized_) throw GlError(GL_ERR_STATE, "gl_finalize called twice");
+    HIPCK(hipSetDevice(device_));
+    if (has_unet_) build_unet();
+    if (has_vae_) build_vae();
+    HIPCK(hipDeviceSynchronize());
+    // matrices now live packed in bf16: drop their fp32 staging copies (vectors stay, they are used as is)
+    for (auto it = raw_.begin(); it != raw_.end();) {
+        if (it->second.shape.size() >= 2 && it->first.find("post_quant_conv") == std::string::npos) {
+            (void)hipFree(it->second.p);
+            it = raw_.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    finalized_ = true;
+}
+
+// ---------------------------------------------------------------- execution helpers
+void Engine::gemm(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, hipStream_t s) {
+    CK(gemm_launch(A, W, M, N, K, E, ws_, ws_bytes_, s));
+    ++n_launches;
+}
+
+bf16* Engine::linear_rows(const bf16* x, int M, const LinW& L, int act, const bf16* res, const float* gate, hipStream_t s) {
+    bf16* out = arena_.get<bf16>((size_t)M * L.N);
+    AOperand A;
+    aoperand_rows(A, x, L.K, L.K);
+    Epilogue E;
+    epilogue_defaults(E);
+    E.out = out;
+    E.ldo = L.N;
+    E.bias = L.b;
+    E.act = act;
+    E.res = res;
+    E.ldres = L.N;
+    E.gate = gate;
+    gemm(A, L.w, M, L.N, L.K, E, s);
+    return out;
+}
+
+bf16* Engine::groupnorm(const TRef& x, int B, int HW, const NormW& n, float eps, bool silu, hipStream_t s) {
+    const int C = x.C();
+    if (n.C != C) throw GlError(GL_ERR_ARG, fmt("groupnorm: %d channels given to a norm with %d", C, n.C));
+    bf16* y = arena_.get<bf16>((size_t)B * HW * C);
+    GNParams P{};
+    P.x0 = x.p0; P.C0 = x.C0; P.x1 = x.p1; P.C1 = x.C1;
+    P.B = B; P.HW = HW; P.eps = eps; P.gamma = n.g; P.beta = n.b; P.y = y; P.silu = silu ? 1 : 0;
+    P.partial = reinterpret_cast<float*>(arena_.alloc(gn_partial_bytes(B, HW)));
+    CK(groupnorm_launch(P, s));
+    n_launches += 2;
+    return y;
+}
+
+bf16* Engine::layernorm(const bf16* x, int B, int N, int C, const NormW& n, bool pad64, hipStream_t s) {
+    const int Tp = pad64 ? round_up(N, 64) : N;
+    bf16* y = arena_.get<bf16>((size_t)B * Tp * C);
+    LNParams P{};
+    P.x = x; P.x2 = nullptr; P.B = B; P.N1 = N; P.N2 = 0; P.Tpad = Tp; P.C = C; P.eps = 1e-5f;
+    P.gamma = n.g; P.beta = n.b; P.y = y;
+    CK(layernorm_launch(P, s));
+    ++n_launches;
+    return y;
+}
+
+bf16* Engine::conv3x3(const TRef& x, int B, int Hin, int Win, const ConvW& c, int stride, int ups, int pad_lo,
+                      const float* bias2, int bias2_ld, const bf16* res, hipStream_t s) {
+    if (x.C() != c.Cin) throw GlError(GL_ERR_ARG, fmt("conv3x3: input has %d channels, weight expects %d", x.C(), c.Cin));
+    const int Hup = Hin << ups, Wup = Win << ups;
+    const int Ho = stride == 1 ? Hup : (pad_lo ? (Hup + 2 - 3) / 2 + 1 : (Hup + 1 - 3) / 2 + 1);
+    const int Wo = stride == 1 ? Wup : (pad_lo ? (Wup + 2 - 3) / 2 + 1 : (Wup + 1 - 3) / 2 + 1);
+    const int M = B * Ho * Wo;
+    bf16* out = arena_.get<bf16>((size_t)M * c.Cout);
+    AOperand A{};
+    A.p0 = x.p0; A.C0 = x.C0; A.ld0 = x.C0;
+    A.p1 = x.p1; A.C1 = x.C1; A.ld1 = x.C1;
+    A.mode = A_CONV3;
+    A.Hin = Hin; A.Win = Win; A.Ho = Ho; A.Wo = Wo; A.stride = stride; A.ups = ups; A.pad_lo = pad_lo;
+    Epilogue E;
+    epilogue_defaults(E);
+    E.out = out; E.ldo = c.Cout; E.bias = c.b;
+    E.bias2 = bias2; E.bias2_ld = bias2_ld; E.rows_per_b = Ho * Wo;
+    E.res = res; E.ldres = c.Cout;
+    gemm(A, c.w, M, c.Cout, 9 * c.Cin, E, s);
+    return out;
+}
+
+// ResBlock._forward (openaimodel.py:212-232) / VAE ResnetBlock.forward (model.py:118-141)
+bf16* Engine::resblock(const ResW& r, const TRef& x, int B, int H, int W, const float* embout, int emb_ld, float eps, hipStream_t s) {
+    const int HW = H * W, M = B * HW;
+    bf16* out = arena_.get<bf16>((size_t)M * r.Cout);
+    const size_t mk = arena_.mark();
+    bf16* a = groupnorm(x, B, HW, r.n1, eps, true, s);
+    bf16* h = conv3x3(TRef{a, r.Cin, nullptr, 0}, B, H, W, r.c1, 1, 0, 1, embout ? embout + r.emb_off : nullptr, emb_ld, nullptr, s);
+    bf16* a2 = groupnorm(TRef{h, r.Cout, nullptr, 0}, B, HW, r.n2, eps, true, s);
+    const bf16* sk;
+    if (r.has_skip) {
+        bf16* skb = arena_.get<bf16>((size_t)M * r.Cout);
+        AOperand A{};
+        A.p0 = x.p0; A.C0 = x.C0; A.ld0 = x.C0; A.p1 = x.p1; A.C1 = x.C1; A.ld1 = x.C1; A.mode = A_ROWS;
+        Epilogue E;
+        epilogue_defaults(E);
+        E.out = skb; E.ldo = r.Cout; E.bias = r.skip.b;
+        gemm(A, r.skip.w, M, r.Cout, r.Cin, E, s);
+        sk = skb;
+    } else {
+        if (x.p1) throw GlError(GL_ERR_STATE, "identity skip over a concatenated input");
+        sk = x.p0;
+    }
+    {
+        AOperand A{};
+        A.p0 = a2; A.C0 = r.Cout; A.ld0 = r.Cout; A.mode = A_CONV3;
+        A.Hin = H; A.Win = W; A.Ho = H; A.Wo = W; A.stride = 1; A.ups = 0; A.pad_lo = 1;
+        Epilogue E;
+        epilogue_defaults(E);
+        E.out = out; E.ldo = r.Cout; E.bias = r.c2.b; E.res = sk; E.ldres = r.Cout;
+        gemm(A, r.c2.w, M, r.Cout, 9 * r.Cout, E, s);
+    }
+    arena_.release(mk);
+    return out;
+}
+
+AttnBufs& Engine::attn_bufs(int B, int H, int d, int Tq, int Tk) {
+    const int Tq_pad = round_up(Tq, 128), Tk_pad = round_up(Tk, 64);
+    const uint64_t key = ((uint64_t)B << 52) ^ ((uint64_t)H << 44) ^ ((uint64_t)d << 34) ^ ((uint64_t)Tq_pad << 17) ^ (uint64_t)Tk_pad;
+    auto it = attn_bufs_.find(key);
+    if (it != attn_bufs_.end()) return it->second;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    int dp, dpv;
+    CK(attn_dims(d, &dp, &dpv));
+    AttnBufs b;
+    b.Tq_pad = Tq_pad;
+    b.Tk_pad = Tk_pad;
+    (void)st;
+    b.q = reinterpret_cast<bf16*>(persist((size_t)B * H * Tq_pad * dp * sizeof(bf16), true));
+    b.k = reinterpret_cast<bf16*>(persist((size_t)B * H * Tk_pad * dp * sizeof(bf16), true));
+    b.vt = reinterpret_cast<bf16*>(persist((size_t)B * H * dpv * Tk_pad * sizeof(bf16), true));
+    return attn_bufs_.emplace(key, b).first->second;
+}
+
+// SelfAttention.forward (attention.py:167-186) on LayerNorm'ed rows ln [B][T][C] (T % 64 == 0,
+// rows >= Nk are zero), queries = first Nq rows, keys/values = first Nk rows.
+void Engine::self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, int Nq, int Nk, int C, int d, bf16* o, hipStream_t s) {
+    const int H = C / d;
+    int dp, dpv;
+    CK(attn_dims(d, &dp, &dpv));
+    AttnBufs& bufs = attn_bufs(B, H, d, T, T);
+    {
+        AOperand A;
+        aoperand_rows(A, ln, C, C);
+        Epilogue E;
+        epilogue_defaults(E);
+        E.mode = EPI_QK_HEADS;
+        E.q = bufs.q; E.k = bufs.k; E.C = C; E.H = H; E.d = d; E.DP = dp; E.T = T;
+        E.Tpad_q = bufs.Tq_pad; E.Tpad_k = bufs.Tk_pad;
+        gemm(A, a.wqk, B * T, 2 * C, C, E, s);
+    }
+    {
+        Epilogue E;
+        epilogue_defaults(E);
+        E.mode = EPI_VT_HEADS;
+        E.out = bufs.vt; E.H = H; E.d = d; E.DPV = dpv; E.T = T; E.Tpad_k = bufs.Tk_pad;
+        CK(gemm_launch_t(a.wv, C, ln, B * T, C, E, s));
+        ++n_launches;
+    }
+    AttnParams P{};
+    P.q = bufs.q; P.k = bufs.k; P.vt = bufs.vt; P.o = o;
+    P.H = H; P.d = d; P.Nq = Nq; P.Nk = Nk; P.Tq_pad = bufs.Tq_pad; P.Tk_pad = bufs.Tk_pad;
+    P.ldo = C; P.o_rows_per_b = Nq;
+    P.scale_log2e = (float)(1.4426950408889634 / std::sqrt((double)d));
+    CK(attn_launch(P, B, s));
+    ++n_launches;
+}
+
+bf16* Engine::feedforward(const FFW& f, const bf16* ln, int M, const bf16* res, const float* gate, hipStream_t s) {
+    const int C = f.C;
+    bf16* hbuf = arena_.get<bf16>((size_t)M * 4 * C);
+    AOperand A;
+    aoperand_rows(A, ln, C, C);
+    Epilogue E;
+    epilogue_defaults(E);
+    E.act = ACT_GEGLU; E.out = hbuf; E.ldo = 4 * C; E.bias = f.b1;
+    gemm(A, f.w1, M, 8 * C, C, E, s);
+    return linear_rows(hbuf, M, f.w2, ACT_NONE, res, gate, s);
+}
+
+// SpatialTransformer.forward + BasicTransformerBlock._forward + GatedSelfAttentionDense.forward
+// (attention.py:366-376, 333-338, 236-244)
+bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipStream_t s) {
+    const int HW = H * W, M = B * HW, C = t.C, d = t.d, heads = C / d;
+    bf16* out = arena_.get<bf16>((size_t)M * C);
+    const size_t mk = arena_.mark();
+    if (cond_.Beff != B) throw GlError(GL_ERR_STATE, fmt("unet_forward batch %d != batch %d of the conditioning set by gl_unet_set_cond", B, cond_.Beff));
+
+    bf16* n = groupnorm(TRef{x, C, nullptr, 0}, B, HW, t.gn, 1e-6f, false, s);
+    bf16* t0 = linear_rows(n, M, t.proj_in, ACT_NONE, nullptr, nullptr, s);
+
+    // x = attn1(norm1(x)) + x
+    const int Tp = round_up(HW, 64);
+    bf16* ln = layernorm(t0, B, HW, C, t.ln1, true, s);
+    bf16* o = arena_.get<bf16>((size_t)M * C);
+    self_attention(t.a1, ln, B, Tp, HW, HW, C, d, o, s);
+    bf16* t1 = linear_rows(o, M, t.a1.out, ACT_NONE, t0, nullptr, s);
+
+    // fuser: x = x + scale*tanh(alpha_attn) * attn(norm1([x ; linear(objs)]))[:, :N]
+    const int Ng = cond_.Ng;
+    const int Tf = round_up(HW + Ng, 64);
+    bf16* lnc = arena_.get<bf16>((size_t)B * Tf * C);
+    {
+        LNParams P{};
+        P.x = t1; P.x2 = cond_.objs[t.idx]; P.B = B; P.N1 = HW; P.N2 = Ng; P.Tpad = Tf; P.C = C; P.eps = 1e-5f;
+        P.gamma = t.fn1.g; P.beta = t.fn1.b; P.y = lnc;
+        CK(layernorm_launch(P, s));
+        ++n_launches;
+    }
+    self_attention(t.fa, lnc, B, Tf, HW, HW + Ng, C, d, o, s);
+    bf16* t2 = linear_rows(o, M, t.fa.out, ACT_NONE, t1, gates_ + 2 * t.idx, s);
+    //        x = x + scale*tanh(alpha_dense) * ff(norm2(x))
+    ln = layernorm(t2, B, HW, C, t.fn2, false, s);
+    bf16* t3 = feedforward(t.fff, ln, M, t2, gates_ + 2 * t.idx + 1, s);
+
+    // x = attn2(norm2(x), context) + x
+    ln = layernorm(t3, B, HW, C, t.ln2, true, s);
+    {
+        int dp, dpv;
+        CK(attn_dims(d, &dp, &dpv));
+        AttnBufs& bufs = attn_bufs(B, heads, d, Tp, cond_.ctx_Tpad);
+        AOperand A;
+        aoperand_rows(A, ln, C, C);
+        Epilogue E;
+        epilogue_defaults(E);
+        E.mode = EPI_QK_HEADS;
+        E.q = bufs.q; E.k = nullptr; E.C = C; E.H = heads; E.d = d; E.DP = dp; E.T = Tp; E.Tpad_q = bufs.Tq_pad; E.Tpad_k = 0;
+        gemm(A, t.a2.q.w, B * Tp, C, C, E, s);
+        AttnParams P{};
+        P.q = bufs.q; P.k = cond_.ctx_k[t.idx]; P.vt = cond_.ctx_vt[t.idx]; P.o = o;
+        P.H = heads; P.d = d; P.Nq = HW; P.Nk = cond_.ctx_T; P.Tq_pad = bufs.Tq_pad; P.Tk_pad = cond_.ctx_Tpad;
+        P.ldo = C; P.o_rows_per_b = HW;
+        P.scale_log2e = (float)(1.4426950408889634 / std::sqrt((double)d));
+        CK(attn_launch(P, B, s));
+        ++n_launches;
+    }
+    bf16* t4 = linear_rows(o, M, t.a2.out, ACT_NONE, t3, nullptr, s);
+
+    // x = ff(norm3(x)) + x
+    ln = layernorm(t4, B, HW, C, t.ln3, false, s);
+    bf16* t5 = feedforward(t.ff, ln, M, t4, nullptr, s);
+
+    // proj_out + x_in
+    {
+        AOperand A;
+        aoperand_rows(A, t5, C, C);
+        Epilogue E;
+        epilogue_defaults(E);
+        E.out = out; E.ldo = C; E.bias = t.proj_out.b; E.res = x; E.ldres = C;
+        gemm(A, t.proj_out.w, M, C, C, E, s);
+    }
+    arena_.release(mk);
+    return out;
+}
+
+// ---------------------------------------------------------------- conditioning
+void Engine::set_fuser_scale(float v, hipStream_t s) {
+    if (!has_unet_ || !finalized_) throw GlError(GL_ERR_STATE, "unet not finalized");
+    CK(set_f32_launch(fuser_scale_, v, s));
+}
+
+void Engine::set_cond(int Beff, const float* context, int n_ctx, const gl_grounding& g, hipStream_t s) {
+    if (!has_unet_ || !finalized_) throw GlError(GL_ERR_STATE, "unet not finalized");
+    if (Beff <= 0 || n_ctx <= 0 || g.n <= 0) throw GlError(GL_ERR_ARG, "set_cond: empty batch / context / grounding");
+    const gl_unet_config& c = ucfg_;
+    const int Ng = gkind_ == 1 ? 2 * g.n : g.n;
+    const int ctx_Tpad = round_up(n_ctx, 64);
+    const int heads = c.num_heads;
+    if (cond_.Beff != Beff || cond_.Ng != Ng || cond_.ctx_Tpad != ctx_Tpad) {
+        HIPCK(hipStreamSynchronize(s));
+        sampler_release_graph();
+        for (void* p : cond_.allocs) (void)hipFree(p);
+        cond_ = Cond{};
+        auto palloc = [&](size_t bytes) {
+            void* p = nullptr;
+            HIPCK(hipMalloc(&p, bytes));
+            HIPCK(hipMemset(p, 0, bytes));
+            cond_.allocs.push_back(p);
+            return p;
+        };
+        for (const STW& t : st_) {
+            int dp, dpv;
+            CK(attn_dims(t.d, &dp, &dpv));
+            cond_.objs.push_back(reinterpret_cast<bf16*>(palloc((size_t)Beff * Ng * t.C * sizeof(bf16))));
+            cond_.ctx_k.push_back(reinterpret_cast<bf16*>(palloc((size_t)Beff * heads * ctx_Tpad * dp * sizeof(bf16))));
+            cond_.ctx_vt.push_back(reinterpret_cast<bf16*>(palloc((size_t)Beff * heads * dpv * ctx_Tpad * sizeof(bf16))));
+        }
+        cond_.Beff = Beff;
+        cond_.Ng = Ng;
+        cond_.ctx_Tpad = ctx_Tpad;
+    }
+    cond_.ctx_T = n_ctx;
+    arena_.reset();
+
+    // ---- grounding tokens: objs = position_net(**grounding_input)  -> [Beff][Ng][out_dim]
+    const int out_dim = c.gr_out_dim;
+    bf16* objs = arena_.get<bf16>((size_t)Beff * Ng * out_dim);
+    const int rows = Beff * g.n;
+    auto mlp = [&](int which, const PosNetIn& pin_in, int remap_off) {
+        PosNetIn pin = pin_in;
+        const int Kp = pn_[which][0].K;
+        pin.out = arena_.get<bf16>((size_t)rows * Kp);
+        pin.ld_out = Kp;
+        pin.rows = rows;
+        CK(posnet_input_launch(pin, s));
+        bf16* h1 = linear_rows(pin.out, rows, pn_[which][0], ACT_SILU, nullptr, nullptr, s);
+        bf16* h2 = linear_rows(h1, rows, pn_[which][1], ACT_SILU, nullptr, nullptr, s);
+        AOperand A;
+        aoperand_rows(A, h2, pn_[which][2].K, pn_[which][2].K);
+        Epilogue E;
+        epilogue_defaults(E);
+        E.out = objs; E.ldo = out_dim; E.bias = pn_[which][2].b;
+        E.remap_in = g.n; E.remap_out = Ng; E.remap_off = remap_off;
+        gemm(A, pn_[which][2].w, rows, out_dim, pn_[which][2].K, E, s);
+    };
+    PosNetIn pin{};
+    pin.null_pos = pn_null_pos_;
+    pin.mask = g.masks;
+    if (gkind_ == 0) {
+        if (!g.boxes || !g.masks || !g.text_embeddings) throw GlError(GL_ERR_ARG, "text grounding needs boxes, masks, text_embeddings");
+        pin.feat = g.text_embeddings; pin.pos = g.boxes; pin.F = c.gr_in_dim; pin.P = 4; pin.null_feat = pn_null_feat_[0];
+        mlp(0, pin, 0);
+    } else if (gkind_ == 1) {
+        if (!g.boxes || !g.masks || !g.text_masks || !g.image_masks || !g.text_embeddings || !g.image_embeddings)
+            throw GlError(GL_ERR_ARG, "text+image grounding needs boxes, masks, text/image masks and embeddings");
+        pin.pos = g.boxes; pin.F = c.gr_in_dim; pin.P = 4;
+        pin.feat = g.text_embeddings; pin.fmask = g.text_masks; pin.null_feat = pn_null_feat_[0];
+        mlp(0, pin, 0);
+        pin.feat = g.image_embeddings; pin.fmask = g.image_masks; pin.null_feat = pn_null_feat_[1];
+        mlp(1, pin, g.n);
+    } else {
+        if (!g.points || !g.masks) throw GlError(GL_ERR_ARG, "keypoint grounding needs points and masks");
+        if (g.n != c.max_persons * 17) throw GlError(GL_ERR_ARG, "keypoint grounding: n must be max_persons*17");
+        pin.feat = kp_table_; pin.feat_mod = g.n; pin.pos = g.points; pin.F = out_dim; pin.P = 2; pin.null_feat = pn_null_feat_[0];
+        mlp(0, pin, 0);
+    }
+
+    // ---- per transformer: fuser.linear(objs), attn2.to_k / to_v (context)
+    bf16* ctxb = arena_.get<bf16>((size_t)Beff * ctx_Tpad * c.context_dim);
+    CK(pad_rows_cast_launch(context, ctxb, Beff, n_ctx, ctx_Tpad, c.context_dim, s));
+    for (const STW& t : st_) {
+        int dp, dpv;
+        CK(attn_dims(t.d, &dp, &dpv));
+        {
+            AOperand A;
+            aoperand_rows(A, objs, t.flin.K, t.flin.K);
+            Epilogue E;
+            epilogue_defaults(E);
+            E.out = cond_.objs[t.idx]; E.ldo = t.C; E.bias = t.flin.b;
+            gemm(A, t.flin.w, Beff * Ng, t.C, t.flin.K, E, s);
+        }
+        {
+            AOperand A;
+            aoperand_rows(A, ctxb, t.a2.ctx_dim, t.a2.ctx_dim);
+            Epilogue E;
+            epilogue_defaults(E);
+            E.mode = EPI_QK_HEADS;
+            E.q = cond_.ctx_k[t.idx]; E.C = t.C; E.H = heads; E.d = t.d; E.DP = dp; E.T = ctx_Tpad; E.Tpad_q = ctx_Tpad;
+            gemm(A, t.a2.wk, Beff * ctx_Tpad, t.C, t.a2.ctx_dim, E, s);
+        }
+        {
+            Epilogue E;
+            epilogue_defaults(E);
+            E.mode = EPI_VT_HEADS;
+            E.out = cond_.ctx_vt[t.idx]; E.H = heads; E.d = t.d; E.DPV = dpv; E.T = ctx_Tpad; E.Tpad_k = ctx_Tpad;
+            CK(gemm_launch_t(t.a2.wv, t.C, ctxb, Beff * ctx_Tpad, t.a2.ctx_dim, E, s));
+        }
+    }
+}
+
+// ---------------------------------------------------------------- UNetModel.forward (openaimodel.py:420-464)
+void Engine::unet_forward(int Beff, int h, int w, const float* x, int xB, const int64_t* t, const float* extra,
+                          int extraB, float* eps, hipStream_t s) {
+    if (!has_unet_ || !finalized_) throw GlError(GL_ERR_STATE, "unet not finalized");
+    if (cond_.Beff != Beff) throw GlError(GL_ERR_STATE, fmt("unet_forward batch %d but conditioning was set for %d", Beff, cond_.Beff));
+    const gl_unet_config& c = ucfg_;
+    if ((c.inpaint_mode != 0) != (extra != nullptr)) throw GlError(GL_ERR_ARG, "inpainting_extra_input must be given iff inpaint_mode");
+    if (xB <= 0 || Beff % xB != 0) throw GlError(GL_ERR_ARG, "x batch must divide the effective batch");
+    const int mc = c.model_channels;
+    arena_.reset();
+
+    // time embedding: emb = time_embed(timestep_embedding(t)); every ResBlock consumes SiLU(emb)
+    bf16* temb = arena_.get<bf16>((size_t)Beff * mc);
+    CK(timestep_embed_launch(t, temb, Beff, mc, s));
+    bf16* e1 = linear_rows(temb, Beff, te0_, ACT_SILU, nullptr, nullptr, s);
+    bf16* semb = linear_rows(e1, Beff, te2_, ACT_SILU, nullptr, nullptr, s);
+    float* embout = arena_.get<float>((size_t)Beff * embcat_.N);
+    {
+        AOperand A;
+        aoperand_rows(A, semb, embcat_.K, embcat_.K);
+        Epilogue E;
+        epilogue_defaults(E);
+        E.out = embout; E.ldo = embcat_.N; E.out_f32 = 1; E.bias = embcat_.b;
+        gemm(A, embcat_.w, Beff, embcat_.N, embcat_.K, E, s);
+    }
+    CK(gates_launch(alpha_ptrs_, fuser_scale_, gates_, 2 * (int)st_.size(), s));
+    n_launches += 2;
+
+    struct Act { bf16* p; int C, H, W; };
+    std::vector<Act> hs;
+    Act cur{nullptr, 0, h, w};
+
+    auto run_layer = [&](const Layer& L, const TRef& in) {
+        switch (L.kind) {
+            case L_CONV_IN: {
+                const int HW = cur.H * cur.W;
+                bf16* col = arena_.get<bf16>((size_t)Beff * HW * conv_in_kpad_);
+                bf16* out = arena_.get<bf16>((size_t)Beff * HW * mc);
+                // sample b reads x[b % xB]: launch per replica group
+                const int reps = Beff / xB;
+                for (int r = 0; r < reps; ++r) {
+                    Im2colParams P{};
+                    P.x0 = x; P.C0 = c.in_channels;
+                    P.x1 = extra; P.C1 = extra ? c.in_channels + 1 : 0;
+                    P.B = xB; P.H = cur.H; P.W = cur.W; P.Kpad = conv_in_kpad_;
+                    P.out = col + (size_t)r * xB * HW * conv_in_kpad_;
+                    if (extra && extraB != xB) throw GlError(GL_ERR_ARG, "inpainting_extra_input batch must equal x batch");
+                    CK(im2col_small_launch(P, s));
+                    ++n_launches;
+                }
+                AOperand A;
+                aoperand_rows(A, col, conv_in_kpad_, conv_in_kpad_);
+                Epilogue E;
+                epilogue_defaults(E);
+                E.out = out; E.ldo = mc; E.bias = conv_in_small_.b;
+                gemm(A, conv_in_small_.w, Beff * HW, mc, conv_in_kpad_, E, s);
+                cur.p = out; cur.C = mc;
+                break;
+            }
+            case L_RES: {
+                const ResW& r = res_[L.idx];
+                cur.p = resblock(r, in, Beff, cur.H, cur.W, embout, embcat_.N, 1e-5f, s);
+                cur.C = r.Cout;
+                break;
+            }
+            case L_ST: {
+                if (in.p1) throw GlError(GL_ERR_STATE, "transformer over concatenated input");
+                cur.p = transformer(st_[L.idx], in.p0, Beff, cur.H, cur.W, s);
+                break;
+            }
+            case L_DOWN: {
+                cur.p = conv3x3(in, Beff, cur.H, cur.W, updown_[L.idx], 2, 0, 1, nullptr, 0, nullptr, s);
+                cur.H = (cur.H + 2 - 3) / 2 + 1;
+                cur.W = (cur.W + 2 - 3) / 2 + 1;
+                break;
+            }
+            case L_UP: {
+                cur.p = conv3x3(in, Beff, cur.H, cur.W, updown_[L.idx], 1, 1, 1, nullptr, 0, nullptr, s);
+                cur.H *= 2;
+                cur.W *= 2;
+                break;
+            }
+        }
+    };
+
+    for (const UNetBlock& b : in_blocks_) {
+        for (const Layer& L : b.layers) run_layer(L, TRef{cur.p, cur.C, nullptr, 0});
+        hs.push_back(cur);
+    }
+    for (const Layer& L : mid_block_.layers) run_layer(L, TRef{cur.p, cur.C, nullptr, 0});
+    for (const UNetBlock& b : out_blocks_) {
+        Act sk = hs.back();
+        hs.pop_back();
+        if (sk.H != cur.H || sk.W != cur.W) throw GlError(GL_ERR_ARG, "latent size must be divisible by the UNet's total stride");
+        bool first = true;
+        for (const Layer& L : b.layers) {
+            if (first) run_layer(L, TRef{cur.p, cur.C, sk.p, sk.C});  // th.cat([h, hs.pop()], dim=1)
+            else run_layer(L, TRef{cur.p, cur.C, nullptr, 0});
+            first = false;
+        }
+    }
+    // out: GroupNorm32 -> SiLU -> conv3x3 -> NCHW fp32
+    {
+        const int HW = cur.H * cur.W;
+        bf16* a = groupnorm(TRef{cur.p, cur.C, nullptr, 0}, Beff, HW, out_norm_, 1e-5f, true, s);
+        AOperand A{};
+        A.p0 = a; A.C0 = cur.C; A.ld0 = cur.C; A.mode = A_CONV3;
+        A.Hin = cur.H; A.Win = cur.W; A.Ho = cur.H; A.Wo = cur.W; A.stride = 1; A.ups = 0; A.pad_lo = 1;
+        Epilogue E;
+        epilogue_defaults(E);
+        E.mode = EPI_NCHW_F32; E.out = eps; E.bias = out_conv_.b; E.rows_per_b = HW; E.n_real = c.out_channels;
+        gemm(A, out_conv_.w, Beff * HW, out_conv_.Npad, 9 * cur.C, E, s);
+    }
+}
+
+// ---------------------------------------------------------------- VAE
+// AttnBlock.forward (model.py:177-202): single head over HW tokens, scale C^-0.5
+bf16* Engine::vae_attn(const VaeAttnW& a, const bf16* x, int B, int HW, hipStream_t s) {
+    const int C = a.gn.C, M = B * HW;
+    if (HW % 64 != 0) throw GlError(GL_ERR_UNSUPPORTED, "VAE attention needs h*w to be a multiple of 64");
+    bf16* out = arena_.get<bf16>((size_t)M * C);
+    const size_t mk = arena_.mark();
+    bf16* n = groupnorm(TRef{x, C, nullptr, 0}, B, HW, a.gn, 1e-6f, false, s);
+    bf16* q = linear_rows(n, M, a.q, ACT_NONE, nullptr, nullptr, s);
+    bf16* k = linear_rows(n, M, a.k, ACT_NONE, nullptr, nullptr, s);
+    bf16* o = arena_.get<bf16>((size_t)M * C);
+    for (int b = 0; b < B; ++b) {
+        const size_t mb = arena_.mark();
+        // v^T [C][HW] = Wv n_b^T  (bias folded into the P v product: rows of P sum to 1)
+        bf16* vT = arena_.get<bf16>((size_t)C * HW);
+        {
+            AOperand A;
+            aoperand_rows(A, a.v.w, C, C);
+            Epilogue E;
+            epilogue_defaults(E);
+            E.out = vT; E.ldo = HW;
+            gemm(A, n + (size_t)b * HW * C, C, HW, C, E, s);
+        }
+        float* S = arena_.get<float>((size_t)HW * HW);
+        {
+            AOperand A;
+            aoperand_rows(A, q + (size_t)b * HW * C, C, C);
+            Epilogue E;
+            epilogue_defaults(E);
+            E.out = S; E.ldo = HW; E.out_f32 = 1;
+            gemm(A, k + (size_t)b * HW * C, HW, HW, C, E, s);
+        }
+        bf16* Pm = arena_.get<bf16>((size_t)HW * HW);
+        CK(softmax_rows_launch(S, Pm, HW, HW, 1.f / std::sqrt((float)C), s));
+        ++n_launches;
+        {
+            AOperand A;
+            aoperand_rows(A, Pm, HW, HW);
+            Epilogue E;
+            epilogue_defaults(E);
+            E.out = o + (size_t)b * HW * C; E.ldo = C; E.bias = a.v.b;
+            gemm(A, vT, HW, C, HW, E, s);
+        }
+        arena_.release(mb);
+    }
+    {
+        AOperand A;
+        aoperand_rows(A, o, C, C);
+        Epilogue E;
+        epilogue_defaults(E);
+        E.out = out; E.ldo = C; E.bias = a.proj.b; E.res = x; E.ldres = C;
+        gemm(A, a.proj.w, M, C, C, E, s);
+    }
+    arena_.release(mk);
+    return out;
+}
+
+// AutoencoderKL.decode (autoencoder.py:40-44) -> Decoder.forward (model.py:535-568)
+void Engine::vae_decode(int B, int h, int w, const float* z, float* out, hipStream_t s) {
+    if (!has_vae_ || !finalized_) throw GlError(GL_ERR_STATE, "vae not finalized");
+    const gl_vae_config& c = vcfg_;
+    arena_.reset();
+    int H = h, W = w;
+    bf16* cur;
+    int C = vae_in_small_.Cout;
+    {
+        const int HW = H * W;
+        bf16* col = arena_.get<bf16>((size_t)B * HW * vae_in_kpad_);
+        Im2colParams P{};
+        P.x0 = z; P.C0 = c.z_channels; P.B = B; P.H = H; P.W = W; P.Kpad = vae_in_kpad_; P.out = col;
+        P.pre_w = pq_w_; P.pre_b = pq_b_; P.pre_scale = 1.f / c.scale_factor;
+        CK(im2col_small_launch(P, s));
+        ++n_launches;
+        cur = arena_.get<bf16>((size_t)B * HW * C);
+        AOperand A;
+        aoperand_rows(A, col, vae_in_kpad_, vae_in_kpad_);
+        Epilogue E;
+        epilogue_defaults(E);
+        E.out = cur; E.ldo = C; E.bias = vae_in_small_.b;
+        gemm(A, vae_in_small_.w, B * HW, C, vae_in_kpad_, E, s);
+    }
+    const float eps = 1e-6f;
+    cur = resblock(vmid1_, TRef{cur, C, nullptr, 0}, B, H, W, nullptr, 0, eps, s);
+    cur = vae_attn(vattn_, cur, B, H * W, s);
+    cur = resblock(vmid2_, TRef{cur, C, nullptr, 0}, B, H, W, nullptr, 0, eps, s);
+    for (int level = c.n_mult - 1; level >= 0; --level) {
+        for (const ResW& r : vup_[level].blocks) {
+            cur = resblock(r, TRef{cur, C, nullptr, 0}, B, H, W, nullptr, 0, eps, s);
+            C = r.Cout;
+        }
+        if (vup_[level].has_up) {
+            cur = conv3x3(TRef{cur, C, nullptr, 0}, B, H, W, vup_[level].up, 1, 1, 1, nullptr, 0, nullptr, s);
+            H *= 2;
+            W *= 2;
+        }
+    }
+    {
+        const int HW = H * W;
+        bf16* a = groupnorm(TRef{cur, C, nullptr, 0}, B, HW, vnorm_out_, eps, true, s);
+        AOperand A{};
+        A.p0 = a; A.C0 = C; A.ld0 = C; A.mode = A_CONV3;
+        A.Hin = H; A.Win = W; A.Ho = H; A.Wo = W; A.stride = 1; A.ups = 0; A.pad_lo = 1;
+        Epilogue E;
+        epilogue_defaults(E);
+        E.mode = EPI_NCHW_F32; E.out = out; E.bias = vconv_out_.b; E.rows_per_b = HW; E.n_real = c.out_ch;
+        gemm(A, vconv_out_.w, B * HW, vconv_out_.Npad, 9 * C, E, s);
+    }
+}
+
+// ---------------------------------------------------------------- PLMS sampler (plms.py:65-162)
+void Engine::sampler_release_graph() {
+    if (smp_.exec) (void)hipGraphExecDestroy(smp_.exec);
+    if (smp_.graph) (void)hipGraphDestroy(smp_.graph);
+    smp_.exec = nullptr;
+    smp_.graph = nullptr;
+}
+
+void Engine::sample_plms(const gl_plms_args& a, hipStream_t s) {
+    if (!has_unet_ || !finalized_) throw GlError(GL_ERR_STATE, "unet not finalized");
+    const gl_unet_config& c = ucfg_;
+    if (a.n_steps < 1 || !a.timesteps || !a.a_t || !a.a_prev || !a.x) throw GlError(GL_ERR_ARG, "sample_plms: missing schedule or latent");
+    if (a.mask && (!a.x0 || !a.noise || !a.sqrt_ac || !a.sqrt_1mac)) throw GlError(GL_ERR_ARG, "sample_plms: mask needs x0, noise and q_sample coefficients");
+    const bool cfg = a.guidance_scale != 1.f;
+    const int Beff = cfg ? 2 * a.B : a.B;
+    if (cond_.Beff != Beff) throw GlError(GL_ERR_STATE, fmt("sample_plms: conditioning batch is %d, need %d", cond_.Beff, Beff));
+    const int Cl = c.in_channels;
+    const int64_t n = (int64_t)a.B * Cl * a.h * a.w;
+    if (smp_.B != a.B || smp_.h != a.h || smp_.w != a.w || smp_.extra != a.inpaint_extra) {
+        HIPCK(hipStreamSynchronize(s));
+        sampler_release_graph();
+        if (smp_.B != a.B || smp_.h != a.h || smp_.w != a.w) {
+            smp_.x2 = reinterpret_cast<float*>(persist(n * sizeof(float), false));
+            smp_.eps_pair = reinterpret_cast<float*>(persist(2 * n * sizeof(float), false));
+            for (int i = 0; i < 4; ++i) smp_.hist[i] = reinterpret_cast<float*>(persist(n * sizeof(float), false));
+            smp_.x_tmp = reinterpret_cast<float*>(persist(n * sizeof(float), false));
+            smp_.t_dev = reinterpret_cast<int64_t*>(persist(2 * a.B * sizeof(int64_t), false));
+        }
+        smp_.B = a.B; smp_.h = a.h; smp_.w = a.w; smp_.extra = a.inpaint_extra;
+    }
+
+    int evals = 0;
+    auto eval = [&](const float* xin, int64_t t) {
+        HIPCK(hipMemcpyAsync(smp_.x2, xin, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        CK(fill_i64_launch(smp_.t_dev, t, Beff, s));
+        if (a.use_graph && evals >= 1) {
+            if (!smp_.exec) {
+                HIPCK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                try {
+                    unet_forward(Beff, a.h, a.w, smp_.x2, a.B, smp_.t_dev, a.inpaint_extra, a.B, smp_.eps_pair, s);
+                } catch (...) {
+                    hipGraph_t g = nullptr;
+                    (void)hipStreamEndCapture(s, &g);
+                    if (g) (void)hipGraphDestroy(g);
+                    throw;
+                }
+                HIPCK(hipStreamEndCapture(s, &smp_.graph));
+                HIPCK(hipGraphInstantiate(&smp_.exec, smp_.graph, nullptr, nullptr, 0));
+            }
+            HIPCK(hipGraphLaunch(smp_.exec, s));
+        } else if (a.use_graph && smp_.exec) {
+            HIPCK(hipGraphLaunch(smp_.exec, s));
+        } else {
+            unet_forward(Beff, a.h, a.w, smp_.x2, a.B, smp_.t_dev, a.inpaint_extra, a.B, smp_.eps_pair, s);
+        }
+        ++evals;
+    };
+
+    for (int i = 0; i < a.n_steps; ++i) {
+        if (a.fuser_scale) set_fuser_scale(a.fuser_scale[i], s);
+        if (a.mask)
+            CK(inpaint_blend_launch(a.x, a.x0, a.noise + (size_t)i * n, a.mask, a.sqrt_ac[i], a.sqrt_1mac[i], a.B, Cl, a.h * a.w, s));
+        eval(a.x, a.timesteps[i]);
+        PlmsParams P{};
+        P.eps_pair = smp_.eps_pair; P.has_uncond = cfg ? 1 : 0; P.guidance = a.guidance_scale;
+        P.a_t = a.a_t[i]; P.a_prev = a.a_prev[i]; P.n = n;
+        float* slot = smp_.hist[i & 3];
+        if (i == 0) {
+            // pseudo improved Euler (plms.py:143-149): x_prev from e_t, evaluate at t_next, average
+            P.e_t_out = slot; P.c0 = 1.f; P.x = a.x; P.x_out = smp_.x_tmp;
+            CK(plms_update_launch(P, s));
+            eval(smp_.x_tmp, a.timesteps[std::min(1, a.n_steps - 1)]);
+            P.e_t_out = smp_.hist[1]; P.c0 = 0.5f; P.o1 = slot; P.c1 = 0.5f; P.x = a.x; P.x_out = a.x;
+            CK(plms_update_launch(P, s));
+        } else {
+            P.e_t_out = slot; P.x = a.x; P.x_out = a.x;
+            P.o1 = smp_.hist[(i - 1) & 3];
+            if (i == 1) { P.c0 = 1.5f; P.c1 = -0.5f; }
+            else if (i == 2) { P.o2 = smp_.hist[(i - 2) & 3]; P.c0 = 23.f / 12.f; P.c1 = -16.f / 12.f; P.c2 = 5.f / 12.f; }
+            else {
+                P.o2 = smp_.hist[(i - 2) & 3]; P.o3 = smp_.hist[(i - 3) & 3];
+                P.c0 = 55.f / 24.f; P.c1 = -59.f / 24.f; P.c2 = 37.f / 24.f; P.c3 = -9.f / 24.f;
+            }
+            CK(plms_update_launch(P, s));
+        }
+    }
+}
+
+}  // namespace gl

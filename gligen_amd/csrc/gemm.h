@@ -1,0 +1,64 @@
+// Host-visible descriptors for the bf16 MFMA GEMM / implicit-GEMM conv kernel (gemm.hip).
+#pragma once
+#include "common.h"
+
+namespace gl {
+
+enum { A_ROWS = 0, A_CONV3 = 1 };
+
+// The activation ("rows") operand: logical matrix [M][K], bf16.
+//  A_ROWS : row m = concat(p0[m*ld0 .. +C0), p1[m*ld1 .. +C1)),  K = C0 + C1
+//  A_CONV3: implicit im2col of an NHWC tensor (channel-concat of p0,p1), 3x3 taps,
+//           k = tap*(C0+C1) + c; optional nearest-2x upsample of the source and stride 1|2.
+struct AOperand {
+    const bf16* p0;
+    const bf16* p1;
+    int C0, C1;
+    int ld0, ld1;
+    int mode;
+    int Hin, Win, Ho, Wo;  // conv geometry (source dims are pre-upsample)
+    int stride, ups, pad_lo;
+};
+
+enum { EPI_ROWMAJOR = 0, EPI_QK_HEADS = 1, EPI_VT_HEADS = 2, EPI_NCHW_F32 = 3 };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GEGLU = 2 };
+
+struct Epilogue {
+    int mode;
+    int act;
+    void* out;    // EPI_ROWMAJOR: [M][ldo] bf16|f32 ; EPI_VT_HEADS: vt ; EPI_NCHW_F32: [B][n_real][HW] f32
+    int ldo;
+    int out_f32;
+    const float* bias;  // [N]
+    const float* bias2; // [M / rows_per_b][bias2_ld] broadcast over the rows of one sample
+    int bias2_ld;
+    int rows_per_b;
+    const bf16* res;    // residual [M][ldres]
+    int ldres;
+    const float* gate;  // optional device scalar: out = res + gate * v
+    // attention head layouts
+    bf16* q;            // EPI_QK_HEADS: columns [0,C) -> q, [C,2C) -> k ; each [B*H][Tpad][DP]
+    bf16* k;
+    int C, H, d, DP, T; // T = rows (tokens) per sample in M (multiple of 64)
+    int Tpad_q, Tpad_k;
+    int DPV;            // EPI_VT_HEADS: vt [B*H][DPV][Tpad_k], tokens permuted within groups of 16
+    int n_real;         // EPI_NCHW_F32: number of real output channels (<= N)
+    // EPI_ROWMAJOR optional row remap: out row = (m / remap_in) * remap_out + m % remap_in + remap_off
+    int remap_in, remap_out, remap_off;
+};
+
+// C[M][N] = A[M][K] * W[N][K]^T (+ epilogue). W is row-major bf16 with leading dim K.
+// ws / ws_bytes: optional fp32 split-K workspace (device); may be null (no split-K then).
+int gemm_launch(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E,
+                float* ws, size_t ws_bytes, hipStream_t stream);
+
+// Same kernel with operand roles exchanged: the "rows" operand is a plain row-major matrix
+// Wrows[Mw][K] (e.g. a weight) and the other operand is the activation X[Nx][K]; used to emit
+// V^T for attention (EPI_VT_HEADS).
+int gemm_launch_t(const bf16* Wrows, int Mw, const bf16* X, int Nx, int K, const Epilogue& E,
+                  hipStream_t stream);
+
+void epilogue_defaults(Epilogue& E);
+void aoperand_rows(AOperand& A, const bf16* p, int K, int ld);
+
+}  // namespace gl

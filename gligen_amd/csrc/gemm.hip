@@ -1,0 +1,495 @@
+// bf16 MFMA GEMM + implicit-GEMM 3x3 convolution for gfx950 (CDNA4, wave64).
+//
+//   C[M][N] = A[M][K] * W[N][K]^T   (+ fused epilogue)
+//
+// Replaces every nn.Linear / 1x1 conv / 3x3 conv the reference's UNet and VAE dispatch to
+// cuBLAS / cuDNN (reference ldm/modules/diffusionmodules/openaimodel.py:116-232 ResBlock convs,
+// ldm/modules/attention.py:37-64,102-186 projections and GEGLU, ldm/modules/diffusionmodules/
+// model.py:82-141 VAE ResnetBlock).
+//
+// Design (CDNA4):
+//  * v_mfma_f32_32x32x16_bf16, fp32 accumulate. Operand roles are exchanged w.r.t. the textbook
+//    mapping: the MFMA "A" fragment holds weight rows (i = n) and the "B" fragment holds
+//    activation rows (j = m), so each lane ends up with ONE output row m and groups of 4
+//    CONSECUTIVE output columns n -> 8-byte bf16 stores, bias as float4, no LDS transpose.
+//  * block tile BM x BN x 64, 4 waves; both operands K-contiguous in LDS, 128-byte rows,
+//    16-byte chunks XOR-swizzled with ((row>>1)&7) so ds_read_b128 fragment reads and
+//    ds_write_b128 staging writes are bank-conflict free (64-bank b128 model).
+//  * register-staged double buffering: global loads of tile t+1 are issued before the MFMAs of
+//    tile t and written to the other LDS buffer after them; one barrier per K tile.
+//  * the activation loader optionally performs the im2col gather of a 3x3 convolution over an
+//    NHWC tensor (stride 1|2, nearest-2x upsample of the source, channel concat of two sources),
+//    so convs never materialise im2col or concat/upsample copies in HBM.
+//  * split-K (grid.z) through an fp32 slab workspace + a deterministic reduce/epilogue kernel for
+//    the low-resolution layers whose M x N grid cannot fill 256 CUs.
+#include "gemm.h"
+
+namespace gl {
+
+void epilogue_defaults(Epilogue& E) {
+    E = Epilogue{};
+    E.mode = EPI_ROWMAJOR;
+    E.act = ACT_NONE;
+    E.rows_per_b = 1;
+}
+
+void aoperand_rows(AOperand& A, const bf16* p, int K, int ld) {
+    A = AOperand{};
+    A.p0 = p;
+    A.C0 = K;
+    A.ld0 = ld;
+    A.mode = A_ROWS;
+}
+
+// tokens are permuted inside groups of 16 so that the attention kernel's P^T fragment (taken
+// straight from MFMA accumulators) lines up with one ds_read_b128 of V^T: [0-3,8-11,4-7,12-15].
+__device__ __forceinline__ int perm_tok4(int t0) {
+    int g = (t0 >> 2) & 3;
+    int gp = ((g & 1) << 1) | (g >> 1);
+    return (t0 & ~15) | (gp << 2);
+}
+
+__device__ __forceinline__ void store_bf16x4(bf16* dst, const float v[4]) {
+    U2BF4 o;
+    o.e[0] = f2bf(v[0]);
+    o.e[1] = f2bf(v[1]);
+    o.e[2] = f2bf(v[2]);
+    o.e[3] = f2bf(v[3]);
+    *reinterpret_cast<uint2*>(dst) = o.u;
+}
+
+__device__ __forceinline__ void epi_finish4(const Epilogue& E, int m, int n0, float v[4]) {
+    if (E.bias) {
+        float4 b = *reinterpret_cast<const float4*>(E.bias + n0);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (E.bias2) {
+        int bb = m / E.rows_per_b;
+        float4 b = *reinterpret_cast<const float4*>(E.bias2 + (size_t)bb * E.bias2_ld + n0);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (E.act == ACT_SILU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = silu_f(v[i]);
+    }
+    switch (E.mode) {
+        case EPI_ROWMAJOR: {
+            if (E.remap_in) m = (m / E.remap_in) * E.remap_out + (m % E.remap_in) + E.remap_off;
+            if (E.res) {
+                U2BF4 r;
+                r.u = *reinterpret_cast<const uint2*>(E.res + (size_t)m * E.ldres + n0);
+                float g = E.gate ? *E.gate : 1.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = bf2f(r.e[i]) + g * v[i];
+            }
+            if (E.out_f32) {
+                float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(E.out) + (size_t)m * E.ldo + n0) = o;
+            } else {
+                store_bf16x4(reinterpret_cast<bf16*>(E.out) + (size_t)m * E.ldo + n0, v);
+            }
+            break;
+        }
+        case EPI_QK_HEADS: {
+            int which = n0 >= E.C;
+            int c = n0 - which * E.C;
+            int h = c / E.d;
+            int dd = c - h * E.d;
+            int b = m / E.T;
+            int t = m - b * E.T;
+            int tp = which ? E.Tpad_k : E.Tpad_q;
+            bf16* base = which ? E.k : E.q;
+            store_bf16x4(base + ((size_t)(b * E.H + h) * tp + t) * E.DP + dd, v);
+            break;
+        }
+        case EPI_VT_HEADS: {  // m = feature, n0 = first of 4 consecutive tokens
+            int h = m / E.d;
+            int dd = m - h * E.d;
+            int b = n0 / E.T;
+            int t0 = n0 - b * E.T;
+            bf16* base = reinterpret_cast<bf16*>(E.out);
+            store_bf16x4(base + ((size_t)(b * E.H + h) * E.DPV + dd) * E.Tpad_k + perm_tok4(t0), v);
+            break;
+        }
+        case EPI_NCHW_F32: {
+            int b = m / E.rows_per_b;
+            int pix = m - b * E.rows_per_b;
+            float* o = reinterpret_cast<float*>(E.out);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (n0 + i < E.n_real) o[((size_t)b * E.n_real + n0 + i) * E.rows_per_b + pix] = v[i];
+            break;
+        }
+    }
+}
+
+// GEGLU: weight/bias rows are pre-packed so that inside every 32-row tile the accumulator
+// groups alternate value,gate,value,gate for the same 4 output features (see pack_geglu_rows).
+__device__ __forceinline__ void epi_geglu4(const Epilogue& E, int m, int nv0, float val[4], float gate[4]) {
+    if (E.bias) {
+        float4 bv = *reinterpret_cast<const float4*>(E.bias + nv0);
+        float4 bg = *reinterpret_cast<const float4*>(E.bias + nv0 + 8);
+        val[0] += bv.x; val[1] += bv.y; val[2] += bv.z; val[3] += bv.w;
+        gate[0] += bg.x; gate[1] += bg.y; gate[2] += bg.z; gate[3] += bg.w;
+    }
+    int j0 = (nv0 >> 5) * 16 + ((nv0 & 31) >> 4) * 8 + (nv0 & 7);
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = val[i] * gelu_erf_f(gate[i]);
+    store_bf16x4(reinterpret_cast<bf16*>(E.out) + (size_t)m * E.ldo + j0, o);
+}
+
+template <int WM, int WN, int TM, int TN, int AMODE>
+__global__ void __launch_bounds__(WM * WN * 64)
+gemm_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilogue E,
+            float* __restrict__ ws, int kt_per_split, int tiles_n) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    constexpr int RPP = NT / 8;  // tile rows covered by one pass of 16-byte loads
+    constexpr int XP = BM / RPP;
+    constexpr int WP = BN / RPP;
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/loader mismatch");
+    constexpr int STAGE = (BM + BN) * 128;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int cc = t & 7;
+    const int r0 = t >> 3;
+
+    const int tile_m = blockIdx.x / tiles_n;
+    const int tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m_base = tile_m * BM;
+    const int n_base = tile_n * BN;
+
+    const int nk = K >> 6;
+    const int kt0 = blockIdx.z * kt_per_split;
+    const int kt1 = min(nk, kt0 + kt_per_split);
+
+    // ---- per-thread row bookkeeping for the activation loader
+    int64_t xo0[XP], xo1[XP];
+    int xb[XP], xy[XP], xx[XP];
+    bool xv[XP];
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+        int m = m_base + r0 + i * RPP;
+        xv[i] = m < M;
+        if constexpr (AMODE == A_ROWS) {
+            xo0[i] = (int64_t)m * A.ld0;
+            xo1[i] = (int64_t)m * A.ld1;
+            xb[i] = xy[i] = xx[i] = 0;
+        } else {
+            int ox = m % A.Wo;
+            int tmp = m / A.Wo;
+            int oy = tmp % A.Ho;
+            xb[i] = tmp / A.Ho;
+            xy[i] = oy * A.stride - A.pad_lo;
+            xx[i] = ox * A.stride - A.pad_lo;
+            xo0[i] = xo1[i] = 0;
+        }
+    }
+    int64_t wo[WP];
+    bool wv[WP];
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        int n = n_base + r0 + i * RPP;
+        wv[i] = n < N;
+        wo[i] = (int64_t)n * K;
+    }
+    const int Cin = A.C0 + A.C1;
+    const int Hup = A.Hin << A.ups;
+    const int Wup = A.Win << A.ups;
+
+    auto load_tiles = [&](int kt, uint4 (&xr)[XP], uint4 (&wr)[WP]) {
+        const int k0 = kt << 6;
+        if constexpr (AMODE == A_ROWS) {
+            const bool first = k0 < A.C0;
+            const bf16* base = first ? A.p0 : A.p1;
+            const int coff = (first ? k0 : k0 - A.C0) + cc * 8;
+#pragma unroll
+            for (int i = 0; i < XP; ++i) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (xv[i]) v = *reinterpret_cast<const uint4*>(base + (first ? xo0[i] : xo1[i]) + coff);
+                xr[i] = v;
+            }
+        } else {
+            const int tap = k0 / Cin;
+            const int c = k0 - tap * Cin;
+            const int ky = tap / 3;
+            const int kx = tap - ky * 3;
+            const bool first = c < A.C0;
+            const bf16* base = first ? A.p0 : A.p1;
+            const int ld = first ? A.ld0 : A.ld1;
+            const int coff = (first ? c : c - A.C0) + cc * 8;
+#pragma unroll
+            for (int i = 0; i < XP; ++i) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                int iy = xy[i] + ky;
+                int ix = xx[i] + kx;
+                if (xv[i] && iy >= 0 && iy < Hup && ix >= 0 && ix < Wup) {
+                    int64_t pix = ((int64_t)xb[i] * A.Hin + (iy >> A.ups)) * A.Win + (ix >> A.ups);
+                    v = *reinterpret_cast<const uint4*>(base + pix * ld + coff);
+                }
+                xr[i] = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WP; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (wv[i]) v = *reinterpret_cast<const uint4*>(W + wo[i] + k0 + cc * 8);
+            wr[i] = v;
+        }
+    };
+
+    auto store_tiles = [&](int buf, const uint4 (&xr)[XP], const uint4 (&wr)[WP]) {
+        unsigned char* xs = smem + buf * STAGE;
+        unsigned char* wsm = xs + BM * 128;
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            int row = r0 + i * RPP;
+            *reinterpret_cast<uint4*>(xs + row * 128 + ((cc ^ ((row >> 1) & 7)) << 4)) = xr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WP; ++i) {
+            int row = r0 + i * RPP;
+            *reinterpret_cast<uint4*>(wsm + row * 128 + ((cc ^ ((row >> 1) & 7)) << 4)) = wr[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31;
+    const int fhalf = lane >> 5;
+
+    auto compute = [&](int buf) {
+        const unsigned char* xs = smem + buf * STAGE;
+        const unsigned char* wsm = xs + BM * 128;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 xf[TM], wf[TN];
+            const int c = 2 * s + fhalf;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                int row = (wm * TM + i) * 32 + frow;
+                xf[i] = *reinterpret_cast<const bf16x8*>(xs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int row = (wn * TN + j) * 32 + frow;
+                wf[j] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (kt0 < kt1) {
+        uint4 xr[XP], wr[WP];
+        load_tiles(kt0, xr, wr);
+        store_tiles(0, xr, wr);
+        __syncthreads();
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int buf = (kt - kt0) & 1;
+            const bool more = kt + 1 < kt1;
+            if (more) load_tiles(kt + 1, xr, wr);
+            compute(buf);
+            if (more) store_tiles(buf ^ 1, xr, wr);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue
+    const bool split = gridDim.z > 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m_base + (wm * TM + i) * 32 + frow;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nb = n_base + (wn * TN + j) * 32 + 4 * fhalf;
+            if (split) {
+                float* dst = ws + ((size_t)blockIdx.z * M + m) * N;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int n0 = nb + 8 * q;
+                    if (n0 < N)
+                        *reinterpret_cast<float4*>(dst + n0) =
+                            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                }
+            } else if (E.act == ACT_GEGLU) {
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    int nv0 = nb + 16 * qq;
+                    if (nv0 < N) {
+                        float val[4], gate[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            val[e] = acc[i][j][8 * qq + e];
+                            gate[e] = acc[i][j][8 * qq + 4 + e];
+                        }
+                        epi_geglu4(E, m, nv0, val, gate);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int n0 = nb + 8 * q;
+                    if (n0 < N) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+                        epi_finish4(E, m, n0, v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Deterministic split-K reduction + epilogue: one thread per (row, group of 4 columns).
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, Epilogue E) {
+    const int groups = N >> 2;
+    const int64_t total = (int64_t)M * groups;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        int m = (int)(idx / groups);
+        int n0 = (int)(idx - (int64_t)m * groups) << 2;
+        if (E.act == ACT_GEGLU) {
+            if (n0 & 8) continue;  // gate groups are consumed by their value group
+            float val[4] = {0, 0, 0, 0}, gate[4] = {0, 0, 0, 0};
+            for (int z = 0; z < splits; ++z) {
+                const float* p = ws + ((size_t)z * M + m) * N + n0;
+                float4 a = *reinterpret_cast<const float4*>(p);
+                float4 b = *reinterpret_cast<const float4*>(p + 8);
+                val[0] += a.x; val[1] += a.y; val[2] += a.z; val[3] += a.w;
+                gate[0] += b.x; gate[1] += b.y; gate[2] += b.z; gate[3] += b.w;
+            }
+            epi_geglu4(E, m, n0, val, gate);
+        } else {
+            float v[4] = {0, 0, 0, 0};
+            for (int z = 0; z < splits; ++z) {
+                float4 a = *reinterpret_cast<const float4*>(ws + ((size_t)z * M + m) * N + n0);
+                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+            }
+            epi_finish4(E, m, n0, v);
+        }
+    }
+}
+
+namespace {
+
+struct Cfg {
+    int bm, bn;
+    float speed;
+};
+const Cfg kCfgs[4] = {{128, 128, 1.0f}, {128, 64, 0.8f}, {64, 64, 0.55f}, {128, 32, 0.45f}};
+
+template <int WM, int WN, int TM, int TN>
+int launch_cfg(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, float* ws,
+               int splits, int kt_per_split, hipStream_t stream) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
+    dim3 grid(tiles_m * tiles_n, 1, splits);
+    dim3 block(WM * WN * 64);
+    size_t lds = 2 * (BM + BN) * 128;
+    if (A.mode == A_ROWS) {
+        auto kfn = gemm_kernel<WM, WN, TM, TN, A_ROWS>;
+        static bool attr_done = false;  // once per instantiation; never inside a stream capture
+        if (!attr_done && lds > 48 * 1024) {
+            GL_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(kfn, grid, block, lds, stream, A, W, M, N, K, E, ws, kt_per_split, tiles_n);
+    } else {
+        auto kfn = gemm_kernel<WM, WN, TM, TN, A_CONV3>;
+        static bool attr_done = false;
+        if (!attr_done && lds > 48 * 1024) {
+            GL_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(kfn, grid, block, lds, stream, A, W, M, N, K, E, ws, kt_per_split, tiles_n);
+    }
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+}  // namespace
+
+int gemm_launch(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, float* ws,
+                size_t ws_bytes, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return set_error(GL_ERR_ARG, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
+    if (K % 64 != 0) return set_error(GL_ERR_ARG, "gemm: K=%d must be a multiple of 64", K);
+    if (N % 4 != 0) return set_error(GL_ERR_ARG, "gemm: N=%d must be a multiple of 4", N);
+    if (A.mode == A_CONV3) {
+        if ((A.C0 + A.C1) % 64 != 0 || A.C0 % 64 != 0 || K != 9 * (A.C0 + A.C1))
+            return set_error(GL_ERR_ARG, "conv3x3: channels (%d,%d) must be multiples of 64 and K=9*Cin (K=%d)", A.C0, A.C1, K);
+    } else {
+        if (K != A.C0 + A.C1 || (A.C1 && A.C0 % 64 != 0))
+            return set_error(GL_ERR_ARG, "gemm: K=%d does not match operand channels (%d,%d)", K, A.C0, A.C1);
+    }
+    if (E.act == ACT_GEGLU && (N % 32 != 0 || E.mode != EPI_ROWMAJOR))
+        return set_error(GL_ERR_ARG, "gemm: GEGLU epilogue needs packed N %% 32 == 0 (N=%d)", N);
+
+    // pick the tile: padding efficiency x relative tile speed x chip fill
+    int best = 0;
+    float best_score = -1.f;
+    for (int c = 0; c < 4; ++c) {
+        if (c == 3 && N > 32) continue;
+        if (c != 3 && N <= 32) continue;
+        const Cfg& cf = kCfgs[c];
+        double tm = cdiv(M, cf.bm), tn = cdiv(N, cf.bn);
+        double pad = ((double)M * N) / (tm * cf.bm * tn * cf.bn);
+        double fill = fmin(1.0, tm * tn / 256.0);
+        float score = (float)(pad * cf.speed * (0.35 + 0.65 * fill));
+        if (score > best_score) { best_score = score; best = c; }
+    }
+    const Cfg& cf = kCfgs[best];
+    const int tiles = cdiv(M, cf.bm) * cdiv(N, cf.bn);
+    const int nk = K / 64;
+    int splits = 1;
+    if (ws && tiles < 256 && nk >= 8) {
+        splits = min(min(cdiv(512, tiles), nk / 4), 16);
+        while (splits > 1 && (size_t)splits * M * N * sizeof(float) > ws_bytes) --splits;
+    }
+    int kt_per_split = cdiv(nk, splits);
+    splits = cdiv(nk, kt_per_split);
+
+    int rc;
+    switch (best) {
+        case 0: rc = launch_cfg<2, 2, 2, 2>(A, W, M, N, K, E, ws, splits, kt_per_split, stream); break;
+        case 1: rc = launch_cfg<2, 2, 2, 1>(A, W, M, N, K, E, ws, splits, kt_per_split, stream); break;
+        case 2: rc = launch_cfg<2, 2, 1, 1>(A, W, M, N, K, E, ws, splits, kt_per_split, stream); break;
+        default: rc = launch_cfg<4, 1, 1, 1>(A, W, M, N, K, E, ws, splits, kt_per_split, stream); break;
+    }
+    GL_TRY(rc);
+    if (splits > 1) {
+        int64_t total = (int64_t)M * (N / 4);
+        int blocks = (int)fmin((double)cdiv64(total, 256), 4096.0);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws, splits, M, N, E);
+        GL_LAUNCH_CHECK();
+    }
+    return GL_OK;
+}
+
+int gemm_launch_t(const bf16* Wrows, int Mw, const bf16* X, int Nx, int K, const Epilogue& E, hipStream_t stream) {
+    AOperand A;
+    aoperand_rows(A, Wrows, K, K);
+    return gemm_launch(A, X, Mw, Nx, K, E, nullptr, 0, stream);
+}
+
+}  // namespace gl

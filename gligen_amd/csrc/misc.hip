@@ -1,0 +1,319 @@
+// Small latency-bound kernels of the GLIGEN denoising path (gfx950): timestep embedding,
+// grounding-token MLP input (Fourier features + null mixing), small-channel im2col, weight
+// packing, fuser gates, the CFG + PLMS update, inpainting blend, uint8 image epilogue.
+#include "misc.h"
+
+namespace gl {
+
+static inline int grid_for(int64_t n, int block = 256, int cap = 4096) {
+    int64_t g = cdiv64(n, block);
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ---- timestep embedding (reference util.py:160-180): [cos(t f_i) | sin(t f_i)], f_i = exp(-ln(1e4) i / half)
+__global__ void timestep_embed_kernel(const int64_t* __restrict__ t, bf16* __restrict__ out, int B, int dim) {
+    const int half = dim / 2;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < B * half; idx += gridDim.x * blockDim.x) {
+        const int b = idx / half, i = idx - b * half;
+        const float freq = expf(-9.210340371976184f * (float)i / (float)half);
+        const float arg = (float)t[b] * freq;
+        out[(size_t)b * dim + i] = f2bf(cosf(arg));
+        out[(size_t)b * dim + half + i] = f2bf(sinf(arg));
+    }
+}
+int timestep_embed_launch(const int64_t* t, bf16* out, int B, int dim, hipStream_t stream) {
+    hipLaunchKernelGGL(timestep_embed_kernel, dim3(grid_for((int64_t)B * dim / 2)), dim3(256), 0, stream, t, out, B, dim);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+// ---- grounding tokenizer input
+__global__ void posnet_input_kernel(PosNetIn p) {
+    const int PD = 16 * p.P;
+    const int64_t total = (int64_t)p.rows * p.ld_out;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / p.ld_out);
+        const int c = (int)(idx - (int64_t)r * p.ld_out);
+        float v = 0.f;
+        if (c < p.F) {
+            const float m = p.fmask ? p.fmask[r] : p.mask[r];
+            const int fr = p.feat_mod > 0 ? r % p.feat_mod : r;
+            v = p.feat[(size_t)fr * p.F + c] * m + (1.f - m) * p.null_feat[c];
+        } else if (c < p.F + PD) {
+            const int e = c - p.F;
+            const int k = e / (2 * p.P);
+            const int rem = e - k * 2 * p.P;
+            const int sc = rem / p.P;
+            const int j = rem - sc * p.P;
+            const float freq = powf(100.f, (float)k / 8.f);
+            const float a = freq * p.pos[(size_t)r * p.P + j];
+            const float f = sc ? cosf(a) : sinf(a);
+            const float m = p.mask[r];
+            v = f * m + (1.f - m) * p.null_pos[e];
+        }
+        p.out[idx] = f2bf(v);
+    }
+}
+int posnet_input_launch(const PosNetIn& p, hipStream_t stream) {
+    if (p.ld_out % 64 != 0 || p.ld_out < p.F + 16 * p.P) return set_error(GL_ERR_ARG, "posnet_input: bad ld_out %d", p.ld_out);
+    hipLaunchKernelGGL(posnet_input_kernel, dim3(grid_for((int64_t)p.rows * p.ld_out)), dim3(256), 0, stream, p);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+// ---- small-channel im2col
+__global__ void im2col_small_kernel(Im2colParams p) {
+    const int Cin = p.C0 + p.C1;
+    const int HW = p.H * p.W;
+    const int64_t total = (int64_t)p.B * HW * p.Kpad;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = idx / p.Kpad;
+        const int k = (int)(idx - m * p.Kpad);
+        float v = 0.f;
+        if (k < 9 * Cin) {
+            const int tap = k / Cin, c = k - tap * Cin;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int b = (int)(m / HW);
+            const int pix = (int)(m - (int64_t)b * HW);
+            const int oy = pix / p.W, ox = pix - oy * p.W;
+            const int iy = oy + ky - 1, ix = ox + kx - 1;
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                const int sp = iy * p.W + ix;
+                if (c < p.C0) {
+                    if (p.pre_w) {
+                        float acc = 0.f;
+                        for (int j = 0; j < p.C0; ++j)
+                            acc += p.pre_w[c * p.C0 + j] * (p.pre_scale * p.x0[((size_t)b * p.C0 + j) * HW + sp]);
+                        v = acc + p.pre_b[c];
+                    } else {
+                        v = p.x0[((size_t)b * p.C0 + c) * HW + sp];
+                    }
+                } else {
+                    v = p.x1[((size_t)b * p.C1 + (c - p.C0)) * HW + sp];
+                }
+            }
+        }
+        p.out[idx] = f2bf(v);
+    }
+}
+int im2col_small_launch(const Im2colParams& p, hipStream_t stream) {
+    if (p.Kpad % 64 != 0 || p.Kpad < 9 * (p.C0 + p.C1)) return set_error(GL_ERR_ARG, "im2col_small: bad Kpad %d", p.Kpad);
+    hipLaunchKernelGGL(im2col_small_kernel, dim3(grid_for((int64_t)p.B * p.H * p.W * p.Kpad, 256, 65535)), dim3(256), 0, stream, p);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+// ---- casts / packing
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ s, bf16* __restrict__ d, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = f2bf(s[i]);
+}
+int cast_f32_bf16_launch(const float* src, bf16* dst, int64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, stream, src, dst, n);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+__global__ void pad_rows_cast_kernel(const float* __restrict__ s, bf16* __restrict__ d, int B, int rows, int rows_pad, int cols) {
+    const int64_t total = (int64_t)B * rows_pad * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cols);
+        const int64_t rr = i / cols;
+        const int r = (int)(rr % rows_pad);
+        const int b = (int)(rr / rows_pad);
+        d[i] = r < rows ? f2bf(s[((size_t)b * rows + r) * cols + c]) : f2bf(0.f);
+    }
+}
+int pad_rows_cast_launch(const float* src, bf16* dst, int B, int rows, int rows_pad, int cols, hipStream_t stream) {
+    hipLaunchKernelGGL(pad_rows_cast_kernel, dim3(grid_for((int64_t)B * rows_pad * cols)), dim3(256), 0, stream, src, dst, B, rows, rows_pad, cols);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+__global__ void cast_pad_cols_kernel(const float* __restrict__ s, bf16* __restrict__ d, int N, int K, int Kpad) {
+    const int64_t total = (int64_t)N * Kpad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kpad);
+        const int64_t n = i / Kpad;
+        d[i] = k < K ? f2bf(s[n * K + k]) : f2bf(0.f);
+    }
+}
+int cast_pad_cols_launch(const float* src, bf16* dst, int N, int K, int Kpad, hipStream_t stream) {
+    hipLaunchKernelGGL(cast_pad_cols_kernel, dim3(grid_for((int64_t)N * Kpad)), dim3(256), 0, stream, src, dst, N, K, Kpad);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+__global__ void pad_rows_bf16_kernel(const bf16* __restrict__ s, bf16* __restrict__ d, int B, int rows, int rows_pad, int cols) {
+    const int64_t total = (int64_t)B * rows_pad * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cols);
+        const int64_t rr = i / cols;
+        const int r = (int)(rr % rows_pad);
+        const int b = (int)(rr / rows_pad);
+        d[i] = r < rows ? s[((size_t)b * rows + r) * cols + c] : f2bf(0.f);
+    }
+}
+int pad_rows_bf16_launch(const bf16* src, bf16* dst, int B, int rows, int rows_pad, int cols, hipStream_t stream) {
+    hipLaunchKernelGGL(pad_rows_bf16_kernel, dim3(grid_for((int64_t)B * rows_pad * cols)), dim3(256), 0, stream, src, dst, B, rows, rows_pad, cols);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+__global__ void set_f32_kernel(float* d, float v) { d[0] = v; }
+int set_f32_launch(float* dst, float v, hipStream_t stream) {
+    hipLaunchKernelGGL(set_f32_kernel, dim3(1), dim3(1), 0, stream, dst, v);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+__global__ void pack_conv_weight_kernel(const float* __restrict__ s, bf16* __restrict__ d, int O, int I, int KH, int KW, int O_pad) {
+    const int taps = KH * KW;
+    const int64_t total = (int64_t)O_pad * taps * I;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % I);
+        const int64_t r = i / I;
+        const int tap = (int)(r % taps);
+        const int o = (int)(r / taps);
+        d[i] = o < O ? f2bf(s[((size_t)o * I + c) * taps + tap]) : f2bf(0.f);
+    }
+}
+int pack_conv_weight_launch(const float* src, bf16* dst, int O, int I, int KH, int KW, int O_pad, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(grid_for((int64_t)O_pad * KH * KW * I)), dim3(256), 0, stream, src, dst, O, I, KH, KW, O_pad);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+__global__ void pack_conv_small_kernel(const float* __restrict__ s, bf16* __restrict__ d, int O, int I, int Kpad) {
+    const int64_t total = (int64_t)O * Kpad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kpad);
+        const int o = (int)(i / Kpad);
+        float v = 0.f;
+        if (k < 9 * I) {
+            const int tap = k / I, c = k - tap * I;
+            v = s[((size_t)o * I + c) * 9 + tap];
+        }
+        d[i] = f2bf(v);
+    }
+}
+int pack_conv_small_launch(const float* src, bf16* dst, int O, int I, int Kpad, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_conv_small_kernel, dim3(grid_for((int64_t)O * Kpad)), dim3(256), 0, stream, src, dst, O, I, Kpad);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+// packed row p (tile = p>>5, i = p&31): quad q = i>>3, half g = (i>>2)&1, e = i&3
+//   -> feature j = tile*16 + e + 4g + 8(q>>1) ; original row = (q&1 ? gate : value) half of proj
+__global__ void pack_geglu_kernel(const float* __restrict__ w, const float* __restrict__ b, bf16* __restrict__ wp, float* __restrict__ bp, int C4, int K) {
+    const int64_t total = (int64_t)2 * C4 * K;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % K);
+        const int p = (int)(idx / K);
+        const int tile = p >> 5, i = p & 31;
+        const int q = i >> 3, g = (i >> 2) & 1, e = i & 3;
+        const int j = tile * 16 + e + 4 * g + 8 * (q >> 1);
+        const int orig = (q & 1) * C4 + j;
+        wp[idx] = f2bf(w[(size_t)orig * K + k]);
+        if (k == 0) bp[p] = b[orig];
+    }
+}
+int pack_geglu_launch(const float* w, const float* b, bf16* wp, float* bp, int C4, int K, hipStream_t stream) {
+    if (C4 % 16 != 0) return set_error(GL_ERR_ARG, "pack_geglu: inner dim %d must be a multiple of 16", C4);
+    hipLaunchKernelGGL(pack_geglu_kernel, dim3(grid_for((int64_t)2 * C4 * K)), dim3(256), 0, stream, w, b, wp, bp, C4, K);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+__global__ void gates_kernel(const float* const* alpha_ptrs, const float* scale, float* gates, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) gates[i] = scale[0] * tanhf(alpha_ptrs[i][0]);
+}
+int gates_launch(const float* const* alpha_ptrs, const float* scale, float* gates, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(gates_kernel, dim3(cdiv(n, 64)), dim3(64), 0, stream, alpha_ptrs, scale, gates, n);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+// ---- CFG + PLMS
+__global__ void plms_update_kernel(PlmsParams p) {
+    const float sa = sqrtf(p.a_t), s1a = sqrtf(1.f - p.a_t);
+    const float sp = sqrtf(p.a_prev), s1p = sqrtf(1.f - p.a_prev);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * blockDim.x) {
+        float e = p.eps_pair[i];
+        if (p.has_uncond) {
+            const float eu = p.eps_pair[p.n + i];
+            e = eu + p.guidance * (e - eu);
+        }
+        p.e_t_out[i] = e;
+        float ep = p.c0 * e;
+        if (p.o1) ep += p.c1 * p.o1[i];
+        if (p.o2) ep += p.c2 * p.o2[i];
+        if (p.o3) ep += p.c3 * p.o3[i];
+        const float x = p.x[i];
+        const float pred = (x - s1a * ep) / sa;
+        p.x_out[i] = sp * pred + s1p * ep;
+    }
+}
+int plms_update_launch(const PlmsParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(plms_update_kernel, dim3(grid_for(p.n)), dim3(256), 0, stream, p);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+__global__ void inpaint_blend_kernel(float* img, const float* x0, const float* noise, const float* mask, float sa, float s1, int B, int C, int HW) {
+    const int64_t total = (int64_t)B * C * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int pix = (int)(i % HW);
+        const int b = (int)(i / ((int64_t)C * HW));
+        const float m = mask[(size_t)b * HW + pix];
+        const float orig = sa * x0[i] + s1 * noise[i];
+        img[i] = orig * m + (1.f - m) * img[i];
+    }
+}
+int inpaint_blend_launch(float* img, const float* x0, const float* noise, const float* mask, float sqrt_ac, float sqrt_1mac, int B, int C, int HW, hipStream_t stream) {
+    hipLaunchKernelGGL(inpaint_blend_kernel, dim3(grid_for((int64_t)B * C * HW)), dim3(256), 0, stream, img, x0, noise, mask, sqrt_ac, sqrt_1mac, B, C, HW);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+__global__ void to_uint8_kernel(const float* __restrict__ s, uint8_t* __restrict__ d, int B, int C, int HW) {
+    const int64_t total = (int64_t)B * HW * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t r = i / C;
+        const int pix = (int)(r % HW);
+        const int b = (int)(r / HW);
+        float v = s[((size_t)b * C + c) * HW + pix];
+        v = fminf(fmaxf(v, -1.f), 1.f) * 0.5f + 0.5f;
+        d[i] = (uint8_t)(v * 255.f);
+    }
+}
+int to_uint8_launch(const float* src, uint8_t* dst, int B, int C, int HW, hipStream_t stream) {
+    hipLaunchKernelGGL(to_uint8_kernel, dim3(grid_for((int64_t)B * C * HW)), dim3(256), 0, stream, src, dst, B, C, HW);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+__global__ void fill_i64_kernel(int64_t* d, int64_t v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = v;
+}
+int fill_i64_launch(int64_t* dst, int64_t v, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(fill_i64_kernel, dim3(cdiv(n, 64)), dim3(64), 0, stream, dst, v, n);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+__global__ void zero_kernel(uint4* d, int64_t n16) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) d[i] = make_uint4(0, 0, 0, 0);
+}
+int zero_launch(void* dst, size_t bytes, hipStream_t stream) {
+    if (bytes % 16 != 0) return set_error(GL_ERR_ARG, "zero: size %zu not a multiple of 16", bytes);
+    hipLaunchKernelGGL(zero_kernel, dim3(grid_for(bytes / 16)), dim3(256), 0, stream, (uint4*)dst, (int64_t)(bytes / 16));
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+}  // namespace gl

@@ -1,0 +1,41 @@
+#pragma once
+#include "common.h"
+
+namespace gl {
+
+// GroupNorm(32 groups) over an NHWC bf16 tensor that may be the channel-concat of two sources
+// (the UNet decoder's skip concat, reference openaimodel.py:461), optional fused SiLU.
+struct GNParams {
+    const bf16* x0;
+    const bf16* x1;
+    int C0, C1;
+    int B, HW;
+    float eps;
+    const float* gamma;
+    const float* beta;
+    bf16* y;       // [B][HW][C0+C1]
+    int silu;
+    float* partial;  // scratch [B][nsplit][32][2]
+};
+int gn_nsplit(int HW);
+size_t gn_partial_bytes(int B, int HW);
+int groupnorm_launch(const GNParams& P, hipStream_t stream);
+
+// LayerNorm over the last dim (C <= 1536, C % 8 == 0) of bf16 rows. Output rows are laid out
+// [B][Tpad]: t < N1 from x, N1 <= t < N1+N2 from x2 (the GLIGEN fuser's [visual ; grounding]
+// concat, reference attention.py:241), remaining pad rows are written as zeros.
+struct LNParams {
+    const bf16* x;
+    const bf16* x2;
+    int B, N1, N2, Tpad, C;
+    float eps;
+    const float* gamma;
+    const float* beta;
+    bf16* y;
+};
+int layernorm_launch(const LNParams& P, hipStream_t stream);
+
+// row softmax: P[r][c] = softmax_c(S[r][c] * scale), fp32 in, bf16 out (VAE AttnBlock)
+int softmax_rows_launch(const float* S, bf16* Pm, int rows, int cols, float scale, hipStream_t stream);
+
+}  // namespace gl

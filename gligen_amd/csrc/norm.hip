@@ -1,0 +1,243 @@
+// HBM-bound normalisation kernels for gfx950: GroupNorm(32)+SiLU over NHWC bf16 (two-source
+// channel concat supported), LayerNorm (with the GLIGEN [visual ; grounding] row concat), and a
+// row softmax for the VAE's single-head attention.
+//
+// Reference semantics:
+//   GroupNorm32 (fp32 statistics, eps 1e-5)      ldm/modules/diffusionmodules/util.py:223-226
+//   Normalize   (GroupNorm 32 groups, eps 1e-6)  ldm/modules/attention.py:76-77, model.py:38-39
+//   nn.LayerNorm (eps 1e-5)                      ldm/modules/attention.py:225-226,309-311
+// All statistics are accumulated in fp32 (cross-block combination in fp64) with a fixed
+// reduction order, so results are bit-reproducible run to run.
+#include "norm.h"
+
+namespace gl {
+
+int gn_nsplit(int HW) { return max(1, min(64, HW / 64)); }
+size_t gn_partial_bytes(int B, int HW) { return (size_t)B * gn_nsplit(HW) * 32 * 2 * sizeof(float); }
+
+// ---- GroupNorm statistics: grid (nsplit, B), block = C8 * R threads.
+// thread (cx, ry) owns the 8 channels [8cx, 8cx+8) (at most two groups) of pixels ry, ry+R, ...
+__global__ void gn_stats_kernel(GNParams P, int nsplit, int C8, int R, int cpg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4* tl = reinterpret_cast<float4*>(smem);
+    const int t = threadIdx.x;
+    const int cx = t % C8;
+    const int ry = t / C8;
+    const int b = blockIdx.y;
+    const int c0 = cx * 8;
+    const bool first = c0 < P.C0;
+    const bf16* base = first ? P.x0 : P.x1;
+    const int ld = first ? P.C0 : P.C1;
+    const int coff = first ? c0 : c0 - P.C0;
+    const int per = (P.HW + nsplit - 1) / nsplit;
+    const int p0 = blockIdx.x * per;
+    const int p1 = min(P.HW, p0 + per);
+    const int g_lo = c0 / cpg;
+    bool hi[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) hi[p] = (c0 + 2 * p) / cpg != g_lo;
+
+    float s_lo = 0.f, q_lo = 0.f, s_hi = 0.f, q_hi = 0.f;
+    for (int p = p0 + ry; p < p1; p += R) {
+        U4BF8 v;
+        v.u = *reinterpret_cast<const uint4*>(base + ((size_t)b * P.HW + p) * ld + coff);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float f = bf2f(v.e[e]);
+            if (hi[e >> 1]) { s_hi += f; q_hi += f * f; }
+            else            { s_lo += f; q_lo += f * f; }
+        }
+    }
+    tl[t] = make_float4(s_lo, q_lo, s_hi, q_hi);
+    __syncthreads();
+    if (t < 32) {
+        const int g = t;
+        const int cx_lo = (g * cpg) / 8;
+        const int cx_hi = ((g + 1) * cpg - 1) / 8;
+        float s = 0.f, q = 0.f;
+        for (int x = max(0, cx_lo - 1); x <= cx_hi; ++x) {
+            const int gl_x = (x * 8) / cpg;
+            for (int y = 0; y < R; ++y) {
+                float4 v = tl[y * C8 + x];
+                if (gl_x == g) { s += v.x; q += v.y; }
+                if (gl_x + 1 == g) { s += v.z; q += v.w; }
+            }
+        }
+        float* dst = P.partial + (((size_t)b * nsplit + blockIdx.x) * 32 + g) * 2;
+        dst[0] = s;
+        dst[1] = q;
+    }
+}
+
+// ---- GroupNorm apply (+SiLU): grid (nblk, B)
+__global__ void __launch_bounds__(256) gn_apply_kernel(GNParams P, int nsplit, int C8, int cpg, int per_block) {
+    __shared__ float mean_s[32], rstd_s[32];
+    const int t = threadIdx.x;
+    const int b = blockIdx.y;
+    if (t < 32) {
+        double s = 0.0, q = 0.0;
+        for (int sp = 0; sp < nsplit; ++sp) {
+            const float* src = P.partial + (((size_t)b * nsplit + sp) * 32 + t) * 2;
+            s += src[0];
+            q += src[1];
+        }
+        const double n = (double)P.HW * cpg;
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mean_s[t] = (float)mean;
+        rstd_s[t] = (float)(1.0 / sqrt(var + (double)P.eps));
+    }
+    __syncthreads();
+    const int C = P.C0 + P.C1;
+    const int64_t total = (int64_t)P.HW * C8;
+    const int64_t beg = (int64_t)blockIdx.x * per_block;
+    const int64_t end = min(total, beg + per_block);
+    for (int64_t id = beg + t; id < end; id += 256) {
+        const int pix = (int)(id / C8);
+        const int cx = (int)(id - (int64_t)pix * C8);
+        const int c0 = cx * 8;
+        const bool first = c0 < P.C0;
+        const bf16* src = first ? P.x0 + ((size_t)b * P.HW + pix) * P.C0 + c0
+                                : P.x1 + ((size_t)b * P.HW + pix) * P.C1 + (c0 - P.C0);
+        U4BF8 v, o;
+        v.u = *reinterpret_cast<const uint4*>(src);
+        const float4 g0 = *reinterpret_cast<const float4*>(P.gamma + c0);
+        const float4 g1 = *reinterpret_cast<const float4*>(P.gamma + c0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(P.beta + c0);
+        const float4 b1 = *reinterpret_cast<const float4*>(P.beta + c0 + 4);
+        const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        const int g_lo = c0 / cpg;
+        const int split_c = (g_lo + 1) * cpg;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (c0 + e >= split_c) ? g_lo + 1 : g_lo;
+            float y = (bf2f(v.e[e]) - mean_s[g]) * rstd_s[g] * gm[e] + bt[e];
+            if (P.silu) y = silu_f(y);
+            o.e[e] = f2bf(y);
+        }
+        *reinterpret_cast<uint4*>(P.y + ((size_t)b * P.HW + pix) * C + c0) = o.u;
+    }
+}
+
+int groupnorm_launch(const GNParams& P, hipStream_t stream) {
+    const int C = P.C0 + P.C1;
+    if (C % 64 != 0 || (P.C1 && P.C0 % 8 != 0)) return set_error(GL_ERR_ARG, "groupnorm: C=%d (C0=%d) unsupported", C, P.C0);
+    const int cpg = C / 32;
+    const int C8 = C / 8;
+    if (C8 > 1024) return set_error(GL_ERR_ARG, "groupnorm: C=%d too large", C);
+    const int R = max(1, 256 / C8);
+    const int nsplit = gn_nsplit(P.HW);
+    const int T = C8 * R;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, P.B), dim3(T), T * sizeof(float4), stream, P, nsplit, C8, R, cpg);
+    GL_LAUNCH_CHECK();
+    const int64_t total = (int64_t)P.HW * C8;
+    int64_t nb64 = cdiv64(total, 1024);
+    int nblk = nb64 > 512 ? 512 : (int)nb64;
+    nblk = max(nblk, 1);
+    const int per_block = (int)cdiv64(total, nblk);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, P.B), dim3(256), 0, stream, P, nsplit, C8, cpg, per_block);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+// ---- LayerNorm: one wave per output row.
+__global__ void __launch_bounds__(256) ln_kernel(LNParams P) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    if (r >= (int64_t)P.B * P.Tpad) return;
+    const int b = (int)(r / P.Tpad);
+    const int t = (int)(r - (int64_t)b * P.Tpad);
+    const int C8 = P.C >> 3;
+    bf16* dst = P.y + r * P.C;
+    const bf16* src;
+    if (t < P.N1) src = P.x + ((size_t)b * P.N1 + t) * P.C;
+    else if (t < P.N1 + P.N2) src = P.x2 + ((size_t)b * P.N2 + (t - P.N1)) * P.C;
+    else {
+        for (int ch = lane; ch < C8; ch += 64) *reinterpret_cast<uint4*>(dst + ch * 8) = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    float v[3][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < C8) {
+            U4BF8 u;
+            u.u = *reinterpret_cast<const uint4*>(src + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[i][e] = bf2f(u.e[e]); s += v[i][e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / P.C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < C8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / P.C + P.eps);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < C8) {
+            const float4 g0 = *reinterpret_cast<const float4*>(P.gamma + ch * 8);
+            const float4 g1 = *reinterpret_cast<const float4*>(P.gamma + ch * 8 + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(P.beta + ch * 8);
+            const float4 b1 = *reinterpret_cast<const float4*>(P.beta + ch * 8 + 4);
+            const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            U4BF8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.e[e] = f2bf((v[i][e] - mean) * rstd * gm[e] + bt[e]);
+            *reinterpret_cast<uint4*>(dst + ch * 8) = o.u;
+        }
+    }
+}
+
+int layernorm_launch(const LNParams& P, hipStream_t stream) {
+    if (P.C % 8 != 0 || P.C > 1536) return set_error(GL_ERR_ARG, "layernorm: C=%d unsupported", P.C);
+    if (P.Tpad < P.N1 + P.N2) return set_error(GL_ERR_ARG, "layernorm: Tpad=%d < %d+%d", P.Tpad, P.N1, P.N2);
+    const int64_t rows = (int64_t)P.B * P.Tpad;
+    hipLaunchKernelGGL(ln_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, stream, P);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+// ---- row softmax (fp32 -> bf16), one block per row
+__global__ void __launch_bounds__(256) softmax_rows_kernel(const float* __restrict__ S, bf16* __restrict__ Pm, int cols, float scale) {
+    __shared__ float red[4];
+    const float* row = S + (size_t)blockIdx.x * cols;
+    bf16* out = Pm + (size_t)blockIdx.x * cols;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float mx = -1e30f;
+    for (int c = t; c < cols; c += 256) mx = fmaxf(mx, row[c]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = t; c < cols; c += 256) s += __expf((row[c] - mx) * scale);
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
+    for (int c = t; c < cols; c += 256) out[c] = f2bf(__expf((row[c] - mx) * scale) * inv);
+}
+
+int softmax_rows_launch(const float* S, bf16* Pm, int rows, int cols, float scale, hipStream_t stream) {
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, stream, S, Pm, cols, scale);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+}  // namespace gl

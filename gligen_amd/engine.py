@@ -1,0 +1,263 @@
+"""Python handle on the native engine (libgligen_amd.so): torch tensors in, torch tensors out.
+
+torch is used only for device memory and the current HIP stream; every computation below is a
+call through the C ABI. Nothing here falls back to torch ops.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Mapping, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Grounding, PlmsArgs, UNetConfig, VaeConfig, check
+
+GROUNDING_KINDS = {"text": 0, "text_image": 1, "keypoint": 2}
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class Engine:
+    """One engine per device; owns packed bf16 weights, workspace arena and cached conditioning."""
+
+    def __init__(self, device: int | torch.device | str = 0, arena_gb: float = 12.0):
+        if not torch.cuda.is_available():
+            raise _lib.GligenAmdError("no HIP device visible: gligen_amd needs an MI355X (gfx950) GPU")
+        dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        self.device = torch.device("cuda", dev.index or 0)
+        self.lib = _lib.load()
+        self._ctx = C.c_void_p()
+        torch.cuda.set_device(self.device)
+        check(self.lib.gl_ctx_create(self.device.index, C.c_size_t(int(arena_gb * (1 << 30))), C.byref(self._ctx)))
+        self.unet_cfg: Optional[dict] = None
+        self.vae_cfg: Optional[dict] = None
+        self._keep: list = []
+
+    def close(self) -> None:
+        if self._ctx:
+            check(self.lib.gl_ctx_destroy(self._ctx))
+            self._ctx = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- configuration / weights -------------------------------------------------
+    def configure_unet(self, *, in_channels, out_channels, model_channels, num_res_blocks, num_heads, context_dim,
+                       channel_mult: Sequence[int], attention_resolutions: Sequence[int], inpaint_mode=False,
+                       grounding_kind="text", gr_in_dim=768, gr_out_dim=768, max_persons=0) -> None:
+        cfg = UNetConfig()
+        cfg.in_channels, cfg.out_channels, cfg.model_channels = in_channels, out_channels, model_channels
+        cfg.num_res_blocks, cfg.num_heads, cfg.context_dim = num_res_blocks, num_heads, context_dim
+        cfg.n_mult = len(channel_mult)
+        for i, v in enumerate(channel_mult):
+            cfg.channel_mult[i] = int(v)
+        cfg.n_attn = len(attention_resolutions)
+        for i, v in enumerate(attention_resolutions):
+            cfg.attention_resolutions[i] = int(v)
+        cfg.inpaint_mode = int(bool(inpaint_mode))
+        cfg.grounding_kind = GROUNDING_KINDS[grounding_kind]
+        cfg.gr_in_dim, cfg.gr_out_dim, cfg.max_persons = gr_in_dim, gr_out_dim, max_persons
+        check(self.lib.gl_unet_configure(self._ctx, C.byref(cfg)))
+        self.unet_cfg = dict(in_channels=in_channels, out_channels=out_channels, inpaint_mode=bool(inpaint_mode),
+                             grounding_kind=grounding_kind, context_dim=context_dim)
+
+    def configure_vae(self, *, ch, out_ch, z_channels, num_res_blocks, embed_dim, ch_mult: Sequence[int],
+                      scale_factor: float) -> None:
+        cfg = VaeConfig()
+        cfg.ch, cfg.out_ch, cfg.z_channels, cfg.num_res_blocks, cfg.embed_dim = ch, out_ch, z_channels, num_res_blocks, embed_dim
+        cfg.n_mult = len(ch_mult)
+        for i, v in enumerate(ch_mult):
+            cfg.ch_mult[i] = int(v)
+        cfg.scale_factor = float(scale_factor)
+        check(self.lib.gl_vae_configure(self._ctx, C.byref(cfg)))
+        self.vae_cfg = dict(out_ch=out_ch, z_channels=z_channels, n_up=len(ch_mult) - 1)
+
+    def upload(self, namespace: str, state_dict: Mapping[str, torch.Tensor], prefix_filter: Optional[str] = None) -> int:
+        """Upload fp32 parameters under '<namespace>/<reference state_dict key>'."""
+        n = 0
+        for key, t in state_dict.items():
+            if prefix_filter is not None and not key.startswith(prefix_filter):
+                continue
+            t = t.detach().to(dtype=torch.float32).contiguous()
+            shape = (C.c_int64 * max(1, t.dim()))(*t.shape)
+            check(self.lib.gl_weight_upload(self._ctx, f"{namespace}/{key}".encode(), C.c_void_p(t.data_ptr()),
+                                            t.dim(), shape, int(t.is_cuda)))
+            n += 1
+        return n
+
+    def finalize(self) -> None:
+        check(self.lib.gl_finalize(self._ctx))
+
+    # ---- denoising path ---------------------------------------------------------
+    def set_cond(self, context: torch.Tensor, grounding: Mapping[str, torch.Tensor]) -> None:
+        """context [Beff,T,768]; grounding = kwargs of the reference PositionNet.forward."""
+        dev = self.device
+        ctx = _f32(context, dev)
+        kind = self.unet_cfg["grounding_kind"]
+        g = Grounding()
+        keep = [ctx]
+
+        def put(name, field=None):
+            t = _f32(grounding[name], dev)
+            keep.append(t)
+            setattr(g, field or name, t.data_ptr())
+            return t
+
+        if kind == "text":
+            b = put("boxes"); put("masks"); put("positive_embeddings", "text_embeddings")
+        elif kind == "text_image":
+            b = put("boxes"); put("masks"); put("text_masks"); put("image_masks")
+            put("text_embeddings"); put("image_embeddings")
+        else:
+            b = put("points"); put("masks")
+        if b.shape[0] != ctx.shape[0]:
+            raise ValueError("grounding batch does not match context batch")
+        g.n = int(b.shape[1])
+        check(self.lib.gl_unet_set_cond(self._ctx, int(ctx.shape[0]), _ptr(ctx), int(ctx.shape[1]), C.byref(g), _stream()))
+        self._keep = keep
+
+    def set_fuser_scale(self, scale: float) -> None:
+        check(self.lib.gl_unet_set_fuser_scale(self._ctx, C.c_float(float(scale)), _stream()))
+
+    def unet_forward(self, x: torch.Tensor, timesteps: torch.Tensor, inpaint_extra: Optional[torch.Tensor] = None,
+                     batch: Optional[int] = None) -> torch.Tensor:
+        dev = self.device
+        x = _f32(x, dev)
+        t = timesteps.to(device=dev, dtype=torch.int64).contiguous()
+        Beff = int(batch or t.shape[0])
+        extra = None if inpaint_extra is None else _f32(inpaint_extra, dev)
+        out = torch.empty((Beff, self.unet_cfg["out_channels"], x.shape[2], x.shape[3]), device=dev, dtype=torch.float32)
+        check(self.lib.gl_unet_forward(self._ctx, Beff, int(x.shape[2]), int(x.shape[3]), _ptr(x), int(x.shape[0]), _ptr(t),
+                                       _ptr(extra), 0 if extra is None else int(extra.shape[0]), _ptr(out), _stream()))
+        return out
+
+    def vae_decode(self, z: torch.Tensor) -> torch.Tensor:
+        dev = self.device
+        z = _f32(z, dev)
+        B, _, h, w = z.shape
+        f = 2 ** self.vae_cfg["n_up"]
+        out = torch.empty((B, self.vae_cfg["out_ch"], h * f, w * f), device=dev, dtype=torch.float32)
+        check(self.lib.gl_vae_decode(self._ctx, int(B), int(h), int(w), _ptr(z), _ptr(out), _stream()))
+        return out
+
+    def sample_plms(self, x: torch.Tensor, timesteps: np.ndarray, a_t: np.ndarray, a_prev: np.ndarray,
+                    fuser_scale: Optional[np.ndarray], guidance_scale: float, *, inpaint_extra=None, mask=None, x0=None,
+                    noise=None, sqrt_ac=None, sqrt_1mac=None, use_graph: bool = True) -> torch.Tensor:
+        """In-place PLMS loop on x (fp32 [B,C,h,w]); conditioning must already be set."""
+        dev = self.device
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        n = len(timesteps)
+        ts = np.ascontiguousarray(timesteps, dtype=np.int64)
+        at = np.ascontiguousarray(a_t, dtype=np.float32)
+        ap = np.ascontiguousarray(a_prev, dtype=np.float32)
+        a = PlmsArgs()
+        a.B, a.h, a.w, a.n_steps = int(x.shape[0]), int(x.shape[2]), int(x.shape[3]), n
+        a.timesteps = ts.ctypes.data_as(C.POINTER(C.c_int64))
+        a.a_t = at.ctypes.data_as(C.POINTER(C.c_float))
+        a.a_prev = ap.ctypes.data_as(C.POINTER(C.c_float))
+        keep = [ts, at, ap]
+        if fuser_scale is not None:
+            fs = np.ascontiguousarray(fuser_scale, dtype=np.float32)
+            a.fuser_scale = fs.ctypes.data_as(C.POINTER(C.c_float))
+            keep.append(fs)
+        a.guidance_scale = float(guidance_scale)
+        a.x = x.data_ptr()
+        if inpaint_extra is not None:
+            inpaint_extra = _f32(inpaint_extra, dev); keep.append(inpaint_extra); a.inpaint_extra = inpaint_extra.data_ptr()
+        if mask is not None:
+            mask, x0, noise = _f32(mask, dev), _f32(x0, dev), _f32(noise, dev)
+            sa = np.ascontiguousarray(sqrt_ac, dtype=np.float32); s1 = np.ascontiguousarray(sqrt_1mac, dtype=np.float32)
+            keep += [mask, x0, noise, sa, s1]
+            a.mask, a.x0, a.noise = mask.data_ptr(), x0.data_ptr(), noise.data_ptr()
+            a.sqrt_ac = sa.ctypes.data_as(C.POINTER(C.c_float)); a.sqrt_1mac = s1.ctypes.data_as(C.POINTER(C.c_float))
+        a.use_graph = int(bool(use_graph))
+        check(self.lib.gl_sample_plms(self._ctx, C.byref(a), _stream()))
+        self._keep_plms = keep
+        return x
+
+    def to_uint8(self, img: torch.Tensor) -> torch.Tensor:
+        img = _f32(img, self.device)
+        B, Cc, H, W = img.shape
+        out = torch.empty((B, H, W, Cc), device=self.device, dtype=torch.uint8)
+        check(self.lib.gl_to_uint8(_ptr(img), _ptr(out), int(B), int(Cc), int(H * W), _stream()))
+        return out
+
+    def arena_high_water(self) -> int:
+        v = C.c_size_t()
+        check(self.lib.gl_arena_high_water(self._ctx, C.byref(v)))
+        return int(v.value)
+
+    def launch_count(self) -> int:
+        v = C.c_int64()
+        check(self.lib.gl_launch_count(self._ctx, C.byref(v)))
+        return int(v.value)
+
+    # ---- single operators (parity tests / per-kernel profiling) -------------------
+    def op_linear(self, x, w, bias=None, res=None, act=0, out_f32=False):
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty((M, N), device=x.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+        check(self.lib.gl_op_linear(self._ctx, _ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(y), M, N, K, act, int(out_f32), _stream()))
+        return y
+
+    def op_geglu(self, x, w_f32, b_f32):
+        M, K = x.shape
+        inner = w_f32.shape[0] // 2
+        y = torch.empty((M, inner), device=x.device, dtype=torch.bfloat16)
+        check(self.lib.gl_op_geglu(self._ctx, _ptr(x), _ptr(w_f32), _ptr(b_f32), _ptr(y), M, inner, K, _stream()))
+        return y
+
+    def op_conv3x3(self, x0, w_oihw, bias, x1=None, stride=1, ups=0, pad_lo=1, res=None):
+        B, H, W, C0 = x0.shape
+        C1 = 0 if x1 is None else x1.shape[3]
+        Cout = w_oihw.shape[0]
+        Hup, Wup = H << ups, W << ups
+        if stride == 1:
+            Ho, Wo = Hup, Wup
+        else:
+            Ho = (Hup + (2 if pad_lo else 1) - 3) // 2 + 1
+            Wo = (Wup + (2 if pad_lo else 1) - 3) // 2 + 1
+        y = torch.empty((B, Ho, Wo, Cout), device=x0.device, dtype=torch.bfloat16)
+        check(self.lib.gl_op_conv3x3(self._ctx, _ptr(x0), C0, _ptr(x1), C1, B, H, W, _ptr(w_oihw), _ptr(bias), Cout,
+                                     stride, ups, pad_lo, _ptr(res), _ptr(y), _stream()))
+        return y
+
+    def op_groupnorm(self, x0, gamma, beta, eps, silu, x1=None):
+        B, HW, C0 = x0.shape
+        C1 = 0 if x1 is None else x1.shape[2]
+        y = torch.empty((B, HW, C0 + C1), device=x0.device, dtype=torch.bfloat16)
+        check(self.lib.gl_op_groupnorm(self._ctx, _ptr(x0), C0, _ptr(x1), C1, B, HW, _ptr(gamma), _ptr(beta),
+                                       C.c_float(eps), int(silu), _ptr(y), _stream()))
+        return y
+
+    def op_layernorm(self, x, gamma, beta, eps=1e-5, x2=None, Tpad=None):
+        B, N1, Cc = x.shape
+        N2 = 0 if x2 is None else x2.shape[1]
+        Tpad = Tpad or (N1 + N2)
+        y = torch.empty((B, Tpad, Cc), device=x.device, dtype=torch.bfloat16)
+        check(self.lib.gl_op_layernorm(self._ctx, _ptr(x), _ptr(x2), B, N1, N2, Tpad, Cc, _ptr(gamma), _ptr(beta),
+                                       C.c_float(eps), _ptr(y), _stream()))
+        return y
+
+    def op_attention(self, xq, xkv, wq, wk, wv, heads):
+        B, Nq, Cc = xq.shape
+        _, Nk, Ck = xkv.shape
+        o = torch.empty((B, Nq, Cc), device=xq.device, dtype=torch.bfloat16)
+        check(self.lib.gl_op_attention(self._ctx, _ptr(xq), _ptr(xkv), B, Nq, Nk, Cc, Ck, heads, _ptr(wq), _ptr(wk), _ptr(wv),
+                                       _ptr(o), _stream()))
+        return o

@@ -1,0 +1,146 @@
+/* gligen_amd.h — C ABI of libgligen_amd.so: the MI355X (gfx950) GLIGEN denoising engine.
+ *
+ * The reference (gligen/GLIGEN) has no FFI: its extension seam is Python classes instantiated
+ * from dotted paths (reference ldm/util.py:71-86). This ABI is what the Python modules that
+ * keep those dotted paths (ldm/…, grounding_input/… in this repo) bind through ctypes; every
+ * entry point names the reference interface it stands behind.
+ *
+ * Conventions
+ *  - every function returns 0 (GL_OK) or an error code; gl_last_error() has the message;
+ *    nothing throws across the boundary;
+ *  - pointers are raw device pointers unless a parameter says "host"; tensors are caller-owned;
+ *  - forward calls do not allocate, do not synchronise the host and do not read device data on
+ *    the host (hipGraph-capturable); all work is enqueued on the passed hipStream_t
+ *    (pass torch.cuda.current_stream().cuda_stream);
+ *  - one context per device/thread: thread-compatible, not thread-safe;
+ *  - activations/latents at the boundary are fp32 NCHW exactly as the reference passes them;
+ *    internally the engine computes in bf16 storage / fp32 accumulate.
+ */
+#ifndef GLIGEN_AMD_H
+#define GLIGEN_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gl_ctx gl_ctx;
+typedef void* gl_stream; /* hipStream_t */
+
+/* UNetModel constructor kwargs (reference ldm/modules/diffusionmodules/openaimodel.py:238-259,
+ * yaml configs/GoldG+SBU+CC3M+O365_box_text.yaml:9-29). */
+typedef struct gl_unet_config {
+    int in_channels, out_channels, model_channels, num_res_blocks, num_heads, context_dim;
+    int n_mult;
+    int channel_mult[8];
+    int n_attn;
+    int attention_resolutions[8];
+    int inpaint_mode;     /* 9-channel first conv (openaimodel.py:299-302) */
+    int grounding_kind;   /* 0 text (text_grounding_net.py), 1 text+image, 2 keypoint */
+    int gr_in_dim;        /* PositionNet in_dim (768) */
+    int gr_out_dim;       /* PositionNet out_dim (768) */
+    int max_persons;      /* keypoint only */
+} gl_unet_config;
+
+/* AutoencoderKL ddconfig (reference ldm/modules/diffusionmodules/model.py:462-533). */
+typedef struct gl_vae_config {
+    int ch, out_ch, z_channels, num_res_blocks, embed_dim;
+    int n_mult;
+    int ch_mult[8];
+    float scale_factor;   /* 0.18215 (autoencoder.py:40-41) */
+} gl_vae_config;
+
+/* kwargs of PositionNet.forward for the three discrete tokenizers (reference
+ * text_grounding_net.py:30, text_image_grounding_net.py:41, keypoint_grounding_net.py:34);
+ * all fp32 device pointers, batch = the Beff passed alongside. */
+typedef struct gl_grounding {
+    int n;                       /* tokens per sample: max_objs (30) or persons*17 (136) */
+    const float* boxes;          /* [Beff][n][4] xyxy in [0,1]          (kinds 0,1) */
+    const float* masks;          /* [Beff][n] */
+    const float* text_masks;     /* [Beff][n]                            (kind 1) */
+    const float* image_masks;    /* [Beff][n]                            (kind 1) */
+    const float* text_embeddings;  /* [Beff][n][in_dim] (kind 0: positive_embeddings) */
+    const float* image_embeddings; /* [Beff][n][in_dim]                  (kind 1) */
+    const float* points;         /* [Beff][n][2]                         (kind 2) */
+} gl_grounding;
+
+/* One PLMS run (reference ldm/models/diffusion/plms.py:65-162): schedule arrays are host
+ * pointers of length n_steps, in sampling order (time descending). */
+typedef struct gl_plms_args {
+    int B, h, w;                 /* latent batch / size; cond must have been set with Beff = 2B
+                                    ([cond ; uncond]) when guidance != 1, else Beff = B */
+    int n_steps;
+    const int64_t* timesteps;    /* host: flipped ddim_timesteps (plms.py:75) */
+    const float* a_t;            /* host: ddim_alphas[index]      (plms.py:126) */
+    const float* a_prev;         /* host: ddim_alphas_prev[index] (plms.py:127) */
+    const float* fuser_scale;    /* host: alpha_generator schedule (gligen_inference.py:31-66) */
+    float guidance_scale;
+    float* x;                    /* device fp32 [B][C][h][w]: x_T in, x_0 out */
+    const float* inpaint_extra;  /* device fp32 [B][C+1][h][w] or NULL (gligen_inference.py:406-407) */
+    const float* mask;           /* device fp32 [B][1][h][w] or NULL     (plms.py:96-100) */
+    const float* x0;             /* device fp32 [B][C][h][w] or NULL */
+    const float* noise;          /* device fp32 [n_steps][B][C][h][w] q_sample noise, required with mask */
+    const float* sqrt_ac;        /* host [n_steps]: sqrt_alphas_cumprod[t] (ldm.py:19-22) */
+    const float* sqrt_1mac;      /* host [n_steps] */
+    int use_graph;               /* capture one UNet evaluation in a hipGraph and replay it */
+} gl_plms_args;
+
+const char* gl_last_error(void);
+
+/* load_ckpt / instantiate_from_config(...).to(device) (reference gligen_inference.py:70-86) */
+int gl_ctx_create(int device, size_t arena_bytes, gl_ctx** out);
+int gl_ctx_destroy(gl_ctx* ctx);
+int gl_unet_configure(gl_ctx* ctx, const gl_unet_config* cfg);
+int gl_vae_configure(gl_ctx* ctx, const gl_vae_config* cfg);
+/* model.load_state_dict(...) (gligen_inference.py:81-84): key = "unet/" or "vae/" + the
+ * reference state_dict key; data is fp32, host or device. */
+int gl_weight_upload(gl_ctx* ctx, const char* key, const void* data, int ndim, const int64_t* shape, int is_device);
+int gl_finalize(gl_ctx* ctx);
+
+/* Step-invariant part of UNetModel.forward: position_net(**grounding_input) (openaimodel.py:433),
+ * fuser.linear(objs) (attention.py:239) and attn2.to_k/to_v(context) (attention.py:130-131). */
+int gl_unet_set_cond(gl_ctx* ctx, int Beff, const float* context, int n_ctx_tokens, const gl_grounding* g, gl_stream s);
+/* set_alpha_scale(model, alpha) (gligen_inference.py:24-28) */
+int gl_unet_set_fuser_scale(gl_ctx* ctx, float scale, gl_stream s);
+/* UNetModel.forward (openaimodel.py:420-464): x [xB][C][h][w] (sample b reads x[b % xB]),
+ * timesteps int64 [Beff], inpaint_extra [extraB][C+1][h][w] or NULL, eps_out [Beff][out_ch][h][w]. */
+int gl_unet_forward(gl_ctx* ctx, int Beff, int h, int w, const float* x, int xB, const int64_t* timesteps,
+                    const float* inpaint_extra, int extraB, float* eps_out, gl_stream s);
+/* AutoencoderKL.decode (autoencoder.py:40-44): z [B][zc][h][w] -> img [B][out_ch][8h][8w] */
+int gl_vae_decode(gl_ctx* ctx, int B, int h, int w, const float* z, float* img, gl_stream s);
+/* PLMSSampler.plms_sampling (plms.py:65-108) with classifier-free guidance (plms.py:116-122) */
+int gl_sample_plms(gl_ctx* ctx, const gl_plms_args* args, gl_stream s);
+/* clamp(-1,1)*0.5+0.5 -> *255 -> uint8 HWC (gligen_inference.py:443-445) */
+int gl_to_uint8(const float* img, uint8_t* out, int B, int C, int HW, gl_stream s);
+
+int gl_arena_high_water(gl_ctx* ctx, size_t* bytes);
+int gl_launch_count(gl_ctx* ctx, int64_t* n);
+
+/* ---- single-operator entry points (parity tests and per-kernel profiling) -------------- */
+/* y = act(x W^T + b) [+ res]; x [M][K] bf16, W [N][K] bf16, b fp32|NULL, res bf16|NULL,
+ * act: 0 none 1 SiLU; y bf16 (out_f32 = 0) or fp32. Replaces nn.Linear / 1x1 conv. */
+int gl_op_linear(gl_ctx* ctx, const void* x, const void* w, const float* bias, const void* res, void* y,
+                 int M, int N, int K, int act, int out_f32, gl_stream s);
+/* GEGLU (reference attention.py:37-44): x [M][K] bf16, proj weight [2*inner][K] fp32 + bias ->
+ * y [M][inner] bf16 = (x Wv^T + bv) * gelu(x Wg^T + bg) */
+int gl_op_geglu(gl_ctx* ctx, const void* x, const float* w_f32, const float* b_f32, void* y, int M, int inner, int K, gl_stream s);
+/* 3x3 conv over NHWC bf16 (channel-concat of x0,x1), weight OIHW fp32, stride 1|2, optional
+ * nearest 2x upsample of the input, pad_lo 1 (symmetric) or 0 (VAE-encoder style). y NHWC bf16. */
+int gl_op_conv3x3(gl_ctx* ctx, const void* x0, int C0, const void* x1, int C1, int B, int H, int W,
+                  const float* w_oihw, const float* bias, int Cout, int stride, int ups, int pad_lo,
+                  const void* res, void* y, gl_stream s);
+/* GroupNorm(32)+optional SiLU over NHWC bf16 (channel-concat of x0,x1) */
+int gl_op_groupnorm(gl_ctx* ctx, const void* x0, int C0, const void* x1, int C1, int B, int HW,
+                    const float* gamma, const float* beta, float eps, int silu, void* y, gl_stream s);
+int gl_op_layernorm(gl_ctx* ctx, const void* x, const void* x2, int B, int N1, int N2, int Tpad, int C,
+                    const float* gamma, const float* beta, float eps, void* y, gl_stream s);
+/* softmax(q k^T d^-0.5) v with q,k,v projections applied to token rows:
+ * xq [B][Nq][C], xkv [B][Nk][Ck] bf16, Wq [C][C], Wk/Wv [C][Ck] fp32 (no bias), heads H -> o [B][Nq][C] bf16 */
+int gl_op_attention(gl_ctx* ctx, const void* xq, const void* xkv, int B, int Nq, int Nk, int C, int Ck, int H,
+                    const float* wq, const float* wk, const float* wv, void* o, gl_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
