@@ -110,6 +110,14 @@ int gl_unet_set_fuser_scale(gl_ctx* ctx, float scale, gl_stream s) {
     GL_API_END
 }
 
+int gl_unet_restore_first_conv(gl_ctx* ctx, const float* w, const float* b, gl_stream s) {
+    NEED(ctx);
+    if (!w || !b) return gl::set_error(GL_ERR_ARG, "null weights");
+    GL_API_BEGIN
+    ctx->eng->restore_first_conv(w, b, S(s));
+    GL_API_END
+}
+
 int gl_unet_forward(gl_ctx* ctx, int Beff, int h, int w, const float* x, int xB, const int64_t* timesteps,
                     const float* inpaint_extra, int extraB, float* eps_out, gl_stream s) {
     NEED(ctx);

@@ -103,6 +103,7 @@ class Engine {
 
     void set_cond(int Beff, const float* context, int n_ctx, const gl_grounding& g, hipStream_t s);
     void set_fuser_scale(float v, hipStream_t s);
+    void restore_first_conv(const float* w, const float* b, hipStream_t s);
     void unet_forward(int Beff, int h, int w, const float* x, int xB, const int64_t* t, const float* extra,
                       int extraB, float* eps, hipStream_t s);
     void vae_decode(int B, int h, int w, const float* z, float* out, hipStream_t s);

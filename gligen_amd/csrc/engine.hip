@@ -244,7 +244,9 @@ void Engine::build_unet() {
         bf16* dst = reinterpret_cast<bf16*>(persist((size_t)mc * conv_in_kpad_ * sizeof(bf16), false));
         CK(pack_conv_small_launch(w.p, dst, mc, in_c, conv_in_kpad_, 0));
         conv_in_small_.w = dst;
-        conv_in_small_.b = F(U + "input_blocks.0.0.bias");
+        float* bcopy = reinterpret_cast<float*>(persist(mc * sizeof(float), false));  // engine-owned: restorable
+        HIPCK(hipMemcpy(bcopy, F(U + "input_blocks.0.0.bias"), mc * sizeof(float), hipMemcpyDeviceToDevice));
+        conv_in_small_.b = bcopy;
         conv_in_small_.Cin = in_c;
         conv_in_small_.Cout = mc;
     }
@@ -740,6 +742,16 @@ void Engine::set_fuser_scale(float v, hipStream_t s) {
     CK(set_f32_launch(fuser_scale_, v, s));
 }
 
+// UNetModel.restore_first_conv_from_SD (openaimodel.py:400-413): overwrite the packed first-conv
+// buffers in place, so captured graphs (which hold these addresses) pick the new weights up.
+void Engine::restore_first_conv(const float* w, const float* b, hipStream_t s) {
+    if (!has_unet_ || !finalized_) throw GlError(GL_ERR_STATE, "unet not finalized");
+    if (ucfg_.inpaint_mode) throw GlError(GL_ERR_STATE, "first conv of an inpainting model is not restorable");
+    const int mc = ucfg_.model_channels;
+    CK(pack_conv_small_launch(w, const_cast<bf16*>(conv_in_small_.w), mc, conv_in_small_.Cin, conv_in_kpad_, s));
+    HIPCK(hipMemcpyAsync(const_cast<float*>(conv_in_small_.b), b, mc * sizeof(float), hipMemcpyDeviceToDevice, s));
+}
+
 void Engine::set_cond(int Beff, const float* context, int n_ctx, const gl_grounding& g, hipStream_t s) {
     if (!has_unet_ || !finalized_) throw GlError(GL_ERR_STATE, "unet not finalized");
     if (Beff <= 0 || n_ctx <= 0 || g.n <= 0) throw GlError(GL_ERR_ARG, "set_cond: empty batch / context / grounding");
@@ -1131,8 +1143,13 @@ void Engine::sample_plms(const gl_plms_args& a, hipStream_t s) {
         ++evals;
     };
 
+    bool restored = false;
     for (int i = 0; i < a.n_steps; ++i) {
         if (a.fuser_scale) set_fuser_scale(a.fuser_scale[i], s);
+        if (a.fuser_scale && a.fuser_scale[i] == 0.f && a.sd_conv_w && a.sd_conv_b && !restored) {
+            restore_first_conv(a.sd_conv_w, a.sd_conv_b, s);
+            restored = true;
+        }
         if (a.mask)
             CK(inpaint_blend_launch(a.x, a.x0, a.noise + (size_t)i * n, a.mask, a.sqrt_ac[i], a.sqrt_1mac[i], a.B, Cl, a.h * a.w, s));
         eval(a.x, a.timesteps[i]);

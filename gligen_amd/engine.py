@@ -134,6 +134,11 @@ class Engine:
     def set_fuser_scale(self, scale: float) -> None:
         check(self.lib.gl_unet_set_fuser_scale(self._ctx, C.c_float(float(scale)), _stream()))
 
+    def restore_first_conv(self, weight: torch.Tensor, bias: torch.Tensor) -> None:
+        w, b = _f32(weight, self.device), _f32(bias, self.device)
+        check(self.lib.gl_unet_restore_first_conv(self._ctx, _ptr(w), _ptr(b), _stream()))
+        self._keep_conv = (w, b)
+
     def unet_forward(self, x: torch.Tensor, timesteps: torch.Tensor, inpaint_extra: Optional[torch.Tensor] = None,
                      batch: Optional[int] = None) -> torch.Tensor:
         dev = self.device
@@ -157,7 +162,7 @@ class Engine:
 
     def sample_plms(self, x: torch.Tensor, timesteps: np.ndarray, a_t: np.ndarray, a_prev: np.ndarray,
                     fuser_scale: Optional[np.ndarray], guidance_scale: float, *, inpaint_extra=None, mask=None, x0=None,
-                    noise=None, sqrt_ac=None, sqrt_1mac=None, use_graph: bool = True) -> torch.Tensor:
+                    noise=None, sqrt_ac=None, sqrt_1mac=None, use_graph: bool = True, sd_first_conv=None) -> torch.Tensor:
         """In-place PLMS loop on x (fp32 [B,C,h,w]); conditioning must already be set."""
         dev = self.device
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
@@ -186,6 +191,10 @@ class Engine:
             a.mask, a.x0, a.noise = mask.data_ptr(), x0.data_ptr(), noise.data_ptr()
             a.sqrt_ac = sa.ctypes.data_as(C.POINTER(C.c_float)); a.sqrt_1mac = s1.ctypes.data_as(C.POINTER(C.c_float))
         a.use_graph = int(bool(use_graph))
+        if sd_first_conv is not None:
+            cw, cb = _f32(sd_first_conv[0], dev), _f32(sd_first_conv[1], dev)
+            keep += [cw, cb]
+            a.sd_conv_w, a.sd_conv_b = cw.data_ptr(), cb.data_ptr()
         check(self.lib.gl_sample_plms(self._ctx, C.byref(a), _stream()))
         self._keep_plms = keep
         return x

@@ -84,6 +84,8 @@ typedef struct gl_plms_args {
     const float* sqrt_ac;        /* host [n_steps]: sqrt_alphas_cumprod[t] (ldm.py:19-22) */
     const float* sqrt_1mac;      /* host [n_steps] */
     int use_graph;               /* capture one UNet evaluation in a hipGraph and replay it */
+    const float* sd_conv_w;      /* device fp32 [mc][C][3][3] + [mc]: SD first-conv weights swapped in at the */
+    const float* sd_conv_b;      /*   first step whose fuser_scale is 0 (plms.py:88-89), or NULL */
 } gl_plms_args;
 
 const char* gl_last_error(void);
@@ -103,6 +105,9 @@ int gl_finalize(gl_ctx* ctx);
 int gl_unet_set_cond(gl_ctx* ctx, int Beff, const float* context, int n_ctx_tokens, const gl_grounding* g, gl_stream s);
 /* set_alpha_scale(model, alpha) (gligen_inference.py:24-28) */
 int gl_unet_set_fuser_scale(gl_ctx* ctx, float scale, gl_stream s);
+/* UNetModel.restore_first_conv_from_SD (openaimodel.py:400-413): replace the first conv's weights
+ * (OIHW fp32 [mc][in_channels][3][3], bias [mc]); stream-ordered, valid under hipGraph replay. */
+int gl_unet_restore_first_conv(gl_ctx* ctx, const float* w, const float* b, gl_stream s);
 /* UNetModel.forward (openaimodel.py:420-464): x [xB][C][h][w] (sample b reads x[b % xB]),
  * timesteps int64 [Beff], inpaint_extra [extraB][C+1][h][w] or NULL, eps_out [Beff][out_ch][h][w]. */
 int gl_unet_forward(gl_ctx* ctx, int Beff, int h, int w, const float* x, int xB, const int64_t* timesteps,

@@ -1,0 +1,220 @@
+"""GLIGEN UNet (SD-1.4 UNet + one gated self-attention fuser per transformer block).
+
+Drop-in for the reference's ldm/modules/diffusionmodules/openaimodel.py: same class names,
+constructor kwargs (openaimodel.py:238-259), attributes, state_dict keys (966 tensors for the
+shipped configs) and `forward(input: dict) -> eps` contract (openaimodel.py:420-464). The
+sub-modules only hold parameters; `UNetModel.forward` hands the whole evaluation to the native
+MI355X engine (gligen_amd/csrc/engine.hip: Engine::unet_forward) — no torch operator runs.
+"""
+import torch
+import torch.nn as nn
+
+from gligen_amd import runtime as _rt
+from ldm.modules.attention import SpatialTransformer, _EngineOnly, _slots, zero_module
+from ldm.modules.diffusionmodules.util import conv_nd, linear, normalization
+from ldm.util import instantiate_from_config
+
+
+class TimestepBlock(_EngineOnly):
+    """Marker: layers that take the timestep embedding as second argument."""
+
+
+class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
+    """Container whose children receive (x, emb), (x, context, objs) or (x) by kind
+    (reference openaimodel.py:37-51); executed by the engine, block by block."""
+
+    def forward(self, *args, **kwargs):
+        return _EngineOnly.forward(self)
+
+
+class Upsample(_EngineOnly):
+    """nearest 2x then conv3x3 (reference openaimodel.py:54-82) — the upsample is folded into the
+    conv's gather on the device."""
+
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        self.channels, self.out_channels, self.use_conv, self.dims = channels, out_channels or channels, use_conv, dims
+        if not use_conv:
+            raise NotImplementedError("conv_resample=False is not implemented")
+        self.conv = conv_nd(dims, self.channels, self.out_channels, 3, padding=padding)
+
+
+class Downsample(_EngineOnly):
+    """conv3x3 stride 2 pad 1 (reference openaimodel.py:87-113)."""
+
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        self.channels, self.out_channels, self.use_conv, self.dims = channels, out_channels or channels, use_conv, dims
+        if not use_conv:
+            raise NotImplementedError("conv_resample=False is not implemented")
+        self.op = conv_nd(dims, self.channels, self.out_channels, 3, stride=2, padding=padding)
+
+
+class ResBlock(TimestepBlock):
+    """GN-SiLU-conv, + Linear(SiLU(emb)), GN-SiLU-conv, + skip (reference openaimodel.py:116-232)."""
+
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False, use_scale_shift_norm=False,
+                 dims=2, use_checkpoint=False, up=False, down=False):
+        super().__init__()
+        if use_scale_shift_norm or up or down or use_conv:
+            raise NotImplementedError("scale-shift norm / resampling ResBlocks are not used by GLIGEN configs")
+        self.channels, self.emb_channels, self.dropout = channels, emb_channels, dropout
+        self.out_channels = out_channels or channels
+        self.use_checkpoint = use_checkpoint
+        self.in_layers = _slots(3, i0=normalization(channels), i2=conv_nd(dims, channels, self.out_channels, 3, padding=1))
+        self.emb_layers = _slots(2, i1=linear(emb_channels, self.out_channels))
+        self.out_layers = _slots(4, i0=normalization(self.out_channels),
+                                 i3=zero_module(conv_nd(dims, self.out_channels, self.out_channels, 3, padding=1)))
+        self.skip_connection = nn.Identity() if self.out_channels == channels else conv_nd(dims, channels, self.out_channels, 1)
+
+
+class UNetModel(nn.Module):
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, use_checkpoint=False, num_heads=8,
+                 use_scale_shift_norm=False, transformer_depth=1, context_dim=None, fuser_type=None, inpaint_mode=False,
+                 grounding_downsampler=None, grounding_tokenizer=None):
+        super().__init__()
+        assert fuser_type in ["gatedSA", "gatedSA2", "gatedCA"]
+        if grounding_downsampler is not None:
+            raise NotImplementedError("spatial grounding downsamplers (canny/hed/depth/normal/sem) are outside the MI355X hot path")
+        self.image_size, self.in_channels, self.model_channels, self.out_channels = image_size, in_channels, model_channels, out_channels
+        self.num_res_blocks, self.attention_resolutions, self.dropout = num_res_blocks, attention_resolutions, dropout
+        self.channel_mult, self.conv_resample, self.use_checkpoint = channel_mult, conv_resample, use_checkpoint
+        self.num_heads, self.context_dim, self.fuser_type, self.inpaint_mode = num_heads, context_dim, fuser_type, inpaint_mode
+        self.grounding_tokenizer_input = None  # set externally (gligen_inference.py:348-349)
+        self.downsample_net = None
+        self.additional_channel_from_downsampler = 0
+        self.first_conv_type = "SD"
+        self.first_conv_restorable = not inpaint_mode
+
+        mc, ted = model_channels, model_channels * 4
+        self.time_embed = _slots(3, i0=linear(mc, ted), i2=linear(ted, ted))
+        in_c = in_channels * 2 + 1 if inpaint_mode else in_channels  # latent | masked latent | mask
+        self.input_blocks = nn.ModuleList([TimestepEmbedSequential(conv_nd(dims, in_c, mc, 3, padding=1))])
+
+        def res(cin, cout):
+            return ResBlock(cin, ted, dropout, out_channels=cout, dims=dims, use_checkpoint=use_checkpoint,
+                            use_scale_shift_norm=use_scale_shift_norm)
+
+        def st(ch):
+            return SpatialTransformer(ch, key_dim=context_dim, value_dim=context_dim, n_heads=num_heads, d_head=ch // num_heads,
+                                      depth=transformer_depth, fuser_type=fuser_type, use_checkpoint=use_checkpoint)
+
+        skip_chans, ch, ds = [mc], mc, 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [res(ch, mult * mc)]
+                ch = mult * mc
+                if ds in attention_resolutions:
+                    layers.append(st(ch))
+                self.input_blocks.append(TimestepEmbedSequential(*layers))
+                skip_chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(TimestepEmbedSequential(Downsample(ch, conv_resample, dims=dims, out_channels=ch)))
+                skip_chans.append(ch)
+                ds *= 2
+        self.middle_block = TimestepEmbedSequential(res(ch, ch), st(ch), res(ch, ch))
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                layers = [res(ch + skip_chans.pop(), mc * mult)]
+                ch = mc * mult
+                if ds in attention_resolutions:
+                    layers.append(st(ch))
+                if level and i == num_res_blocks:
+                    layers.append(Upsample(ch, conv_resample, dims=dims, out_channels=ch))
+                    ds //= 2
+                self.output_blocks.append(TimestepEmbedSequential(*layers))
+        self.out = _slots(3, i0=normalization(ch), i2=zero_module(conv_nd(dims, mc, out_channels, 3, padding=1)))
+        self.position_net = instantiate_from_config(grounding_tokenizer)
+
+        self._engine = None
+        self._cond_key = None
+
+    # ---- engine lifecycle ---------------------------------------------------------------
+    def _apply(self, fn, *a, **k):  # .to()/.cuda()/.float(): parameters move, the packed copy is stale
+        self._drop_engine()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._drop_engine()
+        return super().load_state_dict(*a, **k)
+
+    def _drop_engine(self):
+        eng = self.__dict__.get("_engine")
+        if eng is not None:
+            eng.close()
+        self.__dict__["_engine"] = None
+        self.__dict__["_cond_key"] = None
+        self.__dict__["_first_conv_restored"] = False
+
+    @property
+    def engine(self):
+        """The native engine holding this model's packed bf16 weights (built on first use)."""
+        if self._engine is None:
+            self._engine = _rt.build_unet_engine(self)
+            self._cond_key = None
+        return self._engine
+
+    def fuser_scale(self):
+        from ldm.modules.attention import GatedCrossAttentionDense, GatedSelfAttentionDense
+        scales = {float(m.scale) for m in self.modules() if type(m) in (GatedSelfAttentionDense, GatedCrossAttentionDense)}
+        if len(scales) != 1:
+            raise NotImplementedError(f"per-layer fuser scales {sorted(scales)}: the engine applies one scale to all fusers")
+        return scales.pop()
+
+    def set_conditioning(self, context, grounding_input):
+        """Step-invariant work (grounding tokens, fuser projections, text K/V); cached by tensor identity."""
+        key = (_rt.tensor_fingerprint(context), _rt.mapping_fingerprint(grounding_input))
+        if key != self._cond_key:
+            self.engine.set_cond(context, grounding_input)
+            self._cond_key = key
+
+    # ---- reference API ------------------------------------------------------------------
+    SD_FIRST_CONV_FILE = "SD_input_conv_weight_bias.pth"  # cwd-relative, as in the reference
+
+    def load_sd_first_conv(self):
+        """(weight, bias) of the original SD first conv (reference openaimodel.py:404)."""
+        sd = torch.load(self.SD_FIRST_CONV_FILE)
+        return sd["weight"], sd["bias"]
+
+    def restore_first_conv_from_SD(self):
+        """Swap the first conv for the original SD one (reference openaimodel.py:400-413, called by
+        the samplers whenever the fuser gate is 0). The reference re-reads the file and rebuilds the
+        module at every such step; here the weights are copied in place once (module parameters and
+        the engine's packed copy), later calls are no-ops."""
+        if not self.first_conv_restorable:
+            print("First conv layer is not restorable and skipped this process, probably because this is an inpainting model?")
+            return
+        if self.__dict__.get("_first_conv_restored"):
+            return
+        w, b = self.load_sd_first_conv()
+        conv = self.input_blocks[0][0]
+        with torch.no_grad():
+            conv.weight.copy_(w.to(conv.weight))
+            conv.bias.copy_(b.to(conv.bias))
+        if self._engine is not None:
+            self._engine.restore_first_conv(conv.weight, conv.bias)
+        self.first_conv_type = "SD"
+        self.__dict__["_first_conv_restored"] = True
+
+    def restore_first_conv_from_GLIGEN(self):
+        raise NotImplementedError("not implemented by the reference either (openaimodel.py:416-417)")
+
+    @torch.no_grad()
+    def forward(self, input):
+        if self.training:
+            raise NotImplementedError("the MI355X engine implements inference; call model.eval()")
+        if "grounding_input" in input and input["grounding_input"] is not None:
+            grounding_input = input["grounding_input"]
+        else:  # guidance null case (reference openaimodel.py:422-426)
+            grounding_input = self.grounding_tokenizer_input.get_null_input()
+        eng = self.engine
+        self.set_conditioning(input["context"], grounding_input)
+        eng.set_fuser_scale(self.fuser_scale())
+        extra = input.get("inpainting_extra_input") if self.inpaint_mode else None
+        if self.inpaint_mode and extra is None:
+            raise ValueError("inpaint_mode model needs input['inpainting_extra_input']")
+        x = input["x"]
+        eps = eng.unet_forward(x, input["timesteps"], extra)
+        return eps.to(x.dtype)

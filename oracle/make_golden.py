@@ -1,0 +1,247 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (read-only import from /root/reference).
+
+Test infrastructure. Run in the build container only (the GPU box has no /root/reference):
+
+    cd /tmp && python /root/repo/oracle/make_golden.py [--only NAME ...]
+
+The reference's `ldm` / `grounding_input` packages collide by name with this repo's drop-in
+packages, so this script puts /root/reference first on sys.path and loads this repo's
+gligen_amd/synthetic.py by file path. Weights are never stored: both sides regenerate them from
+the per-key seeds in gligen_amd.synthetic; only inputs' seeds and the reference's outputs are saved.
+"""
+import argparse
+import ast
+import importlib.util
+import json
+import os
+import sys
+import time
+
+REF = "/root/reference"
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path = [p for p in sys.path if os.path.abspath(p or ".") != REPO]
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+syn = _load("gl_synthetic", os.path.join(REPO, "gligen_amd", "synthetic.py"))
+
+from ldm.models.autoencoder import AutoencoderKL  # noqa: E402  (reference)
+from ldm.models.diffusion.ldm import LatentDiffusion  # noqa: E402
+from ldm.models.diffusion.plms import PLMSSampler  # noqa: E402
+from ldm.modules.attention import GatedSelfAttentionDense  # noqa: E402
+from ldm.modules.diffusionmodules.openaimodel import UNetModel  # noqa: E402
+from ldm.util import instantiate_from_config  # noqa: E402
+
+assert sys.modules["ldm.util"].__file__.startswith(REF), "must import the reference's ldm package"
+OUT = os.path.join(REPO, "tests", "golden")
+GINPUT = {
+    "text": "grounding_input.text_grounding_tokinzer_input.GroundingNetInput",
+    "text_image": "grounding_input.text_image_grounding_tokinzer_input.GroundingNetInput",
+    "keypoint": "grounding_input.keypoint_grounding_tokinzer_input.GroundingNetInput",
+}
+
+
+def _extract_function(path, name):
+    """Pull one pure function out of a reference script whose module-level imports are unavailable."""
+    tree = ast.parse(open(path).read())
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == name:
+            ns = {"np": np, "torch": torch, "random": __import__("random")}
+            exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+            return ns[name]
+    raise KeyError(name)
+
+
+ref_alpha_generator = _extract_function(os.path.join(REF, "gligen_inference.py"), "alpha_generator")
+ref_draw_masks = _extract_function(os.path.join(REF, "inpaint_mask_func.py"), "draw_masks_from_boxes")
+
+
+def set_alpha_scale(model, alpha_scale):  # reference gligen_inference.py:24-28
+    for module in model.modules():
+        if type(module) == GatedSelfAttentionDense:
+            module.scale = alpha_scale
+
+
+def build_unet(cfg, kind, inpaint=False, seed=1234):
+    params = dict(cfg, grounding_tokenizer=syn.GROUNDING_TOKENIZERS[kind], inpaint_mode=inpaint)
+    model = UNetModel(**params).eval()
+    syn.fill_module_(model, seed)
+    model.grounding_tokenizer_input = instantiate_from_config(dict(target=GINPUT[kind]))
+    return model
+
+
+def unet_case(name, cfg, kind, B, hw, inpaint=False, n_valid=3):
+    t0 = time.time()
+    model = build_unet(cfg, kind, inpaint)
+    batch = syn.make_batch(kind, B, n_valid=n_valid, seed=1)
+    g = model.grounding_tokenizer_input.prepare(batch)
+    x = syn.make_latent(B, 4, hw, hw, seed=1)
+    ctx = syn.make_context(B, seed=1)
+    t = torch.tensor([981, 441][:B] if B <= 2 else [981] * B, dtype=torch.long)
+    extra = None
+    if inpaint:
+        mask = ref_draw_masks(batch["boxes"], hw)
+        z0 = syn.make_latent(B, 4, hw, hw, seed=2)
+        extra = torch.cat([z0 * mask, mask], dim=1)
+    inp = dict(x=x, timesteps=t, context=ctx, grounding_input=g, inpainting_extra_input=extra, grounding_extra_input=None)
+    out = {}
+    with torch.no_grad():
+        out["eps"] = model(inp).numpy()
+        inp_null = {k: v for k, v in inp.items() if k != "grounding_input"}
+        out["eps_null"] = model(inp_null).numpy()
+        set_alpha_scale(model, 0.3)
+        out["eps_scale03"] = model(inp).numpy()
+        set_alpha_scale(model, 1)
+        out["objs"] = model.position_net(**g).numpy()
+    meta = dict(cfg=cfg, kind=kind, B=B, hw=hw, inpaint=inpaint, n_valid=n_valid, weight_seed=1234,
+                n_keys=len(model.state_dict()), n_params=int(sum(p.numel() for p in model.parameters())))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), meta=json.dumps(meta), **out)
+    shapes = {k: list(v.shape) for k, v in model.state_dict().items()}
+    print(f"{name}: eps std {out['eps'].std():.4f} mean {out['eps'].mean():.4f}; cond-vs-null mse "
+          f"{((out['eps'] - out['eps_null']) ** 2).mean():.3e}; scale mse {((out['eps'] - out['eps_scale03']) ** 2).mean():.3e} "
+          f"[{time.time() - t0:.1f}s]")
+    return shapes
+
+
+def vae_case(name, dd, B, hw):
+    t0 = time.time()
+    ae = AutoencoderKL(ddconfig=dd, embed_dim=4, scale_factor=0.18215).eval()
+    syn.fill_module_(ae, 4321)
+    z = syn.make_latent(B, 4, hw, hw, seed=3) * 0.18215 * 4
+    with torch.no_grad():
+        img = ae.decode(z).numpy()
+    meta = dict(ddconfig=dd, B=B, hw=hw, weight_seed=4321, n_keys=len(ae.state_dict()))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), meta=json.dumps(meta), img=img)
+    print(f"{name}: img std {img.std():.4f} min {img.min():.3f} max {img.max():.3f} [{time.time() - t0:.1f}s]")
+    return {k: list(v.shape) for k, v in ae.state_dict().items()}
+
+
+class Recorder(torch.nn.Module):
+    """Mock UNet that records the call sequence (SURVEY.md §3.1 probe) and returns a cheap function of x."""
+
+    def __init__(self):
+        super().__init__()
+        self.fuser = GatedSelfAttentionDense(8, 8, 1, 8)
+        self.calls = []
+        self.restores = 0
+
+    def restore_first_conv_from_SD(self):
+        self.restores += 1
+
+    def forward(self, inp):
+        self.calls.append((int(inp["timesteps"][0]), "grounding_input" in inp, float(self.fuser.scale)))
+        return torch.tanh(inp["x"]) * (0.5 if "grounding_input" in inp else 0.3) + 0.01 * inp["timesteps"].float().view(-1, 1, 1, 1) / 1000
+
+
+def plms_trace_case(name, S, alpha_type):
+    diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000)
+    mock = Recorder()
+    from functools import partial
+    sampler = PLMSSampler(diffusion, mock, alpha_generator_func=partial(ref_alpha_generator, type=alpha_type), set_alpha_scale=set_alpha_scale)
+    x = syn.make_latent(2, 4, 8, 8, seed=5)
+    inp = dict(x=x.clone(), timesteps=None, context=torch.zeros(2, 1, 1), grounding_input={}, inpainting_extra_input=None, grounding_extra_input=None)
+    out = sampler.sample(S=S, shape=(2, 4, 8, 8), input=inp, uc=torch.ones(2, 1, 1), guidance_scale=7.5)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), x_out=out.numpy(), calls=np.asarray(mock.calls, dtype=np.float64),
+                        restores=mock.restores, ddim_timesteps=sampler.ddim_timesteps, ddim_alphas=np.asarray(sampler.ddim_alphas),
+                        ddim_alphas_prev=np.asarray(sampler.ddim_alphas_prev),
+                        meta=json.dumps(dict(S=S, alpha_type=alpha_type, guidance_scale=7.5)))
+    print(f"{name}: {len(mock.calls)} model calls, {mock.restores} first-conv restores")
+
+
+def plms_unet_case(name, S, hw, alpha_type, inpaint=False):
+    t0 = time.time()
+    from functools import partial
+    diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000)
+    model = build_unet(syn.UNET_CFG_SMALL, "text", inpaint)
+    # restore_first_conv_from_SD th.load()s a cwd-relative file: give it a seeded stand-in for the real
+    # SD weights (same shapes), so the test can rebuild the identical file without /root/reference
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    torch.save(syn.sd_first_conv_state(), os.path.join(tmp, "SD_input_conv_weight_bias.pth"))
+    os.chdir(tmp)
+    B = 2
+    batch = syn.make_batch("text", B, n_valid=3, seed=1)
+    g = model.grounding_tokenizer_input.prepare(batch)
+    x = syn.make_latent(B, 4, hw, hw, seed=6)
+    ctx, uc = syn.make_context(B, seed=1), syn.make_context(B, seed=9)
+    mask = z0 = extra = None
+    noise = None
+    if inpaint:
+        mask = ref_draw_masks(batch["boxes"], hw)
+        z0 = syn.make_latent(B, 4, hw, hw, seed=2)
+        extra = torch.cat([z0 * mask, mask], dim=1)
+        noise = torch.randn(S, B, 4, hw, hw, generator=torch.Generator().manual_seed(77))
+        draws = iter(noise)
+        diffusion_q = diffusion.q_sample
+        diffusion.q_sample = lambda x_start, t, noise=None: diffusion_q(x_start, t, noise=next(draws))
+    sampler = PLMSSampler(diffusion, model, alpha_generator_func=partial(ref_alpha_generator, type=alpha_type), set_alpha_scale=set_alpha_scale)
+    inp = dict(x=x.clone(), timesteps=None, context=ctx, grounding_input=g, inpainting_extra_input=extra, grounding_extra_input=None)
+    with torch.no_grad():
+        out = sampler.sample(S=S, shape=tuple(x.shape), input=inp, uc=uc, guidance_scale=7.5, mask=mask, x0=z0)
+    extra_out = {} if noise is None else dict(noise=noise.numpy())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), x_out=out.numpy(), **extra_out,
+                        meta=json.dumps(dict(S=S, hw=hw, alpha_type=alpha_type, guidance_scale=7.5, B=B, inpaint=inpaint, n_valid=3)))
+    print(f"{name}: x_out std {out.std():.4f} [{time.time() - t0:.1f}s]")
+
+
+def misc_case():
+    out = {}
+    for S in (20, 50):
+        for tp in (None, [0.3, 0.0, 0.7], [0.5, 0.25, 0.25]):
+            out[f"alpha_{S}_{'none' if tp is None else '_'.join(str(v) for v in tp)}"] = np.asarray(ref_alpha_generator(S, tp), dtype=np.float64)
+    boxes, _ = syn.make_boxes(2, 5, seed=3)
+    out["mask64"] = ref_draw_masks(boxes, 64).numpy()
+    out["mask_boxes"] = boxes.numpy()
+    diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000)
+    for k, v in diffusion.state_dict().items():
+        out["diff_" + k] = v.numpy()
+    from ldm.modules.diffusionmodules.util import timestep_embedding
+    out["temb"] = timestep_embedding(torch.tensor([1, 441, 981]), 320).numpy()
+    np.savez_compressed(os.path.join(OUT, "misc.npz"), **out)
+    print("misc: ok")
+
+
+CASES = {
+    "unet_small_text": lambda: unet_case("unet_small_text", syn.UNET_CFG_SMALL, "text", 2, 16),
+    "unet_small_text_image": lambda: unet_case("unet_small_text_image", syn.UNET_CFG_SMALL, "text_image", 2, 16),
+    "unet_small_keypoint": lambda: unet_case("unet_small_keypoint", syn.UNET_CFG_SMALL, "keypoint", 2, 16),
+    "unet_small_inpaint": lambda: unet_case("unet_small_inpaint", syn.UNET_CFG_SMALL, "text", 2, 16, inpaint=True),
+    "unet_full_text": lambda: unet_case("unet_full_text", syn.UNET_CFG, "text", 1, 16),
+    "vae_small": lambda: vae_case("vae_small", syn.VAE_DDCONFIG_SMALL, 2, 16),
+    "vae_full": lambda: vae_case("vae_full", syn.VAE_DDCONFIG, 1, 8),
+    "plms_trace_50": lambda: plms_trace_case("plms_trace_50", 50, [0.3, 0.0, 0.7]),
+    "plms_trace_20": lambda: plms_trace_case("plms_trace_20", 20, None),
+    "plms_unet_small": lambda: plms_unet_case("plms_unet_small", 5, 16, [0.6, 0.0, 0.4]),
+    "plms_unet_small_inpaint": lambda: plms_unet_case("plms_unet_small_inpaint", 4, 16, None, inpaint=True),
+    "misc": misc_case,
+}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*")
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    shapes = {}
+    for name, fn in CASES.items():
+        if args.only and name not in args.only:
+            continue
+        r = fn()
+        if isinstance(r, dict):
+            shapes[name] = r
+    if shapes:
+        path = os.path.join(OUT, "state_dict_shapes.json")
+        old = json.load(open(path)) if os.path.exists(path) else {}
+        old.update(shapes)
+        json.dump(old, open(path, "w"), sort_keys=True)

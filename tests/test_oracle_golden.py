@@ -1,0 +1,130 @@
+"""Pin the CPU oracle (oracle/gligen_oracle.py) to outputs of the REAL reference stored under
+tests/golden/ by oracle/make_golden.py. No GPU. fp32 vs fp32: only op-ordering noise is allowed."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden_shapes, grounding_kwargs, load_golden, mse, oracle_cfg, unet_inputs
+from gligen_amd import synthetic as syn
+from oracle import gligen_oracle as orc
+
+FP32_TOL = 1e-9  # MSE between two fp32 evaluations of the same graph
+
+
+@pytest.mark.parametrize("name", ["unet_small_text", "unet_small_text_image", "unet_small_keypoint", "unet_small_inpaint"])
+def test_unet_small(name):
+    g = load_golden(name)
+    meta = g["meta"]
+    sd = syn.seeded_state_dict(golden_shapes(name), meta["weight_seed"])
+    batch, x, ctx, t, extra = unet_inputs(meta)
+    gk = grounding_kwargs(meta["kind"], batch)
+    cfg = oracle_cfg(meta["cfg"], meta["kind"])
+    inp = dict(x=x, timesteps=t, context=ctx, grounding_input=gk, inpainting_extra_input=extra)
+    with torch.no_grad():
+        assert mse(orc.position_net(sd, "position_net", meta["kind"], gk), g["objs"]) < FP32_TOL
+        assert mse(orc.unet_forward(sd, cfg, inp), g["eps"]) < FP32_TOL
+        inp_null = dict(inp, grounding_input=orc.null_grounding(meta["kind"], gk))
+        assert mse(orc.unet_forward(sd, cfg, inp_null), g["eps_null"]) < FP32_TOL
+        assert mse(orc.unet_forward(sd, cfg, inp, fuser_scale=0.3), g["eps_scale03"]) < FP32_TOL
+    # the fixture is not vacuous: grounding and the gate scale change eps measurably
+    assert mse(g["eps"], g["eps_scale03"]) > 1e-4
+    assert g["eps"].std() > 0.1
+
+
+def test_unet_full():
+    """All 966 tensors / 1.07 B parameters of the shipped SD-1.4 GLIGEN UNet, latent 16x16."""
+    g = load_golden("unet_full_text")
+    meta = g["meta"]
+    shapes = golden_shapes("unet_full_text")
+    assert len(shapes) == 966 and meta["n_params"] == 1068623204
+    sd = syn.seeded_state_dict(shapes, meta["weight_seed"])
+    batch, x, ctx, t, extra = unet_inputs(meta)
+    inp = dict(x=x, timesteps=t, context=ctx, grounding_input=grounding_kwargs("text", batch))
+    with torch.no_grad():
+        assert mse(orc.unet_forward(sd, oracle_cfg(meta["cfg"], "text"), inp), g["eps"]) < FP32_TOL
+
+
+@pytest.mark.parametrize("name", ["vae_small", "vae_full"])
+def test_vae_decode(name):
+    g = load_golden(name)
+    meta = g["meta"]
+    sd = syn.seeded_state_dict(golden_shapes(name), meta["weight_seed"])
+    z = syn.make_latent(meta["B"], 4, meta["hw"], meta["hw"], seed=3) * 0.18215 * 4
+    dd = meta["ddconfig"]
+    with torch.no_grad():
+        img = orc.vae_decode(sd, dict(ch_mult=dd["ch_mult"], num_res_blocks=dd["num_res_blocks"], scale_factor=0.18215), z)
+    assert mse(img, g["img"]) < 1e-8
+
+
+def test_schedule_and_small_functions():
+    m = load_golden("misc")
+    sched = orc.make_schedule()
+    np.testing.assert_allclose(sched["alphas_cumprod"], m["diff_alphas_cumprod"], rtol=1e-6)
+    np.testing.assert_allclose(sched["sqrt_alphas_cumprod"], m["diff_sqrt_alphas_cumprod"], rtol=1e-6)
+    np.testing.assert_allclose(sched["sqrt_one_minus_alphas_cumprod"], m["diff_sqrt_one_minus_alphas_cumprod"], rtol=1e-6)
+    for S in (20, 50):
+        for tp, tag in ((None, "none"), ([0.3, 0.0, 0.7], "0.3_0.0_0.7"), ([0.5, 0.25, 0.25], "0.5_0.25_0.25")):
+            np.testing.assert_allclose(np.asarray(orc.alpha_generator(S, tp), dtype=np.float64), m[f"alpha_{S}_{tag}"])
+    boxes = torch.from_numpy(m["mask_boxes"])
+    assert np.array_equal(orc.draw_masks_from_boxes(boxes, 64).numpy(), m["mask64"])
+    np.testing.assert_allclose(orc.timestep_embedding(torch.tensor([1, 441, 981]), 320).numpy(), m["temb"], atol=1e-6)
+    for name in ("plms_trace_50", "plms_trace_20"):
+        tr = load_golden(name)
+        ps = orc.plms_schedule(tr["meta"]["S"], sched)
+        assert np.array_equal(ps["ddim_timesteps"], tr["ddim_timesteps"])
+        np.testing.assert_allclose(ps["ddim_alphas"], tr["ddim_alphas"], rtol=1e-6)
+        np.testing.assert_allclose(ps["ddim_alphas_prev"], tr["ddim_alphas_prev"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["plms_trace_50", "plms_trace_20"])
+def test_plms_loop_against_reference_trace(name):
+    """Same call sequence (timestep, cond/uncond, gate scale) and same final latent as the reference sampler
+    driving a cheap mock model (102 calls for S=50, 42 for S=20)."""
+    tr = load_golden(name)
+    S, atype = tr["meta"]["S"], tr["meta"]["alpha_type"]
+    calls = []
+
+    def eps_fn(x, t, cond, scale):
+        calls.append((int(t[0]), bool(cond), float(scale)))
+        return torch.tanh(x) * (0.5 if cond else 0.3) + 0.01 * t.float().view(-1, 1, 1, 1) / 1000
+
+    x = syn.make_latent(2, 4, 8, 8, seed=5)
+    out = orc.plms_sample(eps_fn, x, S, orc.make_schedule(), 7.5, alphas=orc.alpha_generator(S, atype))
+    ref_calls = [(int(a), bool(b), float(c)) for a, b, c in tr["calls"]]
+    assert calls == ref_calls
+    assert mse(out, tr["x_out"]) < 1e-10
+
+
+@pytest.mark.parametrize("name", ["plms_unet_small", "plms_unet_small_inpaint"])
+def test_plms_with_unet(name):
+    g = load_golden(name)
+    meta = g["meta"]
+    shapes = golden_shapes("unet_small_inpaint" if meta["inpaint"] else "unet_small_text")
+    sd = syn.seeded_state_dict(shapes, 1234)
+    B, hw, S = meta["B"], meta["hw"], meta["S"]
+    batch = syn.make_batch("text", B, n_valid=meta["n_valid"], seed=1)
+    gk = grounding_kwargs("text", batch)
+    gnull = orc.null_grounding("text", gk)
+    ctx, uc = syn.make_context(B, seed=1), syn.make_context(B, seed=9)
+    cfg = oracle_cfg(syn.UNET_CFG_SMALL, "text")
+    mask = z0 = extra = noise = None
+    if meta["inpaint"]:
+        mask = orc.draw_masks_from_boxes(batch["boxes"], hw)
+        z0 = syn.make_latent(B, 4, hw, hw, seed=2)
+        extra = torch.cat([z0 * mask, mask], dim=1)
+        noise = torch.from_numpy(g["noise"])
+
+    def eps_fn(x, t, cond, scale):
+        inp = dict(x=x, timesteps=t, context=ctx if cond else uc, grounding_input=gk if cond else gnull, inpainting_extra_input=extra)
+        return orc.unet_forward(sd, cfg, inp, fuser_scale=scale)
+
+    def swap_in_sd_first_conv():  # model.restore_first_conv_from_SD(); skipped for inpainting models
+        if not meta["inpaint"]:
+            sdc = syn.sd_first_conv_state()
+            sd["input_blocks.0.0.weight"], sd["input_blocks.0.0.bias"] = sdc["weight"], sdc["bias"]
+
+    with torch.no_grad():
+        out = orc.plms_sample(eps_fn, syn.make_latent(B, 4, hw, hw, seed=6), S, orc.make_schedule(), 7.5,
+                              alphas=orc.alpha_generator(S, meta["alpha_type"]), mask=mask, x0=z0, noise=noise,
+                              on_gate_off=swap_in_sd_first_conv)
+    assert mse(out, g["x_out"]) < 1e-7
