@@ -70,6 +70,7 @@ SYMBOLS = {
     "gl_unet_forward": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P]),
     "gl_vae_decode": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "gl_sample_plms": (_I, [_P, C.POINTER(PlmsArgs), _P]),
+    "gl_sampler_timing": (_I, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(_I)]),
     "gl_to_uint8": (_I, [_P, _P, _I, _I, _I, _P]),
     "gl_arena_high_water": (_I, [_P, C.POINTER(C.c_size_t)]),
     "gl_launch_count": (_I, [_P, C.POINTER(C.c_int64)]),

@@ -143,6 +143,14 @@ int gl_sample_plms(gl_ctx* ctx, const gl_plms_args* args, gl_stream s) {
     GL_API_END
 }
 
+int gl_sampler_timing(gl_ctx* ctx, float* avg_unet_eval_ms, float* first_eval_ms, int* n_evals) {
+    NEED(ctx);
+    if (!avg_unet_eval_ms || !first_eval_ms || !n_evals) return gl::set_error(GL_ERR_ARG, "null pointer");
+    GL_API_BEGIN
+    ctx->eng->sampler_timing(avg_unet_eval_ms, first_eval_ms, n_evals);
+    GL_API_END
+}
+
 int gl_to_uint8(const float* img, uint8_t* out, int B, int C, int HW, gl_stream s) {
     if (!img || !out) return gl::set_error(GL_ERR_ARG, "null pointer");
     return to_uint8_launch(img, out, B, C, HW, S(s));

@@ -108,6 +108,7 @@ class Engine {
                       int extraB, float* eps, hipStream_t s);
     void vae_decode(int B, int h, int w, const float* z, float* out, hipStream_t s);
     void sample_plms(const gl_plms_args& a, hipStream_t s);
+    void sampler_timing(float* avg_ms, float* first_ms, int* n);
 
     // single-op entry points (tests / profiling)
     Arena& arena() { return arena_; }
@@ -214,6 +215,10 @@ class Engine {
         int64_t* t_dev = nullptr;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
+        hipStream_t stream = nullptr;  // engine-owned capture/replay stream
+        hipEvent_t ev_in = nullptr, ev_out = nullptr;
+        std::vector<hipEvent_t> tev;  // (start, stop) per UNet evaluation of the last run
+        int n_evals = 0;
         bool has_extra = false;
         const float* extra = nullptr;
     } smp_;

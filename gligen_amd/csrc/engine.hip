@@ -66,6 +66,10 @@ Engine::Engine(int device) : device_(device) {}
 
 Engine::~Engine() {
     sampler_release_graph();
+    for (hipEvent_t e : smp_.tev) (void)hipEventDestroy(e);
+    if (smp_.ev_in) (void)hipEventDestroy(smp_.ev_in);
+    if (smp_.ev_out) (void)hipEventDestroy(smp_.ev_out);
+    if (smp_.stream) (void)hipStreamDestroy(smp_.stream);
     for (auto& kv : raw_)
         if (kv.second.p) (void)hipFree(kv.second.p);
     for (void* p : owned_) (void)hipFree(p);
@@ -1086,6 +1090,24 @@ void Engine::vae_decode(int B, int h, int w, const float* z, float* out, hipStre
 }
 
 // ---------------------------------------------------------------- PLMS sampler (plms.py:65-162)
+// HIP-event time of the UNet evaluations of the last sample_plms call (on the engine's stream).
+void Engine::sampler_timing(float* avg_ms, float* first_ms, int* n) {
+    if (!smp_.stream || smp_.n_evals == 0) throw GlError(GL_ERR_STATE, "no sampling run to report");
+    HIPCK(hipStreamSynchronize(smp_.stream));
+    double sum = 0;
+    int cnt = 0;
+    float first = 0.f;
+    for (int i = 0; i < smp_.n_evals; ++i) {
+        float ms = 0.f;
+        HIPCK(hipEventElapsedTime(&ms, smp_.tev[2 * i], smp_.tev[2 * i + 1]));
+        if (i == 0) first = ms;
+        if (i >= 2 || smp_.n_evals <= 2) { sum += ms; ++cnt; }  // skip the eager warm-up eval and the capture
+    }
+    *avg_ms = cnt ? (float)(sum / cnt) : 0.f;
+    *first_ms = first;
+    *n = smp_.n_evals;
+}
+
 void Engine::sampler_release_graph() {
     if (smp_.exec) (void)hipGraphExecDestroy(smp_.exec);
     if (smp_.graph) (void)hipGraphDestroy(smp_.graph);
@@ -1093,8 +1115,18 @@ void Engine::sampler_release_graph() {
     smp_.graph = nullptr;
 }
 
-void Engine::sample_plms(const gl_plms_args& a, hipStream_t s) {
+void Engine::sample_plms(const gl_plms_args& a, hipStream_t caller) {
     if (!has_unet_ || !finalized_) throw GlError(GL_ERR_STATE, "unet not finalized");
+    // The loop runs on an engine-owned non-blocking stream (the legacy default stream cannot be
+    // captured into a hipGraph), ordered after / before the caller's stream with events.
+    if (!smp_.stream) {
+        HIPCK(hipStreamCreateWithFlags(&smp_.stream, hipStreamNonBlocking));
+        HIPCK(hipEventCreateWithFlags(&smp_.ev_in, hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&smp_.ev_out, hipEventDisableTiming));
+    }
+    hipStream_t s = smp_.stream;
+    HIPCK(hipEventRecord(smp_.ev_in, caller));
+    HIPCK(hipStreamWaitEvent(s, smp_.ev_in, 0));
     const gl_unet_config& c = ucfg_;
     if (a.n_steps < 1 || !a.timesteps || !a.a_t || !a.a_prev || !a.x) throw GlError(GL_ERR_ARG, "sample_plms: missing schedule or latent");
     if (a.mask && (!a.x0 || !a.noise || !a.sqrt_ac || !a.sqrt_1mac)) throw GlError(GL_ERR_ARG, "sample_plms: mask needs x0, noise and q_sample coefficients");
@@ -1120,6 +1152,12 @@ void Engine::sample_plms(const gl_plms_args& a, hipStream_t s) {
     auto eval = [&](const float* xin, int64_t t) {
         HIPCK(hipMemcpyAsync(smp_.x2, xin, n * sizeof(float), hipMemcpyDeviceToDevice, s));
         CK(fill_i64_launch(smp_.t_dev, t, Beff, s));
+        while ((int)smp_.tev.size() < 2 * (evals + 1)) {
+            hipEvent_t e;
+            HIPCK(hipEventCreate(&e));
+            smp_.tev.push_back(e);
+        }
+        HIPCK(hipEventRecord(smp_.tev[2 * evals], s));
         if (a.use_graph && evals >= 1) {
             if (!smp_.exec) {
                 HIPCK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -1140,7 +1178,9 @@ void Engine::sample_plms(const gl_plms_args& a, hipStream_t s) {
         } else {
             unet_forward(Beff, a.h, a.w, smp_.x2, a.B, smp_.t_dev, a.inpaint_extra, a.B, smp_.eps_pair, s);
         }
+        HIPCK(hipEventRecord(smp_.tev[2 * evals + 1], s));
         ++evals;
+        smp_.n_evals = evals;
     };
 
     bool restored = false;
@@ -1176,6 +1216,8 @@ void Engine::sample_plms(const gl_plms_args& a, hipStream_t s) {
             CK(plms_update_launch(P, s));
         }
     }
+    HIPCK(hipEventRecord(smp_.ev_out, s));
+    HIPCK(hipStreamWaitEvent(caller, smp_.ev_out, 0));
 }
 
 }  // namespace gl

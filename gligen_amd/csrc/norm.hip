@@ -126,6 +126,7 @@ int groupnorm_launch(const GNParams& P, hipStream_t stream) {
     if (C % 64 != 0 || (P.C1 && P.C0 % 8 != 0)) return set_error(GL_ERR_ARG, "groupnorm: C=%d (C0=%d) unsupported", C, P.C0);
     const int cpg = C / 32;
     const int C8 = C / 8;
+    if (cpg < 4 || (cpg & 1)) return set_error(GL_ERR_UNSUPPORTED, "groupnorm: %d channels per group (need an even number >= 4)", cpg);
     if (C8 > 1024) return set_error(GL_ERR_ARG, "groupnorm: C=%d too large", C);
     const int R = max(1, 256 / C8);
     const int nsplit = gn_nsplit(P.HW);

@@ -199,6 +199,12 @@ class Engine:
         self._keep_plms = keep
         return x
 
+    def sampler_timing(self):
+        """(mean UNet-evaluation ms over graph replays, first eager evaluation ms, number of evaluations)."""
+        a, f, n = C.c_float(), C.c_float(), C.c_int()
+        check(self.lib.gl_sampler_timing(self._ctx, C.byref(a), C.byref(f), C.byref(n)))
+        return float(a.value), float(f.value), int(n.value)
+
     def to_uint8(self, img: torch.Tensor) -> torch.Tensor:
         img = _f32(img, self.device)
         B, Cc, H, W = img.shape

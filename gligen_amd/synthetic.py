@@ -20,7 +20,7 @@ UNET_CFG = dict(image_size=64, in_channels=4, out_channels=4, model_channels=320
 UNET_CFG_SMALL = dict(UNET_CFG, channel_mult=[1, 2], attention_resolutions=[2, 1], num_res_blocks=1)
 VAE_DDCONFIG = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
                     num_res_blocks=2, attn_resolutions=[], dropout=0.0)
-VAE_DDCONFIG_SMALL = dict(VAE_DDCONFIG, ch=64, ch_mult=[1, 2], num_res_blocks=1)
+VAE_DDCONFIG_SMALL = dict(VAE_DDCONFIG, ch=128, ch_mult=[1, 2], num_res_blocks=1)
 GROUNDING_TOKENIZERS = {
     "text": dict(target="ldm.modules.diffusionmodules.text_grounding_net.PositionNet", params=dict(in_dim=768, out_dim=768)),
     "text_image": dict(target="ldm.modules.diffusionmodules.text_image_grounding_net.PositionNet", params=dict(in_dim=768, out_dim=768)),
@@ -40,25 +40,39 @@ def _is_norm(key: str, shape) -> bool:
         "in_layers.0.weight", "in_layers.0.bias", "out_layers.0.weight", "out_layers.0.bias", "out.0.weight", "out.0.bias")
 
 
-def seeded_tensor(key: str, shape: Tuple[int, ...], seed: int = 1234) -> torch.Tensor:
-    g = _gen(key, seed)
+def seeded_tensor(key: str, shape: Tuple[int, ...], seed: int = 1234, device="cpu") -> torch.Tensor:
+    """The fixture value of one parameter. device='cpu' is the canonical fixture (what the goldens were made
+    with); on a cuda device the same rules draw from the device generator (fast, for benchmarks)."""
+    if str(device) == "cpu":
+        g = _gen(key, seed)
+    else:
+        g = torch.Generator(device=device).manual_seed((zlib.crc32(key.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
+    kw = dict(generator=g, device=device)
     shape = tuple(shape)
     if len(shape) == 0:  # fuser alpha_attn / alpha_dense: tanh(0.7) ~ 0.6 so the gated path matters
-        return torch.tensor(0.7) + 0.2 * torch.randn((), generator=g)
+        return torch.tensor(0.7, device=device) + 0.2 * torch.randn((), **kw)
     if _is_norm(key, shape):
         if key.endswith(".weight"):
-            return 1.0 + 0.1 * torch.randn(shape, generator=g)
-        return 0.05 * torch.randn(shape, generator=g)
+            return 1.0 + 0.1 * torch.randn(shape, **kw)
+        return 0.05 * torch.randn(shape, **kw)
     if len(shape) >= 2 and "embeddings" not in key:
         fan_in = 1
         for s in shape[1:]:
             fan_in *= s
         bound = fan_in ** -0.5
         gain = 0.5 if any(t in key for t in ("out_layers.3.", "proj_out.", "out.2.")) else 1.0
-        return (torch.rand(shape, generator=g) * 2 - 1) * bound * gain * 1.7320508
+        return (torch.rand(shape, **kw) * 2 - 1) * bound * gain * 1.7320508
     if "null_" in key or "embeddings" in key:
-        return 0.5 * torch.randn(shape, generator=g)
-    return 0.02 * torch.randn(shape, generator=g)  # biases
+        return 0.5 * torch.randn(shape, **kw)
+    return 0.02 * torch.randn(shape, **kw)  # biases
+
+
+def fill_module_on_device_(module: torch.nn.Module, seed: int = 1234) -> torch.nn.Module:
+    """Like fill_module_ but drawing on the module's (cuda) device: same distributions, not the same numbers."""
+    with torch.no_grad():
+        for k, v in module.state_dict().items():
+            v.copy_(seeded_tensor(k, tuple(v.shape), seed, device=v.device))
+    return module
 
 
 def seeded_state_dict(shapes: Mapping[str, Tuple[int, ...]], seed: int = 1234) -> Dict[str, torch.Tensor]:

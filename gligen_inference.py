@@ -247,12 +247,21 @@ def synthetic_config(kind="text", inpaint=False, image_size=64):
     }
 
 
-def load_synthetic(kind="text", inpaint=False, image_size=64, seed=1234):
-    """Seeded random-weight stand-ins for (model, autoencoder, diffusion, config)."""
+def load_synthetic(kind="text", inpaint=False, image_size=64, seed=1234, fast=False):
+    """Seeded random-weight stand-ins for (model, autoencoder, diffusion, config).
+    fast=True materialises the 1.07 B parameters directly on the device (same init distributions,
+    drawn from the device generator) instead of filling them on the CPU and copying."""
     from gligen_amd import synthetic as syn
     config = synthetic_config(kind, inpaint, image_size)
-    model = syn.fill_module_(instantiate_from_config(config["model"]).eval(), seed).to(device)
-    autoencoder = syn.fill_module_(instantiate_from_config(config["autoencoder"]).eval(), seed + 1).to(device)
+    if fast:
+        with torch.device("meta"):
+            model = instantiate_from_config(config["model"]).eval()
+            autoencoder = instantiate_from_config(config["autoencoder"]).eval()
+        model = syn.fill_module_on_device_(model.to_empty(device=device), seed)
+        autoencoder = syn.fill_module_on_device_(autoencoder.to_empty(device=device), seed + 1)
+    else:
+        model = syn.fill_module_(instantiate_from_config(config["model"]).eval(), seed).to(device)
+        autoencoder = syn.fill_module_(instantiate_from_config(config["autoencoder"]).eval(), seed + 1).to(device)
     diffusion = instantiate_from_config(config["diffusion"]).to(device)
     return model, autoencoder, diffusion, config
 

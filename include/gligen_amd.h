@@ -116,6 +116,9 @@ int gl_unet_forward(gl_ctx* ctx, int Beff, int h, int w, const float* x, int xB,
 int gl_vae_decode(gl_ctx* ctx, int B, int h, int w, const float* z, float* img, gl_stream s);
 /* PLMSSampler.plms_sampling (plms.py:65-108) with classifier-free guidance (plms.py:116-122) */
 int gl_sample_plms(gl_ctx* ctx, const gl_plms_args* args, gl_stream s);
+/* HIP-event timing of the UNet evaluations of the last gl_sample_plms call, measured on the stream
+ * they ran on: mean over the graph-replayed evaluations, the first (eager) one, and their count. */
+int gl_sampler_timing(gl_ctx* ctx, float* avg_unet_eval_ms, float* first_eval_ms, int* n_evals);
 /* clamp(-1,1)*0.5+0.5 -> *255 -> uint8 HWC (gligen_inference.py:443-445) */
 int gl_to_uint8(const float* img, uint8_t* out, int B, int C, int HW, gl_stream s);
 

@@ -14,6 +14,10 @@ import torch
 from ldm.modules.diffusionmodules.util import make_ddim_sampling_parameters, make_ddim_timesteps
 
 
+def _np(x):
+    return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+
+
 class PLMSSampler(object):
     def __init__(self, diffusion, model, schedule="linear", alpha_generator_func=None, set_alpha_scale=None):
         super().__init__()
@@ -88,8 +92,8 @@ class PLMSSampler(object):
             model.engine.set_fuser_scale(model.fuser_scale())
 
         img = input["x"].to(device=model.engine.device, dtype=torch.float32).contiguous().clone()
-        a_t = np.asarray(self.ddim_alphas, dtype=np.float32)[::-1].copy()          # index = S - i - 1
-        a_prev = np.asarray(self.ddim_alphas_prev, dtype=np.float32)[::-1].copy()
+        a_t = _np(self.ddim_alphas).astype(np.float32)[::-1].copy()          # index = S - i - 1
+        a_prev = _np(self.ddim_alphas_prev).astype(np.float32)[::-1].copy()
         extra = {}
         if mask is not None:
             assert x0 is not None
@@ -134,7 +138,7 @@ class PLMSSampler(object):
             return e
 
         def step_back(x, e, index):
-            a_t, a_prev = float(self.ddim_alphas[index]), float(self.ddim_alphas_prev[index])
+            a_t, a_prev = float(self.ddim_alphas[index]), float(self.ddim_alphas_prev[index])  # noqa: E501
             pred_x0 = (x - float(np.sqrt(1.0 - a_t)) * e) / float(np.sqrt(a_t))
             return float(np.sqrt(a_prev)) * pred_x0 + float(np.sqrt(1.0 - a_prev)) * e
 
