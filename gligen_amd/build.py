@@ -17,6 +17,9 @@ CSRC = HERE / "csrc"
 INCLUDE = HERE.parent / "include"
 LIB = HERE / "libgligen_amd.so"
 SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "misc.hip", "engine.hip", "capi.hip"]
+# attention: keep MFMA accumulators in VGPRs (gfx950 has one unified register file); the default AGPR
+# form costs a v_accvgpr_read/write pair per accumulator per KV tile around the softmax rescale
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -44,7 +47,7 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
 
     def compile_one(src: str) -> Path:
         obj = objdir / (src + ".o")
-        cmd = [hipcc, *FLAGS, "-I", str(INCLUDE), "-c", str(CSRC / src), "-o", str(obj)]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-I", str(INCLUDE), "-c", str(CSRC / src), "-o", str(obj)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
@@ -58,7 +61,19 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
+    build_kbench()
     return LIB
+
+
+def build_kbench() -> Path:
+    """Developer tool: per-shape kernel micro-benchmark (csrc/kbench.hip), linked against the library."""
+    exe = HERE / "build" / "kbench"
+    cmd = [_hipcc(), *FLAGS, "-I", str(INCLUDE), str(CSRC / "kbench.hip"), "-o", str(exe),
+           "-L", str(HERE), "-lgligen_amd", "-Wl,-rpath,$ORIGIN/.."]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"kbench build failed:\n{r.stderr}")
+    return exe
 
 
 if __name__ == "__main__":

@@ -24,7 +24,10 @@
 
 namespace gl {
 
-template <int DP, int DPV>
+// ONES (DPV > d): the first padding row of V^T (row d) holds 1.0 for every key, so the P V product
+// itself accumulates the softmax denominator in O^T row d (same bf16 P as the numerator) and the
+// per-lane VALU row sum disappears; see attn_vt_ones_launch.
+template <int DP, int DPV, bool ONES>
 __global__ void __launch_bounds__(256) attn_kernel(AttnParams P) {
     constexpr int KS = DP / 16;
     constexpr int DT = DPV / 32;
@@ -153,7 +156,15 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams P) {
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[u][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx * c);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        // the running max stops growing after the first few tiles: rescale O only when some row's did
+        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
+        }
         m_run = m_new;
         float psum = 0.f;
         bf16x8 pb0, pb1, pb2, pb3;
@@ -162,7 +173,7 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams P) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float p = __builtin_amdgcn_exp2f(fmaf(st[u][r], c, -m_new));
-                psum += p;
+                if constexpr (!ONES) psum += p;
                 st[u][r] = p;
             }
 #pragma unroll
@@ -172,11 +183,7 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams P) {
             pb2[e] = f2bf(st[1][e]);
             pb3[e] = f2bf(st[1][8 + e]);
         }
-        l_run = fmaf(l_run, alpha, psum);
-#pragma unroll
-        for (int i = 0; i < DT; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
+        if constexpr (!ONES) l_run += psum;
 
         // ---- O^T += V^T P^T
 #pragma unroll
@@ -196,7 +203,22 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams P) {
         __syncthreads();
     }
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float l_tot;
+    if constexpr (ONES) {
+        // O^T row d: tile i = d / 32, offset off -> register ((off>>3)<<2 | off&3) of the half (off>>2)&1
+        const int off = P.d & 31;
+        const int rr = ((off >> 3) << 2) | (off & 3);
+        float cand = 0.f;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (i == (P.d >> 5) && r == rr) cand = ot[i][r];
+        const float other = __shfl_xor(cand, 32, 64);
+        l_tot = (((off >> 2) & 1) == half) ? cand : other;
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    }
     const float inv = 1.f / l_tot;
     if (myq < P.Nq) {
         bf16* orow = P.o + ((size_t)b * P.o_rows_per_b + myq) * P.ldo + h * P.d;
@@ -215,11 +237,11 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams P) {
     }
 }
 
-template <int DP, int DPV>
+template <int DP, int DPV, bool ONES>
 static int launch_attn(const AttnParams& P, int B, hipStream_t stream) {
     constexpr int KROW = DP * 2 + 16, VROW = 144;
     size_t lds = 2 * (64 * KROW + DPV * VROW);
-    auto kfn = attn_kernel<DP, DPV>;
+    auto kfn = attn_kernel<DP, DPV, ONES>;
     static bool attr_done = false;  // once per instantiation; never inside a stream capture
     if (!attr_done && lds > 48 * 1024) {
         GL_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -240,14 +262,29 @@ int attn_dims(int d, int* DP, int* DPV) {
     }
 }
 
+// Row d of every [DPV][Tk_pad] V^T slab := 1.0 (no-op when DPV == d). Called once per buffer, right
+// after allocation: the projection epilogue only ever writes rows < d.
+__global__ void vt_ones_kernel(bf16* vt, int DPV, int Tk_pad, int d) {
+    bf16* row = vt + ((size_t)blockIdx.x * DPV + d) * Tk_pad;
+    for (int i = threadIdx.x; i < Tk_pad; i += blockDim.x) row[i] = (bf16)1.0f;
+}
+int attn_vt_ones_launch(bf16* vt, int BH, int d, int Tk_pad, hipStream_t stream) {
+    int dp, dpv;
+    GL_TRY(attn_dims(d, &dp, &dpv));
+    if (dpv == d) return GL_OK;
+    hipLaunchKernelGGL(vt_ones_kernel, dim3(BH), dim3(256), 0, stream, vt, dpv, Tk_pad, d);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
 int attn_launch(const AttnParams& P, int B, hipStream_t stream) {
     if (P.Nq <= 0 || P.Nk <= 0) return set_error(GL_ERR_ARG, "attention: empty Nq=%d Nk=%d", P.Nq, P.Nk);
     if (P.Tq_pad % 128 != 0 || P.Tk_pad % 64 != 0 || P.Tq_pad < P.Nq || P.Tk_pad < P.Nk)
         return set_error(GL_ERR_ARG, "attention: bad padding Tq_pad=%d Tk_pad=%d (Nq=%d Nk=%d)", P.Tq_pad, P.Tk_pad, P.Nq, P.Nk);
     switch (P.d) {
-        case 40: return launch_attn<48, 64>(P, B, stream);
-        case 80: return launch_attn<80, 96>(P, B, stream);
-        case 160: return launch_attn<160, 160>(P, B, stream);
+        case 40: return launch_attn<48, 64, true>(P, B, stream);
+        case 80: return launch_attn<80, 96, true>(P, B, stream);
+        case 160: return launch_attn<160, 160, false>(P, B, stream);
         default: return set_error(GL_ERR_UNSUPPORTED, "attention: head dim %d not supported (40, 80, 160)", P.d);
     }
 }

@@ -190,13 +190,14 @@ int gl_op_geglu(gl_ctx* ctx, const void* x, const float* w_f32, const float* b_f
     ar.reset();
     bf16* wp = ar.get<bf16>((size_t)2 * inner * K);
     float* bp = ar.get<float>((size_t)2 * inner);
-    int r = pack_geglu_launch(w_f32, b_f32, wp, bp, inner, K, S(s));
+    const int layout = gl::gemm_geglu_layout();
+    int r = pack_geglu_launch(w_f32, b_f32, wp, bp, inner, K, layout, S(s));
     if (r != GL_OK) throw GlError(r, gl::last_error());
     AOperand A;
     aoperand_rows(A, (const bf16*)x, K, K);
     Epilogue E;
     epilogue_defaults(E);
-    E.act = ACT_GEGLU; E.out = y; E.ldo = inner; E.bias = bp;
+    E.act = ACT_GEGLU; E.geglu16 = layout; E.out = y; E.ldo = inner; E.bias = bp;
     r = gemm_launch(A, wp, M, 2 * inner, K, E, ctx->eng->splitk_ws(), ctx->eng->splitk_ws_bytes(), S(s));
     if (r != GL_OK) throw GlError(r, gl::last_error());
     GL_API_END

@@ -59,7 +59,7 @@ struct ResW {
 };
 struct SelfAttnW { const bf16* wqk = nullptr; const bf16* wv = nullptr; LinW out; };
 struct CrossAttnW { LinW q; const bf16* wk = nullptr; const bf16* wv = nullptr; LinW out; int ctx_dim = 0; };
-struct FFW { const bf16* w1 = nullptr; const float* b1 = nullptr; LinW w2; int C = 0; };
+struct FFW { const bf16* w1 = nullptr; const float* b1 = nullptr; LinW w2; int C = 0; int geglu16 = 0; };
 struct STW {
     int C = 0, d = 0, idx = 0;
     NormW gn;

@@ -194,7 +194,8 @@ FFW Engine::ffw(const std::string& p, int C) {
     if (C8 != 8 * C || K != C) throw GlError(GL_ERR_ARG, "'" + p + "' GEGLU projection has unexpected shape");
     bf16* wp = reinterpret_cast<bf16*>(persist((size_t)C8 * K * sizeof(bf16), false));
     float* bp = reinterpret_cast<float*>(persist(C8 * sizeof(float), false));
-    CK(pack_geglu_launch(w.p, F(p + ".net.0.proj.bias"), wp, bp, 4 * C, K, 0));
+    f.geglu16 = gemm_geglu_layout();
+    CK(pack_geglu_launch(w.p, F(p + ".net.0.proj.bias"), wp, bp, 4 * C, K, f.geglu16, 0));
     f.w1 = wp;
     f.b1 = bp;
     f.w2 = linear(p + ".net.2");
@@ -616,6 +617,8 @@ AttnBufs& Engine::attn_bufs(int B, int H, int d, int Tq, int Tk) {
     b.q = reinterpret_cast<bf16*>(persist((size_t)B * H * Tq_pad * dp * sizeof(bf16), true));
     b.k = reinterpret_cast<bf16*>(persist((size_t)B * H * Tk_pad * dp * sizeof(bf16), true));
     b.vt = reinterpret_cast<bf16*>(persist((size_t)B * H * dpv * Tk_pad * sizeof(bf16), true));
+    CK(attn_vt_ones_launch(b.vt, B * H, d, Tk_pad, 0));  // denominator row (attention.hip), once per buffer
+    HIPCK(hipStreamSynchronize(0));
     return attn_bufs_.emplace(key, b).first->second;
 }
 
@@ -660,7 +663,7 @@ bf16* Engine::feedforward(const FFW& f, const bf16* ln, int M, const bf16* res, 
     aoperand_rows(A, ln, C, C);
     Epilogue E;
     epilogue_defaults(E);
-    E.act = ACT_GEGLU; E.out = hbuf; E.ldo = 4 * C; E.bias = f.b1;
+    E.act = ACT_GEGLU; E.geglu16 = f.geglu16; E.out = hbuf; E.ldo = 4 * C; E.bias = f.b1;
     gemm(A, f.w1, M, 8 * C, C, E, s);
     return linear_rows(hbuf, M, f.w2, ACT_NONE, res, gate, s);
 }
@@ -781,7 +784,9 @@ void Engine::set_cond(int Beff, const float* context, int n_ctx, const gl_ground
             cond_.objs.push_back(reinterpret_cast<bf16*>(palloc((size_t)Beff * Ng * t.C * sizeof(bf16))));
             cond_.ctx_k.push_back(reinterpret_cast<bf16*>(palloc((size_t)Beff * heads * ctx_Tpad * dp * sizeof(bf16))));
             cond_.ctx_vt.push_back(reinterpret_cast<bf16*>(palloc((size_t)Beff * heads * dpv * ctx_Tpad * sizeof(bf16))));
+            CK(attn_vt_ones_launch(cond_.ctx_vt.back(), Beff * heads, t.d, ctx_Tpad, 0));
         }
+        HIPCK(hipStreamSynchronize(0));
         cond_.Beff = Beff;
         cond_.Ng = Ng;
         cond_.ctx_Tpad = ctx_Tpad;

@@ -45,6 +45,7 @@ struct Epilogue {
     int n_real;         // EPI_NCHW_F32: number of real output channels (<= N)
     // EPI_ROWMAJOR optional row remap: out row = (m / remap_in) * remap_out + m % remap_in + remap_off
     int remap_in, remap_out, remap_off;
+    int geglu16;        // ACT_GEGLU: weight rows packed for the 16x16-tile kernel (pack_geglu layout 1)
 };
 
 // C[M][N] = A[M][K] * W[N][K]^T (+ epilogue). W is row-major bf16 with leading dim K.
@@ -59,6 +60,11 @@ int gemm_launch_t(const bf16* Wrows, int Mw, const bf16* X, int Nx, int K, const
                   hipStream_t stream);
 
 void epilogue_defaults(Epilogue& E);
+// developer switch (kbench A/B): 0 = register-staged main loop, 1 = LDS-DMA main loop, 2 = persistent 16x16-tile kernel (default)
+void gemm_set_variant(int v);
+int gemm_geglu_layout();
+void gemm_force_cfg(int tm, int tn, int splits);   // 0,0,0 = automatic
+void gemm_last_cfg(int* tm, int* tn, int* splits);
 void aoperand_rows(AOperand& A, const bf16* p, int K, int ld);
 
 }  // namespace gl

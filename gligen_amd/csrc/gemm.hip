@@ -24,6 +24,8 @@
 //    the low-resolution layers whose M x N grid cannot fill 256 CUs.
 #include "gemm.h"
 
+#include <cstdlib>
+
 namespace gl {
 
 void epilogue_defaults(Epilogue& E) {
@@ -137,6 +139,58 @@ __device__ __forceinline__ void epi_geglu4(const Epilogue& E, int m, int nv0, fl
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = val[i] * gelu_erf_f(gate[i]);
     store_bf16x4(reinterpret_cast<bf16*>(E.out) + (size_t)m * E.ldo + j0, o);
+}
+
+// Accumulator -> memory for one wave: lane (frow, fhalf) holds output row m0 + 32 i and, per 32x32
+// tile, four groups of 4 consecutive columns starting at n0 + 32 j + 8 q.
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const Epilogue& E, int M, int N, int m0, int n0w,
+                                              float* __restrict__ ws) {
+    const bool split = gridDim.z > 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + i * 32;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nb = n0w + j * 32;
+            if (split) {
+                float* dst = ws + ((size_t)blockIdx.z * M + m) * N;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int n0 = nb + 8 * q;
+                    if (n0 < N)
+                        *reinterpret_cast<float4*>(dst + n0) =
+                            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                }
+            } else if (E.act == ACT_GEGLU) {
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    int nv0 = nb + 16 * qq;
+                    if (nv0 < N) {
+                        float val[4], gate[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            val[e] = acc[i][j][8 * qq + e];
+                            gate[e] = acc[i][j][8 * qq + 4 + e];
+                        }
+                        epi_geglu4(E, m, nv0, val, gate);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int n0 = nb + 8 * q;
+                    if (n0 < N) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+                        epi_finish4(E, m, n0, v);
+                    }
+                }
+            }
+        }
+    }
 }
 
 template <int WM, int WN, int TM, int TN, int AMODE>
@@ -312,50 +366,435 @@ gemm_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilogu
         }
     }
 
-    // ---- epilogue
-    const bool split = gridDim.z > 1;
+    gemm_epilogue<TM, TN>(acc, E, M, N, m_base + wm * TM * 32 + frow, n_base + wn * TN * 32 + 4 * fhalf, ws);
+}
+
+// 128 zero bytes: the source of every out-of-range 16-byte chunk (conv padding taps, M / N tails)
+// for the LDS-DMA loader below, which cannot write an immediate.
+__device__ uint4 g_zero_chunk[8];
+
+#define GL_GLDS16(gsrc, ldst)                                                                      \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),       \
+                                     (__attribute__((address_space(3))) void*)(ldst), 16, 0, 0)
+
+// v2 main loop: both operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per
+// wave-instruction = 8 tile rows x 128 B), no VGPR staging and no ds_write pass. The LDS image a
+// wave-instruction writes is lane-linear, so the bank swizzle is applied to the per-lane SOURCE
+// chunk (lane at position p of row r fetches logical chunk p ^ ((r>>1)&7)) and undone by the same
+// XOR in the fragment reads. Two LDS stages: tile t+1 is in flight while tile t is multiplied.
+template <int WM, int WN, int TM, int TN, int AMODE>
+__global__ void __launch_bounds__(WM * WN * 64)
+gemm_glds_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilogue E,
+                 float* __restrict__ ws, int kt_per_split, int tiles_n, int n_tiles) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    constexpr int RPP = NT / 8;  // tile rows covered by one pass of 16-byte loads
+    constexpr int XP = BM / RPP;
+    constexpr int WP = BN / RPP;
+    static_assert(BM % RPP == 0 && BN % RPP == 0 && RPP % 16 == 0, "tile/loader mismatch");
+    constexpr int STAGE = (BM + BN) * 128;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int r0 = t >> 3;
+    const int ch8 = ((t & 7) ^ ((r0 >> 1) & 7)) * 8;  // element offset of this lane's source chunk
+
+    // XCD-aware tile order: hardware places block b on XCD b % 8; give every XCD a contiguous
+    // range of tiles so the blocks that share an activation row-panel share an L2.
+    int bid = blockIdx.x;
+    {
+        const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid / tiles_n;
+    const int tile_n = bid - tile_m * tiles_n;
+    const int m_base = tile_m * BM;
+    const int n_base = tile_n * BN;
+
+    const int nk = K >> 6;
+    const int kt0 = blockIdx.z * kt_per_split;
+    const int kt1 = min(nk, kt0 + kt_per_split);
+
+    const bf16* zsrc = reinterpret_cast<const bf16*>(g_zero_chunk);
+
+    int64_t xo0[XP], xo1[XP];
+    int xb[XP], xy[XP], xx[XP];
+    bool xv[XP];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m_base + (wm * TM + i) * 32 + frow;
-        if (m >= M) continue;
+    for (int i = 0; i < XP; ++i) {
+        int m = m_base + r0 + i * RPP;
+        xv[i] = m < M;
+        if constexpr (AMODE == A_ROWS) {
+            xo0[i] = (int64_t)m * A.ld0;
+            xo1[i] = (int64_t)m * A.ld1;
+            xb[i] = xy[i] = xx[i] = 0;
+        } else {
+            int ox = m % A.Wo;
+            int tmp = m / A.Wo;
+            int oy = tmp % A.Ho;
+            xb[i] = (tmp / A.Ho) * A.Hin;
+            xy[i] = oy * A.stride - A.pad_lo;
+            xx[i] = ox * A.stride - A.pad_lo;
+            xo0[i] = xo1[i] = 0;
+        }
+    }
+    const bf16* wp[WP];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int nb = n_base + (wn * TN + j) * 32 + 4 * fhalf;
-            if (split) {
-                float* dst = ws + ((size_t)blockIdx.z * M + m) * N;
+    for (int i = 0; i < WP; ++i) {
+        int n = n_base + r0 + i * RPP;
+        wp[i] = n < N ? W + (int64_t)n * K + ch8 : nullptr;
+    }
+    const int Cin = A.C0 + A.C1;
+    const int Hup = A.Hin << A.ups;
+    const int Wup = A.Win << A.ups;
+
+    auto issue = [&](int kt, int buf) {
+        unsigned char* xs = smem + buf * STAGE + wave * 1024;
+        unsigned char* wsm = xs + BM * 128;
+        const int k0 = kt << 6;
+        if constexpr (AMODE == A_ROWS) {
+            const bool first = k0 < A.C0;
+            const bf16* base = (first ? A.p0 : A.p1) + (first ? k0 : k0 - A.C0) + ch8;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    int n0 = nb + 8 * q;
-                    if (n0 < N)
-                        *reinterpret_cast<float4*>(dst + n0) =
-                            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-                }
-            } else if (E.act == ACT_GEGLU) {
+            for (int i = 0; i < XP; ++i) {
+                const bf16* src = xv[i] ? base + (first ? xo0[i] : xo1[i]) : zsrc;
+                GL_GLDS16(src, xs + i * RPP * 128);
+            }
+        } else {
+            const int tap = k0 / Cin;
+            const int c = k0 - tap * Cin;
+            const int ky = tap / 3;
+            const int kx = tap - ky * 3;
+            const bool first = c < A.C0;
+            const bf16* base = (first ? A.p0 : A.p1) + (first ? c : c - A.C0) + ch8;
+            const int ld = first ? A.ld0 : A.ld1;
 #pragma unroll
-                for (int qq = 0; qq < 2; ++qq) {
-                    int nv0 = nb + 16 * qq;
-                    if (nv0 < N) {
-                        float val[4], gate[4];
+            for (int i = 0; i < XP; ++i) {
+                const int iy = xy[i] + ky;
+                const int ix = xx[i] + kx;
+                const bool ok = xv[i] && iy >= 0 && iy < Hup && ix >= 0 && ix < Wup;
+                const int64_t pix = ((int64_t)(xb[i] + (iy >> A.ups))) * A.Win + (ix >> A.ups);
+                const bf16* src = ok ? base + pix * ld : zsrc;
+                GL_GLDS16(src, xs + i * RPP * 128);
+            }
+        }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            val[e] = acc[i][j][8 * qq + e];
-                            gate[e] = acc[i][j][8 * qq + 4 + e];
-                        }
-                        epi_geglu4(E, m, nv0, val, gate);
-                    }
-                }
+        for (int i = 0; i < WP; ++i) {
+            const bf16* src = wp[i] ? wp[i] + k0 : zsrc;
+            GL_GLDS16(src, wsm + i * RPP * 128);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31;
+    const int fhalf = lane >> 5;
+
+    // fragments of k-step s+1 are fetched from LDS while the MFMAs of k-step s issue
+    auto compute = [&](int buf) {
+        const unsigned char* xs = smem + buf * STAGE;
+        const unsigned char* wsm = xs + BM * 128;
+        auto ldfrag = [&](int s, bf16x8 (&xf)[TM], bf16x8 (&wf)[TN]) {
+            const int c = 2 * s + fhalf;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                int row = (wm * TM + i) * 32 + frow;
+                xf[i] = *reinterpret_cast<const bf16x8*>(xs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int row = (wn * TN + j) * 32 + frow;
+                wf[j] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+            }
+        };
+        auto mma = [&](const bf16x8 (&xf)[TM], const bf16x8 (&wf)[TN]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        };
+        bf16x8 xa[TM], wa[TN], xb2[TM], wb2[TN];
+        ldfrag(0, xa, wa);
+        ldfrag(1, xb2, wb2);
+        mma(xa, wa);
+        ldfrag(2, xa, wa);
+        mma(xb2, wb2);
+        ldfrag(3, xb2, wb2);
+        mma(xa, wa);
+        mma(xb2, wb2);
+    };
+
+    if (kt0 < kt1) {
+        issue(kt0, 0);
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int buf = (kt - kt0) & 1;
+            // tile kt has landed (own DMA drained, then the barrier covers the other waves') and every
+            // wave is done reading the other stage, which the next issue overwrites
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < kt1) issue(kt + 1, buf ^ 1);
+            compute(buf);
+        }
+    }
+
+    gemm_epilogue<TM, TN>(acc, E, M, N, m_base + wm * TM * 32 + frow, n_base + wn * TN * 32 + 4 * fhalf, ws);
+}
+
+// GEGLU epilogue for the 16x16-tile kernel: packed weight rows come in groups of 32 = 16 value
+// features followed by the 16 matching gate features (pack_geglu layout 1), so accumulator tile
+// 2g holds values and tile 2g+1 gates for the same (row, 4 features) in the same lane.
+__device__ __forceinline__ void epi_geglu4_t16(const Epilogue& E, int m, int nv0, float val[4], float gate[4]) {
+    if (E.bias) {
+        float4 bv = *reinterpret_cast<const float4*>(E.bias + nv0);
+        float4 bg = *reinterpret_cast<const float4*>(E.bias + nv0 + 16);
+        val[0] += bv.x; val[1] += bv.y; val[2] += bv.z; val[3] += bv.w;
+        gate[0] += bg.x; gate[1] += bg.y; gate[2] += bg.z; gate[3] += bg.w;
+    }
+    const int j0 = (nv0 >> 5) * 16 + (nv0 & 15);
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = val[i] * gelu_erf_f(gate[i]);
+    store_bf16x4(reinterpret_cast<bf16*>(E.out) + (size_t)m * E.ldo + j0, o);
+}
+
+// ---------------------------------------------------------------------------------------------
+// v3: persistent tile loop. grid = min(#work items, 2 blocks x 256 CUs); a block walks work items
+// (output tile x K split) item = blockIdx.x, + gridDim.x, ... and keeps ONE software pipeline
+// running across item boundaries: the LDS-DMA of the next item's first K tile is issued before
+// the last MFMAs of the current item, so its latency (and the other resident block's epilogue)
+// hides behind matrix work instead of serialising with it. Tiles are 2x2 waves of TM x TN
+// v_mfma_f32_16x16x32_bf16 fragments: BN = 160 divides every UNet channel count (320 / 640 /
+// 960 / 1280 / 1920 / 2560 ...) exactly, BN = 128 serves GEGLU pairs and the VAE.
+struct WorkDesc {
+    int tiles_n;
+    int splits;
+    int kt_per_split;
+    int n_items;
+};
+
+template <int TM, int TN, int AMODE>
+__global__ void __launch_bounds__(256, 2)
+gemm_p_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilogue E, float* __restrict__ ws, WorkDesc wd) {
+    constexpr int BM = TM * 32;
+    constexpr int BN = TN * 32;
+    constexpr int XP = BM / 32;
+    constexpr int WP = BN / 32;
+    constexpr int STAGE = (BM + BN) * 128;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1;
+    const int wn = wave & 1;
+    const int r0 = t >> 3;
+    const int ch8 = ((t & 7) ^ ((r0 >> 1) & 7)) * 8;  // element offset of this lane's source chunk
+    const int nk = K >> 6;
+    const bf16* zsrc = reinterpret_cast<const bf16*>(g_zero_chunk);
+    const int Cin = A.C0 + A.C1;
+    const int Hup = A.Hin << A.ups;
+    const int Wup = A.Win << A.ups;
+
+    // work item -> (tile_m, tile_n, split); items are renumbered so every XCD (block b sits on XCD b % 8,
+    // and gridDim.x % 8 == 0 whenever a block runs more than one item) walks a contiguous range
+    auto decode = [&](int w, int& tm, int& tn, int& z) {
+        const int q = wd.n_items >> 3, r = wd.n_items & 7, xcd = w & 7, idx = w >> 3;
+        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int tile = id / wd.splits;
+        z = id - tile * wd.splits;
+        tm = tile / wd.tiles_n;
+        tn = tile - tm * wd.tiles_n;
+    };
+
+    // ---- load cursor
+    int l_item = blockIdx.x, l_kt = 0, l_kt_end = 0;
+    int xm[XP], xy[XP], xx[XP];  // A_ROWS: xm = row or -1.  A_CONV3: xm = b * Hin, (xy, xx) = top-left tap
+    int wrow[WP];
+    auto setup_load = [&](int item) {
+        int tm, tn, z;
+        decode(item, tm, tn, z);
+        l_kt = z * wd.kt_per_split;
+        l_kt_end = min(nk, l_kt + wd.kt_per_split);
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const int m = tm * BM + r0 + i * 32;
+            const bool ok = m < M;
+            if constexpr (AMODE == A_ROWS) {
+                xm[i] = ok ? m : -1;
+                xy[i] = xx[i] = 0;
             } else {
+                const int ox = m % A.Wo;
+                const int tmp = m / A.Wo;
+                const int oy = tmp % A.Ho;
+                xm[i] = (tmp / A.Ho) * A.Hin;
+                xy[i] = ok ? oy * A.stride - A.pad_lo : -(1 << 20);
+                xx[i] = ox * A.stride - A.pad_lo;
+            }
+        }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    int n0 = nb + 8 * q;
-                    if (n0 < N) {
-                        float v[4];
+        for (int i = 0; i < WP; ++i) {
+            const int n = tn * BN + r0 + i * 32;
+            wrow[i] = n < N ? n : -1;
+        }
+    };
+
+    auto issue = [&](int kt, int buf) {
+        unsigned char* xs = smem + buf * STAGE + wave * 1024;
+        unsigned char* wsm = xs + BM * 128;
+        const int k0 = kt << 6;
+        if constexpr (AMODE == A_ROWS) {
+            const bool first = k0 < A.C0;
+            const bf16* base = (first ? A.p0 : A.p1) + (first ? k0 : k0 - A.C0) + ch8;
+            const int ld = first ? A.ld0 : A.ld1;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-                        epi_finish4(E, m, n0, v);
+            for (int i = 0; i < XP; ++i) {
+                const bf16* src = xm[i] >= 0 ? base + (int64_t)xm[i] * ld : zsrc;
+                GL_GLDS16(src, xs + i * 4096);
+            }
+        } else {
+            const int tap = k0 / Cin;
+            const int c = k0 - tap * Cin;
+            const int ky = tap / 3;
+            const int kx = tap - ky * 3;
+            const bool first = c < A.C0;
+            const bf16* base = (first ? A.p0 : A.p1) + (first ? c : c - A.C0) + ch8;
+            const int ld = first ? A.ld0 : A.ld1;
+#pragma unroll
+            for (int i = 0; i < XP; ++i) {
+                const int iy = xy[i] + ky;
+                const int ix = xx[i] + kx;
+                const bool ok = iy >= 0 && iy < Hup && ix >= 0 && ix < Wup;
+                const int64_t pix = ((int64_t)(xm[i] + (iy >> A.ups))) * A.Win + (ix >> A.ups);
+                const bf16* src = ok ? base + pix * ld : zsrc;
+                GL_GLDS16(src, xs + i * 4096);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WP; ++i) {
+            const bf16* src = wrow[i] >= 0 ? W + (int64_t)wrow[i] * K + k0 + ch8 : zsrc;
+            GL_GLDS16(src, wsm + i * 4096);
+        }
+    };
+
+    f32x4 acc[TM][TN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+
+    // fragment addressing: lane reads row (16 t + l15), 16-byte chunk 4 s + (lane >> 4); rows start at
+    // multiples of 16, so the swizzle term ((row >> 1) & 7) is the lane constant l15 >> 1
+    const int l15 = lane & 15;
+    const int foff0 = l15 * 128 + ((((lane >> 4)) ^ (l15 >> 1)) << 4);
+    const int foff1 = l15 * 128 + ((((lane >> 4) + 4) ^ (l15 >> 1)) << 4);
+    const int xrow0 = wm * TM * 16 * 128;
+    const int wrow0 = BM * 128 + wn * TN * 16 * 128;
+
+    auto compute = [&](int buf) {
+        const unsigned char* st = smem + buf * STAGE;
+        bf16x8 xa[TM], wa[TN], xb[TM], wb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xa[i] = *reinterpret_cast<const bf16x8*>(st + xrow0 + i * 2048 + foff0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wa[j] = *reinterpret_cast<const bf16x8*>(st + wrow0 + j * 2048 + foff0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xb[i] = *reinterpret_cast<const bf16x8*>(st + xrow0 + i * 2048 + foff1);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wb[j] = *reinterpret_cast<const bf16x8*>(st + wrow0 + j * 2048 + foff1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xa[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xb[i], acc[i][j], 0, 0, 0);
+    };
+
+    auto epilogue = [&](int tm, int tn, int z) {
+        const int mrow = tm * BM + wm * TM * 16 + l15;
+        const int ncol = tn * BN + wn * TN * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = mrow + i * 16;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n0 = ncol + j * 16;
+                if (n0 >= N) continue;
+                if (wd.splits > 1) {
+                    *reinterpret_cast<float4*>(ws + ((size_t)z * M + m) * N + n0) =
+                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                } else if (E.act == ACT_GEGLU) {
+                    if constexpr (TN % 2 == 0) {
+                        if ((j & 1) == 0) {
+                            float val[4], gate[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                val[e] = acc[i][j][e];
+                                gate[e] = acc[i][j + 1 < TN ? j + 1 : j][e];
+                            }
+                            epi_geglu4_t16(E, m, n0, val, gate);
+                        }
                     }
+                } else {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
+                    epi_finish4(E, m, n0, v);
                 }
             }
+        }
+    };
+
+    // ---- pipeline over the flattened (item, K tile) sequence
+    if (l_item >= wd.n_items) return;
+    setup_load(l_item);
+    int c_item = l_item, c_tm, c_tn, c_z;
+    decode(c_item, c_tm, c_tn, c_z);
+    int c_left = l_kt_end - l_kt;
+    issue(l_kt, 0);
+    int buf = 0;
+    for (;;) {
+        // tile in stage `buf` has landed (own DMA drained, barrier covers the other waves') and every wave
+        // has finished reading stage buf^1, which the next issue overwrites
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        bool more = true;
+        if (++l_kt >= l_kt_end) {
+            l_item += gridDim.x;
+            more = l_item < wd.n_items;
+            if (more) setup_load(l_item);
+        }
+        if (more) issue(l_kt, buf ^ 1);
+        compute(buf);
+        buf ^= 1;
+        if (--c_left == 0) {
+            epilogue(c_tm, c_tn, c_z);
+            c_item += gridDim.x;
+            if (c_item >= wd.n_items) break;
+            zero_acc();
+            decode(c_item, c_tm, c_tn, c_z);
+            c_left = min(nk, (c_z + 1) * wd.kt_per_split) - c_z * wd.kt_per_split;
         }
     }
 }
@@ -369,7 +808,18 @@ splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, Epi
          idx += (int64_t)gridDim.x * blockDim.x) {
         int m = (int)(idx / groups);
         int n0 = (int)(idx - (int64_t)m * groups) << 2;
-        if (E.act == ACT_GEGLU) {
+        if (E.act == ACT_GEGLU && E.geglu16) {
+            if (n0 & 16) continue;  // gate groups are consumed by their value group
+            float val[4] = {0, 0, 0, 0}, gate[4] = {0, 0, 0, 0};
+            for (int z = 0; z < splits; ++z) {
+                const float* p = ws + ((size_t)z * M + m) * N + n0;
+                float4 a = *reinterpret_cast<const float4*>(p);
+                float4 b = *reinterpret_cast<const float4*>(p + 16);
+                val[0] += a.x; val[1] += a.y; val[2] += a.z; val[3] += a.w;
+                gate[0] += b.x; gate[1] += b.y; gate[2] += b.z; gate[3] += b.w;
+            }
+            epi_geglu4_t16(E, m, n0, val, gate);
+        } else if (E.act == ACT_GEGLU) {
             if (n0 & 8) continue;  // gate groups are consumed by their value group
             float val[4] = {0, 0, 0, 0}, gate[4] = {0, 0, 0, 0};
             for (int z = 0; z < splits; ++z) {
@@ -391,6 +841,23 @@ splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, Epi
     }
 }
 
+static int g_gemm_variant = -1;  // 0: register-staged v1, 1: LDS-DMA v2, 2: persistent 16x16-tile v3 (default)
+void gemm_set_variant(int v) { g_gemm_variant = v; }
+static int gemm_variant() {
+    if (g_gemm_variant < 0) {
+        const char* e = getenv("GL_GEMM_VARIANT");
+        g_gemm_variant = e ? atoi(e) : 2;
+    }
+    return g_gemm_variant;
+}
+// GEGLU weight-row packing the current main-loop variant expects (pack_geglu_launch layout argument)
+int gemm_geglu_layout() { return gemm_variant() == 2 ? 1 : 0; }
+
+static int g_force_tm = 0, g_force_tn = 0, g_force_splits = 0;  // developer override (kbench sweeps)
+void gemm_force_cfg(int tm, int tn, int splits) { g_force_tm = tm; g_force_tn = tn; g_force_splits = splits; }
+static int g_last_cfg[3] = {0, 0, 0};
+void gemm_last_cfg(int* tm, int* tn, int* splits) { *tm = g_last_cfg[0]; *tn = g_last_cfg[1]; *splits = g_last_cfg[2]; }
+
 namespace {
 
 struct Cfg {
@@ -407,24 +874,109 @@ int launch_cfg(const AOperand& A, const bf16* W, int M, int N, int K, const Epil
     dim3 grid(tiles_m * tiles_n, 1, splits);
     dim3 block(WM * WN * 64);
     size_t lds = 2 * (BM + BN) * 128;
-    if (A.mode == A_ROWS) {
-        auto kfn = gemm_kernel<WM, WN, TM, TN, A_ROWS>;
-        static bool attr_done = false;  // once per instantiation; never inside a stream capture
-        if (!attr_done && lds > 48 * 1024) {
-            GL_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_done = true;
-        }
-        hipLaunchKernelGGL(kfn, grid, block, lds, stream, A, W, M, N, K, E, ws, kt_per_split, tiles_n);
+    const int n_tiles = tiles_m * tiles_n;
+#define GL_LAUNCH_ONE(KFN, ...)                                                                                  \
+    do {                                                                                                         \
+        auto kfn = KFN;                                                                                          \
+        static bool attr_done = false; /* once per instantiation; never inside a stream capture */              \
+        if (!attr_done && lds > 48 * 1024) {                                                                     \
+            GL_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            attr_done = true;                                                                                    \
+        }                                                                                                        \
+        hipLaunchKernelGGL(kfn, grid, block, lds, stream, A, W, M, N, K, E, ws, kt_per_split, tiles_n, ##__VA_ARGS__); \
+    } while (0)
+    if (gemm_variant() == 0) {
+        if (A.mode == A_ROWS) GL_LAUNCH_ONE((gemm_kernel<WM, WN, TM, TN, A_ROWS>));
+        else GL_LAUNCH_ONE((gemm_kernel<WM, WN, TM, TN, A_CONV3>));
     } else {
-        auto kfn = gemm_kernel<WM, WN, TM, TN, A_CONV3>;
-        static bool attr_done = false;
-        if (!attr_done && lds > 48 * 1024) {
-            GL_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_done = true;
-        }
-        hipLaunchKernelGGL(kfn, grid, block, lds, stream, A, W, M, N, K, E, ws, kt_per_split, tiles_n);
+        if (A.mode == A_ROWS) GL_LAUNCH_ONE((gemm_glds_kernel<WM, WN, TM, TN, A_ROWS>), n_tiles);
+        else GL_LAUNCH_ONE((gemm_glds_kernel<WM, WN, TM, TN, A_CONV3>), n_tiles);
     }
+#undef GL_LAUNCH_ONE
     GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+}  // namespace
+
+namespace {
+
+template <int TM, int TN>
+int launch_p(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, float* ws, const WorkDesc& wd,
+             hipStream_t stream) {
+    dim3 grid(wd.n_items < 512 ? wd.n_items : 512);
+    dim3 block(256);
+    const size_t lds = 2 * (TM * 32 + TN * 32) * 128;
+#define GL_LAUNCH_P(KFN)                                                                                         \
+    do {                                                                                                         \
+        auto kfn = KFN;                                                                                          \
+        static bool attr_done = false; /* once per instantiation; never inside a stream capture */              \
+        if (!attr_done && lds > 48 * 1024) {                                                                     \
+            GL_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            attr_done = true;                                                                                    \
+        }                                                                                                        \
+        hipLaunchKernelGGL(kfn, grid, block, lds, stream, A, W, M, N, K, E, ws, wd);                             \
+    } while (0)
+    if (A.mode == A_ROWS) GL_LAUNCH_P((gemm_p_kernel<TM, TN, A_ROWS>));
+    else GL_LAUNCH_P((gemm_p_kernel<TM, TN, A_CONV3>));
+#undef GL_LAUNCH_P
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+// Tile shape + K split for the persistent kernel: minimise a cycle model of
+//   (items per block) x (K tiles per item x cycles per K tile + fixed per-item cost) + split-K reduce pass
+// over the tile shapes {128,64} x {160,128} and a few split counts.
+int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, float* ws, size_t ws_bytes,
+                  hipStream_t stream) {
+    static const int kTm[4] = {4, 4, 2, 2}, kTn[4] = {5, 4, 5, 4};
+    static const int kSp[9] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
+    const int nk = K / 64;
+    double best_t = 1e30;
+    int best_c = -1, best_sp = 1;
+    for (int c = 0; c < 4; ++c) {
+        const int tm = kTm[c], tn = kTn[c];
+        if (g_force_tm && (tm != g_force_tm || tn != g_force_tn)) continue;
+        if (E.act == ACT_GEGLU && (tn & 1)) continue;
+        const int tiles = cdiv(M, tm * 32) * cdiv(N, tn * 32);
+        for (int si = 0; si < 9; ++si) {
+            int sp = kSp[si];
+            if (g_force_splits && sp != g_force_splits) continue;
+            if (sp > 1 && (!ws || nk / sp < 2 || (size_t)sp * M * N * sizeof(float) > ws_bytes)) continue;
+            const int kps = cdiv(nk, sp);
+            sp = cdiv(nk, kps);
+            const int items = tiles * sp;
+            const int per_block = cdiv(items, 512);
+            const double mfma = tm * tn * 2;                                  // 16x16x32 MFMAs per wave per K tile
+            const double t_kt = items <= 256 ? 30.0 * mfma : 44.0 * mfma;   // alone on the CU / sharing its SIMDs
+            const double t_item = kps * t_kt + 2500.0;
+            double tt = per_block * t_item;
+            if (sp > 1) tt += 4000.0 + (double)sp * M * N * 8.0 / 2400.0;
+            if (tt < best_t) { best_t = tt; best_c = c; best_sp = sp; }
+        }
+    }
+    if (best_c < 0) return set_error(GL_ERR_ARG, "gemm: no tile configuration for M=%d N=%d K=%d", M, N, K);
+    WorkDesc wd;
+    const int tm = kTm[best_c], tn = kTn[best_c];
+    wd.tiles_n = cdiv(N, tn * 32);
+    wd.kt_per_split = cdiv(nk, best_sp);
+    wd.splits = cdiv(nk, wd.kt_per_split);
+    wd.n_items = cdiv(M, tm * 32) * wd.tiles_n * wd.splits;
+    g_last_cfg[0] = tm; g_last_cfg[1] = tn; g_last_cfg[2] = wd.splits;
+    int rc;
+    switch (best_c) {
+        case 0: rc = launch_p<4, 5>(A, W, M, N, K, E, ws, wd, stream); break;
+        case 1: rc = launch_p<4, 4>(A, W, M, N, K, E, ws, wd, stream); break;
+        case 2: rc = launch_p<2, 5>(A, W, M, N, K, E, ws, wd, stream); break;
+        default: rc = launch_p<2, 4>(A, W, M, N, K, E, ws, wd, stream); break;
+    }
+    GL_TRY(rc);
+    if (wd.splits > 1) {
+        int64_t total = (int64_t)M * (N / 4);
+        int blocks = (int)fmin((double)cdiv64(total, 256), 4096.0);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws, wd.splits, M, N, E);
+        GL_LAUNCH_CHECK();
+    }
     return GL_OK;
 }
 
@@ -444,6 +996,9 @@ int gemm_launch(const AOperand& A, const bf16* W, int M, int N, int K, const Epi
     }
     if (E.act == ACT_GEGLU && (N % 32 != 0 || E.mode != EPI_ROWMAJOR))
         return set_error(GL_ERR_ARG, "gemm: GEGLU epilogue needs packed N %% 32 == 0 (N=%d)", N);
+    if (E.act == ACT_GEGLU && E.geglu16 != gemm_geglu_layout())
+        return set_error(GL_ERR_STATE, "gemm: GEGLU weights were packed for a different main-loop variant");
+    if (gemm_variant() == 2 && (N >= 128 || E.act == ACT_GEGLU)) return gemm_p_launch(A, W, M, N, K, E, ws, ws_bytes, stream);
 
     // pick the tile: padding efficiency x relative tile speed x chip fill
     int best = 0;

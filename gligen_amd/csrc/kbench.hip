@@ -1,0 +1,291 @@
+// kbench — per-shape micro-benchmark of the gligen_amd kernels (developer tool, not shipped in
+// the library). Reads the launch inventory written by tools/shapes.py, runs every distinct shape on
+// random bf16 data through the same launch functions the engine uses, times it with HIP events on
+// the launch stream and prints µs, TFLOP/s / GB/s and the count-weighted total per forward.
+//
+//   kbench <shapes-file> [reps] [filter]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "attention.h"
+#include "gemm.h"
+#include "misc.h"
+#include "norm.h"
+
+using namespace gl;
+
+#define HC(expr)                                                                          \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            exit(2);                                                                      \
+        }                                                                                 \
+    } while (0)
+#define GC(expr)                                                          \
+    do {                                                                  \
+        int _r = (expr);                                                  \
+        if (_r != GL_OK) {                                                \
+            fprintf(stderr, "%s:%d gl error %d: %s\n", __FILE__, __LINE__, _r, gl::last_error()); \
+            exit(3);                                                      \
+        }                                                                 \
+    } while (0)
+
+__global__ void fill_bf16_kernel(bf16* p, size_t n, uint32_t seed, float scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t x = (uint32_t)i * 2654435761u + seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        p[i] = (bf16)(((float)(x & 0xffff) / 32768.f - 1.f) * scale);
+    }
+}
+__global__ void fill_f32_kernel(float* p, size_t n, uint32_t seed, float scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t x = (uint32_t)i * 2654435761u + seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        p[i] = ((float)(x & 0xffff) / 32768.f - 1.f) * scale;
+    }
+}
+
+__global__ void checksum_kernel(const uint32_t* p, size_t n, unsigned long long* out) {
+    unsigned long long acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        acc += (unsigned long long)p[i] * (2 * (i % 1000003) + 1);
+    atomicAdd(out, acc);
+}
+static unsigned long long checksum(const void* p, size_t bytes, hipStream_t s) {
+    static unsigned long long* d = nullptr;
+    if (!d) HC(hipMalloc(&d, 8));
+    HC(hipMemsetAsync(d, 0, 8, s));
+    hipLaunchKernelGGL(checksum_kernel, dim3(4096), dim3(256), 0, s, (const uint32_t*)p, bytes / 4, d);
+    unsigned long long h = 0;
+    HC(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, s));
+    HC(hipStreamSynchronize(s));
+    return h;
+}
+
+__global__ void maxdiff_kernel(const bf16* a, const bf16* b, size_t n, unsigned* out) {
+    float d = 0.f, m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float x = (float)a[i], y = (float)b[i];
+        if (x != x || y != y) { d = 1e30f; continue; }
+        d = fmaxf(d, fabsf(x - y));
+        m = fmaxf(m, fabsf(y));
+    }
+    atomicMax(out, __float_as_uint(d));
+    atomicMax(out + 1, __float_as_uint(m));
+}
+static void maxdiff(const bf16* a, const bf16* b, size_t n, hipStream_t s, float* d, float* m) {
+    static unsigned* dev = nullptr;
+    if (!dev) HC(hipMalloc(&dev, 8));
+    HC(hipMemsetAsync(dev, 0, 8, s));
+    hipLaunchKernelGGL(maxdiff_kernel, dim3(4096), dim3(256), 0, s, a, b, n, dev);
+    unsigned h[2];
+    HC(hipMemcpyAsync(h, dev, 8, hipMemcpyDeviceToHost, s));
+    HC(hipStreamSynchronize(s));
+    memcpy(d, &h[0], 4);
+    memcpy(m, &h[1], 4);
+}
+
+static bf16* dev_bf16(size_t n, uint32_t seed, float scale = 1.f) {
+    bf16* p;
+    HC(hipMalloc(&p, n * sizeof(bf16) + 256));
+    hipLaunchKernelGGL(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, p, n, seed, scale);
+    return p;
+}
+static float* dev_f32(size_t n, uint32_t seed, float scale = 1.f) {
+    float* p;
+    HC(hipMalloc(&p, n * sizeof(float) + 256));
+    hipLaunchKernelGGL(fill_f32_kernel, dim3(2048), dim3(256), 0, 0, p, n, seed, scale);
+    return p;
+}
+
+template <class F>
+static float time_us(F&& fn, int reps, hipStream_t s) {
+    hipEvent_t e0, e1;
+    HC(hipEventCreate(&e0));
+    HC(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) fn();
+    HC(hipStreamSynchronize(s));
+    HC(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; ++i) fn();
+    HC(hipEventRecord(e1, s));
+    HC(hipEventSynchronize(e1));
+    float ms = 0;
+    HC(hipEventElapsedTime(&ms, e0, e1));
+    HC(hipEventDestroy(e0));
+    HC(hipEventDestroy(e1));
+    return ms * 1000.f / reps;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) {
+        fprintf(stderr, "usage: kbench <shapes-file> [reps] [filter]\n");
+        return 1;
+    }
+    const int reps = argc > 2 ? atoi(argv[2]) : 10;
+    const char* filter = argc > 3 && strcmp(argv[3], "-") ? argv[3] : nullptr;
+    // "check": run every gemm/conv shape with main-loop variant 0 and 1 and require bit-identical outputs
+    const bool check = argc > 4 && !strcmp(argv[4], "check");
+    int n_bad = 0;
+    FILE* f = fopen(argv[1], "r");
+    if (!f) { perror(argv[1]); return 1; }
+    hipStream_t s;
+    HC(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+
+    const size_t ACT = (size_t)320 << 20;  // elements: covers 4*512*512*256 (VAE) and the GEGLU outputs
+    bf16* a0 = dev_bf16(ACT, 1);
+    bf16* a1 = dev_bf16(ACT, 2);
+    bf16* a2 = dev_bf16(ACT, 3);
+    bf16* w = dev_bf16((size_t)64 << 20, 4, 0.05f);
+    float* bias = dev_f32(1 << 16, 5, 0.1f);
+    float* gam = dev_f32(1 << 16, 6, 1.f);
+    size_t ws_bytes = (size_t)256 << 20;
+    float* ws;
+    HC(hipMalloc(&ws, ws_bytes));
+    float* partial;
+    HC(hipMalloc(&partial, 1 << 20));
+    const size_t CMP = check ? ACT : 0;  // reference copies of the two output buffers
+    bf16 *r1 = nullptr, *r2 = nullptr;
+    if (check) {
+        HC(hipMalloc(&r1, ACT * 2));
+        HC(hipMalloc(&r2, ACT * 2));
+    }
+    HC(hipDeviceSynchronize());
+
+    double tot_us[5] = {0, 0, 0, 0, 0}, tot_flop[5] = {0, 0, 0, 0, 0};
+    const char* cat[5] = {"gemm", "conv", "attn", "gn", "ln"};
+    char line[512];
+    printf("%-58s %9s %9s %8s %5s\n", "shape", "us", "TF/s|GB/s", "tot_ms", "cnt");
+    while (fgets(line, sizeof line, f)) {
+        if (line[0] == '#' || strlen(line) < 3) continue;
+        if (filter && !strstr(line, filter)) continue;
+        char kind[16];
+        int v[12] = {0};
+        int n = sscanf(line, "%15s %d %d %d %d %d %d %d %d %d %d", kind, v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7, v + 8, v + 9);
+        (void)n;
+        line[strcspn(line, "\n")] = 0;
+        float us = 0;
+        std::function<void()> relaunch;
+        double flop = 0, bytes = 0;
+        int count = 1, c = 0;
+        if (!strcmp(kind, "gemm")) {
+            const int M = v[0], N = v[1], K = v[2], epi = v[3];
+            count = v[4]; c = 0;
+            flop = 2.0 * M * N * K;
+            Epilogue E;
+            epilogue_defaults(E);
+            AOperand A;
+            if (epi == 3) {  // transposed launch: rows operand = weights [M][K], other = activations [N][K]
+                const int C = M, H = 8, d = C / H, B = 8, T = N / B;
+                int dp, dpv;
+                GC(attn_dims(d, &dp, &dpv));
+                E.mode = EPI_VT_HEADS; E.out = a2; E.H = H; E.d = d; E.DPV = dpv; E.T = T; E.Tpad_k = T;
+                relaunch = [=] { GC(gemm_launch_t(w, C, a0, N, K, E, s)); };
+                us = time_us(relaunch, reps, s);
+            } else {
+                aoperand_rows(A, a0, K, K);
+                if (epi == 0) {
+                    E.out = a2; E.ldo = N; E.bias = bias; E.res = a1; E.ldres = N;
+                } else if (epi == 1) {
+                    E.act = ACT_GEGLU; E.geglu16 = gemm_geglu_layout(); E.out = a2; E.ldo = N / 2; E.bias = bias;
+                } else {
+                    const int H = 8, B = 8, T = M / B;
+                    const int C = K, d = C / H;
+                    int dp, dpv;
+                    GC(attn_dims(d, &dp, &dpv));
+                    E.mode = EPI_QK_HEADS; E.q = a1; E.k = a2; E.C = C; E.H = H; E.d = d; E.DP = dp; E.T = T;
+                    E.Tpad_q = round_up(T, 128); E.Tpad_k = T;
+                }
+                relaunch = [=] { GC(gemm_launch(A, w, M, N, K, E, ws, ws_bytes, s)); };
+                us = time_us(relaunch, reps, s);
+            }
+        } else if (!strcmp(kind, "conv")) {
+            const int B = v[0], H = v[1], W = v[2], C0 = v[3], C1 = v[4], Cout = v[5], stride = v[6], ups = v[7];
+            count = v[8]; c = 1;
+            const int Hup = H << ups, Wup = W << ups;
+            const int Ho = stride == 1 ? Hup : (Hup + 2 - 3) / 2 + 1, Wo = stride == 1 ? Wup : (Wup + 2 - 3) / 2 + 1;
+            const int M = B * Ho * Wo, K = 9 * (C0 + C1);
+            flop = 2.0 * M * Cout * K;
+            AOperand A{};
+            A.p0 = a0; A.C0 = C0; A.ld0 = C0; A.p1 = C1 ? a1 : nullptr; A.C1 = C1; A.ld1 = C1;
+            A.mode = A_CONV3; A.Hin = H; A.Win = W; A.Ho = Ho; A.Wo = Wo; A.stride = stride; A.ups = ups; A.pad_lo = 1;
+            Epilogue E;
+            epilogue_defaults(E);
+            E.out = a2; E.ldo = Cout; E.bias = bias; E.bias2 = gam; E.bias2_ld = Cout; E.rows_per_b = Ho * Wo;
+            if (Cout == 32) { E.mode = EPI_NCHW_F32; E.n_real = 4; E.bias2 = nullptr; }
+            relaunch = [=] { GC(gemm_launch(A, w, M, Cout, K, E, ws, ws_bytes, s)); };
+            us = time_us(relaunch, reps, s);
+        } else if (!strcmp(kind, "attn")) {
+            const int B = v[0], H = v[1], d = v[2], Nq = v[3], Nk = v[4];
+            count = v[5]; c = 2;
+            flop = 4.0 * B * H * d * (double)Nq * Nk;
+            int dp, dpv;
+            GC(attn_dims(d, &dp, &dpv));
+            AttnParams P{};
+            P.q = a0; P.k = a1; P.vt = a2;
+            bf16* o = a2 + ((size_t)200 << 20);
+            P.o = o;
+            P.H = H; P.d = d; P.Nq = Nq; P.Nk = Nk; P.Tq_pad = round_up(Nq, 128); P.Tk_pad = round_up(Nk, 64);
+            P.ldo = H * d; P.o_rows_per_b = Nq;
+            P.scale_log2e = 1.4426950408889634f / sqrtf((float)d);
+            GC(attn_vt_ones_launch(a2, B * H, d, P.Tk_pad, s));
+            us = time_us([&] { GC(attn_launch(P, B, s)); }, reps, s);
+        } else if (!strcmp(kind, "gn")) {
+            const int B = v[0], HW = v[1], C0 = v[2], C1 = v[3], silu = v[4];
+            count = v[5]; c = 3;
+            bytes = 2.0 * B * HW * (double)(C0 + C1) * 2;  // algorithmic: read once + write once
+            GNParams P{};
+            P.x0 = a0; P.C0 = C0; P.x1 = C1 ? a1 : nullptr; P.C1 = C1; P.B = B; P.HW = HW; P.eps = 1e-5f;
+            P.gamma = gam; P.beta = bias; P.y = a2; P.silu = silu; P.partial = partial;
+            us = time_us([&] { GC(groupnorm_launch(P, s)); }, reps, s);
+        } else if (!strcmp(kind, "ln")) {
+            const int B = v[0], N1 = v[1], N2 = v[2], Tpad = v[3], C = v[4];
+            count = v[5]; c = 4;
+            bytes = 2.0 * B * (double)(N1 + N2) * C * 2;
+            LNParams P{};
+            P.x = a0; P.x2 = N2 ? a1 : nullptr; P.B = B; P.N1 = N1; P.N2 = N2; P.Tpad = Tpad; P.C = C; P.eps = 1e-5f;
+            P.gamma = gam; P.beta = bias; P.y = a2;
+            us = time_us([&] { GC(layernorm_launch(P, s)); }, reps, s);
+        } else {
+            continue;
+        }
+        if (check && c <= 1 && !(c == 0 && v[3] == 1)) {
+            // variant 2 (persistent 16x16-tile kernel) against variant 1 (LDS-DMA 32x32-tile kernel): different
+            // accumulation order, so compare with a tolerance of a few bf16 ulps of the largest output
+            gemm_set_variant(1);
+            relaunch();
+            HC(hipMemcpyAsync(r1, a1, CMP * 2, hipMemcpyDeviceToDevice, s));
+            HC(hipMemcpyAsync(r2, a2, CMP * 2, hipMemcpyDeviceToDevice, s));
+            gemm_set_variant(2);
+            relaunch();
+            gemm_set_variant(-1);
+            float d1, m1, d2, m2;
+            maxdiff(a1, r1, CMP, s, &d1, &m1);
+            maxdiff(a2, r2, CMP, s, &d2, &m2);
+            const bool ok = d1 <= 0.02f * m1 + 1e-6f && d2 <= 0.02f * m2 + 1e-6f;
+            if (!ok) { ++n_bad; printf("MISMATCH v1 vs v2: %s  (maxdiff %g of %g ; %g of %g)\n", line, d1, m1, d2, m2); }
+        }
+        const double rate = flop > 0 ? flop / us * 1e-6 : bytes / us * 1e-3;
+        int ctm = 0, ctn = 0, csp = 0;
+        if (c <= 1) gemm_last_cfg(&ctm, &ctn, &csp);
+        printf("%-58s %9.1f %9.1f %8.3f %5d  %dx%d/%d\n", line, us, rate, us * count * 1e-3, count, ctm * 32, ctn * 32, csp);
+        tot_us[c] += (double)us * count;
+        tot_flop[c] += flop * count;
+    }
+    double all = 0, allf = 0;
+    for (int i = 0; i < 5; ++i) {
+        printf("TOTAL %-5s %9.3f ms", cat[i], tot_us[i] * 1e-3);
+        if (tot_flop[i] > 0) printf("  %8.1f TF/s", tot_flop[i] / tot_us[i] * 1e-6);
+        printf("\n");
+        all += tot_us[i];
+        allf += tot_flop[i];
+    }
+    if (check) printf("CHECK v1~v2: %s (%d mismatching shapes)\n", n_bad ? "FAILED" : "ok", n_bad);
+    printf("TOTAL all   %9.3f ms  %8.1f TF/s (sum of isolated kernels, back-to-back launches of each shape)\n", all * 1e-3,
+           allf / all * 1e-6);
+    return n_bad ? 4 : 0;
+}

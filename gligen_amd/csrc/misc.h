@@ -53,7 +53,8 @@ int pack_conv_weight_launch(const float* src, bf16* dst, int O, int I, int KH, i
 // small-Cin conv weight OIHW fp32 -> [O][Kpad] bf16 with k = tap*I + c
 int pack_conv_small_launch(const float* src, bf16* dst, int O, int I, int Kpad, hipStream_t stream);
 // GEGLU projection [8C][K] fp32 (+bias [8C]) -> row-interleaved bf16 / fp32 (see gemm.hip epi_geglu4)
-int pack_geglu_launch(const float* w, const float* b, bf16* wp, float* bp, int C4, int K, hipStream_t stream);
+// layout: gemm_geglu_layout() of the GEMM variant that will consume the packed rows
+int pack_geglu_launch(const float* w, const float* b, bf16* wp, float* bp, int C4, int K, int layout, hipStream_t stream);
 
 // gates[i] = scale * tanh(alpha[i])   (reference attention.py:241-242)
 int gates_launch(const float* const* alpha_ptrs, const float* scale, float* gates, int n, hipStream_t stream);

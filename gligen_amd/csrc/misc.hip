@@ -206,22 +206,27 @@ int pack_conv_small_launch(const float* src, bf16* dst, int O, int I, int Kpad, 
 
 // packed row p (tile = p>>5, i = p&31): quad q = i>>3, half g = (i>>2)&1, e = i&3
 //   -> feature j = tile*16 + e + 4g + 8(q>>1) ; original row = (q&1 ? gate : value) half of proj
-__global__ void pack_geglu_kernel(const float* __restrict__ w, const float* __restrict__ b, bf16* __restrict__ wp, float* __restrict__ bp, int C4, int K) {
+__global__ void pack_geglu_kernel(const float* __restrict__ w, const float* __restrict__ b, bf16* __restrict__ wp, float* __restrict__ bp, int C4, int K, int layout) {
     const int64_t total = (int64_t)2 * C4 * K;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int k = (int)(idx % K);
         const int p = (int)(idx / K);
         const int tile = p >> 5, i = p & 31;
-        const int q = i >> 3, g = (i >> 2) & 1, e = i & 3;
-        const int j = tile * 16 + e + 4 * g + 8 * (q >> 1);
-        const int orig = (q & 1) * C4 + j;
+        int orig;
+        if (layout == 1) {  // 16 value rows then the 16 matching gate rows (gemm.hip epi_geglu4_t16)
+            orig = (i >> 4) * C4 + tile * 16 + (i & 15);
+        } else {            // 32x32-tile interleave (gemm.hip epi_geglu4)
+            const int q = i >> 3, g = (i >> 2) & 1, e = i & 3;
+            const int j = tile * 16 + e + 4 * g + 8 * (q >> 1);
+            orig = (q & 1) * C4 + j;
+        }
         wp[idx] = f2bf(w[(size_t)orig * K + k]);
         if (k == 0) bp[p] = b[orig];
     }
 }
-int pack_geglu_launch(const float* w, const float* b, bf16* wp, float* bp, int C4, int K, hipStream_t stream) {
+int pack_geglu_launch(const float* w, const float* b, bf16* wp, float* bp, int C4, int K, int layout, hipStream_t stream) {
     if (C4 % 16 != 0) return set_error(GL_ERR_ARG, "pack_geglu: inner dim %d must be a multiple of 16", C4);
-    hipLaunchKernelGGL(pack_geglu_kernel, dim3(grid_for((int64_t)2 * C4 * K)), dim3(256), 0, stream, w, b, wp, bp, C4, K);
+    hipLaunchKernelGGL(pack_geglu_kernel, dim3(grid_for((int64_t)2 * C4 * K)), dim3(256), 0, stream, w, b, wp, bp, C4, K, layout);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }

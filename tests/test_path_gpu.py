@@ -160,10 +160,11 @@ def test_plms_vs_reference(name, tmp_path, monkeypatch):
             mask = draw_masks_from_boxes(batch["boxes"], hw).to(dev)
             z0 = syn.make_latent(B, 4, hw, hw, seed=2).to(dev)
             extra = torch.cat([z0 * mask, mask], dim=1)
-            noise = torch.from_numpy(g["noise"]).to(dev)
-            monkeypatch.setattr(torch, "randn", lambda *a, **k: noise.clone())  # the S q_sample draws, as recorded
         inp = dict(x=syn.make_latent(B, 4, hw, hw, seed=6).to(dev), timesteps=None, context=ctx, grounding_input=gin,
                    inpainting_extra_input=extra, grounding_extra_input=None)
+        if meta["inpaint"]:  # patch only around the sampler call: make_latent above draws through torch.randn too
+            noise = torch.from_numpy(g["noise"]).to(dev)
+            monkeypatch.setattr(torch, "randn", lambda *a, **k: noise.clone())  # the S q_sample draws, as recorded
         out = sampler.sample(S=S, shape=(B, 4, hw, hw), input=inp, uc=uc, guidance_scale=7.5, mask=mask, x0=z0)
         monkeypatch.undo()
         monkeypatch.chdir(tmp_path)
