@@ -64,6 +64,7 @@ void epilogue_defaults(Epilogue& E);
 void gemm_set_variant(int v);
 int gemm_geglu_layout();
 void gemm_force_cfg(int tm, int tn, int splits);   // 0,0,0 = automatic
+void gemm_force_grid(int blocks);                  // 0 = automatic (512)
 void gemm_last_cfg(int* tm, int* tn, int* splits);
 void aoperand_rows(AOperand& A, const bf16* p, int K, int ld);
 

@@ -799,6 +799,251 @@ gemm_p_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v4: the persistent tile loop of v3 on a 4-slot LDS ring of K=32 groups. LDS-DMA latency on this
+// chip is ~1 us (MI355X_MICROARCH.md ldsdma-fill), several times one K-tile's MFMA time, so a
+// one-tile-ahead double buffer leaves the matrix pipe waiting; here up to three groups stay in
+// flight across raw s_barriers and the main loop only ever waits with COUNTED vmcnt (2 / 1 / 0
+// groups may remain outstanding), never a full drain.
+//   slot   = [BM + BN rows][32 k] bf16 (64-byte rows), one v_mfma_f32_16x16x32_bf16 k-step
+//   DMA    = every wave issues exactly NI wave-instructions per group (16 rows x 64 B each; the
+//            remainder of (BM+BN)/16 over 4 waves is padded with DMAs of the zero chunk into a dump
+//            area), so one immediate vmcnt count is right for all waves
+//   swizzle: 16-byte chunk c of row r is stored at position c ^ g4(r >> 2 & 3), g4 = {0,2,3,1},
+//            applied on the DMA source side; makes the ds_read_b128 fragment reads conflict-free
+//   stores : vmcnt also counts stores and loads/stores may retire out of order with each other, so
+//            an item's last iteration issues no new group, drains (vmcnt 0: the next two groups have
+//            landed), runs the epilogue, and the following two iterations need no wait; by the third
+//            the epilogue's stores are old. The wait used then (<= 2 NI outstanding in total) is safe
+//            whatever the store/load retirement order, because DMA loads retire in order.
+template <int TM, int TN, int AMODE>
+__global__ void __launch_bounds__(256, 2)
+gemm_r_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilogue E, float* __restrict__ ws, WorkDesc wd) {
+    constexpr int BM = TM * 32;
+    constexpr int BN = TN * 32;
+    constexpr int AB = BM / 16;           // 16-row DMA blocks of the activation tile
+    constexpr int WB = BN / 16;           // ... of the weight tile
+    constexpr int XI = AB / 4;            // activation DMA instructions per wave per group
+    constexpr int WI = (WB + 3) / 4;      // weight DMA instructions per wave per group (incl. padding)
+    constexpr int NI = XI + WI;
+    constexpr int SLOT = (BM + BN) * 64;
+    constexpr int DUMP = 4 * SLOT;
+    static_assert(AB % 4 == 0, "BM must be a multiple of 64");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1;
+    const int wn = wave & 1;
+    const int lr = lane >> 2;                                          // DMA: row inside the 16-row block
+    const int ch8 = ((lane & 3) ^ ((0x78 >> ((lr >> 2) * 2)) & 3)) * 8;  // DMA: element offset of the source chunk
+    const int ng = K >> 5;
+    const int gps = wd.kt_per_split * 2;                               // K=32 groups per split
+    const bf16* zsrc = reinterpret_cast<const bf16*>(g_zero_chunk);
+    const int Cin = A.C0 + A.C1;
+    const int Hup = A.Hin << A.ups;
+    const int Wup = A.Win << A.ups;
+
+    auto decode = [&](int w, int& tm, int& tn, int& z) {
+        const int q = wd.n_items >> 3, r = wd.n_items & 7, xcd = w & 7, idx = w >> 3;
+        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int tile = id / wd.splits;
+        z = id - tile * wd.splits;
+        tm = tile / wd.tiles_n;
+        tn = tile - tm * wd.tiles_n;
+    };
+
+    // ---- load cursor
+    int l_item = blockIdx.x, l_g = 0, l_g_end = 0;
+    int xm[XI], xy[XI], xx[XI];  // A_ROWS: xm = row or -1.  A_CONV3: xm = b * Hin, (xy, xx) = top-left tap
+    int wrow[WI];
+    auto setup_load = [&](int item) {
+        int tm, tn, z;
+        decode(item, tm, tn, z);
+        l_g = z * gps;
+        l_g_end = min(ng, l_g + gps);
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int m = tm * BM + (wave + 4 * i) * 16 + lr;
+            const bool ok = m < M;
+            if constexpr (AMODE == A_ROWS) {
+                xm[i] = ok ? m : -1;
+                xy[i] = xx[i] = 0;
+            } else {
+                const int ox = m % A.Wo;
+                const int tmp = m / A.Wo;
+                const int oy = tmp % A.Ho;
+                xm[i] = (tmp / A.Ho) * A.Hin;
+                xy[i] = ok ? oy * A.stride - A.pad_lo : -(1 << 20);
+                xx[i] = ox * A.stride - A.pad_lo;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int rb = wave + 4 * i;
+            const int n = tn * BN + rb * 16 + lr;
+            wrow[i] = (rb < WB && n < N) ? n : -1;
+        }
+    };
+
+    auto issue = [&](int g, int slot) {
+        unsigned char* xs = smem + slot * SLOT + wave * 1024;
+        unsigned char* wsm = smem + slot * SLOT + BM * 64 + wave * 1024;
+        const int k0 = g << 5;
+        if constexpr (AMODE == A_ROWS) {
+            const bool first = k0 < A.C0;
+            const bf16* base = (first ? A.p0 : A.p1) + (first ? k0 : k0 - A.C0) + ch8;
+            const int ld = first ? A.ld0 : A.ld1;
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const bf16* src = xm[i] >= 0 ? base + (int64_t)xm[i] * ld : zsrc;
+                GL_GLDS16(src, xs + i * 4096);
+            }
+        } else {
+            const int tap = k0 / Cin;
+            const int c = k0 - tap * Cin;
+            const int ky = tap / 3;
+            const int kx = tap - ky * 3;
+            const bool first = c < A.C0;
+            const bf16* base = (first ? A.p0 : A.p1) + (first ? c : c - A.C0) + ch8;
+            const int ld = first ? A.ld0 : A.ld1;
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const int iy = xy[i] + ky;
+                const int ix = xx[i] + kx;
+                const bool ok = iy >= 0 && iy < Hup && ix >= 0 && ix < Wup;
+                const int64_t pix = ((int64_t)(xm[i] + (iy >> A.ups))) * A.Win + (ix >> A.ups);
+                const bf16* src = ok ? base + pix * ld : zsrc;
+                GL_GLDS16(src, xs + i * 4096);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const bf16* src = wrow[i] >= 0 ? W + (int64_t)wrow[i] * K + k0 + ch8 : zsrc;
+            unsigned char* dst = (WB % 4 == 0 || wave + 4 * i < WB) ? wsm + i * 4096 : smem + DUMP;
+            GL_GLDS16(src, dst);
+        }
+    };
+
+    f32x4 acc[TM][TN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+
+    // fragment read: lane -> row l15 of the 16-row block, logical chunk lane >> 4
+    const int l15 = lane & 15;
+    const int foff = l15 * 64 + (((lane >> 4) ^ ((0x78 >> ((l15 >> 2) * 2)) & 3)) << 4);
+    const int xoff = wm * TM * 1024 + foff;
+    const int woff = BM * 64 + wn * TN * 1024 + foff;
+
+    auto compute = [&](int slot) {
+        const unsigned char* st = smem + slot * SLOT;
+        bf16x8 xf[TM], wf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xoff + i * 1024);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(st + woff + j * 1024);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    };
+
+    auto epilogue = [&](int tm, int tn, int z) {
+        const int mrow = tm * BM + wm * TM * 16 + l15;
+        const int ncol = tn * BN + wn * TN * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = mrow + i * 16;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n0 = ncol + j * 16;
+                if (n0 >= N) continue;
+                if (wd.splits > 1) {
+                    *reinterpret_cast<float4*>(ws + ((size_t)z * M + m) * N + n0) =
+                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                } else if (E.act == ACT_GEGLU) {
+                    if constexpr (TN % 2 == 0) {
+                        if ((j & 1) == 0) {
+                            float val[4], gate[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                val[e] = acc[i][j][e];
+                                gate[e] = acc[i][j + 1 < TN ? j + 1 : j][e];
+                            }
+                            epi_geglu4_t16(E, m, n0, val, gate);
+                        }
+                    }
+                } else {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
+                    epi_finish4(E, m, n0, v);
+                }
+            }
+        }
+    };
+
+#define GL_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+    // ---- pipeline over the flattened (item, K=32 group) sequence; c = index of the group being multiplied
+    if (l_item >= wd.n_items) return;
+    setup_load(l_item);
+    int c_item = l_item, c_tm, c_tn, c_z;
+    decode(c_item, c_tm, c_tn, c_z);
+    int c_left = l_g_end - l_g;
+    bool more = true;
+    int issued = 0;   // groups issued so far
+    auto issue_next = [&]() {
+        issue(l_g, issued & 3);
+        ++issued;
+        if (++l_g >= l_g_end) {
+            l_item += gridDim.x;
+            more = l_item < wd.n_items;
+            if (more) setup_load(l_item);
+        }
+    };
+    for (int i = 0; i < 3 && more; ++i) issue_next();
+    int nowait = 0;
+    for (int c = 0;; ++c) {
+        if (nowait > 0) {
+            --nowait;
+        } else {
+            const int younger = issued - c - 1;  // groups issued after group c
+            if (younger >= 2) GL_VMCNT(2 * NI);
+            else if (younger == 1) GL_VMCNT(NI);
+            else GL_VMCNT(0);
+        }
+        // group c is in LDS for every wave after this barrier, and every wave has finished reading group c-1
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const bool last = c_left == 1;
+        if (!last) {
+            while (more && issued < c + 4) issue_next();  // ring slot (c+3)&3 == (c-1)&3 is free now
+        }
+        compute(c & 3);
+        if (--c_left == 0) {
+            GL_VMCNT(0);  // groups c+1, c+2 (all that is in flight) have landed; no DMA is pending under the epilogue
+            epilogue(c_tm, c_tn, c_z);
+            nowait = 2;
+            c_item += gridDim.x;
+            if (c_item >= wd.n_items) break;
+            zero_acc();
+            decode(c_item, c_tm, c_tn, c_z);
+            c_left = min(ng, (c_z + 1) * gps) - c_z * gps;
+        }
+    }
+#undef GL_VMCNT
+}
+
 // Deterministic split-K reduction + epilogue: one thread per (row, group of 4 columns).
 __global__ void __launch_bounds__(256)
 splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, Epilogue E) {
@@ -841,7 +1086,7 @@ splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, Epi
     }
 }
 
-static int g_gemm_variant = -1;  // 0: register-staged v1, 1: LDS-DMA v2, 2: persistent 16x16-tile v3 (default)
+static int g_gemm_variant = -1;  // 0: register-staged v1, 1: LDS-DMA v2, 2: persistent v3 (default), 3: persistent + 4-slot K32 ring v4
 void gemm_set_variant(int v) { g_gemm_variant = v; }
 static int gemm_variant() {
     if (g_gemm_variant < 0) {
@@ -851,10 +1096,12 @@ static int gemm_variant() {
     return g_gemm_variant;
 }
 // GEGLU weight-row packing the current main-loop variant expects (pack_geglu_launch layout argument)
-int gemm_geglu_layout() { return gemm_variant() == 2 ? 1 : 0; }
+int gemm_geglu_layout() { return gemm_variant() >= 2 ? 1 : 0; }
 
 static int g_force_tm = 0, g_force_tn = 0, g_force_splits = 0;  // developer override (kbench sweeps)
+static int g_force_grid = 0;
 void gemm_force_cfg(int tm, int tn, int splits) { g_force_tm = tm; g_force_tn = tn; g_force_splits = splits; }
+void gemm_force_grid(int g) { g_force_grid = g; }
 static int g_last_cfg[3] = {0, 0, 0};
 void gemm_last_cfg(int* tm, int* tn, int* splits) { *tm = g_last_cfg[0]; *tn = g_last_cfg[1]; *splits = g_last_cfg[2]; }
 
@@ -904,9 +1151,11 @@ namespace {
 template <int TM, int TN>
 int launch_p(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, float* ws, const WorkDesc& wd,
              hipStream_t stream) {
-    dim3 grid(wd.n_items < 512 ? wd.n_items : 512);
+    const int cap = g_force_grid ? g_force_grid : 512;
+    dim3 grid(wd.n_items < cap ? wd.n_items : cap);
     dim3 block(256);
-    const size_t lds = 2 * (TM * 32 + TN * 32) * 128;
+    const bool ring = gemm_variant() == 3;
+    const size_t lds = ring ? 4 * (TM * 32 + TN * 32) * 64 + 1024 : 2 * (TM * 32 + TN * 32) * 128;
 #define GL_LAUNCH_P(KFN)                                                                                         \
     do {                                                                                                         \
         auto kfn = KFN;                                                                                          \
@@ -917,8 +1166,13 @@ int launch_p(const AOperand& A, const bf16* W, int M, int N, int K, const Epilog
         }                                                                                                        \
         hipLaunchKernelGGL(kfn, grid, block, lds, stream, A, W, M, N, K, E, ws, wd);                             \
     } while (0)
-    if (A.mode == A_ROWS) GL_LAUNCH_P((gemm_p_kernel<TM, TN, A_ROWS>));
-    else GL_LAUNCH_P((gemm_p_kernel<TM, TN, A_CONV3>));
+    if (ring) {
+        if (A.mode == A_ROWS) GL_LAUNCH_P((gemm_r_kernel<TM, TN, A_ROWS>));
+        else GL_LAUNCH_P((gemm_r_kernel<TM, TN, A_CONV3>));
+    } else {
+        if (A.mode == A_ROWS) GL_LAUNCH_P((gemm_p_kernel<TM, TN, A_ROWS>));
+        else GL_LAUNCH_P((gemm_p_kernel<TM, TN, A_CONV3>));
+    }
 #undef GL_LAUNCH_P
     GL_LAUNCH_CHECK();
     return GL_OK;
@@ -930,7 +1184,7 @@ int launch_p(const AOperand& A, const bf16* W, int M, int N, int K, const Epilog
 int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, float* ws, size_t ws_bytes,
                   hipStream_t stream) {
     static const int kTm[4] = {4, 4, 2, 2}, kTn[4] = {5, 4, 5, 4};
-    static const int kSp[9] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
+    static const int kSp[10] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
     const int nk = K / 64;
     double best_t = 1e30;
     int best_c = -1, best_sp = 1;
@@ -938,8 +1192,9 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
         const int tm = kTm[c], tn = kTn[c];
         if (g_force_tm && (tm != g_force_tm || tn != g_force_tn)) continue;
         if (E.act == ACT_GEGLU && (tn & 1)) continue;
-        const int tiles = cdiv(M, tm * 32) * cdiv(N, tn * 32);
-        for (int si = 0; si < 9; ++si) {
+        const int bm = tm * 32, bn = tn * 32;
+        const int tiles = cdiv(M, bm) * cdiv(N, bn);
+        for (int si = 0; si < 10; ++si) {
             int sp = kSp[si];
             if (g_force_splits && sp != g_force_splits) continue;
             if (sp > 1 && (!ws || nk / sp < 2 || (size_t)sp * M * N * sizeof(float) > ws_bytes)) continue;
@@ -947,11 +1202,13 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
             sp = cdiv(nk, kps);
             const int items = tiles * sp;
             const int per_block = cdiv(items, 512);
-            const double mfma = tm * tn * 2;                                  // 16x16x32 MFMAs per wave per K tile
-            const double t_kt = items <= 256 ? 30.0 * mfma : 44.0 * mfma;   // alone on the CU / sharing its SIMDs
-            const double t_item = kps * t_kt + 2500.0;
+            // cycles per K tile of one block with two blocks per CU, fitted to kbench sweeps on MI355X
+            // (128x160: ~4600, 64x160: ~2600); a block alone on its CU runs ~25% faster
+            double t_kt = 0.197 * bm * bn + 560.0;
+            if (items <= 256) t_kt *= 0.75;
+            const double t_item = kps * t_kt + (E.act == ACT_GEGLU ? 7000.0 : 4000.0);
             double tt = per_block * t_item;
-            if (sp > 1) tt += 4000.0 + (double)sp * M * N * 8.0 / 2400.0;
+            if (sp > 1) tt += 6000.0 + (double)sp * M * N * 8.0 / 2000.0;  // fp32 slabs out and back + reduce launch
             if (tt < best_t) { best_t = tt; best_c = c; best_sp = sp; }
         }
     }
@@ -998,7 +1255,7 @@ int gemm_launch(const AOperand& A, const bf16* W, int M, int N, int K, const Epi
         return set_error(GL_ERR_ARG, "gemm: GEGLU epilogue needs packed N %% 32 == 0 (N=%d)", N);
     if (E.act == ACT_GEGLU && E.geglu16 != gemm_geglu_layout())
         return set_error(GL_ERR_STATE, "gemm: GEGLU weights were packed for a different main-loop variant");
-    if (gemm_variant() == 2 && (N >= 128 || E.act == ACT_GEGLU)) return gemm_p_launch(A, W, M, N, K, E, ws, ws_bytes, stream);
+    if (gemm_variant() >= 2 && (N >= 128 || E.act == ACT_GEGLU)) return gemm_p_launch(A, W, M, N, K, E, ws, ws_bytes, stream);
 
     // pick the tile: padding efficiency x relative tile speed x chip fill
     int best = 0;

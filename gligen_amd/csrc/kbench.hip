@@ -130,6 +130,8 @@ int main(int argc, char** argv) {
     const char* filter = argc > 3 && strcmp(argv[3], "-") ? argv[3] : nullptr;
     // "check": run every gemm/conv shape with main-loop variant 0 and 1 and require bit-identical outputs
     const bool check = argc > 4 && !strcmp(argv[4], "check");
+    // "sweep": time every persistent-kernel tile shape x K split x grid cap per gemm/conv shape, print the best
+    const bool sweep = argc > 4 && !strcmp(argv[4], "sweep");
     int n_bad = 0;
     FILE* f = fopen(argv[1], "r");
     if (!f) { perror(argv[1]); return 1; }
@@ -170,12 +172,14 @@ int main(int argc, char** argv) {
         line[strcspn(line, "\n")] = 0;
         float us = 0;
         std::function<void()> relaunch;
+        int gM = 0, gN = 0, gK = 0;
         double flop = 0, bytes = 0;
         int count = 1, c = 0;
         if (!strcmp(kind, "gemm")) {
             const int M = v[0], N = v[1], K = v[2], epi = v[3];
             count = v[4]; c = 0;
             flop = 2.0 * M * N * K;
+            gM = M; gN = N; gK = K;
             Epilogue E;
             epilogue_defaults(E);
             AOperand A;
@@ -210,6 +214,7 @@ int main(int argc, char** argv) {
             const int Ho = stride == 1 ? Hup : (Hup + 2 - 3) / 2 + 1, Wo = stride == 1 ? Wup : (Wup + 2 - 3) / 2 + 1;
             const int M = B * Ho * Wo, K = 9 * (C0 + C1);
             flop = 2.0 * M * Cout * K;
+            gM = M; gN = Cout; gK = K;
             AOperand A{};
             A.p0 = a0; A.C0 = C0; A.ld0 = C0; A.p1 = C1 ? a1 : nullptr; A.C1 = C1; A.ld1 = C1;
             A.mode = A_CONV3; A.Hin = H; A.Win = W; A.Ho = Ho; A.Wo = Wo; A.stride = stride; A.ups = ups; A.pad_lo = 1;
@@ -253,21 +258,54 @@ int main(int argc, char** argv) {
         } else {
             continue;
         }
+        if (sweep && c <= 1) {
+            static const int tms[4] = {4, 4, 2, 2}, tns[4] = {5, 4, 5, 4};
+            static const int sps[8] = {1, 2, 3, 4, 6, 8, 12, 16};
+            float best = 1e30f;
+            int btm = 0, btn = 0, bsp = 0, bgrid = 0;
+            std::string all;
+            for (int gi = 0; gi < 2; ++gi)
+                for (int ci = 0; ci < 4; ++ci)
+                    for (int si = 0; si < 8; ++si) {
+                        if (c == 0 && v[3] == 1 && (tns[ci] & 1)) continue;
+                        const int grid = gi ? 768 : 512;
+                        if (gi && tms[ci] * 32 + tns[ci] * 32 > 192) continue;  // 3 blocks/CU only fit for <= 48 KB of LDS
+                        gemm_force_cfg(tms[ci], tns[ci], sps[si]);
+                        gemm_force_grid(grid);
+                        const int nk = gK / 64;
+                        if (sps[si] > 1 && (nk / sps[si] < 2 || (size_t)sps[si] * gM * gN * 4 > ws_bytes)) continue;
+                        if (gN < 128 && !(c == 0 && v[3] == 1)) continue;  // small N runs the non-persistent kernel
+                        if (c == 0 && v[3] == 3 && sps[si] > 1) continue;       // transposed launch has no split-K workspace
+                        int ctm2, ctn2, csp2;
+                        relaunch();
+                        gemm_last_cfg(&ctm2, &ctn2, &csp2);
+                        if (csp2 != sps[si]) continue;  // split count was rounded: duplicate of another entry
+                        float tus = time_us(relaunch, 5, s);
+                        char buf[64];
+                        snprintf(buf, sizeof buf, " %dx%d/%d@%d=%.1f", tms[ci] * 32, tns[ci] * 32, csp2, grid, tus);
+                        all += buf;
+                        if (tus < best) { best = tus; btm = tms[ci]; btn = tns[ci]; bsp = csp2; bgrid = grid; }
+                    }
+            gemm_force_cfg(0, 0, 0);
+            gemm_force_grid(0);
+            if (best < 1e29f)
+                printf("SWEEP %-52s auto %.1f us | best %.1f us %dx%d/%d@%d\n", line, us, best, btm * 32, btn * 32, bsp, bgrid);
+            printf("      %s\n", all.c_str());
+        }
         if (check && c <= 1 && !(c == 0 && v[3] == 1)) {
-            // variant 2 (persistent 16x16-tile kernel) against variant 1 (LDS-DMA 32x32-tile kernel): different
+            // the selected variant (persistent 16x16-tile kernels) against variant 1 (LDS-DMA 32x32-tile kernel): different
             // accumulation order, so compare with a tolerance of a few bf16 ulps of the largest output
             gemm_set_variant(1);
             relaunch();
             HC(hipMemcpyAsync(r1, a1, CMP * 2, hipMemcpyDeviceToDevice, s));
             HC(hipMemcpyAsync(r2, a2, CMP * 2, hipMemcpyDeviceToDevice, s));
-            gemm_set_variant(2);
+            gemm_set_variant(-1);  // back to GL_GEMM_VARIANT / the default
             relaunch();
-            gemm_set_variant(-1);
             float d1, m1, d2, m2;
             maxdiff(a1, r1, CMP, s, &d1, &m1);
             maxdiff(a2, r2, CMP, s, &d2, &m2);
             const bool ok = d1 <= 0.02f * m1 + 1e-6f && d2 <= 0.02f * m2 + 1e-6f;
-            if (!ok) { ++n_bad; printf("MISMATCH v1 vs v2: %s  (maxdiff %g of %g ; %g of %g)\n", line, d1, m1, d2, m2); }
+            if (!ok) { ++n_bad; printf("MISMATCH v1 vs selected: %s  (maxdiff %g of %g ; %g of %g)\n", line, d1, m1, d2, m2); }
         }
         const double rate = flop > 0 ? flop / us * 1e-6 : bytes / us * 1e-3;
         int ctm = 0, ctn = 0, csp = 0;
@@ -284,7 +322,7 @@ int main(int argc, char** argv) {
         all += tot_us[i];
         allf += tot_flop[i];
     }
-    if (check) printf("CHECK v1~v2: %s (%d mismatching shapes)\n", n_bad ? "FAILED" : "ok", n_bad);
+    if (check) printf("CHECK v1~selected: %s (%d mismatching shapes)\n", n_bad ? "FAILED" : "ok", n_bad);
     printf("TOTAL all   %9.3f ms  %8.1f TF/s (sum of isolated kernels, back-to-back launches of each shape)\n", all * 1e-3,
            allf / all * 1e-6);
     return n_bad ? 4 : 0;
