@@ -60,11 +60,13 @@ int gemm_launch_t(const bf16* Wrows, int Mw, const bf16* X, int Nx, int K, const
                   hipStream_t stream);
 
 void epilogue_defaults(Epilogue& E);
-// developer switch (kbench A/B): 0 = register-staged main loop, 1 = LDS-DMA main loop, 2 = persistent 16x16-tile kernel (default)
+// developer switch (kbench A/B): 0 = register-staged main loop, 1 = LDS-DMA main loop, 2 = persistent 16x16-tile kernel (v3),
+// 3 = v3 on a 4-slot K32 ring, 4 = v5: persistent, buffer-descriptor LDS-DMA, load-first epilogue (default)
 void gemm_set_variant(int v);
 int gemm_geglu_layout();
 void gemm_force_cfg(int tm, int tn, int splits);   // 0,0,0 = automatic
 void gemm_force_grid(int blocks);                  // 0 = automatic (512)
+void gemm_set_autotune(int on);                    // 1 (default): time candidates at the first eager launch of a problem
 void gemm_last_cfg(int* tm, int* tn, int* splits);
 void aoperand_rows(AOperand& A, const bf16* p, int K, int ld);
 

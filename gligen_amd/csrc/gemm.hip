@@ -24,7 +24,10 @@
 //    the low-resolution layers whose M x N grid cannot fill 256 CUs.
 #include "gemm.h"
 
+#include <algorithm>
 #include <cstdlib>
+#include <string>
+#include <unordered_map>
 
 namespace gl {
 
@@ -84,6 +87,59 @@ __device__ __forceinline__ void epi_finish4(const Epilogue& E, int m, int n0, fl
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = bf2f(r.e[i]) + g * v[i];
             }
+            if (E.out_f32) {
+                float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(E.out) + (size_t)m * E.ldo + n0) = o;
+            } else {
+                store_bf16x4(reinterpret_cast<bf16*>(E.out) + (size_t)m * E.ldo + n0, v);
+            }
+            break;
+        }
+        case EPI_QK_HEADS: {
+            int which = n0 >= E.C;
+            int c = n0 - which * E.C;
+            int h = c / E.d;
+            int dd = c - h * E.d;
+            int b = m / E.T;
+            int t = m - b * E.T;
+            int tp = which ? E.Tpad_k : E.Tpad_q;
+            bf16* base = which ? E.k : E.q;
+            store_bf16x4(base + ((size_t)(b * E.H + h) * tp + t) * E.DP + dd, v);
+            break;
+        }
+        case EPI_VT_HEADS: {  // m = feature, n0 = first of 4 consecutive tokens
+            int h = m / E.d;
+            int dd = m - h * E.d;
+            int b = n0 / E.T;
+            int t0 = n0 - b * E.T;
+            bf16* base = reinterpret_cast<bf16*>(E.out);
+            store_bf16x4(base + ((size_t)(b * E.H + h) * E.DPV + dd) * E.Tpad_k + perm_tok4(t0), v);
+            break;
+        }
+        case EPI_NCHW_F32: {
+            int b = m / E.rows_per_b;
+            int pix = m - b * E.rows_per_b;
+            float* o = reinterpret_cast<float*>(E.out);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (n0 + i < E.n_real) o[((size_t)b * E.n_real + n0 + i) * E.rows_per_b + pix] = v[i];
+            break;
+        }
+    }
+}
+
+// Store half of epi_finish4 for epilogues that load bias / residual for ALL their fragments up front
+// (v already holds bias and residual; for EPI_ROWMAJOR m is the remapped output row). A wave's vmcnt is one
+// in-order counter for loads and stores, so a load issued after a store cannot be waited for without
+// waiting for that store: an epilogue that alternates {load bias/residual, store} per fragment pays one
+// memory round trip per fragment (measured: 18 of the 27 us of a 32768 x 320 x 320 GEMM).
+__device__ __forceinline__ void epi_store4(const Epilogue& E, int m, int n0, float v[4]) {
+    if (E.act == ACT_SILU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = silu_f(v[i]);
+    }
+    switch (E.mode) {
+        case EPI_ROWMAJOR: {
             if (E.out_f32) {
                 float4 o = make_float4(v[0], v[1], v[2], v[3]);
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(E.out) + (size_t)m * E.ldo + n0) = o;
@@ -583,6 +639,7 @@ struct WorkDesc {
     int splits;
     int kt_per_split;
     int n_items;
+    int dbg;  // developer ablation (GL_GEMM_DBG): bit 0 = skip the DMA, bit 1 = skip the MFMAs, bit 2 = skip the epilogue (results are garbage)
 };
 
 template <int TM, int TN, int AMODE>
@@ -1044,6 +1101,428 @@ gemm_r_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
 #undef GL_VMCNT
 }
 
+// ---------------------------------------------------------------------------------------------
+// v5 (unified persistent kernel, variant 4). Two geometries of the same code:
+//   WMW = 4: 8 waves (4 M x 2 N), 256 x (TN*32) tile, THREE LDS stages, one workgroup per CU
+//   WMW = 2: 4 waves (2 M x 2 N), (TM*32) x (TN*32) tile, two LDS stages, two workgroups per CU
+// What changed against v3/v4 is the loader. PMC showed v3 spending ~300 VALU/SALU instructions per
+// K tile per wave on 64-bit DMA source addresses against 20-40 MFMAs (SQ_ACTIVE_INST_ANY ~ the
+// whole budget of a wave, MFMA pipe 28 % busy), so:
+//   * both operands are fetched with buffer_load_dwordx4 ... lds through wave-uniform buffer
+//     descriptors: the per-lane byte offset (row, swizzled 16-byte chunk) is computed once per
+//     work item (conv: once per filter tap), the K-tile offset rides in the SGPR soffset, and a
+//     DMA costs one s_mov m0 + one buffer_load. Rows outside M / N and conv padding taps use an
+//     offset beyond num_records, for which the hardware returns zeros.
+//   * (WMW = 4) two K tiles are in flight behind the one being multiplied and the main loop only
+//     waits with COUNTED vmcnt (raw s_barrier, one per K tile):
+//       top(c): vmcnt(NI) -> s_barrier -> DMA of tile c+2 into slot (c+2)%3 -> MFMAs on slot c%3
+//     Every wave issues exactly NI DMAs per tile (a partial last weight pass is padded with an
+//     out-of-range DMA into a dump area), so one immediate count is right for all waves. vmcnt also
+//     counts the epilogue's stores; outstanding stores can only make a counted wait stricter (DMA
+//     loads retire in order among themselves). At an item's last K tile the next DMA is issued
+//     AFTER the epilogue (whose bias/residual loads would otherwise drain the in-order counter
+//     through a freshly issued tile); tile c+1, drained there, is not waited for again.
+#define GL_BLDS16(rsrc, ldst, voff, soff)                                                                   \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(ldst), 16, \
+                                             (int)(voff), (int)(soff), 0, 0)
+
+template <int WMW, int TM, int TN, int AMODE>
+__global__ void __launch_bounds__(WMW * 128, 2)
+gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilogue E, float* __restrict__ ws, WorkDesc wd) {
+    constexpr int NT = WMW * 128;               // threads
+    constexpr int RPP = NT / 8;                 // tile rows per DMA pass (one 128-byte row per 8 lanes)
+    constexpr int BM = WMW * TM * 16;
+    constexpr int BN = TN * 32;
+    constexpr int XP = BM / RPP;                // activation passes
+    constexpr int WPF = BN / RPP;               // full weight passes
+    constexpr int WREM = BN % RPP;              // rows of the partial last weight pass (issued by the first WREM/8 waves)
+    constexpr int WP = WPF + (WREM ? 1 : 0);
+    constexpr int NI = XP + WP;                 // DMA wave-instructions per wave per K tile
+    constexpr int NST = WMW == 4 ? 3 : 2;       // LDS stages
+    constexpr int AHEAD = NST - 1;              // K tiles in flight ahead of the one being multiplied
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int DUMP = NST * STAGE;
+    constexpr unsigned SENT = 0x80000000u;      // >= num_records of every descriptor: reads as zeros
+    static_assert(BM % RPP == 0 && WREM % 8 == 0, "tile/loader mismatch");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1;
+    const int wn = wave & 1;
+    const int r0 = t >> 3;                                          // row inside a DMA pass
+    const unsigned chb = (((t & 7) ^ ((r0 >> 1) & 7)) * 16);        // byte offset of this lane's (swizzled) source chunk
+    const int nk = K >> 6;
+    const int Cin = A.C0 + A.C1;
+    const int Hup = A.Hin << A.ups;
+    const int Wup = A.Win << A.ups;
+
+    const __amdgpu_buffer_rsrc_t ra0 = __builtin_amdgcn_make_buffer_rsrc((void*)A.p0, 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc((void*)(A.p1 ? A.p1 : A.p0), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0x80000000u, 0x00020000);
+
+    auto decode = [&](int w, int& tm, int& tn, int& z) {
+        const int q = wd.n_items >> 3, r = wd.n_items & 7, xcd = w & 7, idx = w >> 3;
+        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int tile = id / wd.splits;
+        z = id - tile * wd.splits;
+        tm = tile / wd.tiles_n;
+        tn = tile - tm * wd.tiles_n;
+    };
+
+    // ---- load cursor: (item, K tile) plus, for the conv gather, the filter tap and channel offset of that tile
+    int l_item = blockIdx.x, l_kt = 0, l_kt_end = 0;
+    int l_tap = 0, l_cc = 0;     // A_CONV3: k = l_tap * Cin + l_cc.   A_ROWS: l_cc = k
+    int xm[XP], xy[XP], xx[XP];  // A_ROWS: xm = row or -1.  A_CONV3: xm = b * Hin, (xy, xx) = top-left tap (xy very negative: no row)
+    unsigned va[XP], vw[WP];     // per-lane byte offsets into the current activation source / the weight matrix
+
+    // byte offsets of this lane's activation chunks for the current (tap, source)
+    auto a_offsets = [&]() {
+        const bool first = l_cc < A.C0;
+        const int ld = first ? A.ld0 : A.ld1;
+        if constexpr (AMODE == A_ROWS) {
+#pragma unroll
+            for (int i = 0; i < XP; ++i) va[i] = xm[i] >= 0 ? (unsigned)(xm[i] * ld) * 2u + chb : SENT;
+        } else {
+            const int ky = l_tap / 3;
+            const int kx = l_tap - ky * 3;
+#pragma unroll
+            for (int i = 0; i < XP; ++i) {
+                const int iy = xy[i] + ky;
+                const int ix = xx[i] + kx;
+                const bool ok = iy >= 0 && iy < Hup && ix >= 0 && ix < Wup;
+                const int pix = (xm[i] + (iy >> A.ups)) * A.Win + (ix >> A.ups);
+                va[i] = ok ? (unsigned)(pix * ld) * 2u + chb : SENT;
+            }
+        }
+    };
+
+    auto setup_load = [&](int item) {
+        int tm, tn, z;
+        decode(item, tm, tn, z);
+        l_kt = z * wd.kt_per_split;
+        l_kt_end = min(nk, l_kt + wd.kt_per_split);
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const int m = tm * BM + r0 + i * RPP;
+            const bool ok = m < M;
+            if constexpr (AMODE == A_ROWS) {
+                xm[i] = ok ? m : -1;
+                xy[i] = xx[i] = 0;
+            } else {
+                const int ox = m % A.Wo;
+                const int tmp = m / A.Wo;
+                const int oy = tmp % A.Ho;
+                xm[i] = (tmp / A.Ho) * A.Hin;
+                xy[i] = ok ? oy * A.stride - A.pad_lo : -(1 << 20);
+                xx[i] = ox * A.stride - A.pad_lo;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WP; ++i) {
+            const int n = tn * BN + r0 + i * RPP;
+            const bool in_tile = !(WREM && i == WP - 1) || wave < WREM / 8;
+            vw[i] = (in_tile && n < N) ? (unsigned)(n * K) * 2u + chb : SENT;
+        }
+        const int k0 = l_kt << 6;
+        if constexpr (AMODE == A_ROWS) {
+            l_tap = 0;
+            l_cc = k0;
+        } else {
+            l_tap = k0 / Cin;
+            l_cc = k0 - l_tap * Cin;
+        }
+        a_offsets();
+    };
+
+    // DMA of K tile l_kt into ring slot `slot`, then advance the cursor by one tile
+    bool more = true;
+    auto issue_next = [&](int slot_) {
+        // the cursor is wave-uniform by construction; say so, or one value merged through a divergent
+        // branch makes hipcc wrap every buffer_load in a waterfall loop (descriptor / soffset / m0 "divergent")
+        const int slot = __builtin_amdgcn_readfirstlane(slot_);
+        l_cc = __builtin_amdgcn_readfirstlane(l_cc);
+        l_kt = __builtin_amdgcn_readfirstlane(l_kt);
+        unsigned char* xs = smem + slot * STAGE + wave * 1024;
+        unsigned char* wsm = xs + BM * 128;
+        const bool first = l_cc < A.C0;
+        const int soff = (first ? l_cc : l_cc - A.C0) * 2;
+        if (!(wd.dbg & 1)) {
+        if (first) {
+#pragma unroll
+            for (int i = 0; i < XP; ++i) GL_BLDS16(ra0, xs + i * RPP * 128, va[i], soff);
+        } else {
+#pragma unroll
+            for (int i = 0; i < XP; ++i) GL_BLDS16(ra1, xs + i * RPP * 128, va[i], soff);
+        }
+        const int woff = l_kt << 7;
+#pragma unroll
+        for (int i = 0; i < WP; ++i) {
+            unsigned char* dst = (WREM && i == WP - 1 && wave >= WREM / 8) ? smem + DUMP : wsm + i * RPP * 128;
+            GL_BLDS16(rw, dst, vw[i], woff);
+        }
+        }
+        // advance
+        l_cc += 64;
+        if (++l_kt >= l_kt_end) {
+            l_item += gridDim.x;
+            more = l_item < wd.n_items;
+            if (more) setup_load(l_item);
+        } else if constexpr (AMODE == A_CONV3) {
+            if (l_cc == Cin) {
+                l_cc = 0;
+                ++l_tap;
+                a_offsets();
+            } else if (l_cc == A.C0) {
+                a_offsets();
+            }
+        } else {
+            if (A.C1 && l_cc == A.C0) a_offsets();
+        }
+    };
+
+    f32x4 acc[TM][TN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+
+    // fragment addressing: lane reads row (16 t + l15), 16-byte chunk 4 s + (lane >> 4); rows start at
+    // multiples of 16, so the swizzle term ((row >> 1) & 7) is the lane constant l15 >> 1
+    const int l15 = lane & 15;
+    const int foff0 = l15 * 128 + ((((lane >> 4)) ^ (l15 >> 1)) << 4);
+    const int foff1 = l15 * 128 + ((((lane >> 4) + 4) ^ (l15 >> 1)) << 4);
+    const int xrow0 = wm * TM * 16 * 128;
+    const int wrow0 = BM * 128 + wn * TN * 16 * 128;
+
+    auto compute = [&](int slot) {
+        const unsigned char* st = smem + slot * STAGE;
+        bf16x8 xa[TM], wa[TN], xb[TM], wb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xa[i] = *reinterpret_cast<const bf16x8*>(st + xrow0 + i * 2048 + foff0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wa[j] = *reinterpret_cast<const bf16x8*>(st + wrow0 + j * 2048 + foff0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xb[i] = *reinterpret_cast<const bf16x8*>(st + xrow0 + i * 2048 + foff1);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wb[j] = *reinterpret_cast<const bf16x8*>(st + wrow0 + j * 2048 + foff1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xa[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xb[i], acc[i][j], 0, 0, 0);
+    };
+
+    // Epilogue: every load (bias, time-embedding bias, residual, gate) of the wave's TM x TN fragments is issued
+    // before the first store (see epi_store4).
+    auto epilogue = [&](int tm, int tn, int z) {
+        const int mrow = tm * BM + wm * TM * 16 + l15;
+        const int ncol = tn * BN + wn * TN * 16 + (lane >> 4) * 4;
+        if (wd.splits > 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = mrow + i * 16;
+                if (m >= M) continue;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n0 = ncol + j * 16;
+                    if (n0 >= N) continue;
+                    *reinterpret_cast<float4*>(ws + ((size_t)z * M + m) * N + n0) =
+                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                }
+            }
+            return;
+        }
+        if (E.act == ACT_GEGLU) {
+            if constexpr (TN % 2 == 0) {
+                float4 bv[TN / 2], bg[TN / 2];
+#pragma unroll
+                for (int jj = 0; jj < TN / 2; ++jj) {
+                    const int n0 = ncol + jj * 32;
+                    bv[jj] = bg[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (E.bias && n0 < N) {
+                        bv[jj] = *reinterpret_cast<const float4*>(E.bias + n0);
+                        bg[jj] = *reinterpret_cast<const float4*>(E.bias + n0 + 16);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int m = mrow + i * 16;
+                    if (m >= M) continue;
+#pragma unroll
+                    for (int jj = 0; jj < TN / 2; ++jj) {
+                        const int n0 = ncol + jj * 32;
+                        if (n0 >= N) continue;
+                        const float bvv[4] = {bv[jj].x, bv[jj].y, bv[jj].z, bv[jj].w};
+                        const float bgg[4] = {bg[jj].x, bg[jj].y, bg[jj].z, bg[jj].w};
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (acc[i][2 * jj][e] + bvv[e]) * gelu_erf_f(acc[i][2 * jj + 1][e] + bgg[e]);
+                        const int j0 = (n0 >> 5) * 16 + (n0 & 15);
+                        store_bf16x4(reinterpret_cast<bf16*>(E.out) + (size_t)m * E.ldo + j0, o);
+                    }
+                }
+            }
+            return;
+        }
+        float4 bj[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n0 = ncol + j * 16;
+            bj[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (E.bias && n0 < N) bj[j] = *reinterpret_cast<const float4*>(E.bias + n0);
+        }
+        int mo[TM];  // output row (EPI_ROWMAJOR row remap applied)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = mrow + i * 16;
+            mo[i] = (E.mode == EPI_ROWMAJOR && E.remap_in) ? (m / E.remap_in) * E.remap_out + (m % E.remap_in) + E.remap_off : m;
+        }
+        if (E.bias2) {  // + broadcast per-sample bias (ResBlock time embedding); never combined with a residual
+            float4 b2[TM][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = mrow + i * 16;
+                const int bb = m / E.rows_per_b;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n0 = ncol + j * 16;
+                    b2[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (m < M && n0 < N) b2[i][j] = *reinterpret_cast<const float4*>(E.bias2 + (size_t)bb * E.bias2_ld + n0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = mrow + i * 16;
+                if (m >= M) continue;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n0 = ncol + j * 16;
+                    if (n0 >= N) continue;
+                    float v[4] = {acc[i][j][0] + bj[j].x + b2[i][j].x, acc[i][j][1] + bj[j].y + b2[i][j].y,
+                                  acc[i][j][2] + bj[j].z + b2[i][j].z, acc[i][j][3] + bj[j].w + b2[i][j].w};
+                    epi_store4(E, mo[i], n0, v);
+                }
+            }
+        } else if (E.mode == EPI_ROWMAJOR && E.res) {
+            uint2 rs[TM][TN];
+            const float g = E.gate ? *E.gate : 1.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = mrow + i * 16;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n0 = ncol + j * 16;
+                    rs[i][j] = make_uint2(0, 0);
+                    if (m < M && n0 < N) rs[i][j] = *reinterpret_cast<const uint2*>(E.res + (size_t)mo[i] * E.ldres + n0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = mrow + i * 16;
+                if (m >= M) continue;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n0 = ncol + j * 16;
+                    if (n0 >= N) continue;
+                    U2BF4 r;
+                    r.u = rs[i][j];
+                    float v[4] = {acc[i][j][0] + bj[j].x, acc[i][j][1] + bj[j].y, acc[i][j][2] + bj[j].z, acc[i][j][3] + bj[j].w};
+                    if (E.act == ACT_SILU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = bf2f(r.e[e]) + g * v[e];
+                    if (E.out_f32) {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(E.out) + (size_t)mo[i] * E.ldo + n0) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        store_bf16x4(reinterpret_cast<bf16*>(E.out) + (size_t)mo[i] * E.ldo + n0, v);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = mrow + i * 16;
+                if (m >= M) continue;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n0 = ncol + j * 16;
+                    if (n0 >= N) continue;
+                    float v[4] = {acc[i][j][0] + bj[j].x, acc[i][j][1] + bj[j].y, acc[i][j][2] + bj[j].z, acc[i][j][3] + bj[j].w};
+                    epi_store4(E, mo[i], n0, v);
+                }
+            }
+        }
+    };
+
+#define GL_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+    if (l_item >= wd.n_items) return;
+    setup_load(l_item);
+    int c_item = l_item, c_tm, c_tn, c_z;
+    decode(c_item, c_tm, c_tn, c_z);
+    int c_left = l_kt_end - l_kt;
+    int ahead = 0;       // tiles issued and not yet multiplied (including the one about to be)
+    int slot_i = 0;      // ring slot of the next issue
+    int slot_c = 0;      // ring slot of the tile being multiplied
+    auto issue_one = [&]() {
+        issue_next(slot_i);
+        slot_i = slot_i == NST - 1 ? 0 : slot_i + 1;
+        ++ahead;
+    };
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i)
+        if (more) issue_one();
+    bool landed = false;  // the tile about to be multiplied is known to have landed (drained before the previous epilogue)
+    for (;;) {
+        ahead = __builtin_amdgcn_readfirstlane(ahead);
+        c_left = __builtin_amdgcn_readfirstlane(c_left);
+        slot_c = __builtin_amdgcn_readfirstlane(slot_c);
+        more = __builtin_amdgcn_readfirstlane((int)more) != 0;
+        landed = __builtin_amdgcn_readfirstlane((int)landed) != 0;
+        if (!landed) {
+            if (AHEAD >= 2 && ahead >= 2) GL_VMCNT(NI);   // all but the newest tile's DMAs are done
+            else GL_VMCNT(0);
+        }
+        landed = false;
+        // tile c is in LDS for every wave after this barrier, and every wave has finished reading tile c-1
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const bool last = c_left == 1;
+        const bool defer = AHEAD >= 2 && last;
+        if (!defer && more) issue_one();
+        if (!(wd.dbg & 2)) compute(slot_c);
+        slot_c = slot_c == NST - 1 ? 0 : slot_c + 1;
+        --ahead;
+        if (--c_left == 0) {
+            if constexpr (AHEAD >= 2) {
+                GL_VMCNT(0);      // only tile c+1 can be in flight (issued one K tile ago): it has landed now
+                landed = true;
+            }
+            if (!(wd.dbg & 4)) epilogue(c_tm, c_tn, c_z);
+            c_item += gridDim.x;
+            if (c_item >= wd.n_items) break;
+            if (defer && more) issue_one();
+            zero_acc();
+            decode(c_item, c_tm, c_tn, c_z);
+            c_left = min(nk, (c_z + 1) * wd.kt_per_split) - c_z * wd.kt_per_split;
+        }
+    }
+#undef GL_VMCNT
+}
+
 // Deterministic split-K reduction + epilogue: one thread per (row, group of 4 columns).
 __global__ void __launch_bounds__(256)
 splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, Epilogue E) {
@@ -1086,12 +1565,12 @@ splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, Epi
     }
 }
 
-static int g_gemm_variant = -1;  // 0: register-staged v1, 1: LDS-DMA v2, 2: persistent v3 (default), 3: persistent + 4-slot K32 ring v4
+static int g_gemm_variant = -1;  // 0: register-staged v1, 1: LDS-DMA v2, 2: persistent v3, 3: persistent + 4-slot K32 ring v4, 4: v5 buffer-DMA persistent (default)
 void gemm_set_variant(int v) { g_gemm_variant = v; }
 static int gemm_variant() {
     if (g_gemm_variant < 0) {
         const char* e = getenv("GL_GEMM_VARIANT");
-        g_gemm_variant = e ? atoi(e) : 2;
+        g_gemm_variant = e ? atoi(e) : 4;
     }
     return g_gemm_variant;
 }
@@ -1102,6 +1581,7 @@ static int g_force_tm = 0, g_force_tn = 0, g_force_splits = 0;  // developer ove
 static int g_force_grid = 0;
 void gemm_force_cfg(int tm, int tn, int splits) { g_force_tm = tm; g_force_tn = tn; g_force_splits = splits; }
 void gemm_force_grid(int g) { g_force_grid = g; }
+void gemm_set_autotune(int on);
 static int g_last_cfg[3] = {0, 0, 0};
 void gemm_last_cfg(int* tm, int* tn, int* splits) { *tm = g_last_cfg[0]; *tn = g_last_cfg[1]; *splits = g_last_cfg[2]; }
 
@@ -1178,66 +1658,195 @@ int launch_p(const AOperand& A, const bf16* W, int M, int N, int K, const Epilog
     return GL_OK;
 }
 
+template <int WMW, int TM, int TN>
+int launch_u(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, float* ws, const WorkDesc& wd,
+             hipStream_t stream) {
+    constexpr int NT = WMW * 128, RPP = NT / 8, BM = WMW * TM * 16, BN = TN * 32, NST = WMW == 4 ? 3 : 2;
+    const int cap_def = WMW == 4 ? 256 : 512;  // workgroups resident per launch: 1 (8 waves) or 2 (4 waves) per CU
+    const int cap = (g_force_grid && (WMW == 2 || g_force_grid < 256)) ? g_force_grid : cap_def;
+    dim3 grid(wd.n_items < cap ? wd.n_items : cap);
+    dim3 block(NT);
+    const size_t lds = NST * (BM + BN) * 128 + (BN % RPP ? 1024 : 0);
+#define GL_LAUNCH_U(KFN)                                                                                         \
+    do {                                                                                                         \
+        auto kfn = KFN;                                                                                          \
+        static bool attr_done = false; /* once per instantiation; never inside a stream capture */              \
+        if (!attr_done && lds > 48 * 1024) {                                                                     \
+            GL_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            attr_done = true;                                                                                    \
+        }                                                                                                        \
+        hipLaunchKernelGGL(kfn, grid, block, lds, stream, A, W, M, N, K, E, ws, wd);                             \
+    } while (0)
+    if (A.mode == A_ROWS) GL_LAUNCH_U((gemm_u_kernel<WMW, TM, TN, A_ROWS>));
+    else GL_LAUNCH_U((gemm_u_kernel<WMW, TM, TN, A_CONV3>));
+#undef GL_LAUNCH_U
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
 // Tile shape + K split for the persistent kernel: minimise a cycle model of
 //   (items per block) x (K tiles per item x cycles per K tile + fixed per-item cost) + split-K reduce pass
 // over the tile shapes {128,64} x {160,128} and a few split counts.
+// Autotuner: the first (eager, non-capturing) launch of every distinct problem times the feasible tile / split /
+// residency candidates on the device with the caller's own buffers and caches the winner; captured launches and
+// GL_GEMM_AUTOTUNE=0 use the analytic cost model below. A launch only writes E.out (and the split-K workspace),
+// and the engine never aliases E.out with an input, so re-running a launch is idempotent.
+struct TunedCfg { int c, sp, grid; };
+static std::unordered_map<std::string, TunedCfg> g_tuned;
+static int g_autotune = -1;
+static hipEvent_t g_tune_ev[2] = {nullptr, nullptr};
+void gemm_set_autotune_impl(int on) { g_autotune = on; }
+
 int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, float* ws, size_t ws_bytes,
                   hipStream_t stream) {
-    static const int kTm[4] = {4, 4, 2, 2}, kTn[4] = {5, 4, 5, 4};
+    // candidates 0-3: 4 waves, two (or three) workgroups per CU; 4-5: v5 wide (8 waves, 256-row tile, one workgroup per CU)
+    static const int kTm[6] = {4, 4, 2, 2, 8, 8}, kTn[6] = {5, 4, 5, 4, 5, 4};
     static const int kSp[10] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
     const int nk = K / 64;
+    // v5 addresses both operands through 32-bit buffer offsets: every operand must be < 2 GiB
+    const size_t a_rows = A.mode == A_CONV3 ? (size_t)(M / (A.Ho * A.Wo)) * A.Hin * A.Win : (size_t)M;
+    const bool fits32 = a_rows * (size_t)std::max(A.ld0, A.ld1) * 2 < 0x7fff0000ull && (size_t)N * K * 2 < 0x7fff0000ull;
+    const bool use_u = gemm_variant() == 4 && fits32 && !(E.bias2 && E.res);  // v5's epilogue has no bias2 + residual form
+    static const int dbg = getenv("GL_GEMM_DBG") ? atoi(getenv("GL_GEMM_DBG")) : 0;
+
+    auto feasible = [&](int c, int& sp) {
+        const int tm = kTm[c], tn = kTn[c];
+        if (tm == 8 && !use_u) return false;
+        if (E.act == ACT_GEGLU && (tn & 1)) return false;
+        if (sp > 1 && (!ws || nk / sp < 2 || (size_t)sp * M * N * sizeof(float) > ws_bytes)) return false;
+        const int kps = cdiv(nk, sp);
+        sp = cdiv(nk, kps);
+        return true;
+    };
+    auto run_cfg = [&](int c, int sp, int grid_cap) -> int {
+        WorkDesc wd;
+        wd.dbg = dbg;
+        const int tm = kTm[c], tn = kTn[c];
+        wd.tiles_n = cdiv(N, tn * 32);
+        wd.kt_per_split = cdiv(nk, sp);
+        wd.splits = cdiv(nk, wd.kt_per_split);
+        wd.n_items = cdiv(M, tm * 32) * wd.tiles_n * wd.splits;
+        g_last_cfg[0] = tm; g_last_cfg[1] = tn; g_last_cfg[2] = wd.splits;
+        const int saved_grid = g_force_grid;
+        if (grid_cap) g_force_grid = grid_cap;
+        int rc;
+        if (use_u) {
+            switch (c) {
+                case 0: rc = launch_u<2, 4, 5>(A, W, M, N, K, E, ws, wd, stream); break;
+                case 1: rc = launch_u<2, 4, 4>(A, W, M, N, K, E, ws, wd, stream); break;
+                case 2: rc = launch_u<2, 2, 5>(A, W, M, N, K, E, ws, wd, stream); break;
+                case 3: rc = launch_u<2, 2, 4>(A, W, M, N, K, E, ws, wd, stream); break;
+                case 4: rc = launch_u<4, 4, 5>(A, W, M, N, K, E, ws, wd, stream); break;
+                default: rc = launch_u<4, 4, 4>(A, W, M, N, K, E, ws, wd, stream); break;
+            }
+        } else {
+            switch (c) {
+                case 0: rc = launch_p<4, 5>(A, W, M, N, K, E, ws, wd, stream); break;
+                case 1: rc = launch_p<4, 4>(A, W, M, N, K, E, ws, wd, stream); break;
+                case 2: rc = launch_p<2, 5>(A, W, M, N, K, E, ws, wd, stream); break;
+                default: rc = launch_p<2, 4>(A, W, M, N, K, E, ws, wd, stream); break;
+            }
+        }
+        g_force_grid = saved_grid;
+        GL_TRY(rc);
+        if (wd.splits > 1) {
+            int64_t total = (int64_t)M * (N / 4);
+            int blocks = (int)fmin((double)cdiv64(total, 256), 4096.0);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws, wd.splits, M, N, E);
+            GL_LAUNCH_CHECK();
+        }
+        return GL_OK;
+    };
+
+    // ---- developer override (kbench sweeps): exactly this tile / split if it fits the problem
+    if (g_force_tm) {
+        for (int c = 0; c < 6; ++c) {
+            if (kTm[c] != g_force_tm || kTn[c] != g_force_tn) continue;
+            for (int si = 0; si < 10; ++si) {
+                int sp = kSp[si];
+                if (g_force_splits && sp != g_force_splits) continue;
+                if (!feasible(c, sp)) continue;
+                if (g_force_splits && sp != g_force_splits) continue;
+                if (!g_force_splits && si > 0) break;  // no split given: unsplit
+                return run_cfg(c, sp, 0);
+            }
+        }
+    }
+
+    // ---- autotuned choice
+    if (g_autotune < 0) {
+        const char* e = getenv("GL_GEMM_AUTOTUNE");
+        g_autotune = e ? atoi(e) : 1;
+    }
+    char key[160];
+    snprintf(key, sizeof key, "%d,%d,%d|%d,%d,%d,%d,%d,%d,%d|%d,%d,%d,%d,%d,%d|%d", M, N, K, A.mode, A.C0, A.C1, A.stride, A.ups, A.Win,
+             A.Hin, E.mode, E.act, E.res != nullptr, E.bias2 != nullptr, E.out_f32, E.gate != nullptr, (int)use_u);
+    auto it = g_tuned.find(key);
+    if (it != g_tuned.end()) return run_cfg(it->second.c, it->second.sp, it->second.grid);
+
+    // ---- analytic model (also the capture-time / tuning-off fallback)
     double best_t = 1e30;
     int best_c = -1, best_sp = 1;
     for (int c = 0; c < 4; ++c) {
         const int tm = kTm[c], tn = kTn[c];
-        if (g_force_tm && (tm != g_force_tm || tn != g_force_tn)) continue;
-        if (E.act == ACT_GEGLU && (tn & 1)) continue;
         const int bm = tm * 32, bn = tn * 32;
         const int tiles = cdiv(M, bm) * cdiv(N, bn);
         for (int si = 0; si < 10; ++si) {
             int sp = kSp[si];
-            if (g_force_splits && sp != g_force_splits) continue;
-            if (sp > 1 && (!ws || nk / sp < 2 || (size_t)sp * M * N * sizeof(float) > ws_bytes)) continue;
+            if (!feasible(c, sp)) continue;
             const int kps = cdiv(nk, sp);
-            sp = cdiv(nk, kps);
             const int items = tiles * sp;
             const int per_block = cdiv(items, 512);
             // cycles per K tile of one block with two blocks per CU, fitted to kbench sweeps on MI355X
-            // (128x160: ~4600, 64x160: ~2600); a block alone on its CU runs ~25% faster
-            double t_kt = 0.197 * bm * bn + 560.0;
+            double t_kt = 0.15 * bm * bn + 500.0;
             if (items <= 256) t_kt *= 0.75;
-            const double t_item = kps * t_kt + (E.act == ACT_GEGLU ? 7000.0 : 4000.0);
+            const double t_item = kps * t_kt + (E.act == ACT_GEGLU ? 9000.0 : 6000.0) * (bm * bn / 20480.0);
             double tt = per_block * t_item;
             if (sp > 1) tt += 6000.0 + (double)sp * M * N * 8.0 / 2000.0;  // fp32 slabs out and back + reduce launch
             if (tt < best_t) { best_t = tt; best_c = c; best_sp = sp; }
         }
     }
     if (best_c < 0) return set_error(GL_ERR_ARG, "gemm: no tile configuration for M=%d N=%d K=%d", M, N, K);
-    WorkDesc wd;
-    const int tm = kTm[best_c], tn = kTn[best_c];
-    wd.tiles_n = cdiv(N, tn * 32);
-    wd.kt_per_split = cdiv(nk, best_sp);
-    wd.splits = cdiv(nk, wd.kt_per_split);
-    wd.n_items = cdiv(M, tm * 32) * wd.tiles_n * wd.splits;
-    g_last_cfg[0] = tm; g_last_cfg[1] = tn; g_last_cfg[2] = wd.splits;
-    int rc;
-    switch (best_c) {
-        case 0: rc = launch_p<4, 5>(A, W, M, N, K, E, ws, wd, stream); break;
-        case 1: rc = launch_p<4, 4>(A, W, M, N, K, E, ws, wd, stream); break;
-        case 2: rc = launch_p<2, 5>(A, W, M, N, K, E, ws, wd, stream); break;
-        default: rc = launch_p<2, 4>(A, W, M, N, K, E, ws, wd, stream); break;
+
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream) (void)hipStreamIsCapturing(stream, &cap);
+    if (!g_autotune || cap != hipStreamCaptureStatusNone) return run_cfg(best_c, best_sp, 0);
+
+    if (!g_tune_ev[0]) {
+        GL_HIP(hipEventCreate(&g_tune_ev[0]));
+        GL_HIP(hipEventCreate(&g_tune_ev[1]));
     }
-    GL_TRY(rc);
-    if (wd.splits > 1) {
-        int64_t total = (int64_t)M * (N / 4);
-        int blocks = (int)fmin((double)cdiv64(total, 256), 4096.0);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws, wd.splits, M, N, E);
-        GL_LAUNCH_CHECK();
+    TunedCfg win{best_c, best_sp, 0};
+    float win_ms = 1e30f;
+    for (int c = 0; c < 4; ++c) {
+        const int tiles = cdiv(M, kTm[c] * 32) * cdiv(N, kTn[c] * 32);
+        int last_sp = -1;
+        for (int si = 0; si < 10; ++si) {
+            int sp = kSp[si];
+            if (!feasible(c, sp) || sp == last_sp) continue;
+            last_sp = sp;
+            if (sp > 1 && tiles * sp > 4096) continue;      // splitting an already over-subscribed grid never paid
+            for (int gi = 0; gi < 2; ++gi) {
+                const int grid = gi ? 768 : 0;
+                if (gi && (kTm[c] * 32 + kTn[c] * 32 > 192 || tiles * sp <= 512)) continue;  // 3 workgroups/CU need <= 48 KB LDS each
+                GL_TRY(run_cfg(c, sp, grid));  // warm-up (also sets the kernel's LDS attribute outside the timed region)
+                GL_HIP(hipEventRecord(g_tune_ev[0], stream));
+                for (int r = 0; r < 3; ++r) GL_TRY(run_cfg(c, sp, grid));
+                GL_HIP(hipEventRecord(g_tune_ev[1], stream));
+                GL_HIP(hipEventSynchronize(g_tune_ev[1]));
+                float ms = 0.f;
+                GL_HIP(hipEventElapsedTime(&ms, g_tune_ev[0], g_tune_ev[1]));
+                if (ms < win_ms) { win_ms = ms; win = TunedCfg{c, sp, grid}; }
+            }
+        }
     }
-    return GL_OK;
+    g_tuned[key] = win;
+    return run_cfg(win.c, win.sp, win.grid);
 }
 
 }  // namespace
+
+void gemm_set_autotune(int on) { gemm_set_autotune_impl(on); }
 
 int gemm_launch(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, float* ws,
                 size_t ws_bytes, hipStream_t stream) {

@@ -133,6 +133,11 @@ int main(int argc, char** argv) {
     // "sweep": time every persistent-kernel tile shape x K split x grid cap per gemm/conv shape, print the best
     const bool sweep = argc > 4 && !strcmp(argv[4], "sweep");
     int n_bad = 0;
+    if (const char* kf = getenv("KB_FORCE")) {  // "tm,tn,splits" developer override for every gemm/conv shape it fits
+        int a = 0, b = 0, c2 = 0;
+        sscanf(kf, "%d,%d,%d", &a, &b, &c2);
+        gemm_force_cfg(a, b, c2);
+    }
     FILE* f = fopen(argv[1], "r");
     if (!f) { perror(argv[1]); return 1; }
     hipStream_t s;
@@ -259,15 +264,16 @@ int main(int argc, char** argv) {
             continue;
         }
         if (sweep && c <= 1) {
-            static const int tms[4] = {4, 4, 2, 2}, tns[4] = {5, 4, 5, 4};
+            static const int tms[6] = {4, 4, 2, 2, 8, 8}, tns[6] = {5, 4, 5, 4, 5, 4};
             static const int sps[8] = {1, 2, 3, 4, 6, 8, 12, 16};
             float best = 1e30f;
             int btm = 0, btn = 0, bsp = 0, bgrid = 0;
             std::string all;
             for (int gi = 0; gi < 2; ++gi)
-                for (int ci = 0; ci < 4; ++ci)
+                for (int ci = 0; ci < 6; ++ci)
                     for (int si = 0; si < 8; ++si) {
                         if (c == 0 && v[3] == 1 && (tns[ci] & 1)) continue;
+                        if (tms[ci] == 8 && gi) continue;  // the wide kernel always runs one workgroup per CU
                         const int grid = gi ? 768 : 512;
                         if (gi && tms[ci] * 32 + tns[ci] * 32 > 192) continue;  // 3 blocks/CU only fit for <= 48 KB of LDS
                         gemm_force_cfg(tms[ci], tns[ci], sps[si]);
@@ -279,7 +285,7 @@ int main(int argc, char** argv) {
                         int ctm2, ctn2, csp2;
                         relaunch();
                         gemm_last_cfg(&ctm2, &ctn2, &csp2);
-                        if (csp2 != sps[si]) continue;  // split count was rounded: duplicate of another entry
+                        if (csp2 != sps[si] || ctm2 != tms[ci] || ctn2 != tns[ci]) continue;  // rounded split / override did not fit
                         float tus = time_us(relaunch, 5, s);
                         char buf[64];
                         snprintf(buf, sizeof buf, " %dx%d/%d@%d=%.1f", tms[ci] * 32, tns[ci] * 32, csp2, grid, tus);

@@ -12,11 +12,17 @@
 
 namespace gl {
 
-int gn_nsplit(int HW) { return max(1, min(64, HW / 64)); }
-size_t gn_partial_bytes(int B, int HW) { return (size_t)B * gn_nsplit(HW) * 32 * 2 * sizeof(float); }
+// Both kernels use the same thread shape: block = C8 * R threads, thread (cx, ry) owns the 8 channels [8cx, 8cx+8)
+// (at most two groups) and walks pixels ry, ry+R, ... of its block's pixel range, UNR pixels per trip with all UNR
+// 16-byte loads issued before the first use (these kernels are latency-bound otherwise: one load in flight per thread
+// ran at 1.1 TB/s).
+constexpr int GN_UNR = 8;
+static int gn_rows(int C8) { return C8 >= 256 ? 1 : 256 / C8; }
+int gn_nsplit_c(int HW, int C8) { return max(1, min(64, cdiv(HW, gn_rows(C8) * GN_UNR))); }
+int gn_nsplit(int HW) { return max(1, min(64, HW / 8)); }  // upper bound over all channel counts (workspace sizing)
+size_t gn_partial_bytes(int B, int HW) { return (size_t)B * 64 * 32 * 2 * sizeof(float); }
 
-// ---- GroupNorm statistics: grid (nsplit, B), block = C8 * R threads.
-// thread (cx, ry) owns the 8 channels [8cx, 8cx+8) (at most two groups) of pixels ry, ry+R, ...
+// ---- GroupNorm statistics: grid (nsplit, B)
 __global__ void gn_stats_kernel(GNParams P, int nsplit, int C8, int R, int cpg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4* tl = reinterpret_cast<float4*>(smem);
@@ -26,9 +32,8 @@ __global__ void gn_stats_kernel(GNParams P, int nsplit, int C8, int R, int cpg) 
     const int b = blockIdx.y;
     const int c0 = cx * 8;
     const bool first = c0 < P.C0;
-    const bf16* base = first ? P.x0 : P.x1;
     const int ld = first ? P.C0 : P.C1;
-    const int coff = first ? c0 : c0 - P.C0;
+    const bf16* base = (first ? P.x0 + c0 : P.x1 + (c0 - P.C0)) + (size_t)b * P.HW * ld;
     const int per = (P.HW + nsplit - 1) / nsplit;
     const int p0 = blockIdx.x * per;
     const int p1 = min(P.HW, p0 + per);
@@ -38,14 +43,22 @@ __global__ void gn_stats_kernel(GNParams P, int nsplit, int C8, int R, int cpg) 
     for (int p = 0; p < 4; ++p) hi[p] = (c0 + 2 * p) / cpg != g_lo;
 
     float s_lo = 0.f, q_lo = 0.f, s_hi = 0.f, q_hi = 0.f;
-    for (int p = p0 + ry; p < p1; p += R) {
-        U4BF8 v;
-        v.u = *reinterpret_cast<const uint4*>(base + ((size_t)b * P.HW + p) * ld + coff);
+    for (int p = p0 + ry; p < p1; p += R * GN_UNR) {
+        U4BF8 v[GN_UNR];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float f = bf2f(v.e[e]);
-            if (hi[e >> 1]) { s_hi += f; q_hi += f * f; }
-            else            { s_lo += f; q_lo += f * f; }
+        for (int u = 0; u < GN_UNR; ++u) {
+            const int pp = p + u * R;
+            v[u].u = make_uint4(0, 0, 0, 0);
+            if (pp < p1) v[u].u = *reinterpret_cast<const uint4*>(base + (size_t)pp * ld);
+        }
+#pragma unroll
+        for (int u = 0; u < GN_UNR; ++u) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = bf2f(v[u].e[e]);
+                if (hi[e >> 1]) { s_hi += f; q_hi += f * f; }
+                else            { s_lo += f; q_lo += f * f; }
+            }
         }
     }
     tl[t] = make_float4(s_lo, q_lo, s_hi, q_hi);
@@ -69,18 +82,33 @@ __global__ void gn_stats_kernel(GNParams P, int nsplit, int C8, int R, int cpg) 
     }
 }
 
-// ---- GroupNorm apply (+SiLU): grid (nblk, B)
-__global__ void __launch_bounds__(256) gn_apply_kernel(GNParams P, int nsplit, int C8, int cpg, int per_block) {
+// ---- GroupNorm apply (+SiLU): grid (nblk, B), same thread shape; y = x * a + c with a = rstd * gamma, c = beta - mean * a
+__global__ void gn_apply_kernel(GNParams P, int nsplit, int C8, int R, int cpg, int per) {
     __shared__ float mean_s[32], rstd_s[32];
+    __shared__ double red_s[4][32][2];
     const int t = threadIdx.x;
     const int b = blockIdx.y;
-    if (t < 32) {
+    // per-group sums over the nsplit partials: 4 x 32 threads, each 16 independent loads, then a fixed-order combine
+    if (t < 128) {
+        const int g = t & 31, part = t >> 5;
         double s = 0.0, q = 0.0;
-        for (int sp = 0; sp < nsplit; ++sp) {
-            const float* src = P.partial + (((size_t)b * nsplit + sp) * 32 + t) * 2;
-            s += src[0];
-            q += src[1];
+        const float2* src = reinterpret_cast<const float2*>(P.partial) + (size_t)b * nsplit * 32 + g;
+        float2 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int sp = part + 4 * i;
+            v[i] = make_float2(0.f, 0.f);
+            if (sp < nsplit) v[i] = src[(size_t)sp * 32];
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s += v[i].x; q += v[i].y; }
+        red_s[part][g][0] = s;
+        red_s[part][g][1] = q;
+    }
+    __syncthreads();
+    if (t < 32) {
+        const double s = ((red_s[0][t][0] + red_s[1][t][0]) + red_s[2][t][0]) + red_s[3][t][0];
+        const double q = ((red_s[0][t][1] + red_s[1][t][1]) + red_s[2][t][1]) + red_s[3][t][1];
         const double n = (double)P.HW * cpg;
         const double mean = s / n;
         double var = q / n - mean * mean;
@@ -89,35 +117,52 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(GNParams P, int nsplit, i
         rstd_s[t] = (float)(1.0 / sqrt(var + (double)P.eps));
     }
     __syncthreads();
+    const int cx = t % C8;
+    const int ry = t / C8;
+    const int c0 = cx * 8;
     const int C = P.C0 + P.C1;
-    const int64_t total = (int64_t)P.HW * C8;
-    const int64_t beg = (int64_t)blockIdx.x * per_block;
-    const int64_t end = min(total, beg + per_block);
-    for (int64_t id = beg + t; id < end; id += 256) {
-        const int pix = (int)(id / C8);
-        const int cx = (int)(id - (int64_t)pix * C8);
-        const int c0 = cx * 8;
-        const bool first = c0 < P.C0;
-        const bf16* src = first ? P.x0 + ((size_t)b * P.HW + pix) * P.C0 + c0
-                                : P.x1 + ((size_t)b * P.HW + pix) * P.C1 + (c0 - P.C0);
-        U4BF8 v, o;
-        v.u = *reinterpret_cast<const uint4*>(src);
+    const bool first = c0 < P.C0;
+    const int ld = first ? P.C0 : P.C1;
+    const bf16* base = (first ? P.x0 + c0 : P.x1 + (c0 - P.C0)) + (size_t)b * P.HW * ld;
+    bf16* obase = P.y + (size_t)b * P.HW * C + c0;
+    float a[8], c[8];
+    {
         const float4 g0 = *reinterpret_cast<const float4*>(P.gamma + c0);
         const float4 g1 = *reinterpret_cast<const float4*>(P.gamma + c0 + 4);
         const float4 b0 = *reinterpret_cast<const float4*>(P.beta + c0);
         const float4 b1 = *reinterpret_cast<const float4*>(P.beta + c0 + 4);
         const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
         const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-        const int g_lo = c0 / cpg;
-        const int split_c = (g_lo + 1) * cpg;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int g = (c0 + e >= split_c) ? g_lo + 1 : g_lo;
-            float y = (bf2f(v.e[e]) - mean_s[g]) * rstd_s[g] * gm[e] + bt[e];
-            if (P.silu) y = silu_f(y);
-            o.e[e] = f2bf(y);
+            const int g = (c0 + e) / cpg;
+            a[e] = rstd_s[g] * gm[e];
+            c[e] = bt[e] - mean_s[g] * a[e];
         }
-        *reinterpret_cast<uint4*>(P.y + ((size_t)b * P.HW + pix) * C + c0) = o.u;
+    }
+    const int p0 = blockIdx.x * per;
+    const int p1 = min(P.HW, p0 + per);
+    for (int p = p0 + ry; p < p1; p += R * GN_UNR) {
+        U4BF8 v[GN_UNR];
+#pragma unroll
+        for (int u = 0; u < GN_UNR; ++u) {
+            const int pp = p + u * R;
+            if (pp < p1) v[u].u = *reinterpret_cast<const uint4*>(base + (size_t)pp * ld);
+        }
+#pragma unroll
+        for (int u = 0; u < GN_UNR; ++u) {
+            const int pp = p + u * R;
+            if (pp < p1) {
+                U4BF8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float y = fmaf(bf2f(v[u].e[e]), a[e], c[e]);
+                    if (P.silu) y = silu_f(y);
+                    o.e[e] = f2bf(y);
+                }
+                *reinterpret_cast<uint4*>(obase + (size_t)pp * C) = o.u;
+            }
+        }
     }
 }
 
@@ -128,17 +173,16 @@ int groupnorm_launch(const GNParams& P, hipStream_t stream) {
     const int C8 = C / 8;
     if (cpg < 4 || (cpg & 1)) return set_error(GL_ERR_UNSUPPORTED, "groupnorm: %d channels per group (need an even number >= 4)", cpg);
     if (C8 > 1024) return set_error(GL_ERR_ARG, "groupnorm: C=%d too large", C);
-    const int R = max(1, 256 / C8);
-    const int nsplit = gn_nsplit(P.HW);
+    const int R = gn_rows(C8);
+    const int nsplit = gn_nsplit_c(P.HW, C8);
     const int T = C8 * R;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, P.B), dim3(T), T * sizeof(float4), stream, P, nsplit, C8, R, cpg);
     GL_LAUNCH_CHECK();
-    const int64_t total = (int64_t)P.HW * C8;
-    int64_t nb64 = cdiv64(total, 1024);
-    int nblk = nb64 > 512 ? 512 : (int)nb64;
-    nblk = max(nblk, 1);
-    const int per_block = (int)cdiv64(total, nblk);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, P.B), dim3(256), 0, stream, P, nsplit, C8, cpg, per_block);
+    // apply: one trip (R * GN_UNR pixels) per block until the grid holds ~2048 blocks, then several trips per block
+    const int trips = cdiv(P.HW, R * GN_UNR);
+    const int nblk = max(1, min(trips, max(1, 2048 / P.B)));
+    const int per = cdiv(cdiv(P.HW, nblk), R) * R;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(cdiv(P.HW, per), P.B), dim3(T), 0, stream, P, nsplit, C8, R, cpg, per);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }
