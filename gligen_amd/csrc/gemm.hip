@@ -1122,6 +1122,31 @@ gemm_r_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
 //     loads retire in order among themselves). At an item's last K tile the next DMA is issued
 //     AFTER the epilogue (whose bias/residual loads would otherwise drain the in-order counter
 //     through a freshly issued tile); tile c+1, drained there, is not waited for again.
+// LDS fragment reads in inline asm. hipcc cannot tell that a ds_read of one ring slot does not alias the LDS-DMA
+// just issued into another, so with compiler-visible LDS loads it puts s_waitcnt vmcnt(0) in front of the first
+// ds_read after every DMA issue: the "prefetch" is drained before the multiply it should run under (seen in the
+// ISA, and in the ablation as DMA time + MFMA time adding up exactly). Asm reads are invisible to that pass; their
+// completion is waited for by hand (counted lgkmcnt, LDS returns in order) and the consumers are pinned below the
+// wait through "+v" operands (an MFMA is register-only, a "memory" clobber does not order it).
+template <int OFF>
+__device__ __forceinline__ void lds_rd16(bf16x8& d, unsigned addr) {
+    // no "memory" clobber: an asm that "may touch memory" makes the waitcnt pass drain the pending DMA exactly like a
+    // visible LDS load would; volatile keeps it ordered against the barrier, the DMA issues and the other asm statements
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int N, int STRIDE, int I = 0>
+__device__ __forceinline__ void lds_rd16_n(bf16x8 (&d)[N], unsigned addr) {
+    if constexpr (I < N) {
+        lds_rd16<I * STRIDE>(d[I], addr);
+        lds_rd16_n<N, STRIDE, I + 1>(d, addr);
+    }
+}
+template <int N>
+__device__ __forceinline__ void pin_regs(bf16x8 (&d)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(d[i]));
+}
+
 #define GL_BLDS16(rsrc, ldst, voff, soff)                                                                   \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(ldst), 16, \
                                              (int)(voff), (int)(soff), 0, 0)
@@ -1300,22 +1325,29 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
     const int xrow0 = wm * TM * 16 * 128;
     const int wrow0 = BM * 128 + wn * TN * 16 * 128;
 
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     auto compute = [&](int slot) {
-        const unsigned char* st = smem + slot * STAGE;
+        const unsigned st = lds0 + slot * STAGE;
+        const unsigned ax0 = st + xrow0 + foff0, ax1 = st + xrow0 + foff1;
+        const unsigned aw0 = st + wrow0 + foff0, aw1 = st + wrow0 + foff1;
         bf16x8 xa[TM], wa[TN], xb[TM], wb[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) xa[i] = *reinterpret_cast<const bf16x8*>(st + xrow0 + i * 2048 + foff0);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) wa[j] = *reinterpret_cast<const bf16x8*>(st + wrow0 + j * 2048 + foff0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) xb[i] = *reinterpret_cast<const bf16x8*>(st + xrow0 + i * 2048 + foff1);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) wb[j] = *reinterpret_cast<const bf16x8*>(st + wrow0 + j * 2048 + foff1);
+        lds_rd16_n<TM, 2048>(xa, ax0);
+        lds_rd16_n<TN, 2048>(wa, aw0);
+        lds_rd16_n<TM, 2048>(xb, ax1);
+        lds_rd16_n<TN, 2048>(wb, aw1);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN));  // the k-step 0 fragments have returned
+        pin_regs(xa);
+        pin_regs(wa);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xa[i], acc[i][j], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)");
+        pin_regs(xb);
+        pin_regs(wb);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1494,7 +1526,10 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
         landed = __builtin_amdgcn_readfirstlane((int)landed) != 0;
         if (!landed) {
             if (AHEAD >= 2 && ahead >= 2) GL_VMCNT(NI);   // all but the newest tile's DMAs are done
-            else GL_VMCNT(0);
+            // full drain through the builtin: hipcc then KNOWS nothing is pending. With an asm wait its scoreboard still
+            // carries the epilogue's bias/residual loads (whose destination VGPRs the fragments reuse) around the loop and
+            // it re-waits vmcnt(0) in front of the first fragment register write, i.e. right after the next DMA issue.
+            else __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), gfx9 encoding
         }
         landed = false;
         // tile c is in LDS for every wave after this barrier, and every wave has finished reading tile c-1
@@ -1508,7 +1543,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
         --ahead;
         if (--c_left == 0) {
             if constexpr (AHEAD >= 2) {
-                GL_VMCNT(0);      // only tile c+1 can be in flight (issued one K tile ago): it has landed now
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): only tile c+1 can be in flight (issued one K tile ago)
                 landed = true;
             }
             if (!(wd.dbg & 4)) epilogue(c_tm, c_tn, c_z);
