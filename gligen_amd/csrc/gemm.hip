@@ -1151,8 +1151,8 @@ __device__ __forceinline__ void pin_regs(bf16x8 (&d)[N]) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(ldst), 16, \
                                              (int)(voff), (int)(soff), 0, 0)
 
-template <int WMW, int TM, int TN, int AMODE>
-__global__ void __launch_bounds__(WMW * 128, 2)
+template <int WMW, int TM, int TN, int AMODE, int NST>
+__global__ void __launch_bounds__(WMW * 128, (WMW == 2 && NST > 2) ? 1 : 2)
 gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilogue E, float* __restrict__ ws, WorkDesc wd) {
     constexpr int NT = WMW * 128;               // threads
     constexpr int RPP = NT / 8;                 // tile rows per DMA pass (one 128-byte row per 8 lanes)
@@ -1163,7 +1163,8 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
     constexpr int WREM = BN % RPP;              // rows of the partial last weight pass (issued by the first WREM/8 waves)
     constexpr int WP = WPF + (WREM ? 1 : 0);
     constexpr int NI = XP + WP;                 // DMA wave-instructions per wave per K tile
-    constexpr int NST = WMW == 4 ? 3 : 2;       // LDS stages
+    // NST = LDS stages: 2 (two 4-wave workgroups per CU hide each other's DMA latency), 3 (8 waves), or 4 with 4 waves
+    // and ONE workgroup per CU: three K tiles in flight, for the small-M problems whose K loop is a latency chain
     constexpr int AHEAD = NST - 1;              // K tiles in flight ahead of the one being multiplied
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int DUMP = NST * STAGE;
@@ -1517,21 +1518,28 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
 #pragma unroll
     for (int i = 0; i < AHEAD; ++i)
         if (more) issue_one();
-    bool landed = false;  // the tile about to be multiplied is known to have landed (drained before the previous epilogue)
+    int landed = 0;  // upcoming tiles known to have landed already (drained before the previous epilogue)
     for (;;) {
         ahead = __builtin_amdgcn_readfirstlane(ahead);
         c_left = __builtin_amdgcn_readfirstlane(c_left);
         slot_c = __builtin_amdgcn_readfirstlane(slot_c);
         more = __builtin_amdgcn_readfirstlane((int)more) != 0;
-        landed = __builtin_amdgcn_readfirstlane((int)landed) != 0;
-        if (!landed) {
-            if (AHEAD >= 2 && ahead >= 2) GL_VMCNT(NI);   // all but the newest tile's DMAs are done
+        landed = __builtin_amdgcn_readfirstlane(landed);
+        if constexpr (AHEAD == 1) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): unconditional, so that hipcc knows it (see below)
+        } else if (landed > 0) {
+            --landed;
+        } else {
+            // tile c must have landed; the ahead - 1 tiles issued after it may stay in flight (DMA loads retire in order)
+            const int keep = ahead - 1;
+            if (AHEAD >= 4 && keep >= 3) GL_VMCNT(3 * NI);
+            else if (AHEAD >= 3 && keep == 2) GL_VMCNT(2 * NI);
+            else if (AHEAD >= 2 && keep == 1) GL_VMCNT(NI);
             // full drain through the builtin: hipcc then KNOWS nothing is pending. With an asm wait its scoreboard still
             // carries the epilogue's bias/residual loads (whose destination VGPRs the fragments reuse) around the loop and
             // it re-waits vmcnt(0) in front of the first fragment register write, i.e. right after the next DMA issue.
             else __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), gfx9 encoding
         }
-        landed = false;
         // tile c is in LDS for every wave after this barrier, and every wave has finished reading tile c-1
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -1543,8 +1551,8 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
         --ahead;
         if (--c_left == 0) {
             if constexpr (AHEAD >= 2) {
-                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): only tile c+1 can be in flight (issued one K tile ago)
-                landed = true;
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): tiles c+1 .. c+AHEAD-1 (issued 1+ K tiles ago) have landed now
+                landed = min(ahead, AHEAD - 1);
             }
             if (!(wd.dbg & 4)) epilogue(c_tm, c_tn, c_z);
             c_item += gridDim.x;
@@ -1693,12 +1701,12 @@ int launch_p(const AOperand& A, const bf16* W, int M, int N, int K, const Epilog
     return GL_OK;
 }
 
-template <int WMW, int TM, int TN>
+template <int WMW, int TM, int TN, int NST>
 int launch_u(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, float* ws, const WorkDesc& wd,
              hipStream_t stream) {
-    constexpr int NT = WMW * 128, RPP = NT / 8, BM = WMW * TM * 16, BN = TN * 32, NST = WMW == 4 ? 3 : 2;
-    const int cap_def = WMW == 4 ? 256 : 512;  // workgroups resident per launch: 1 (8 waves) or 2 (4 waves) per CU
-    const int cap = (g_force_grid && (WMW == 2 || g_force_grid < 256)) ? g_force_grid : cap_def;
+    constexpr int NT = WMW * 128, RPP = NT / 8, BM = WMW * TM * 16, BN = TN * 32;
+    const int cap_def = (WMW == 4 || NST > 2) ? 256 : 512;  // workgroups resident per launch: 1 or 2 per CU
+    const int cap = (g_force_grid && ((WMW == 2 && NST == 2) || g_force_grid < 256)) ? g_force_grid : cap_def;
     dim3 grid(wd.n_items < cap ? wd.n_items : cap);
     dim3 block(NT);
     const size_t lds = NST * (BM + BN) * 128 + (BN % RPP ? 1024 : 0);
@@ -1712,8 +1720,8 @@ int launch_u(const AOperand& A, const bf16* W, int M, int N, int K, const Epilog
         }                                                                                                        \
         hipLaunchKernelGGL(kfn, grid, block, lds, stream, A, W, M, N, K, E, ws, wd);                             \
     } while (0)
-    if (A.mode == A_ROWS) GL_LAUNCH_U((gemm_u_kernel<WMW, TM, TN, A_ROWS>));
-    else GL_LAUNCH_U((gemm_u_kernel<WMW, TM, TN, A_CONV3>));
+    if (A.mode == A_ROWS) GL_LAUNCH_U((gemm_u_kernel<WMW, TM, TN, A_ROWS, NST>));
+    else GL_LAUNCH_U((gemm_u_kernel<WMW, TM, TN, A_CONV3, NST>));
 #undef GL_LAUNCH_U
     GL_LAUNCH_CHECK();
     return GL_OK;
@@ -1735,6 +1743,8 @@ void gemm_set_autotune_impl(int on) { g_autotune = on; }
 int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, float* ws, size_t ws_bytes,
                   hipStream_t stream) {
     // candidates 0-3: 4 waves, two (or three) workgroups per CU; 4-5: v5 wide (8 waves, 256-row tile, one workgroup per CU)
+    // (the 4-wave tiles on a 4-stage ring with one workgroup per CU -- three K tiles in flight -- were tried for the
+    //  latency-chain small-M problems and never won a sweep against two workgroups per CU; dropped)
     static const int kTm[6] = {4, 4, 2, 2, 8, 8}, kTn[6] = {5, 4, 5, 4, 5, 4};
     static const int kSp[10] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
     const int nk = K / 64;
@@ -1767,12 +1777,12 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
         int rc;
         if (use_u) {
             switch (c) {
-                case 0: rc = launch_u<2, 4, 5>(A, W, M, N, K, E, ws, wd, stream); break;
-                case 1: rc = launch_u<2, 4, 4>(A, W, M, N, K, E, ws, wd, stream); break;
-                case 2: rc = launch_u<2, 2, 5>(A, W, M, N, K, E, ws, wd, stream); break;
-                case 3: rc = launch_u<2, 2, 4>(A, W, M, N, K, E, ws, wd, stream); break;
-                case 4: rc = launch_u<4, 4, 5>(A, W, M, N, K, E, ws, wd, stream); break;
-                default: rc = launch_u<4, 4, 4>(A, W, M, N, K, E, ws, wd, stream); break;
+                case 0: rc = launch_u<2, 4, 5, 2>(A, W, M, N, K, E, ws, wd, stream); break;
+                case 1: rc = launch_u<2, 4, 4, 2>(A, W, M, N, K, E, ws, wd, stream); break;
+                case 2: rc = launch_u<2, 2, 5, 2>(A, W, M, N, K, E, ws, wd, stream); break;
+                case 3: rc = launch_u<2, 2, 4, 2>(A, W, M, N, K, E, ws, wd, stream); break;
+                case 4: rc = launch_u<4, 4, 5, 3>(A, W, M, N, K, E, ws, wd, stream); break;
+                default: rc = launch_u<4, 4, 4, 3>(A, W, M, N, K, E, ws, wd, stream); break;
             }
         } else {
             switch (c) {
@@ -1853,7 +1863,7 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
     }
     TunedCfg win{best_c, best_sp, 0};
     float win_ms = 1e30f;
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < 4; ++c) {  // (the 8-wave tiles 4, 5 never won a sweep)
         const int tiles = cdiv(M, kTm[c] * 32) * cdiv(N, kTn[c] * 32);
         int last_sp = -1;
         for (int si = 0; si < 10; ++si) {

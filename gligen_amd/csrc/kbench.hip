@@ -6,6 +6,7 @@
 //   kbench <shapes-file> [reps] [filter]
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -17,6 +18,8 @@
 #include "norm.h"
 
 using namespace gl;
+
+static hipStream_t cur_s = nullptr;  // stream the recorded launch closures enqueue on (switched by the "seq" mode)
 
 #define HC(expr)                                                                          \
     do {                                                                                  \
@@ -133,6 +136,11 @@ int main(int argc, char** argv) {
     // "sweep": time every persistent-kernel tile shape x K split x grid cap per gemm/conv shape, print the best
     const bool sweep = argc > 4 && !strcmp(argv[4], "sweep");
     int n_bad = 0;
+    const int kb_batch = getenv("KB_B") ? atoi(getenv("KB_B")) : 8;  // samples behind the gemm rows (head-layout epilogues)
+    // "seq": after the per-shape table, enqueue the whole list (count launches per shape, no host sync in between) on one
+    // stream, then on two streams concurrently, and print the wall times
+    const bool seq = argc > 4 && !strcmp(argv[4], "seq");
+    std::vector<std::pair<std::function<void()>, int>> recorded;
     if (const char* kf = getenv("KB_FORCE")) {  // "tm,tn,splits" developer override for every gemm/conv shape it fits
         int a = 0, b = 0, c2 = 0;
         sscanf(kf, "%d,%d,%d", &a, &b, &c2);
@@ -142,6 +150,7 @@ int main(int argc, char** argv) {
     if (!f) { perror(argv[1]); return 1; }
     hipStream_t s;
     HC(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    cur_s = s;
 
     const size_t ACT = (size_t)320 << 20;  // elements: covers 4*512*512*256 (VAE) and the GEGLU outputs
     bf16* a0 = dev_bf16(ACT, 1);
@@ -151,8 +160,9 @@ int main(int argc, char** argv) {
     float* bias = dev_f32(1 << 16, 5, 0.1f);
     float* gam = dev_f32(1 << 16, 6, 1.f);
     size_t ws_bytes = (size_t)256 << 20;
-    float* ws;
+    float *ws, *ws2;
     HC(hipMalloc(&ws, ws_bytes));
+    HC(hipMalloc(&ws2, ws_bytes));
     float* partial;
     HC(hipMalloc(&partial, 1 << 20));
     const size_t CMP = check ? ACT : 0;  // reference copies of the two output buffers
@@ -189,11 +199,11 @@ int main(int argc, char** argv) {
             epilogue_defaults(E);
             AOperand A;
             if (epi == 3) {  // transposed launch: rows operand = weights [M][K], other = activations [N][K]
-                const int C = M, H = 8, d = C / H, B = 8, T = N / B;
+                const int C = M, H = 8, d = C / H, B = kb_batch, T = N / B;
                 int dp, dpv;
                 GC(attn_dims(d, &dp, &dpv));
                 E.mode = EPI_VT_HEADS; E.out = a2; E.H = H; E.d = d; E.DPV = dpv; E.T = T; E.Tpad_k = T;
-                relaunch = [=] { GC(gemm_launch_t(w, C, a0, N, K, E, s)); };
+                relaunch = [=] { GC(gemm_launch_t(w, C, a0, N, K, E, cur_s)); };
                 us = time_us(relaunch, reps, s);
             } else {
                 aoperand_rows(A, a0, K, K);
@@ -202,14 +212,14 @@ int main(int argc, char** argv) {
                 } else if (epi == 1) {
                     E.act = ACT_GEGLU; E.geglu16 = gemm_geglu_layout(); E.out = a2; E.ldo = N / 2; E.bias = bias;
                 } else {
-                    const int H = 8, B = 8, T = M / B;
+                    const int H = 8, B = kb_batch, T = M / B;
                     const int C = K, d = C / H;
                     int dp, dpv;
                     GC(attn_dims(d, &dp, &dpv));
                     E.mode = EPI_QK_HEADS; E.q = a1; E.k = a2; E.C = C; E.H = H; E.d = d; E.DP = dp; E.T = T;
                     E.Tpad_q = round_up(T, 128); E.Tpad_k = T;
                 }
-                relaunch = [=] { GC(gemm_launch(A, w, M, N, K, E, ws, ws_bytes, s)); };
+                relaunch = [=] { GC(gemm_launch(A, w, M, N, K, E, cur_s == s ? ws : ws2, ws_bytes, cur_s)); };
                 us = time_us(relaunch, reps, s);
             }
         } else if (!strcmp(kind, "conv")) {
@@ -227,7 +237,7 @@ int main(int argc, char** argv) {
             epilogue_defaults(E);
             E.out = a2; E.ldo = Cout; E.bias = bias; E.bias2 = gam; E.bias2_ld = Cout; E.rows_per_b = Ho * Wo;
             if (Cout == 32) { E.mode = EPI_NCHW_F32; E.n_real = 4; E.bias2 = nullptr; }
-            relaunch = [=] { GC(gemm_launch(A, w, M, Cout, K, E, ws, ws_bytes, s)); };
+            relaunch = [=] { GC(gemm_launch(A, w, M, Cout, K, E, cur_s == s ? ws : ws2, ws_bytes, cur_s)); };
             us = time_us(relaunch, reps, s);
         } else if (!strcmp(kind, "attn")) {
             const int B = v[0], H = v[1], d = v[2], Nq = v[3], Nk = v[4];
@@ -243,7 +253,8 @@ int main(int argc, char** argv) {
             P.ldo = H * d; P.o_rows_per_b = Nq;
             P.scale_log2e = 1.4426950408889634f / sqrtf((float)d);
             GC(attn_vt_ones_launch(a2, B * H, d, P.Tk_pad, s));
-            us = time_us([&] { GC(attn_launch(P, B, s)); }, reps, s);
+            relaunch = [=] { GC(attn_launch(P, B, cur_s)); };
+            us = time_us(relaunch, reps, s);
         } else if (!strcmp(kind, "gn")) {
             const int B = v[0], HW = v[1], C0 = v[2], C1 = v[3], silu = v[4];
             count = v[5]; c = 3;
@@ -251,7 +262,8 @@ int main(int argc, char** argv) {
             GNParams P{};
             P.x0 = a0; P.C0 = C0; P.x1 = C1 ? a1 : nullptr; P.C1 = C1; P.B = B; P.HW = HW; P.eps = 1e-5f;
             P.gamma = gam; P.beta = bias; P.y = a2; P.silu = silu; P.partial = partial;
-            us = time_us([&] { GC(groupnorm_launch(P, s)); }, reps, s);
+            relaunch = [=] { GC(groupnorm_launch(P, cur_s)); };
+            us = time_us(relaunch, reps, s);
         } else if (!strcmp(kind, "ln")) {
             const int B = v[0], N1 = v[1], N2 = v[2], Tpad = v[3], C = v[4];
             count = v[5]; c = 4;
@@ -259,7 +271,8 @@ int main(int argc, char** argv) {
             LNParams P{};
             P.x = a0; P.x2 = N2 ? a1 : nullptr; P.B = B; P.N1 = N1; P.N2 = N2; P.Tpad = Tpad; P.C = C; P.eps = 1e-5f;
             P.gamma = gam; P.beta = bias; P.y = a2;
-            us = time_us([&] { GC(layernorm_launch(P, s)); }, reps, s);
+            relaunch = [=] { GC(layernorm_launch(P, cur_s)); };
+            us = time_us(relaunch, reps, s);
         } else {
             continue;
         }
@@ -273,9 +286,9 @@ int main(int argc, char** argv) {
                 for (int ci = 0; ci < 6; ++ci)
                     for (int si = 0; si < 8; ++si) {
                         if (c == 0 && v[3] == 1 && (tns[ci] & 1)) continue;
-                        if (tms[ci] == 8 && gi) continue;  // the wide kernel always runs one workgroup per CU
+                        if (tms[ci] >= 8 && gi) continue;  // the wide / deep kernels always run one workgroup per CU
                         const int grid = gi ? 768 : 512;
-                        if (gi && tms[ci] * 32 + tns[ci] * 32 > 192) continue;  // 3 blocks/CU only fit for <= 48 KB of LDS
+                        if (gi && (tms[ci] >= 8 || tms[ci] * 32 + tns[ci] * 32 > 192)) continue;  // 3 blocks/CU only fit for <= 48 KB of LDS
                         gemm_force_cfg(tms[ci], tns[ci], sps[si]);
                         gemm_force_grid(grid);
                         const int nk = gK / 64;
@@ -285,10 +298,10 @@ int main(int argc, char** argv) {
                         int ctm2, ctn2, csp2;
                         relaunch();
                         gemm_last_cfg(&ctm2, &ctn2, &csp2);
-                        if (csp2 != sps[si] || ctm2 != tms[ci] || ctn2 != tns[ci]) continue;  // rounded split / override did not fit
+                        if (csp2 != sps[si] || ctm2 != (tms[ci] > 8 ? tms[ci] - 8 : tms[ci]) || ctn2 != tns[ci]) continue;  // rounded split / override did not fit
                         float tus = time_us(relaunch, 5, s);
                         char buf[64];
-                        snprintf(buf, sizeof buf, " %dx%d/%d@%d=%.1f", tms[ci] * 32, tns[ci] * 32, csp2, grid, tus);
+                        snprintf(buf, sizeof buf, " %s%dx%d/%d@%d=%.1f", tms[ci] > 8 ? "D" : "", ctm2 * 32, tns[ci] * 32, csp2, grid, tus);
                         all += buf;
                         if (tus < best) { best = tus; btm = tms[ci]; btn = tns[ci]; bsp = csp2; bgrid = grid; }
                     }
@@ -317,6 +330,7 @@ int main(int argc, char** argv) {
         int ctm = 0, ctn = 0, csp = 0;
         if (c <= 1) gemm_last_cfg(&ctm, &ctn, &csp);
         printf("%-58s %9.1f %9.1f %8.3f %5d  %dx%d/%d\n", line, us, rate, us * count * 1e-3, count, ctm * 32, ctn * 32, csp);
+        if (seq && relaunch) recorded.emplace_back(relaunch, count);
         tot_us[c] += (double)us * count;
         tot_flop[c] += flop * count;
     }
@@ -327,6 +341,43 @@ int main(int argc, char** argv) {
         printf("\n");
         all += tot_us[i];
         allf += tot_flop[i];
+    }
+    if (seq) {
+        hipStream_t s1;
+        HC(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+        hipEvent_t e0, e1, e2;
+        HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1)); HC(hipEventCreate(&e2));
+        auto enqueue_all = [&](hipStream_t st, size_t start = 0) {  // start: rotate the list so two streams are out of phase
+            cur_s = st;
+            for (size_t k = 0; k < recorded.size(); ++k) {
+                auto& rc = recorded[(k + start) % recorded.size()];
+                for (int i = 0; i < rc.second; ++i) rc.first();
+            }
+        };
+        for (int rep = 0; rep < 3; ++rep) {
+            HC(hipDeviceSynchronize());
+            HC(hipEventRecord(e0, s));
+            enqueue_all(s);
+            HC(hipEventRecord(e1, s));
+            HC(hipEventSynchronize(e1));
+            float one = 0, two = 0;
+            HC(hipEventElapsedTime(&one, e0, e1));
+            HC(hipDeviceSynchronize());
+            auto t0 = std::chrono::steady_clock::now();
+            enqueue_all(s);
+            enqueue_all(s1, recorded.size() / 3);
+            HC(hipStreamSynchronize(s));
+            HC(hipStreamSynchronize(s1));
+            two = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            HC(hipDeviceSynchronize());
+            t0 = std::chrono::steady_clock::now();
+            enqueue_all(s);
+            enqueue_all(s);
+            HC(hipStreamSynchronize(s));
+            const float twice = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            printf("SEQ one pass on one stream %.3f ms | two passes back to back %.3f ms | two passes on two streams %.3f ms\n", one, twice, two);
+        }
+        cur_s = s;
     }
     if (check) printf("CHECK v1~selected: %s (%d mismatching shapes)\n", n_bad ? "FAILED" : "ok", n_bad);
     printf("TOTAL all   %9.3f ms  %8.1f TF/s (sum of isolated kernels, back-to-back launches of each shape)\n", all * 1e-3,

@@ -6,16 +6,15 @@ conv 8 64 64 320 0 320 1 0 7
 gemm 32768 320 1280 0 10
 gemm 32768 2560 320 1 10
 gemm 32768 320 320 0 25
-gemm 32768 640 320 2 5
-gemm 320 32768 320 3 5
+gemm 8192 5120 640 1 10
+gemm 2048 10240 1280 1 10
 conv 8 32 32 640 0 640 1 0 6
 gemm 8192 640 640 0 25
 gemm 2048 1280 1280 0 25
 EOS
-for f in 4,5,1 2,5,1 2,4,1; do
-for d in 0 4 7 3 5 6; do
+for f in 4,5,1 4,4,1 2,5,1; do
+for d in 0 4 7 3; do
 echo "== force $f dbg $d"
-GL_GEMM_VARIANT=4 KB_FORCE=$f GL_GEMM_DBG=$d timeout 100 $K /tmp/abl.shapes 20 | grep "^conv\|^gemm" | cut -c1-110
+GL_GEMM_AUTOTUNE=0 KB_FORCE=$f GL_GEMM_DBG=$d timeout 100 $K /tmp/abl.shapes 20 | grep "^conv\|^gemm" | cut -c1-110
 done
-done > gpurun_out/abl2.txt 2>&1
-cat gpurun_out/abl2.txt
+done > gpurun_out/abl3.txt 2>&1
