@@ -125,6 +125,14 @@ def main():
     assert out.shape == (B, 512, 512, 3) and out.dtype == torch.uint8
     assert all(torch.equal(o, out) for o in outs), "lanes disagree on identical inputs"
 
+    # per-kernel profile of one eager [cond ; uncond] evaluation on lane 0 (conditioning is still set from the last pass):
+    # HIP events on the launch stream around every launch, aggregated by kernel symbol
+    with torch.cuda.stream(lanes[0][3]):
+        tt = torch.full((2 * B,), 501, device=dev, dtype=torch.long)
+        lanes[0][0].engine.unet_profile(x_T, tt, batch=2 * B)          # warm
+        prof = lanes[0][0].engine.unet_profile(x_T, tt, batch=2 * B)
+    torch.cuda.synchronize()
+
     autoencoder = lanes[0][1]
     t0 = time.perf_counter(); d = autoencoder.decode(torch.randn(B, 4, 64, 64, device=dev)); torch.cuda.synchronize()
     dec_ms = (time.perf_counter() - t0) * 1e3
@@ -134,6 +142,23 @@ def main():
         n_images = B * world * args.steps
         value = n_images / elapsed
         unet_tflops = 2 * B * F_UNET / (unet_ms * 1e-3) / 1e12
+        # dominant kernel = the symbol with the largest total time inside one UNet evaluation; its launches' algorithmic
+        # FLOPs / their HIP-event time. profiles/<round>/bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this
+        # same command) lists the same symbol with its average duration over the whole run.
+        mm = [p for p in prof if p["flops"] > 0]
+        dom = mm[0]
+        tot_ms = sum(p["ms"] for p in prof)
+        roofline = {"bound": "mfma", "kernel": dom["name"], "achieved": dom["flops"] / (dom["ms"] * 1e-3) / 1e12,
+                    "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": dom["flops"] / (dom["ms"] * 1e-3) / PEAK_BF16,
+                    "traffic": None, "launches_per_unet_eval": dom["calls"], "avg_launch_us": dom["ms"] / dom["calls"] * 1e3,
+                    "flops_per_launch_avg": dom["flops"] / dom["calls"], "share_of_unet_eval": dom["ms"] / tot_ms,
+                    "measured": "HIP events on the launch stream around each launch of one eager UNet evaluation at batch 2B",
+                    "unet_eval": {"achieved": unet_tflops, "frac": unet_tflops * 1e12 / PEAK_BF16, "flops_per_launch": 2 * B * F_UNET,
+                                  "desc": "whole [cond ; uncond] evaluation (one hipGraph launch) against the same roof"},
+                    "whole_image": {"achieved": value / world * F_IMG / 1e12, "frac": value / world * F_IMG / PEAK_BF16},
+                    "kernels": [{"kernel": p["name"], "launches": p["calls"], "ms": round(p["ms"], 4),
+                                 **({"TFLOP/s": round(p["flops"] / (p["ms"] * 1e-3) / 1e12, 1)} if p["flops"] > 0 else
+                                    {"GB/s": round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1)})} for p in prof[:12]]}
         line = {
             "metric": "512x512 images/sec @ 50 PLMS steps, box+text (CFG 7.5), UNet step ms",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -145,11 +170,7 @@ def main():
             "unet_step_ms": unet_ms, "unet_step_desc": f"one [cond ; uncond] UNet evaluation at batch {2 * B} (hipGraph replay, HIP events on the engine stream, "
                                                        f"measured in an untimed pass with one batch in flight)",
             "vae_decode_ms": dec_ms,
-            "roofline": {"bound": "mfma", "kernel": "UNet CFG-pair evaluation (one hipGraph launch, all kernels of UNetModel.forward at batch 2B)",
-                         "achieved": unet_tflops, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": unet_tflops * 1e12 / PEAK_BF16,
-                         "traffic": None,
-                         "whole_image_achieved": value / world * F_IMG / 1e12, "whole_image_frac": value / world * F_IMG / PEAK_BF16,
-                         "flops_per_launch": 2 * B * F_UNET},
+            "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()

@@ -53,6 +53,10 @@ class PlmsArgs(C.Structure):
     ]
 
 
+class ProfRec(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("calls", C.c_int), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
 # every symbol include/gligen_amd.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 _I = C.c_int
@@ -71,6 +75,7 @@ SYMBOLS = {
     "gl_vae_decode": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "gl_sample_plms": (_I, [_P, C.POINTER(PlmsArgs), _P]),
     "gl_sampler_timing": (_I, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(_I)]),
+    "gl_unet_profile": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _P, C.POINTER(ProfRec), _I, C.POINTER(_I), _P]),
     "gl_to_uint8": (_I, [_P, _P, _I, _I, _I, _P]),
     "gl_arena_high_water": (_I, [_P, C.POINTER(C.c_size_t)]),
     "gl_launch_count": (_I, [_P, C.POINTER(C.c_int64)]),

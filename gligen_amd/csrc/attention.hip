@@ -277,6 +277,10 @@ int attn_vt_ones_launch(bf16* vt, int BH, int d, int Tk_pad, hipStream_t stream)
     return GL_OK;
 }
 
+const char* attn_kernel_name(int d) {
+    return d == 40 ? "attn_kernel<48, 64, true>" : d == 80 ? "attn_kernel<80, 96, true>" : "attn_kernel<160, 160, false>";
+}
+
 int attn_launch(const AttnParams& P, int B, hipStream_t stream) {
     if (P.Nq <= 0 || P.Nk <= 0) return set_error(GL_ERR_ARG, "attention: empty Nq=%d Nk=%d", P.Nq, P.Nk);
     if (P.Tq_pad % 128 != 0 || P.Tk_pad % 64 != 0 || P.Tq_pad < P.Nq || P.Tk_pad < P.Nk)

@@ -151,6 +151,32 @@ int gl_sampler_timing(gl_ctx* ctx, float* avg_unet_eval_ms, float* first_eval_ms
     GL_API_END
 }
 
+int gl_unet_profile(gl_ctx* ctx, int Beff, int h, int w, const float* x, int xB, const int64_t* timesteps,
+                    const float* inpaint_extra, int extraB, float* eps_out, gl_prof_rec* recs, int max_recs, int* n_recs,
+                    gl_stream s) {
+    NEED(ctx);
+    if (!x || !timesteps || !eps_out || !recs || !n_recs || max_recs <= 0) return gl::set_error(GL_ERR_ARG, "null pointer");
+    GL_API_BEGIN
+    ctx->eng->profile_begin();
+    std::vector<Engine::ProfRec> out;
+    try {
+        ctx->eng->unet_forward(Beff, h, w, x, xB, timesteps, inpaint_extra, extraB, eps_out, S(s));
+    } catch (...) {
+        (void)ctx->eng->profile_end(S(s));
+        throw;
+    }
+    out = ctx->eng->profile_end(S(s));
+    int n = 0;
+    for (const auto& r : out) {
+        if (n >= max_recs) break;
+        gl_prof_rec& d = recs[n++];
+        snprintf(d.name, sizeof d.name, "%s", r.name.c_str());
+        d.calls = r.calls; d.ms = r.ms; d.flops = r.flops; d.bytes = r.bytes;
+    }
+    *n_recs = n;
+    GL_API_END
+}
+
 int gl_to_uint8(const float* img, uint8_t* out, int B, int C, int HW, gl_stream s) {
     if (!img || !out) return gl::set_error(GL_ERR_ARG, "null pointer");
     return to_uint8_launch(img, out, B, C, HW, S(s));

@@ -121,7 +121,25 @@ class Engine {
     int device() const { return device_; }
     int64_t n_launches = 0;
 
+    // ---- per-kernel profile of one eager UNetModel.forward: HIP events around every GEMM / conv / attention /
+    // norm launch on the stream it is launched on, aggregated by kernel symbol (bench.py's roofline block)
+    struct ProfRec { std::string name; int calls = 0; double ms = 0, flops = 0, bytes = 0; };
+    void profile_begin();
+    std::vector<ProfRec> profile_end(hipStream_t s);
+
    private:
+    struct ProfEvt { std::string name; double flops, bytes; hipEvent_t e0, e1; };
+    bool profiling_ = false;
+    std::vector<ProfEvt> prof_;
+    std::vector<hipEvent_t> prof_pool_;
+    // RAII: records an event pair around the launches issued in its scope (no-op unless profiling)
+    struct ProfScope {
+        Engine* e; hipStream_t s; size_t idx;
+        ProfScope(Engine* eng, hipStream_t st, const std::string& name, double flops, double bytes);
+        ~ProfScope();
+        void rename(const std::string& n) { if (e->profiling_) e->prof_[idx].name = n; }
+    };
+    friend struct ProfScope;
     const RawTensor& raw(const std::string& key) const;
     bool has(const std::string& key) const { return raw_.count(key) != 0; }
     const float* F(const std::string& key) const { return raw(key).p; }

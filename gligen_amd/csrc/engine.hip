@@ -77,6 +77,45 @@ Engine::~Engine() {
     arena_.destroy();
 }
 
+// ---------------------------------------------------------------- per-kernel profile
+Engine::ProfScope::ProfScope(Engine* eng, hipStream_t st, const std::string& name, double flops, double bytes) : e(eng), s(st), idx(0) {
+    if (!e->profiling_) return;
+    auto get = [&]() {
+        hipEvent_t ev;
+        if (!e->prof_pool_.empty()) { ev = e->prof_pool_.back(); e->prof_pool_.pop_back(); }
+        else if (hipEventCreate(&ev) != hipSuccess) throw GlError(GL_ERR_HIP, "hipEventCreate failed");
+        return ev;
+    };
+    ProfEvt pe{name, flops, bytes, get(), get()};
+    idx = e->prof_.size();
+    e->prof_.push_back(pe);
+    (void)hipEventRecord(pe.e0, s);
+}
+Engine::ProfScope::~ProfScope() {
+    if (e->profiling_) (void)hipEventRecord(e->prof_[idx].e1, s);
+}
+void Engine::profile_begin() {
+    prof_.clear();
+    profiling_ = true;
+}
+std::vector<Engine::ProfRec> Engine::profile_end(hipStream_t s) {
+    profiling_ = false;
+    HIPCK(hipStreamSynchronize(s));
+    std::vector<ProfRec> out;
+    for (auto& pe : prof_) {
+        float ms = 0.f;
+        HIPCK(hipEventElapsedTime(&ms, pe.e0, pe.e1));
+        prof_pool_.push_back(pe.e0);
+        prof_pool_.push_back(pe.e1);
+        auto it = std::find_if(out.begin(), out.end(), [&](const ProfRec& r) { return r.name == pe.name; });
+        if (it == out.end()) { out.push_back(ProfRec{pe.name}); it = out.end() - 1; }
+        it->calls += 1; it->ms += ms; it->flops += pe.flops; it->bytes += pe.bytes;
+    }
+    prof_.clear();
+    std::sort(out.begin(), out.end(), [](const ProfRec& a, const ProfRec& b) { return a.ms > b.ms; });
+    return out;
+}
+
 void Engine::init_workspace() {
     if (ws_) return;
     ws_bytes_ = size_t(256) << 20;  // fp32 split-K slabs
@@ -500,7 +539,9 @@ void Engine::finalize() {
 
 // ---------------------------------------------------------------- execution helpers
 void Engine::gemm(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, hipStream_t s) {
+    ProfScope ps(this, s, "gemm", 2.0 * M * N * K, 0.0);
     CK(gemm_launch(A, W, M, N, K, E, ws_, ws_bytes_, s));
+    if (profiling_) ps.rename(gemm_last_kernel_name());  // the symbol the tile selection actually launched
     ++n_launches;
 }
 
@@ -529,6 +570,7 @@ bf16* Engine::groupnorm(const TRef& x, int B, int HW, const NormW& n, float eps,
     P.x0 = x.p0; P.C0 = x.C0; P.x1 = x.p1; P.C1 = x.C1;
     P.B = B; P.HW = HW; P.eps = eps; P.gamma = n.g; P.beta = n.b; P.y = y; P.silu = silu ? 1 : 0;
     P.partial = reinterpret_cast<float*>(arena_.alloc(gn_partial_bytes(B, HW)));
+    ProfScope ps(this, s, "gn_stats_kernel + gn_apply_kernel", 0.0, 2.0 * B * HW * (double)C * 2);
     CK(groupnorm_launch(P, s));
     n_launches += 2;
     return y;
@@ -540,6 +582,7 @@ bf16* Engine::layernorm(const bf16* x, int B, int N, int C, const NormW& n, bool
     LNParams P{};
     P.x = x; P.x2 = nullptr; P.B = B; P.N1 = N; P.N2 = 0; P.Tpad = Tp; P.C = C; P.eps = 1e-5f;
     P.gamma = n.g; P.beta = n.b; P.y = y;
+    ProfScope ps(this, s, "ln_kernel", 0.0, 2.0 * B * N * (double)C * 2);
     CK(layernorm_launch(P, s));
     ++n_launches;
     return y;
@@ -644,7 +687,9 @@ void Engine::self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, in
         epilogue_defaults(E);
         E.mode = EPI_VT_HEADS;
         E.out = bufs.vt; E.H = H; E.d = d; E.DPV = dpv; E.T = T; E.Tpad_k = bufs.Tk_pad;
+        ProfScope ps(this, s, "gemm", 2.0 * C * (double)B * T * C, 0.0);
         CK(gemm_launch_t(a.wv, C, ln, B * T, C, E, s));
+        if (profiling_) ps.rename(gemm_last_kernel_name());
         ++n_launches;
     }
     AttnParams P{};
@@ -652,7 +697,10 @@ void Engine::self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, in
     P.H = H; P.d = d; P.Nq = Nq; P.Nk = Nk; P.Tq_pad = bufs.Tq_pad; P.Tk_pad = bufs.Tk_pad;
     P.ldo = C; P.o_rows_per_b = Nq;
     P.scale_log2e = (float)(1.4426950408889634 / std::sqrt((double)d));
-    CK(attn_launch(P, B, s));
+    {
+        ProfScope ps(this, s, attn_kernel_name(d), 4.0 * B * H * (double)Nq * Nk * d, 0.0);
+        CK(attn_launch(P, B, s));
+    }
     ++n_launches;
 }
 
@@ -694,6 +742,7 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
         LNParams P{};
         P.x = t1; P.x2 = cond_.objs[t.idx]; P.B = B; P.N1 = HW; P.N2 = Ng; P.Tpad = Tf; P.C = C; P.eps = 1e-5f;
         P.gamma = t.fn1.g; P.beta = t.fn1.b; P.y = lnc;
+        ProfScope ps(this, s, "ln_kernel", 0.0, 2.0 * B * (HW + Ng) * (double)C * 2);
         CK(layernorm_launch(P, s));
         ++n_launches;
     }
@@ -721,7 +770,10 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
         P.H = heads; P.d = d; P.Nq = HW; P.Nk = cond_.ctx_T; P.Tq_pad = bufs.Tq_pad; P.Tk_pad = cond_.ctx_Tpad;
         P.ldo = C; P.o_rows_per_b = HW;
         P.scale_log2e = (float)(1.4426950408889634 / std::sqrt((double)d));
-        CK(attn_launch(P, B, s));
+        {
+            ProfScope ps(this, s, attn_kernel_name(d), 4.0 * B * heads * (double)HW * cond_.ctx_T * d, 0.0);
+            CK(attn_launch(P, B, s));
+        }
         ++n_launches;
     }
     bf16* t4 = linear_rows(o, M, t.a2.out, ACT_NONE, t3, nullptr, s);

@@ -68,6 +68,7 @@ void gemm_force_cfg(int tm, int tn, int splits);   // 0,0,0 = automatic
 void gemm_force_grid(int blocks);                  // 0 = automatic (512)
 void gemm_set_autotune(int on);                    // 1 (default): time candidates at the first eager launch of a problem
 void gemm_last_cfg(int* tm, int* tn, int* splits);
+const char* gemm_last_kernel_name();  // kernel symbol (template arguments included) of the most recent gemm_launch
 void aoperand_rows(AOperand& A, const bf16* p, int K, int ld);
 
 }  // namespace gl

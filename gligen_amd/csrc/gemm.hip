@@ -25,7 +25,9 @@
 #include "gemm.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <unordered_map>
 
@@ -1626,6 +1628,8 @@ void gemm_force_cfg(int tm, int tn, int splits) { g_force_tm = tm; g_force_tn = 
 void gemm_force_grid(int g) { g_force_grid = g; }
 void gemm_set_autotune(int on);
 static int g_last_cfg[3] = {0, 0, 0};
+static char g_last_name[96] = "gemm";
+const char* gemm_last_kernel_name() { return g_last_name; }
 void gemm_last_cfg(int* tm, int* tn, int* splits) { *tm = g_last_cfg[0]; *tn = g_last_cfg[1]; *splits = g_last_cfg[2]; }
 
 namespace {
@@ -1772,6 +1776,9 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
         wd.splits = cdiv(nk, wd.kt_per_split);
         wd.n_items = cdiv(M, tm * 32) * wd.tiles_n * wd.splits;
         g_last_cfg[0] = tm; g_last_cfg[1] = tn; g_last_cfg[2] = wd.splits;
+        if (use_u) snprintf(g_last_name, sizeof g_last_name, "gemm_u_kernel<%d, %d, %d, %d, %d>", tm == 8 ? 4 : 2, tm == 8 ? 4 : tm, tn, A.mode, tm == 8 ? 3 : 2);
+        else snprintf(g_last_name, sizeof g_last_name, "gemm_p_kernel<%d, %d, %d>", tm, tn, A.mode);
+        if (wd.splits > 1) strncat(g_last_name, " + splitk_reduce_kernel", sizeof g_last_name - strlen(g_last_name) - 1);
         const int saved_grid = g_force_grid;
         if (grid_cap) g_force_grid = grid_cap;
         int rc;
@@ -1925,6 +1932,7 @@ int gemm_launch(const AOperand& A, const bf16* W, int M, int N, int K, const Epi
         if (score > best_score) { best_score = score; best = c; }
     }
     const Cfg& cf = kCfgs[best];
+    snprintf(g_last_name, sizeof g_last_name, "gemm_glds_kernel<%dx%d, %d>", cf.bm, cf.bn, A.mode);
     const int tiles = cdiv(M, cf.bm) * cdiv(N, cf.bn);
     const int nk = K / 64;
     int splits = 1;

@@ -122,6 +122,19 @@ int gl_sampler_timing(gl_ctx* ctx, float* avg_unet_eval_ms, float* first_eval_ms
 /* clamp(-1,1)*0.5+0.5 -> *255 -> uint8 HWC (gligen_inference.py:443-445) */
 int gl_to_uint8(const float* img, uint8_t* out, int B, int C, int HW, gl_stream s);
 
+/* Per-kernel profile of ONE eager UNetModel.forward (same arguments as gl_unet_forward): HIP events are recorded on
+ * `s` around every GEMM / conv / attention / norm launch and aggregated by kernel symbol, longest total first. flops /
+ * bytes are the ALGORITHMIC work of those launches (2 M N K; 4 B H Nq Nk d; read-once + write-once bytes for the
+ * norms). Synchronises the stream; measurement aid for bench.py's roofline block, not part of the reference's surface. */
+typedef struct gl_prof_rec {
+    char name[96];
+    int calls;
+    double ms, flops, bytes;
+} gl_prof_rec;
+int gl_unet_profile(gl_ctx* ctx, int Beff, int h, int w, const float* x, int xB, const int64_t* timesteps,
+                    const float* inpaint_extra, int extraB, float* eps_out, gl_prof_rec* recs, int max_recs, int* n_recs,
+                    gl_stream s);
+
 int gl_arena_high_water(gl_ctx* ctx, size_t* bytes);
 int gl_launch_count(gl_ctx* ctx, int64_t* n);
 
