@@ -1893,6 +1893,10 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
         }
     }
     g_tuned[key] = win;
+    static const bool tune_log = getenv("GL_GEMM_TUNE_LOG") != nullptr;
+    if (tune_log)
+        fprintf(stderr, "[gemm autotune] %s -> %dx%d / %d splits @%d (%.1f us; model said %dx%d / %d)\n", key, kTm[win.c] * 32, kTn[win.c] * 32,
+                win.sp, win.grid ? win.grid : 512, win_ms * 1e3f / 3.f, kTm[best_c] * 32, kTn[best_c] * 32, best_sp);
     return run_cfg(win.c, win.sp, win.grid);
 }
 
