@@ -49,7 +49,7 @@ class PlmsArgs(C.Structure):
         ("fuser_scale", C.POINTER(C.c_float)), ("guidance_scale", C.c_float),
         ("x", C.c_void_p), ("inpaint_extra", C.c_void_p), ("mask", C.c_void_p), ("x0", C.c_void_p),
         ("noise", C.c_void_p), ("sqrt_ac", C.POINTER(C.c_float)), ("sqrt_1mac", C.POINTER(C.c_float)),
-        ("use_graph", C.c_int), ("sd_conv_w", C.c_void_p), ("sd_conv_b", C.c_void_p),
+        ("use_graph", C.c_int), ("sd_conv_w", C.c_void_p), ("sd_conv_b", C.c_void_p), ("ddim", C.c_int),
     ]
 
 
@@ -73,6 +73,7 @@ SYMBOLS = {
     "gl_unet_restore_first_conv": (_I, [_P, _P, _P, _P]),
     "gl_unet_forward": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P]),
     "gl_vae_decode": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "gl_vae_encode": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
     "gl_sample_plms": (_I, [_P, C.POINTER(PlmsArgs), _P]),
     "gl_sampler_timing": (_I, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(_I)]),
     "gl_unet_profile": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _P, C.POINTER(ProfRec), _I, C.POINTER(_I), _P]),

@@ -151,6 +151,14 @@ int gl_sampler_timing(gl_ctx* ctx, float* avg_unet_eval_ms, float* first_eval_ms
     GL_API_END
 }
 
+int gl_vae_encode(gl_ctx* ctx, int B, int H, int W, const float* img, const float* noise, float* z, gl_stream s) {
+    NEED(ctx);
+    if (!img || !noise || !z) return gl::set_error(GL_ERR_ARG, "null pointer");
+    GL_API_BEGIN
+    ctx->eng->vae_encode(B, H, W, img, noise, z, S(s));
+    GL_API_END
+}
+
 int gl_unet_profile(gl_ctx* ctx, int Beff, int h, int w, const float* x, int xB, const int64_t* timesteps,
                     const float* inpaint_extra, int extraB, float* eps_out, gl_prof_rec* recs, int max_recs, int* n_recs,
                     gl_stream s) {

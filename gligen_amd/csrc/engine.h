@@ -107,6 +107,8 @@ class Engine {
     void unet_forward(int Beff, int h, int w, const float* x, int xB, const int64_t* t, const float* extra,
                       int extraB, float* eps, hipStream_t s);
     void vae_decode(int B, int h, int w, const float* z, float* out, hipStream_t s);
+    void vae_encode(int B, int H, int W, const float* img, const float* noise, float* z, hipStream_t s);
+    bool has_vae_encoder() const { return has_venc_; }
     void sample_plms(const gl_plms_args& a, hipStream_t s);
     void sampler_timing(float* avg_ms, float* first_ms, int* n);
 
@@ -222,6 +224,19 @@ class Engine {
     std::vector<VaeUp> vup_;  // index = level (0 = full resolution)
     NormW vnorm_out_;
     ConvW vconv_out_;
+    // ---- VAE encoder (inpainting configuration; built when the encoder.* / quant_conv.* weights were uploaded)
+    bool has_venc_ = false;
+    ConvW venc_in_small_;
+    int venc_in_kpad_ = 0;
+    struct VaeDown { std::vector<ResW> blocks; bool has_down = false; ConvW down; };
+    std::vector<VaeDown> vdown_;
+    ResW vemid1_, vemid2_;
+    VaeAttnW veattn_;
+    NormW venorm_out_;
+    ConvW veconv_out_;
+    const float* qc_w_ = nullptr;
+    const float* qc_b_ = nullptr;
+    void build_vae_encoder();
 
     // ---- sampler state
     struct Sampler {

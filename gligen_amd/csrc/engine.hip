@@ -519,15 +519,62 @@ void Engine::build_vae() {
     vconv_out_ = conv3(V + "decoder.conv_out", 32);
 }
 
+// Encoder of AutoencoderKL (reference model.py:368-459)
+void Engine::build_vae_encoder() {
+    const gl_vae_config& c = vcfg_;
+    const std::string V = "vae/";
+    {
+        const RawTensor& w = raw(V + "encoder.conv_in.weight");
+        const int in_c = (int)w.shape[1];
+        venc_in_kpad_ = round_up(9 * in_c, 64);
+        bf16* dst = reinterpret_cast<bf16*>(persist((size_t)c.ch * venc_in_kpad_ * sizeof(bf16), false));
+        CK(pack_conv_small_launch(w.p, dst, c.ch, in_c, venc_in_kpad_, 0));
+        venc_in_small_.w = dst;
+        venc_in_small_.b = F(V + "encoder.conv_in.bias");
+        venc_in_small_.Cin = in_c;
+        venc_in_small_.Cout = c.ch;
+    }
+    vdown_.assign(c.n_mult, VaeDown{});
+    int block_in = c.ch;
+    for (int level = 0; level < c.n_mult; ++level) {
+        const int block_out = c.ch * c.ch_mult[level];
+        for (int i = 0; i < c.num_res_blocks; ++i) {
+            vdown_[level].blocks.push_back(resw(V + fmt("encoder.down.%d.block.%d", level, i), block_in, block_out, false));
+            block_in = block_out;
+        }
+        if (level != c.n_mult - 1) {
+            vdown_[level].has_down = true;
+            vdown_[level].down = conv3(V + fmt("encoder.down.%d.downsample.conv", level));
+        }
+    }
+    vemid1_ = resw(V + "encoder.mid.block_1", block_in, block_in, false);
+    vemid2_ = resw(V + "encoder.mid.block_2", block_in, block_in, false);
+    veattn_.gn = norm(V + "encoder.mid.attn_1.norm");
+    veattn_.q = conv1(V + "encoder.mid.attn_1.q");
+    veattn_.k = conv1(V + "encoder.mid.attn_1.k");
+    veattn_.v = conv1(V + "encoder.mid.attn_1.v");
+    veattn_.proj = conv1(V + "encoder.mid.attn_1.proj_out");
+    venorm_out_ = norm(V + "encoder.norm_out");
+    veconv_out_ = conv3(V + "encoder.conv_out", 32);
+    if (veconv_out_.Cout != 2 * c.z_channels) throw GlError(GL_ERR_ARG, "encoder.conv_out must produce 2 * z_channels moments");
+    const RawTensor& q = raw(V + "quant_conv.weight");
+    if (q.shape[0] != 2 * c.z_channels || q.shape[1] != 2 * c.z_channels)
+        throw GlError(GL_ERR_UNSUPPORTED, "quant_conv must map 2*z_channels -> 2*z_channels (embed_dim == z_channels)");
+    qc_w_ = F(V + "quant_conv.weight");
+    qc_b_ = F(V + "quant_conv.bias");
+    has_venc_ = true;
+}
+
 void Engine::finalize() {
     if (finalized_) throw GlError(GL_ERR_STATE, "gl_finalize called twice");
     HIPCK(hipSetDevice(device_));
     if (has_unet_) build_unet();
     if (has_vae_) build_vae();
+    if (has_vae_ && has("vae/encoder.conv_in.weight")) build_vae_encoder();
     HIPCK(hipDeviceSynchronize());
     // matrices now live packed in bf16: drop their fp32 staging copies (vectors stay, they are used as is)
     for (auto it = raw_.begin(); it != raw_.end();) {
-        if (it->second.shape.size() >= 2 && it->first.find("post_quant_conv") == std::string::npos) {
+        if (it->second.shape.size() >= 2 && it->first.find("quant_conv") == std::string::npos) {
             (void)hipFree(it->second.p);
             it = raw_.erase(it);
         } else {
@@ -1146,6 +1193,63 @@ void Engine::vae_decode(int B, int h, int w, const float* z, float* out, hipStre
     }
 }
 
+// AutoencoderKL.encode (autoencoder.py:34-38) -> Encoder.forward (model.py:434-459) -> quant_conv -> posterior sample
+void Engine::vae_encode(int B, int H, int W, const float* img, const float* noise, float* z, hipStream_t s) {
+    if (!has_venc_ || !finalized_) throw GlError(GL_ERR_STATE, "vae encoder weights were not uploaded / not finalized");
+    const gl_vae_config& c = vcfg_;
+    const int total_stride = 1 << (c.n_mult - 1);
+    if (H % total_stride || W % total_stride) throw GlError(GL_ERR_ARG, "vae_encode: image size must be divisible by the encoder stride");
+    arena_.reset();
+    int C = venc_in_small_.Cout;
+    bf16* cur;
+    {
+        const int HW = H * W;
+        bf16* col = arena_.get<bf16>((size_t)B * HW * venc_in_kpad_);
+        Im2colParams P{};
+        P.x0 = img; P.C0 = venc_in_small_.Cin; P.B = B; P.H = H; P.W = W; P.Kpad = venc_in_kpad_; P.out = col;
+        P.pre_scale = 1.f;
+        CK(im2col_small_launch(P, s));
+        ++n_launches;
+        cur = arena_.get<bf16>((size_t)B * HW * C);
+        AOperand A;
+        aoperand_rows(A, col, venc_in_kpad_, venc_in_kpad_);
+        Epilogue E;
+        epilogue_defaults(E);
+        E.out = cur; E.ldo = C; E.bias = venc_in_small_.b;
+        gemm(A, venc_in_small_.w, B * HW, C, venc_in_kpad_, E, s);
+    }
+    const float eps = 1e-6f;
+    for (int level = 0; level < c.n_mult; ++level) {
+        for (const ResW& r : vdown_[level].blocks) {
+            cur = resblock(r, TRef{cur, C, nullptr, 0}, B, H, W, nullptr, 0, eps, s);
+            C = r.Cout;
+        }
+        if (vdown_[level].has_down) {
+            // Downsample: F.pad(x, (0,1,0,1)) + conv3x3 stride 2 padding 0 (model.py:72-76) = pad_lo 0 in the gather
+            cur = conv3x3(TRef{cur, C, nullptr, 0}, B, H, W, vdown_[level].down, 2, 0, 0, nullptr, 0, nullptr, s);
+            H /= 2;
+            W /= 2;
+        }
+    }
+    cur = resblock(vemid1_, TRef{cur, C, nullptr, 0}, B, H, W, nullptr, 0, eps, s);
+    cur = vae_attn(veattn_, cur, B, H * W, s);
+    cur = resblock(vemid2_, TRef{cur, C, nullptr, 0}, B, H, W, nullptr, 0, eps, s);
+    const int HW = H * W;
+    float* moments = arena_.get<float>((size_t)B * 2 * c.z_channels * HW);
+    {
+        bf16* a = groupnorm(TRef{cur, C, nullptr, 0}, B, HW, venorm_out_, eps, true, s);
+        AOperand A{};
+        A.p0 = a; A.C0 = C; A.ld0 = C; A.mode = A_CONV3;
+        A.Hin = H; A.Win = W; A.Ho = H; A.Wo = W; A.stride = 1; A.ups = 0; A.pad_lo = 1;
+        Epilogue E;
+        epilogue_defaults(E);
+        E.mode = EPI_NCHW_F32; E.out = moments; E.bias = veconv_out_.b; E.rows_per_b = HW; E.n_real = 2 * c.z_channels;
+        gemm(A, veconv_out_.w, B * HW, veconv_out_.Npad, 9 * C, E, s);
+    }
+    CK(vae_posterior_launch(moments, qc_w_, qc_b_, noise, z, B, c.z_channels, HW, c.scale_factor, s));
+    ++n_launches;
+}
+
 // ---------------------------------------------------------------- PLMS sampler (plms.py:65-162)
 // HIP-event time of the UNet evaluations of the last sample_plms call (on the engine's stream).
 void Engine::sampler_timing(float* avg_ms, float* first_ms, int* n) {
@@ -1254,7 +1358,11 @@ void Engine::sample_plms(const gl_plms_args& a, hipStream_t caller) {
         P.eps_pair = smp_.eps_pair; P.has_uncond = cfg ? 1 : 0; P.guidance = a.guidance_scale;
         P.a_t = a.a_t[i]; P.a_prev = a.a_prev[i]; P.n = n;
         float* slot = smp_.hist[i & 3];
-        if (i == 0) {
+        if (a.ddim) {
+            // DDIMSampler.p_sample_ddim, eta = 0 (ddim.py:111-134): same x_prev formula driven by e_t itself
+            P.e_t_out = slot; P.c0 = 1.f; P.x = a.x; P.x_out = a.x;
+            CK(plms_update_launch(P, s));
+        } else if (i == 0) {
             // pseudo improved Euler (plms.py:143-149): x_prev from e_t, evaluate at t_next, average
             P.e_t_out = slot; P.c0 = 1.f; P.x = a.x; P.x_out = smp_.x_tmp;
             CK(plms_update_launch(P, s));

@@ -80,6 +80,11 @@ int inpaint_blend_launch(float* img, const float* x0, const float* noise, const 
 // NCHW fp32 in [-1,1] -> NHWC u8: trunc(255 * (clamp(x,-1,1)*0.5+0.5)) (reference gligen_inference.py:443-445)
 int to_uint8_launch(const float* src, uint8_t* dst, int B, int C, int HW, hipStream_t stream);
 
+// quant_conv 1x1 + posterior sample: h [B][2zc][HW] fp32 (encoder output), wq [2zc][2zc], bq [2zc], noise / z [B][zc][HW]
+// (reference autoencoder.py:34-38, distributions.py:24-37)
+int vae_posterior_launch(const float* h, const float* wq, const float* bq, const float* noise, float* z, int B, int zc, int HW,
+                         float scale, hipStream_t stream);
+
 int fill_i64_launch(int64_t* dst, int64_t v, int n, hipStream_t stream);
 int zero_launch(void* dst, size_t bytes, hipStream_t stream);
 

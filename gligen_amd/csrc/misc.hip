@@ -301,6 +301,34 @@ int to_uint8_launch(const float* src, uint8_t* dst, int B, int C, int HW, hipStr
     return GL_OK;
 }
 
+// quant_conv (1x1, 2zc -> 2zc) + DiagonalGaussianDistribution.sample() * scale_factor, per latent pixel
+// (reference autoencoder.py:34-38, distributions.py:24-37): moments = Wq h + bq ; mean, logvar = chunk(moments) ;
+// z = (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise) * scale
+__global__ void vae_posterior_kernel(const float* __restrict__ h, const float* __restrict__ wq, const float* __restrict__ bq,
+                                     const float* __restrict__ noise, float* __restrict__ z, int B, int zc, int HW, float scale) {
+    const int64_t total = (int64_t)B * zc * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int pix = (int)(i % HW);
+        const int c = (int)((i / HW) % zc);
+        const int b = (int)(i / ((int64_t)HW * zc));
+        const float* hp = h + (size_t)b * 2 * zc * HW + pix;
+        float mean = bq[c], logvar = bq[zc + c];
+        for (int k = 0; k < 2 * zc; ++k) {
+            const float v = hp[(size_t)k * HW];
+            mean = fmaf(wq[c * 2 * zc + k], v, mean);
+            logvar = fmaf(wq[(zc + c) * 2 * zc + k], v, logvar);
+        }
+        logvar = fminf(fmaxf(logvar, -30.f), 20.f);
+        z[i] = (mean + expf(0.5f * logvar) * noise[i]) * scale;
+    }
+}
+int vae_posterior_launch(const float* h, const float* wq, const float* bq, const float* noise, float* z, int B, int zc, int HW,
+                         float scale, hipStream_t stream) {
+    hipLaunchKernelGGL(vae_posterior_kernel, dim3(grid_for((int64_t)B * zc * HW)), dim3(256), 0, stream, h, wq, bq, noise, z, B, zc, HW, scale);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
 __global__ void fill_i64_kernel(int64_t* d, int64_t v, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) d[i] = v;

@@ -178,10 +178,20 @@ class Engine:
         check(self.lib.gl_vae_decode(self._ctx, int(B), int(h), int(w), _ptr(z), _ptr(out), _stream()))
         return out
 
+    def vae_encode(self, img: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+        """AutoencoderKL.encode: img [B,3,H,W] in [-1,1], noise [B,zc,H/8,W/8] (the posterior's randn draw) -> latent."""
+        dev = self.device
+        img, noise = _f32(img, dev), _f32(noise, dev)
+        B, _, H, W = img.shape
+        out = torch.empty_like(noise)
+        check(self.lib.gl_vae_encode(self._ctx, int(B), int(H), int(W), _ptr(img), _ptr(noise), _ptr(out), _stream()))
+        return out
+
     def sample_plms(self, x: torch.Tensor, timesteps: np.ndarray, a_t: np.ndarray, a_prev: np.ndarray,
                     fuser_scale: Optional[np.ndarray], guidance_scale: float, *, inpaint_extra=None, mask=None, x0=None,
-                    noise=None, sqrt_ac=None, sqrt_1mac=None, use_graph: bool = True, sd_first_conv=None) -> torch.Tensor:
-        """In-place PLMS loop on x (fp32 [B,C,h,w]); conditioning must already be set."""
+                    noise=None, sqrt_ac=None, sqrt_1mac=None, use_graph: bool = True, sd_first_conv=None,
+                    ddim: bool = False) -> torch.Tensor:
+        """In-place PLMS (or, ddim=True, eta-0 DDIM) loop on x (fp32 [B,C,h,w]); conditioning must already be set."""
         dev = self.device
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
         n = len(timesteps)
@@ -209,6 +219,7 @@ class Engine:
             a.mask, a.x0, a.noise = mask.data_ptr(), x0.data_ptr(), noise.data_ptr()
             a.sqrt_ac = sa.ctypes.data_as(C.POINTER(C.c_float)); a.sqrt_1mac = s1.ctypes.data_as(C.POINTER(C.c_float))
         a.use_graph = int(bool(use_graph))
+        a.ddim = int(bool(ddim))
         if sd_first_conv is not None:
             cw, cb = _f32(sd_first_conv[0], dev), _f32(sd_first_conv[1], dev)
             keep += [cw, cb]

@@ -59,7 +59,6 @@ def build_vae_engine(ae, arena_gb: float = 8.0) -> Engine:
     dd = ae.ddconfig
     eng.configure_vae(ch=dd["ch"], out_ch=dd["out_ch"], z_channels=dd["z_channels"], num_res_blocks=dd["num_res_blocks"],
                       embed_dim=ae.embed_dim, ch_mult=list(dd["ch_mult"]), scale_factor=ae.scale_factor)
-    sd = {k: v for k, v in ae.state_dict().items() if k.startswith("decoder.") or k.startswith("post_quant_conv.")}
-    eng.upload("vae", sd)
+    eng.upload("vae", ae.state_dict())  # decoder + post_quant_conv (decode), encoder + quant_conv (encode, inpainting)
     eng.finalize()
     return eng

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 from PIL import Image
 
+from ldm.models.diffusion.ddim import DDIMSampler
 from ldm.models.diffusion.plms import PLMSSampler
 from ldm.util import instantiate_from_config
 
@@ -269,9 +270,11 @@ def load_synthetic(kind="text", inpaint=False, image_size=64, seed=1234, fast=Fa
 # ---- run ---------------------------------------------------------------------------------------------
 @torch.no_grad()
 def generate(model, autoencoder, diffusion, batch, context, uc, *, steps=50, guidance_scale=7.5, alpha_type=None,
-             starting_noise=None, inpainting_mask=None, z0=None, use_graph=True):
+             starting_noise=None, inpainting_mask=None, z0=None, use_graph=True, no_plms=False):
     """The sampling core of run() (reference gligen_inference.py:389-431) on already-encoded inputs."""
-    sampler = PLMSSampler(diffusion, model, alpha_generator_func=partial(alpha_generator, type=alpha_type), set_alpha_scale=set_alpha_scale)
+    # reference gligen_inference.py:385-390: DDIM (250 steps) with --no_plms, else PLMS (50 steps)
+    sampler_cls = DDIMSampler if no_plms else PLMSSampler
+    sampler = sampler_cls(diffusion, model, alpha_generator_func=partial(alpha_generator, type=alpha_type), set_alpha_scale=set_alpha_scale)
     sampler.use_graph = use_graph
     inpainting_extra_input = None
     if inpainting_mask is not None:
@@ -307,8 +310,6 @@ def run(meta, config, starting_noise=None, models=None):
     model.grounding_tokenizer_input = instantiate_from_config(ckpt_config["grounding_tokenizer_input"])
     if "grounding_downsampler_input" in ckpt_config:
         raise NotImplementedError("spatial-map checkpoints (hed/canny/depth/normal/sem) are outside the MI355X hot path")
-    if args.get("no_plms"):
-        raise NotImplementedError("--no_plms (250-step DDIM) is not implemented on MI355X yet; the reference flags it untested")
     B = args["batch_size"]
     batch = prepare_batch_kp(meta, B) if "keypoint" in meta["ckpt"] else prepare_batch(meta, B)
     if "context" in meta:  # precomputed CLIP last_hidden_state (B,77,768)
@@ -325,8 +326,9 @@ def run(meta, config, starting_noise=None, models=None):
         else:
             img = torch.from_numpy(np.asarray(Image.open(meta["input_image"]).convert("RGB").resize((512, 512)))).permute(2, 0, 1)
             z0 = autoencoder.encode((img.float().unsqueeze(0).to(device) / 255 - 0.5) / 0.5)
-    samples = generate(model, autoencoder, diffusion, batch, context, uc, steps=50, guidance_scale=args["guidance_scale"],
-                       alpha_type=meta.get("alpha_type"), starting_noise=starting_noise, inpainting_mask=mask, z0=z0)
+    no_plms = bool(args.get("no_plms"))
+    samples = generate(model, autoencoder, diffusion, batch, context, uc, steps=250 if no_plms else 50, guidance_scale=args["guidance_scale"],
+                       alpha_type=meta.get("alpha_type"), starting_noise=starting_noise, inpainting_mask=mask, z0=z0, no_plms=no_plms)
     save_images(samples, os.path.join(args["folder"], meta["save_folder_name"]))
     return samples
 

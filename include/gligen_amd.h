@@ -86,6 +86,9 @@ typedef struct gl_plms_args {
     int use_graph;               /* capture one UNet evaluation in a hipGraph and replay it */
     const float* sd_conv_w;      /* device fp32 [mc][C][3][3] + [mc]: SD first-conv weights swapped in at the */
     const float* sd_conv_b;      /*   first step whose fuser_scale is 0 (plms.py:88-89), or NULL */
+    int ddim;                    /* 0: PLMS (Adams-Bashforth multistep, plms.py:111-162). 1: DDIMSampler with eta = 0
+                                    (reference ldm/models/diffusion/ddim.py:65-134): one evaluation per step,
+                                    x_prev = sqrt(a_prev) pred_x0 + sqrt(1 - a_prev) e_t */
 } gl_plms_args;
 
 const char* gl_last_error(void);
@@ -114,7 +117,12 @@ int gl_unet_forward(gl_ctx* ctx, int Beff, int h, int w, const float* x, int xB,
                     const float* inpaint_extra, int extraB, float* eps_out, gl_stream s);
 /* AutoencoderKL.decode (autoencoder.py:40-44): z [B][zc][h][w] -> img [B][out_ch][8h][8w] */
 int gl_vae_decode(gl_ctx* ctx, int B, int h, int w, const float* z, float* img, gl_stream s);
-/* PLMSSampler.plms_sampling (plms.py:65-108) with classifier-free guidance (plms.py:116-122) */
+/* AutoencoderKL.encode (autoencoder.py:34-38; inpainting, gligen_inference.py:402-407): img [B][3][H][W] fp32 in [-1,1]
+ * -> z [B][zc][H/8][W/8] = (mean + std * noise) * scale_factor. `noise` [B][zc][H/8][W/8] is the caller's draw for the
+ * reference's torch.randn(mean.shape) (distributions.py:35). Needs the encoder.* and quant_conv.* weights uploaded. */
+int gl_vae_encode(gl_ctx* ctx, int B, int H, int W, const float* img, const float* noise, float* z, gl_stream s);
+/* PLMSSampler.plms_sampling (plms.py:65-108) / DDIMSampler.ddim_sampling (ddim.py:65-108, args->ddim) with
+ * classifier-free guidance (plms.py:116-122, ddim.py:113-117) */
 int gl_sample_plms(gl_ctx* ctx, const gl_plms_args* args, gl_stream s);
 /* HIP-event timing of the UNet evaluations of the last gl_sample_plms call, measured on the stream
  * they ran on: mean over the graph-replayed evaluations, the first (eager) one, and their count. */

@@ -1,8 +1,8 @@
 """AutoencoderKL (SD-1.4 KL-f8 VAE) — drop-in for the reference's ldm/models/autoencoder.py.
 
 decode(z) = Decoder(post_quant_conv(z / scale_factor)) (autoencoder.py:40-44) runs entirely in the
-native engine (Engine::vae_decode). encode() belongs to the inpainting configuration, which is the
-next row of the hot-path scope, and is not implemented on the device yet.
+native engine (Engine::vae_decode); encode(x) = posterior.sample() * scale_factor (autoencoder.py:34-38, the
+inpainting configuration: once per prompt) runs in Engine::vae_encode.
 """
 import torch
 import torch.nn as nn
@@ -44,10 +44,13 @@ class AutoencoderKL(nn.Module):
             self._engine = _rt.build_vae_engine(self)
         return self._engine
 
+    @torch.no_grad()
     def encode(self, x):
-        raise NotImplementedError(
-            "AutoencoderKL.encode (inpainting, reference autoencoder.py:34-38) is not implemented on MI355X yet; "
-            "pass a pre-encoded latent x0 to the sampler")
+        """posterior.sample() * scale_factor (autoencoder.py:34-38). The reference draws the posterior noise with the CPU
+        generator (distributions.py:35: torch.randn(mean.shape).to(device)); so does this, for seed-for-seed parity."""
+        f = 2 ** (len(self.ddconfig["ch_mult"]) - 1)
+        noise = torch.randn((x.shape[0], self.ddconfig["z_channels"], x.shape[2] // f, x.shape[3] // f))
+        return self.engine.vae_encode(x, noise).to(x.dtype)
 
     @torch.no_grad()
     def decode(self, z):

@@ -19,6 +19,8 @@ def _np(x):
 
 
 class PLMSSampler(object):
+    multistep = True  # False in ldm.models.diffusion.ddim.DDIMSampler: e' = e_t, one model evaluation per step
+
     def __init__(self, diffusion, model, schedule="linear", alpha_generator_func=None, set_alpha_scale=None):
         super().__init__()
         self.diffusion = diffusion
@@ -110,7 +112,7 @@ class PLMSSampler(object):
             sd_conv = model.load_sd_first_conv()  # swapped in on the device at the first gated-off step
         model.engine.sample_plms(img, time_range, a_t, a_prev, alphas, guidance_scale if cfg else 1.0,
                                  inpaint_extra=input.get("inpainting_extra_input"), use_graph=self.use_graph,
-                                 sd_first_conv=sd_conv, **extra)
+                                 sd_first_conv=sd_conv, ddim=not self.multistep, **extra)
         if sd_conv is not None:
             model.restore_first_conv_from_SD()  # bring the module parameters in line with the engine
         if alphas is not None and self.set_alpha_scale is not None:
@@ -157,7 +159,9 @@ class PLMSSampler(object):
             x = input["x"].clone()
             input["timesteps"] = ts
             e_t = denoiser(input)
-            if len(history) == 0:
+            if not self.multistep:
+                e_prime = e_t
+            elif len(history) == 0:
                 input["x"] = step_back(x, e_t, index)
                 input["timesteps"] = ts_next
                 e_prime = (e_t + denoiser(input)) / 2

@@ -267,6 +267,30 @@ def vae_decode(sd: SD, cfg: Mapping, z: torch.Tensor) -> torch.Tensor:
     return F.conv2d(h, sd[f"{d}.conv_out.weight"], sd[f"{d}.conv_out.bias"], padding=1)
 
 
+def vae_encode(sd: SD, cfg: Mapping, x: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    """AutoencoderKL.encode -> Encoder.forward -> quant_conv -> DiagonalGaussianDistribution.sample() * scale_factor —
+    autoencoder.py:34-38, model.py:434-459 (Downsample: zero pad (0,1,0,1) then 3x3 stride-2 conv, model.py:72-76),
+    distributions.py:24-37. `noise` stands for the reference's torch.randn(mean.shape) draw (CPU generator)."""
+    e = "encoder"
+    h = F.conv2d(x, sd[f"{e}.conv_in.weight"], sd[f"{e}.conv_in.bias"], padding=1)
+    nres = len(cfg["ch_mult"])
+    for level in range(nres):
+        for i in range(cfg["num_res_blocks"]):
+            h = vae_resblock(sd, f"{e}.down.{level}.block.{i}", h)
+        if level != nres - 1:
+            h = F.pad(h, (0, 1, 0, 1), mode="constant", value=0)
+            h = F.conv2d(h, sd[f"{e}.down.{level}.downsample.conv.weight"], sd[f"{e}.down.{level}.downsample.conv.bias"], stride=2)
+    h = vae_resblock(sd, f"{e}.mid.block_1", h)
+    h = vae_attn(sd, f"{e}.mid.attn_1", h)
+    h = vae_resblock(sd, f"{e}.mid.block_2", h)
+    h = F.silu(_gn(sd, f"{e}.norm_out", h, 1e-6))
+    h = F.conv2d(h, sd[f"{e}.conv_out.weight"], sd[f"{e}.conv_out.bias"], padding=1)
+    moments = F.conv2d(h, sd["quant_conv.weight"], sd["quant_conv.bias"])
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
+    return (mean + std * noise) * cfg["scale_factor"]
+
+
 def to_uint8(img: torch.Tensor) -> np.ndarray:
     """clamp(-1,1)*0.5+0.5, *255, astype(uint8) truncation, HWC — gligen_inference.py:443-445."""
     s = torch.clamp(img, min=-1, max=1) * 0.5 + 0.5
@@ -360,6 +384,36 @@ def plms_sample(eps_fn: Callable[[torch.Tensor, torch.Tensor, bool, float], torc
         old_eps.append(e_t)
         if len(old_eps) >= 4:
             old_eps.pop(0)
+    return x
+
+
+def ddim_sample(eps_fn: Callable[[torch.Tensor, torch.Tensor, bool, float], torch.Tensor], x: torch.Tensor, S: int,
+                sched: Mapping[str, np.ndarray], guidance_scale: float, alphas: Optional[Sequence[float]] = None,
+                mask: Optional[torch.Tensor] = None, x0: Optional[torch.Tensor] = None,
+                noise: Optional[torch.Tensor] = None, on_gate_off: Optional[Callable[[], None]] = None) -> torch.Tensor:
+    """DDIMSampler.ddim_sampling + p_sample_ddim with eta = 0 (the only value the reference uses: make_schedule's
+    default, ddim.py:27,59-62) — ddim.py:65-134. One model evaluation pair per step, no multistep history:
+    x_prev = sqrt(a_prev) * pred_x0 + sqrt(1 - a_prev) * e_t (sigma_t = 0, so the randn term vanishes)."""
+    ps = plms_schedule(S, sched)  # same ddim_timesteps / ddim_alphas / ddim_alphas_prev as the PLMS sampler (util.py:55-83)
+    time_range = np.flip(ps["ddim_timesteps"])
+    b = x.shape[0]
+    for i, step in enumerate(time_range):
+        scale = 1.0 if alphas is None else float(alphas[i])
+        if alphas is not None and alphas[i] == 0 and on_gate_off is not None:
+            on_gate_off()
+        index = len(time_range) - i - 1
+        ts = torch.full((b,), int(step), dtype=torch.long)
+        if mask is not None:
+            sa = float(sched["sqrt_alphas_cumprod"][int(step)])
+            s1 = float(sched["sqrt_one_minus_alphas_cumprod"][int(step)])
+            x = (sa * x0 + s1 * noise[i]) * mask + (1.0 - mask) * x
+        e = eps_fn(x, ts, True, scale)
+        if guidance_scale != 1:
+            eu = eps_fn(x, ts, False, scale)
+            e = eu + guidance_scale * (e - eu)
+        a_t, a_prev = float(ps["ddim_alphas"][index]), float(ps["ddim_alphas_prev"][index])
+        pred_x0 = (x - math.sqrt(1.0 - a_t) * e) / math.sqrt(a_t)
+        x = math.sqrt(a_prev) * pred_x0 + math.sqrt(1.0 - a_prev) * e
     return x
 
 

@@ -39,6 +39,7 @@ syn = _load("gl_synthetic", os.path.join(REPO, "gligen_amd", "synthetic.py"))
 from ldm.models.autoencoder import AutoencoderKL  # noqa: E402  (reference)
 from ldm.models.diffusion.ldm import LatentDiffusion  # noqa: E402
 from ldm.models.diffusion.plms import PLMSSampler  # noqa: E402
+from ldm.models.diffusion.ddim import DDIMSampler  # noqa: E402
 from ldm.modules.attention import GatedSelfAttentionDense  # noqa: E402
 from ldm.modules.diffusionmodules.openaimodel import UNetModel  # noqa: E402
 from ldm.util import instantiate_from_config  # noqa: E402
@@ -127,6 +128,32 @@ def vae_case(name, dd, B, hw):
     return {k: list(v.shape) for k, v in ae.state_dict().items()}
 
 
+def vae_encode_case(name, dd, B, res):
+    """AutoencoderKL.encode of the reference on a seeded image; the posterior's torch.randn draw is recorded."""
+    t0 = time.time()
+    ae = AutoencoderKL(ddconfig=dd, embed_dim=4, scale_factor=0.18215).eval()
+    syn.fill_module_(ae, 4321)
+    x = torch.rand(B, 3, res, res, generator=torch.Generator().manual_seed(8)) * 2 - 1
+    draws = []
+    real_randn = torch.randn
+
+    def rec_randn(*a, **k):
+        t = real_randn(*a, generator=torch.Generator().manual_seed(99), **k)
+        draws.append(t)
+        return t
+
+    torch.randn = rec_randn
+    try:
+        with torch.no_grad():
+            z = ae.encode(x)
+    finally:
+        torch.randn = real_randn
+    assert len(draws) == 1
+    meta = dict(ddconfig=dd, B=B, res=res, weight_seed=4321)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), meta=json.dumps(meta), z=z.numpy(), noise=draws[0].numpy())
+    print(f"{name}: z {tuple(z.shape)} std {z.std():.4f} [{time.time() - t0:.1f}s]")
+
+
 class Recorder(torch.nn.Module):
     """Mock UNet that records the call sequence (SURVEY.md §3.1 probe) and returns a cheap function of x."""
 
@@ -144,11 +171,12 @@ class Recorder(torch.nn.Module):
         return torch.tanh(inp["x"]) * (0.5 if "grounding_input" in inp else 0.3) + 0.01 * inp["timesteps"].float().view(-1, 1, 1, 1) / 1000
 
 
-def plms_trace_case(name, S, alpha_type):
+def plms_trace_case(name, S, alpha_type, sampler_cls=None):
     diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000)
     mock = Recorder()
     from functools import partial
-    sampler = PLMSSampler(diffusion, mock, alpha_generator_func=partial(ref_alpha_generator, type=alpha_type), set_alpha_scale=set_alpha_scale)
+    sampler_cls = sampler_cls or PLMSSampler
+    sampler = sampler_cls(diffusion, mock, alpha_generator_func=partial(ref_alpha_generator, type=alpha_type), set_alpha_scale=set_alpha_scale)
     x = syn.make_latent(2, 4, 8, 8, seed=5)
     inp = dict(x=x.clone(), timesteps=None, context=torch.zeros(2, 1, 1), grounding_input={}, inpainting_extra_input=None, grounding_extra_input=None)
     out = sampler.sample(S=S, shape=(2, 4, 8, 8), input=inp, uc=torch.ones(2, 1, 1), guidance_scale=7.5)
@@ -159,9 +187,10 @@ def plms_trace_case(name, S, alpha_type):
     print(f"{name}: {len(mock.calls)} model calls, {mock.restores} first-conv restores")
 
 
-def plms_unet_case(name, S, hw, alpha_type, inpaint=False):
+def plms_unet_case(name, S, hw, alpha_type, inpaint=False, sampler_cls=None):
     t0 = time.time()
     from functools import partial
+    sampler_cls = sampler_cls or PLMSSampler
     diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000)
     model = build_unet(syn.UNET_CFG_SMALL, "text", inpaint)
     # restore_first_conv_from_SD th.load()s a cwd-relative file: give it a seeded stand-in for the real
@@ -185,7 +214,7 @@ def plms_unet_case(name, S, hw, alpha_type, inpaint=False):
         draws = iter(noise)
         diffusion_q = diffusion.q_sample
         diffusion.q_sample = lambda x_start, t, noise=None: diffusion_q(x_start, t, noise=next(draws))
-    sampler = PLMSSampler(diffusion, model, alpha_generator_func=partial(ref_alpha_generator, type=alpha_type), set_alpha_scale=set_alpha_scale)
+    sampler = sampler_cls(diffusion, model, alpha_generator_func=partial(ref_alpha_generator, type=alpha_type), set_alpha_scale=set_alpha_scale)
     inp = dict(x=x.clone(), timesteps=None, context=ctx, grounding_input=g, inpainting_extra_input=extra, grounding_extra_input=None)
     with torch.no_grad():
         out = sampler.sample(S=S, shape=tuple(x.shape), input=inp, uc=uc, guidance_scale=7.5, mask=mask, x0=z0)
@@ -224,6 +253,11 @@ CASES = {
     "plms_trace_20": lambda: plms_trace_case("plms_trace_20", 20, None),
     "plms_unet_small": lambda: plms_unet_case("plms_unet_small", 5, 16, [0.6, 0.0, 0.4]),
     "plms_unet_small_inpaint": lambda: plms_unet_case("plms_unet_small_inpaint", 4, 16, None, inpaint=True),
+    "ddim_trace_25": lambda: plms_trace_case("ddim_trace_25", 25, [0.4, 0.2, 0.4], sampler_cls=DDIMSampler),
+    "ddim_unet_small": lambda: plms_unet_case("ddim_unet_small", 6, 16, [0.5, 0.0, 0.5], sampler_cls=DDIMSampler),
+    "ddim_unet_small_inpaint": lambda: plms_unet_case("ddim_unet_small_inpaint", 4, 16, None, inpaint=True, sampler_cls=DDIMSampler),
+    "vae_enc_small": lambda: vae_encode_case("vae_enc_small", syn.VAE_DDCONFIG_SMALL, 2, 64),
+    "vae_enc_full": lambda: vae_encode_case("vae_enc_full", syn.VAE_DDCONFIG, 1, 64),
     "misc": misc_case,
 }
 

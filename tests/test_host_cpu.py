@@ -164,6 +164,29 @@ def test_sampler_orchestration_matches_reference_trace(name):
     assert inp["x"] is out and int(inp["timesteps"][0]) == int(tr["calls"][-1][0])
 
 
+def test_ddim_sampler_orchestration_matches_reference_trace():
+    """DDIMSampler (ldm.models.diffusion.ddim, eta 0) drives an arbitrary model exactly like the reference's."""
+    from functools import partial
+    from gligen_inference import alpha_generator, set_alpha_scale
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.models.diffusion.ldm import LatentDiffusion
+    tr = load_golden("ddim_trace_25")
+    S, atype = tr["meta"]["S"], tr["meta"]["alpha_type"]
+    mock = _Recorder()
+    sampler = DDIMSampler(LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000), mock,
+                          alpha_generator_func=partial(alpha_generator, type=atype), set_alpha_scale=set_alpha_scale)
+    x = syn.make_latent(2, 4, 8, 8, seed=5)
+    inp = dict(x=x.clone(), timesteps=None, context=torch.zeros(2, 1, 1), grounding_input={}, inpainting_extra_input=None, grounding_extra_input=None)
+    out = sampler.sample(S=S, shape=(2, 4, 8, 8), input=inp, uc=torch.ones(2, 1, 1), guidance_scale=7.5)
+    assert [(int(a), bool(b), float(c)) for a, b, c in tr["calls"]] == mock.calls
+    assert mock.restores == int(tr["restores"])
+    assert np.array_equal(sampler.ddim_timesteps, tr["ddim_timesteps"])
+    assert mse(out, tr["x_out"]) < 1e-10
+    assert inp["x"] is out and int(inp["timesteps"][0]) == int(tr["calls"][-1][0])
+    with pytest.raises(NotImplementedError):
+        sampler.make_schedule(10, ddim_eta=0.5)
+
+
 def test_set_alpha_scale_is_exact_type_match():
     from gligen_inference import set_alpha_scale
     from ldm.modules.attention import GatedSelfAttentionDense

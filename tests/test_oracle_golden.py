@@ -128,3 +128,69 @@ def test_plms_with_unet(name):
                               alphas=orc.alpha_generator(S, meta["alpha_type"]), mask=mask, x0=z0, noise=noise,
                               on_gate_off=swap_in_sd_first_conv)
     assert mse(out, g["x_out"]) < 1e-7
+
+
+def test_ddim_loop_against_reference_trace():
+    """DDIMSampler (eta 0) of the reference driving the cheap mock model: same call sequence, same final latent."""
+    tr = load_golden("ddim_trace_25")
+    S, atype = tr["meta"]["S"], tr["meta"]["alpha_type"]
+    calls = []
+
+    def eps_fn(x, t, cond, scale):
+        calls.append((int(t[0]), bool(cond), float(scale)))
+        return torch.tanh(x) * (0.5 if cond else 0.3) + 0.01 * t.float().view(-1, 1, 1, 1) / 1000
+
+    x = syn.make_latent(2, 4, 8, 8, seed=5)
+    out = orc.ddim_sample(eps_fn, x, S, orc.make_schedule(), 7.5, alphas=orc.alpha_generator(S, atype))
+    assert calls == [(int(a), bool(b), float(c)) for a, b, c in tr["calls"]]
+    assert len(calls) == 2 * S
+    assert mse(out, tr["x_out"]) < 1e-10
+
+
+@pytest.mark.parametrize("name", ["ddim_unet_small", "ddim_unet_small_inpaint"])
+def test_ddim_with_unet(name):
+    g = load_golden(name)
+    meta = g["meta"]
+    shapes = golden_shapes("unet_small_inpaint" if meta["inpaint"] else "unet_small_text")
+    sd = syn.seeded_state_dict(shapes, 1234)
+    B, hw, S = meta["B"], meta["hw"], meta["S"]
+    batch = syn.make_batch("text", B, n_valid=meta["n_valid"], seed=1)
+    gk = grounding_kwargs("text", batch)
+    gnull = orc.null_grounding("text", gk)
+    ctx, uc = syn.make_context(B, seed=1), syn.make_context(B, seed=9)
+    cfg = oracle_cfg(syn.UNET_CFG_SMALL, "text")
+    mask = z0 = extra = noise = None
+    if meta["inpaint"]:
+        mask = orc.draw_masks_from_boxes(batch["boxes"], hw)
+        z0 = syn.make_latent(B, 4, hw, hw, seed=2)
+        extra = torch.cat([z0 * mask, mask], dim=1)
+        noise = torch.from_numpy(g["noise"])
+
+    def eps_fn(x, t, cond, scale):
+        inp = dict(x=x, timesteps=t, context=ctx if cond else uc, grounding_input=gk if cond else gnull, inpainting_extra_input=extra)
+        return orc.unet_forward(sd, cfg, inp, fuser_scale=scale)
+
+    def swap_in_sd_first_conv():
+        if not meta["inpaint"]:
+            sdc = syn.sd_first_conv_state()
+            sd["input_blocks.0.0.weight"], sd["input_blocks.0.0.bias"] = sdc["weight"], sdc["bias"]
+
+    sched = orc.make_schedule()
+    n_steps = len(orc.plms_schedule(S, sched)["ddim_timesteps"])  # S = 6 -> arange(0, 1000, 166) has 7 entries (util.py:55-69)
+    with torch.no_grad():
+        out = orc.ddim_sample(eps_fn, syn.make_latent(B, 4, hw, hw, seed=6), S, sched, 7.5,
+                              alphas=orc.alpha_generator(n_steps, meta["alpha_type"]), mask=mask, x0=z0, noise=noise,
+                              on_gate_off=swap_in_sd_first_conv)
+    assert mse(out, g["x_out"]) / float(g["x_out"].var()) < 1e-8
+
+
+@pytest.mark.parametrize("name", ["vae_enc_small", "vae_enc_full"])
+def test_vae_encode(name):
+    g = load_golden(name)
+    dd = g["meta"]["ddconfig"]
+    sd = syn.seeded_state_dict(golden_shapes("vae_small" if name.endswith("small") else "vae_full"), 4321)
+    x = torch.rand(g["meta"]["B"], 3, g["meta"]["res"], g["meta"]["res"], generator=torch.Generator().manual_seed(8)) * 2 - 1
+    with torch.no_grad():
+        z = orc.vae_encode(sd, dict(ch_mult=dd["ch_mult"], num_res_blocks=dd["num_res_blocks"], scale_factor=0.18215), x,
+                           torch.from_numpy(g["noise"]))
+    assert mse(z, g["z"]) / float(g["z"].var()) < 1e-9

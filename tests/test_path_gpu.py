@@ -132,13 +132,33 @@ def test_vae_decode_vs_reference(name, dd):
         assert diff.mean() < 3.0
 
 
-@pytest.mark.parametrize("name", ["plms_unet_small", "plms_unet_small_inpaint"])
+@pytest.mark.parametrize("name,dd", [("vae_enc_small", "VAE_DDCONFIG_SMALL"), ("vae_enc_full", "VAE_DDCONFIG")])
+def test_vae_encode_vs_reference(name, dd, monkeypatch):
+    """AutoencoderKL.encode (inpainting: once per prompt) on the device vs the reference's output for the same image, the
+    same seeded weights and the same posterior noise draw."""
+    dev = _dev()
+    g = load_golden(name)
+    ae = build_product_vae(getattr(syn, dd), device=dev)
+    x = torch.rand(g["meta"]["B"], 3, g["meta"]["res"], g["meta"]["res"], generator=torch.Generator().manual_seed(8)) * 2 - 1
+    noise = torch.from_numpy(g["noise"])
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: noise.clone())  # the one posterior draw, as recorded
+    z = ae.encode(x.to(dev))
+    monkeypatch.undo()
+    rel = mse(z, g["z"]) / float(g["z"].var())
+    REPORT[name] = dict(z_rel_mse=rel)
+    assert z.shape == tuple(g["z"].shape) and rel < 5e-3, REPORT[name]
+    ae._drop_engine()
+
+
+@pytest.mark.parametrize("name", ["plms_unet_small", "plms_unet_small_inpaint", "ddim_unet_small", "ddim_unet_small_inpaint"])
 def test_plms_vs_reference(name, tmp_path, monkeypatch):
     dev = _dev()
     from functools import partial
     from gligen_inference import alpha_generator, set_alpha_scale
     from ldm.models.diffusion.ldm import LatentDiffusion
     from ldm.models.diffusion.plms import PLMSSampler
+    if name.startswith("ddim"):  # the reference's DDIMSampler (eta 0) behind the same device loop
+        from ldm.models.diffusion.ddim import DDIMSampler as PLMSSampler  # noqa: F811
     from oracle.gligen_oracle import draw_masks_from_boxes
     g = load_golden(name)
     meta = g["meta"]
