@@ -641,7 +641,7 @@ struct WorkDesc {
     int splits;
     int kt_per_split;
     int n_items;
-    int dbg;  // developer ablation (GL_GEMM_DBG): bit 0 = skip the DMA, bit 1 = skip the MFMAs, bit 2 = skip the epilogue (results are garbage)
+    int dbg;  // developer ablation (GL_GEMM_DBG): bit 0 = skip the DMA, bit 1 = skip the MFMAs, bit 2 = skip the epilogue (results are garbage), bit 3 = fragment-layout epilogue stores
 };
 
 template <int TM, int TN, int AMODE>
@@ -1502,6 +1502,102 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
         }
     };
 
+    // Row-major bf16 outputs leave through LDS: a fragment-layout store writes 16 rows x 32 B per instruction (measured
+    // 2.7 TB/s for the tile set of one 32768 x 320 output, tools/storebench.hip), whole-row pieces of 16 B per lane reach 3.9,
+    // and the residual is read the same way. Each wave stages one 16-row fragment row of its sub-tile at a time, in fp32
+    // (single rounding, as before), in a private piece of the ring slot whose K tile was multiplied last.
+    constexpr int WCOLS = TN * 16;                 // columns of a wave's sub-tile
+    constexpr int LPR = WCOLS / 8;                 // lanes per staged row (8 columns each)
+    constexpr int RPI = 64 / LPR;                  // rows per read instruction
+    constexpr int NRI = (16 + RPI - 1) / RPI;      // read instructions per 16-row fragment row
+    constexpr int RS = WCOLS * 4 + 16;             // staged row stride (bytes): +16 keeps the b128 writes conflict-free
+    constexpr int EPW = 16 * RS;                   // bytes per wave
+    static_assert(WMW * 2 * EPW <= STAGE, "epilogue staging does not fit one ring slot");
+    auto epilogue_staged = [&](int tm, int tn, int slot_done) -> bool {
+        if (wd.splits > 1 || E.mode != EPI_ROWMAJOR || E.out_f32 || (N & 7) || E.act == ACT_GEGLU) return false;
+        unsigned char* ep = smem + slot_done * STAGE + wave * EPW;
+        const int mrow = tm * BM + wm * TM * 16;               // first row of the wave's sub-tile
+        const int ncb = tn * BN + wn * WCOLS;                  // first column
+        const int rr = lane / LPR, cc = lane - rr * LPR;       // read side: row inside a read instruction, 8-column group
+        const int ncol = ncb + cc * 8;
+        const bool col_ok = rr < RPI && ncol < N;
+        // every wave is done with the fragments of the last K tile before any wave overwrites the slot
+        __builtin_amdgcn_s_barrier();
+        // ---- loads first (one in-order vmcnt for loads and stores): bias, time-embedding bias, residual
+        float4 bj[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n0 = ncb + j * 16 + (lane >> 4) * 4;
+            bj[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (E.bias && n0 < N) bj[j] = *reinterpret_cast<const float4*>(E.bias + n0);
+        }
+        const float g = E.gate ? *E.gate : 1.f;
+        auto out_row = [&](int i, int k) {  // output row of read instruction k of fragment row i, or -1
+            const int r = k * RPI + rr;
+            const int m = mrow + i * 16 + r;
+            if (!(col_ok && r < 16 && m < M)) return -1;
+            return E.remap_in ? (m / E.remap_in) * E.remap_out + (m % E.remap_in) + E.remap_off : m;
+        };
+        // the residual is prefetched for two fragment rows at a time (register budget); the second pair's loads queue behind
+        // the first pair's stores, one extra store round trip per work item instead of one per fragment
+        constexpr int PF = TM >= 2 ? 2 : 1;
+        uint4 rs[PF][NRI];
+        auto prefetch_res = [&](int i0) {
+#pragma unroll
+            for (int ii = 0; ii < PF; ++ii)
+#pragma unroll
+                for (int k = 0; k < NRI; ++k) {
+                    const int mo = out_row(i0 + ii, k);
+                    rs[ii][k] = make_uint4(0, 0, 0, 0);
+                    if (E.res && mo >= 0) rs[ii][k] = *reinterpret_cast<const uint4*>(E.res + (size_t)mo * E.ldres + ncol);
+                }
+        };
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (i % PF == 0) prefetch_res(i);
+            // fragment layout -> LDS: lane (l15, q) holds row l15, columns 16 j + 4 q .. + 3
+            const int mf = mrow + i * 16 + l15;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float4 v = make_float4(acc[i][j][0] + bj[j].x, acc[i][j][1] + bj[j].y, acc[i][j][2] + bj[j].z, acc[i][j][3] + bj[j].w);
+                if (E.bias2) {
+                    const int n0 = ncb + j * 16 + (lane >> 4) * 4;
+                    if (mf < M && n0 < N) {
+                        const float4 b2 = *reinterpret_cast<const float4*>(E.bias2 + (size_t)(mf / E.rows_per_b) * E.bias2_ld + n0);
+                        v.x += b2.x; v.y += b2.y; v.z += b2.z; v.w += b2.w;
+                    }
+                }
+                *reinterpret_cast<float4*>(ep + l15 * RS + (j * 16 + (lane >> 4) * 4) * 4) = v;
+            }
+            // LDS -> whole-row pieces: 8 consecutive columns per lane
+#pragma unroll
+            for (int k = 0; k < NRI; ++k) {
+                const int r = k * RPI + rr;
+                const int mo = out_row(i, k);
+                if (mo < 0) continue;
+                const float4 a = *reinterpret_cast<const float4*>(ep + r * RS + cc * 32);
+                const float4 b = *reinterpret_cast<const float4*>(ep + r * RS + cc * 32 + 16);
+                float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                if (E.act == ACT_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+                }
+                U4BF8 o;
+                if (E.res) {
+                    U4BF8 rv;
+                    rv.u = rs[i % PF][k];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o.e[e] = f2bf(bf2f(rv.e[e]) + g * v[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o.e[e] = f2bf(v[e]);
+                }
+                *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(E.out) + (size_t)mo * E.ldo + ncol) = o.u;
+            }
+        }
+        return true;
+    };
+
 #define GL_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
     if (l_item >= wd.n_items) return;
@@ -1549,6 +1645,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
         const bool defer = AHEAD >= 2 && last;
         if (!defer && more) issue_one();
         if (!(wd.dbg & 2)) compute(slot_c);
+        const int slot_done = slot_c;
         slot_c = slot_c == NST - 1 ? 0 : slot_c + 1;
         --ahead;
         if (--c_left == 0) {
@@ -1556,7 +1653,9 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): tiles c+1 .. c+AHEAD-1 (issued 1+ K tiles ago) have landed now
                 landed = min(ahead, AHEAD - 1);
             }
-            if (!(wd.dbg & 4)) epilogue(c_tm, c_tn, c_z);
+            if (!(wd.dbg & 4)) {
+                if ((wd.dbg & 8) || !epilogue_staged(c_tm, c_tn, slot_done)) epilogue(c_tm, c_tn, c_z);  // dbg 8: fragment-layout stores
+            }
             c_item += gridDim.x;
             if (c_item >= wd.n_items) break;
             if (defer && more) issue_one();
