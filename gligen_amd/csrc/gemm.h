@@ -60,8 +60,8 @@ int gemm_launch_t(const bf16* Wrows, int Mw, const bf16* X, int Nx, int K, const
                   hipStream_t stream);
 
 void epilogue_defaults(Epilogue& E);
-// developer switch (kbench A/B): 0 = register-staged main loop, 1 = LDS-DMA main loop, 2 = persistent 16x16-tile kernel (v3),
-// 3 = v3 on a 4-slot K32 ring, 4 = v5: persistent, buffer-descriptor LDS-DMA, load-first epilogue (default)
+// developer switch (kbench A/B): 1 = one-tile-per-workgroup LDS-DMA kernel (v2), 2 = persistent 16x16-tile kernel (v3),
+// 4 = v5: persistent, buffer-descriptor LDS-DMA, asm fragment reads, staged epilogue (default)
 void gemm_set_variant(int v);
 int gemm_geglu_layout();
 void gemm_force_cfg(int tm, int tn, int splits);   // 0,0,0 = automatic

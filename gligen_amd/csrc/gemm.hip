@@ -7,21 +7,19 @@
 // ldm/modules/attention.py:37-64,102-186 projections and GEGLU, ldm/modules/diffusionmodules/
 // model.py:82-141 VAE ResnetBlock).
 //
-// Design (CDNA4):
-//  * v_mfma_f32_32x32x16_bf16, fp32 accumulate. Operand roles are exchanged w.r.t. the textbook
-//    mapping: the MFMA "A" fragment holds weight rows (i = n) and the "B" fragment holds
-//    activation rows (j = m), so each lane ends up with ONE output row m and groups of 4
-//    CONSECUTIVE output columns n -> 8-byte bf16 stores, bias as float4, no LDS transpose.
-//  * block tile BM x BN x 64, 4 waves; both operands K-contiguous in LDS, 128-byte rows,
-//    16-byte chunks XOR-swizzled with ((row>>1)&7) so ds_read_b128 fragment reads and
-//    ds_write_b128 staging writes are bank-conflict free (64-bank b128 model).
-//  * register-staged double buffering: global loads of tile t+1 are issued before the MFMAs of
-//    tile t and written to the other LDS buffer after them; one barrier per K tile.
-//  * the activation loader optionally performs the im2col gather of a 3x3 convolution over an
-//    NHWC tensor (stride 1|2, nearest-2x upsample of the source, channel concat of two sources),
-//    so convs never materialise im2col or concat/upsample copies in HBM.
-//  * split-K (grid.z) through an fp32 slab workspace + a deterministic reduce/epilogue kernel for
-//    the low-resolution layers whose M x N grid cannot fill 256 CUs.
+// Kernels in this file (all: v_mfma_f32_*_bf16, fp32 accumulate, both operands K-contiguous in LDS with 128-byte rows whose
+// 16-byte chunks are XOR-swizzled by ((row >> 1) & 7): ds_read_b128 fragment reads and LDS-DMA writes are conflict free):
+//  * gemm_u_kernel ("v5", default): persistent work-item loop, buffer-descriptor LDS-DMA loader, inline-asm fragment
+//    reads, load-first / LDS-staged epilogue, on-device autotuned tile / split-K / residency. See its header comment.
+//  * gemm_p_kernel ("v3"): the same persistent loop with a flat-address global_load_lds loader and compiler-visible LDS
+//    reads; used when an operand exceeds the 2 GiB a 32-bit buffer offset can address, and as an A/B reference.
+//  * gemm_glds_kernel ("v2"): one 32x32-MFMA tile per workgroup; serves N < 128 problems (first / last convs' GEMMs,
+//    PositionNet) and is the independent implementation `kbench check` compares the others against.
+// Operand roles are exchanged w.r.t. the textbook mapping (MFMA "A" = weight rows, "B" = activation rows), so a lane owns
+// ONE output row and groups of 4 CONSECUTIVE output columns: 8-byte bf16 stores, bias as float4, no transpose.
+// The activation loader optionally performs the im2col gather of a 3x3 convolution over an NHWC tensor (stride 1|2,
+// nearest-2x upsample of the source, channel concat of two sources, asymmetric padding), so convs never materialise
+// im2col or concat / upsample copies in HBM. Split-K goes through an fp32 slab workspace + a deterministic reduce kernel.
 #include "gemm.h"
 
 #include <algorithm>
@@ -249,182 +247,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const Epilo
             }
         }
     }
-}
-
-template <int WM, int WN, int TM, int TN, int AMODE>
-__global__ void __launch_bounds__(WM * WN * 64)
-gemm_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilogue E,
-            float* __restrict__ ws, int kt_per_split, int tiles_n) {
-    constexpr int NT = WM * WN * 64;
-    constexpr int BM = WM * TM * 32;
-    constexpr int BN = WN * TN * 32;
-    constexpr int RPP = NT / 8;  // tile rows covered by one pass of 16-byte loads
-    constexpr int XP = BM / RPP;
-    constexpr int WP = BN / RPP;
-    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/loader mismatch");
-    constexpr int STAGE = (BM + BN) * 128;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = t >> 6;
-    const int wm = wave / WN;
-    const int wn = wave % WN;
-    const int cc = t & 7;
-    const int r0 = t >> 3;
-
-    const int tile_m = blockIdx.x / tiles_n;
-    const int tile_n = blockIdx.x - tile_m * tiles_n;
-    const int m_base = tile_m * BM;
-    const int n_base = tile_n * BN;
-
-    const int nk = K >> 6;
-    const int kt0 = blockIdx.z * kt_per_split;
-    const int kt1 = min(nk, kt0 + kt_per_split);
-
-    // ---- per-thread row bookkeeping for the activation loader
-    int64_t xo0[XP], xo1[XP];
-    int xb[XP], xy[XP], xx[XP];
-    bool xv[XP];
-#pragma unroll
-    for (int i = 0; i < XP; ++i) {
-        int m = m_base + r0 + i * RPP;
-        xv[i] = m < M;
-        if constexpr (AMODE == A_ROWS) {
-            xo0[i] = (int64_t)m * A.ld0;
-            xo1[i] = (int64_t)m * A.ld1;
-            xb[i] = xy[i] = xx[i] = 0;
-        } else {
-            int ox = m % A.Wo;
-            int tmp = m / A.Wo;
-            int oy = tmp % A.Ho;
-            xb[i] = tmp / A.Ho;
-            xy[i] = oy * A.stride - A.pad_lo;
-            xx[i] = ox * A.stride - A.pad_lo;
-            xo0[i] = xo1[i] = 0;
-        }
-    }
-    int64_t wo[WP];
-    bool wv[WP];
-#pragma unroll
-    for (int i = 0; i < WP; ++i) {
-        int n = n_base + r0 + i * RPP;
-        wv[i] = n < N;
-        wo[i] = (int64_t)n * K;
-    }
-    const int Cin = A.C0 + A.C1;
-    const int Hup = A.Hin << A.ups;
-    const int Wup = A.Win << A.ups;
-
-    auto load_tiles = [&](int kt, uint4 (&xr)[XP], uint4 (&wr)[WP]) {
-        const int k0 = kt << 6;
-        if constexpr (AMODE == A_ROWS) {
-            const bool first = k0 < A.C0;
-            const bf16* base = first ? A.p0 : A.p1;
-            const int coff = (first ? k0 : k0 - A.C0) + cc * 8;
-#pragma unroll
-            for (int i = 0; i < XP; ++i) {
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (xv[i]) v = *reinterpret_cast<const uint4*>(base + (first ? xo0[i] : xo1[i]) + coff);
-                xr[i] = v;
-            }
-        } else {
-            const int tap = k0 / Cin;
-            const int c = k0 - tap * Cin;
-            const int ky = tap / 3;
-            const int kx = tap - ky * 3;
-            const bool first = c < A.C0;
-            const bf16* base = first ? A.p0 : A.p1;
-            const int ld = first ? A.ld0 : A.ld1;
-            const int coff = (first ? c : c - A.C0) + cc * 8;
-#pragma unroll
-            for (int i = 0; i < XP; ++i) {
-                uint4 v = make_uint4(0, 0, 0, 0);
-                int iy = xy[i] + ky;
-                int ix = xx[i] + kx;
-                if (xv[i] && iy >= 0 && iy < Hup && ix >= 0 && ix < Wup) {
-                    int64_t pix = ((int64_t)xb[i] * A.Hin + (iy >> A.ups)) * A.Win + (ix >> A.ups);
-                    v = *reinterpret_cast<const uint4*>(base + pix * ld + coff);
-                }
-                xr[i] = v;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < WP; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (wv[i]) v = *reinterpret_cast<const uint4*>(W + wo[i] + k0 + cc * 8);
-            wr[i] = v;
-        }
-    };
-
-    auto store_tiles = [&](int buf, const uint4 (&xr)[XP], const uint4 (&wr)[WP]) {
-        unsigned char* xs = smem + buf * STAGE;
-        unsigned char* wsm = xs + BM * 128;
-#pragma unroll
-        for (int i = 0; i < XP; ++i) {
-            int row = r0 + i * RPP;
-            *reinterpret_cast<uint4*>(xs + row * 128 + ((cc ^ ((row >> 1) & 7)) << 4)) = xr[i];
-        }
-#pragma unroll
-        for (int i = 0; i < WP; ++i) {
-            int row = r0 + i * RPP;
-            *reinterpret_cast<uint4*>(wsm + row * 128 + ((cc ^ ((row >> 1) & 7)) << 4)) = wr[i];
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int frow = lane & 31;
-    const int fhalf = lane >> 5;
-
-    auto compute = [&](int buf) {
-        const unsigned char* xs = smem + buf * STAGE;
-        const unsigned char* wsm = xs + BM * 128;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            bf16x8 xf[TM], wf[TN];
-            const int c = 2 * s + fhalf;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                int row = (wm * TM + i) * 32 + frow;
-                xf[i] = *reinterpret_cast<const bf16x8*>(xs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                int row = (wn * TN + j) * 32 + frow;
-                wf[j] = *reinterpret_cast<const bf16x8*>(wsm + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-        }
-    };
-
-    if (kt0 < kt1) {
-        uint4 xr[XP], wr[WP];
-        load_tiles(kt0, xr, wr);
-        store_tiles(0, xr, wr);
-        __syncthreads();
-        for (int kt = kt0; kt < kt1; ++kt) {
-            const int buf = (kt - kt0) & 1;
-            const bool more = kt + 1 < kt1;
-            if (more) load_tiles(kt + 1, xr, wr);
-            compute(buf);
-            if (more) store_tiles(buf ^ 1, xr, wr);
-            __syncthreads();
-        }
-    }
-
-    gemm_epilogue<TM, TN>(acc, E, M, N, m_base + wm * TM * 32 + frow, n_base + wn * TN * 32 + 4 * fhalf, ws);
 }
 
 // 128 zero bytes: the source of every out-of-range 16-byte chunk (conv padding taps, M / N tails)
@@ -856,251 +678,6 @@ gemm_p_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
             c_left = min(nk, (c_z + 1) * wd.kt_per_split) - c_z * wd.kt_per_split;
         }
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// v4: the persistent tile loop of v3 on a 4-slot LDS ring of K=32 groups. LDS-DMA latency on this
-// chip is ~1 us (MI355X_MICROARCH.md ldsdma-fill), several times one K-tile's MFMA time, so a
-// one-tile-ahead double buffer leaves the matrix pipe waiting; here up to three groups stay in
-// flight across raw s_barriers and the main loop only ever waits with COUNTED vmcnt (2 / 1 / 0
-// groups may remain outstanding), never a full drain.
-//   slot   = [BM + BN rows][32 k] bf16 (64-byte rows), one v_mfma_f32_16x16x32_bf16 k-step
-//   DMA    = every wave issues exactly NI wave-instructions per group (16 rows x 64 B each; the
-//            remainder of (BM+BN)/16 over 4 waves is padded with DMAs of the zero chunk into a dump
-//            area), so one immediate vmcnt count is right for all waves
-//   swizzle: 16-byte chunk c of row r is stored at position c ^ g4(r >> 2 & 3), g4 = {0,2,3,1},
-//            applied on the DMA source side; makes the ds_read_b128 fragment reads conflict-free
-//   stores : vmcnt also counts stores and loads/stores may retire out of order with each other, so
-//            an item's last iteration issues no new group, drains (vmcnt 0: the next two groups have
-//            landed), runs the epilogue, and the following two iterations need no wait; by the third
-//            the epilogue's stores are old. The wait used then (<= 2 NI outstanding in total) is safe
-//            whatever the store/load retirement order, because DMA loads retire in order.
-template <int TM, int TN, int AMODE>
-__global__ void __launch_bounds__(256, 2)
-gemm_r_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilogue E, float* __restrict__ ws, WorkDesc wd) {
-    constexpr int BM = TM * 32;
-    constexpr int BN = TN * 32;
-    constexpr int AB = BM / 16;           // 16-row DMA blocks of the activation tile
-    constexpr int WB = BN / 16;           // ... of the weight tile
-    constexpr int XI = AB / 4;            // activation DMA instructions per wave per group
-    constexpr int WI = (WB + 3) / 4;      // weight DMA instructions per wave per group (incl. padding)
-    constexpr int NI = XI + WI;
-    constexpr int SLOT = (BM + BN) * 64;
-    constexpr int DUMP = 4 * SLOT;
-    static_assert(AB % 4 == 0, "BM must be a multiple of 64");
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 1;
-    const int wn = wave & 1;
-    const int lr = lane >> 2;                                          // DMA: row inside the 16-row block
-    const int ch8 = ((lane & 3) ^ ((0x78 >> ((lr >> 2) * 2)) & 3)) * 8;  // DMA: element offset of the source chunk
-    const int ng = K >> 5;
-    const int gps = wd.kt_per_split * 2;                               // K=32 groups per split
-    const bf16* zsrc = reinterpret_cast<const bf16*>(g_zero_chunk);
-    const int Cin = A.C0 + A.C1;
-    const int Hup = A.Hin << A.ups;
-    const int Wup = A.Win << A.ups;
-
-    auto decode = [&](int w, int& tm, int& tn, int& z) {
-        const int q = wd.n_items >> 3, r = wd.n_items & 7, xcd = w & 7, idx = w >> 3;
-        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        const int tile = id / wd.splits;
-        z = id - tile * wd.splits;
-        tm = tile / wd.tiles_n;
-        tn = tile - tm * wd.tiles_n;
-    };
-
-    // ---- load cursor
-    int l_item = blockIdx.x, l_g = 0, l_g_end = 0;
-    int xm[XI], xy[XI], xx[XI];  // A_ROWS: xm = row or -1.  A_CONV3: xm = b * Hin, (xy, xx) = top-left tap
-    int wrow[WI];
-    auto setup_load = [&](int item) {
-        int tm, tn, z;
-        decode(item, tm, tn, z);
-        l_g = z * gps;
-        l_g_end = min(ng, l_g + gps);
-#pragma unroll
-        for (int i = 0; i < XI; ++i) {
-            const int m = tm * BM + (wave + 4 * i) * 16 + lr;
-            const bool ok = m < M;
-            if constexpr (AMODE == A_ROWS) {
-                xm[i] = ok ? m : -1;
-                xy[i] = xx[i] = 0;
-            } else {
-                const int ox = m % A.Wo;
-                const int tmp = m / A.Wo;
-                const int oy = tmp % A.Ho;
-                xm[i] = (tmp / A.Ho) * A.Hin;
-                xy[i] = ok ? oy * A.stride - A.pad_lo : -(1 << 20);
-                xx[i] = ox * A.stride - A.pad_lo;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < WI; ++i) {
-            const int rb = wave + 4 * i;
-            const int n = tn * BN + rb * 16 + lr;
-            wrow[i] = (rb < WB && n < N) ? n : -1;
-        }
-    };
-
-    auto issue = [&](int g, int slot) {
-        unsigned char* xs = smem + slot * SLOT + wave * 1024;
-        unsigned char* wsm = smem + slot * SLOT + BM * 64 + wave * 1024;
-        const int k0 = g << 5;
-        if constexpr (AMODE == A_ROWS) {
-            const bool first = k0 < A.C0;
-            const bf16* base = (first ? A.p0 : A.p1) + (first ? k0 : k0 - A.C0) + ch8;
-            const int ld = first ? A.ld0 : A.ld1;
-#pragma unroll
-            for (int i = 0; i < XI; ++i) {
-                const bf16* src = xm[i] >= 0 ? base + (int64_t)xm[i] * ld : zsrc;
-                GL_GLDS16(src, xs + i * 4096);
-            }
-        } else {
-            const int tap = k0 / Cin;
-            const int c = k0 - tap * Cin;
-            const int ky = tap / 3;
-            const int kx = tap - ky * 3;
-            const bool first = c < A.C0;
-            const bf16* base = (first ? A.p0 : A.p1) + (first ? c : c - A.C0) + ch8;
-            const int ld = first ? A.ld0 : A.ld1;
-#pragma unroll
-            for (int i = 0; i < XI; ++i) {
-                const int iy = xy[i] + ky;
-                const int ix = xx[i] + kx;
-                const bool ok = iy >= 0 && iy < Hup && ix >= 0 && ix < Wup;
-                const int64_t pix = ((int64_t)(xm[i] + (iy >> A.ups))) * A.Win + (ix >> A.ups);
-                const bf16* src = ok ? base + pix * ld : zsrc;
-                GL_GLDS16(src, xs + i * 4096);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < WI; ++i) {
-            const bf16* src = wrow[i] >= 0 ? W + (int64_t)wrow[i] * K + k0 + ch8 : zsrc;
-            unsigned char* dst = (WB % 4 == 0 || wave + 4 * i < WB) ? wsm + i * 4096 : smem + DUMP;
-            GL_GLDS16(src, dst);
-        }
-    };
-
-    f32x4 acc[TM][TN];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-    zero_acc();
-
-    // fragment read: lane -> row l15 of the 16-row block, logical chunk lane >> 4
-    const int l15 = lane & 15;
-    const int foff = l15 * 64 + (((lane >> 4) ^ ((0x78 >> ((l15 >> 2) * 2)) & 3)) << 4);
-    const int xoff = wm * TM * 1024 + foff;
-    const int woff = BM * 64 + wn * TN * 1024 + foff;
-
-    auto compute = [&](int slot) {
-        const unsigned char* st = smem + slot * SLOT;
-        bf16x8 xf[TM], wf[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xoff + i * 1024);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(st + woff + j * 1024);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-    };
-
-    auto epilogue = [&](int tm, int tn, int z) {
-        const int mrow = tm * BM + wm * TM * 16 + l15;
-        const int ncol = tn * BN + wn * TN * 16 + (lane >> 4) * 4;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = mrow + i * 16;
-            if (m >= M) continue;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n0 = ncol + j * 16;
-                if (n0 >= N) continue;
-                if (wd.splits > 1) {
-                    *reinterpret_cast<float4*>(ws + ((size_t)z * M + m) * N + n0) =
-                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                } else if (E.act == ACT_GEGLU) {
-                    if constexpr (TN % 2 == 0) {
-                        if ((j & 1) == 0) {
-                            float val[4], gate[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                val[e] = acc[i][j][e];
-                                gate[e] = acc[i][j + 1 < TN ? j + 1 : j][e];
-                            }
-                            epi_geglu4_t16(E, m, n0, val, gate);
-                        }
-                    }
-                } else {
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
-                    epi_finish4(E, m, n0, v);
-                }
-            }
-        }
-    };
-
-#define GL_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-
-    // ---- pipeline over the flattened (item, K=32 group) sequence; c = index of the group being multiplied
-    if (l_item >= wd.n_items) return;
-    setup_load(l_item);
-    int c_item = l_item, c_tm, c_tn, c_z;
-    decode(c_item, c_tm, c_tn, c_z);
-    int c_left = l_g_end - l_g;
-    bool more = true;
-    int issued = 0;   // groups issued so far
-    auto issue_next = [&]() {
-        issue(l_g, issued & 3);
-        ++issued;
-        if (++l_g >= l_g_end) {
-            l_item += gridDim.x;
-            more = l_item < wd.n_items;
-            if (more) setup_load(l_item);
-        }
-    };
-    for (int i = 0; i < 3 && more; ++i) issue_next();
-    int nowait = 0;
-    for (int c = 0;; ++c) {
-        if (nowait > 0) {
-            --nowait;
-        } else {
-            const int younger = issued - c - 1;  // groups issued after group c
-            if (younger >= 2) GL_VMCNT(2 * NI);
-            else if (younger == 1) GL_VMCNT(NI);
-            else GL_VMCNT(0);
-        }
-        // group c is in LDS for every wave after this barrier, and every wave has finished reading group c-1
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const bool last = c_left == 1;
-        if (!last) {
-            while (more && issued < c + 4) issue_next();  // ring slot (c+3)&3 == (c-1)&3 is free now
-        }
-        compute(c & 3);
-        if (--c_left == 0) {
-            GL_VMCNT(0);  // groups c+1, c+2 (all that is in flight) have landed; no DMA is pending under the epilogue
-            epilogue(c_tm, c_tn, c_z);
-            nowait = 2;
-            c_item += gridDim.x;
-            if (c_item >= wd.n_items) break;
-            zero_acc();
-            decode(c_item, c_tm, c_tn, c_z);
-            c_left = min(ng, (c_z + 1) * gps) - c_z * gps;
-        }
-    }
-#undef GL_VMCNT
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1709,7 +1286,7 @@ splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, Epi
     }
 }
 
-static int g_gemm_variant = -1;  // 0: register-staged v1, 1: LDS-DMA v2, 2: persistent v3, 3: persistent + 4-slot K32 ring v4, 4: v5 buffer-DMA persistent (default)
+static int g_gemm_variant = -1;  // 1: LDS-DMA v2 (one tile per workgroup), 2: persistent v3, 4: v5 buffer-DMA persistent (default)
 void gemm_set_variant(int v) { g_gemm_variant = v; }
 static int gemm_variant() {
     if (g_gemm_variant < 0) {
@@ -1758,13 +1335,8 @@ int launch_cfg(const AOperand& A, const bf16* W, int M, int N, int K, const Epil
         }                                                                                                        \
         hipLaunchKernelGGL(kfn, grid, block, lds, stream, A, W, M, N, K, E, ws, kt_per_split, tiles_n, ##__VA_ARGS__); \
     } while (0)
-    if (gemm_variant() == 0) {
-        if (A.mode == A_ROWS) GL_LAUNCH_ONE((gemm_kernel<WM, WN, TM, TN, A_ROWS>));
-        else GL_LAUNCH_ONE((gemm_kernel<WM, WN, TM, TN, A_CONV3>));
-    } else {
-        if (A.mode == A_ROWS) GL_LAUNCH_ONE((gemm_glds_kernel<WM, WN, TM, TN, A_ROWS>), n_tiles);
-        else GL_LAUNCH_ONE((gemm_glds_kernel<WM, WN, TM, TN, A_CONV3>), n_tiles);
-    }
+    if (A.mode == A_ROWS) GL_LAUNCH_ONE((gemm_glds_kernel<WM, WN, TM, TN, A_ROWS>), n_tiles);
+    else GL_LAUNCH_ONE((gemm_glds_kernel<WM, WN, TM, TN, A_CONV3>), n_tiles);
 #undef GL_LAUNCH_ONE
     GL_LAUNCH_CHECK();
     return GL_OK;
@@ -1780,8 +1352,7 @@ int launch_p(const AOperand& A, const bf16* W, int M, int N, int K, const Epilog
     const int cap = g_force_grid ? g_force_grid : 512;
     dim3 grid(wd.n_items < cap ? wd.n_items : cap);
     dim3 block(256);
-    const bool ring = gemm_variant() == 3;
-    const size_t lds = ring ? 4 * (TM * 32 + TN * 32) * 64 + 1024 : 2 * (TM * 32 + TN * 32) * 128;
+    const size_t lds = 2 * (TM * 32 + TN * 32) * 128;
 #define GL_LAUNCH_P(KFN)                                                                                         \
     do {                                                                                                         \
         auto kfn = KFN;                                                                                          \
@@ -1792,13 +1363,8 @@ int launch_p(const AOperand& A, const bf16* W, int M, int N, int K, const Epilog
         }                                                                                                        \
         hipLaunchKernelGGL(kfn, grid, block, lds, stream, A, W, M, N, K, E, ws, wd);                             \
     } while (0)
-    if (ring) {
-        if (A.mode == A_ROWS) GL_LAUNCH_P((gemm_r_kernel<TM, TN, A_ROWS>));
-        else GL_LAUNCH_P((gemm_r_kernel<TM, TN, A_CONV3>));
-    } else {
-        if (A.mode == A_ROWS) GL_LAUNCH_P((gemm_p_kernel<TM, TN, A_ROWS>));
-        else GL_LAUNCH_P((gemm_p_kernel<TM, TN, A_CONV3>));
-    }
+    if (A.mode == A_ROWS) GL_LAUNCH_P((gemm_p_kernel<TM, TN, A_ROWS>));
+    else GL_LAUNCH_P((gemm_p_kernel<TM, TN, A_CONV3>));
 #undef GL_LAUNCH_P
     GL_LAUNCH_CHECK();
     return GL_OK;
