@@ -34,7 +34,7 @@ def _stale() -> bool:
     if not LIB.exists():
         return True
     lib_m = LIB.stat().st_mtime
-    deps = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + list(INCLUDE.glob("*.h"))
+    deps = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + list(INCLUDE.glob("*.h"))
     return any(p.stat().st_mtime > lib_m for p in deps)
 
 
