@@ -617,7 +617,7 @@ bf16* Engine::groupnorm(const TRef& x, int B, int HW, const NormW& n, float eps,
     P.x0 = x.p0; P.C0 = x.C0; P.x1 = x.p1; P.C1 = x.C1;
     P.B = B; P.HW = HW; P.eps = eps; P.gamma = n.g; P.beta = n.b; P.y = y; P.silu = silu ? 1 : 0;
     P.partial = reinterpret_cast<float*>(arena_.alloc(gn_partial_bytes(B, HW)));
-    ProfScope ps(this, s, "gn_stats_kernel + gn_apply_kernel", 0.0, 2.0 * B * HW * (double)C * 2);
+    ProfScope ps(this, s, HW <= 256 ? "gn_small_kernel" : "gn_stats_kernel + gn_apply_kernel", 0.0, 2.0 * B * HW * (double)C * 2);
     CK(groupnorm_launch(P, s));
     n_launches += 2;
     return y;

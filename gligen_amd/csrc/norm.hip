@@ -166,6 +166,70 @@ __global__ void gn_apply_kernel(GNParams P, int nsplit, int C8, int R, int cpg, 
     }
 }
 
+// ---- fused GroupNorm for the low-resolution levels (HW <= 256: the 16x16 and 8x8 UNet levels, 43 of the 61 GroupNorms of a
+// forward): one workgroup per (sample, group) reads its cpg x HW slab twice (statistics, then normalise + SiLU; the slab is
+// a few KB and L1/L2-resident), so the statistics never leave the CU and one launch + one dependent-kernel boundary go away.
+// Same fixed-order fp32 / fp64 reduction discipline as the two-kernel path.
+template <int NT>
+__global__ void __launch_bounds__(NT) gn_small_kernel(GNParams P, int cpg) {
+    constexpr int NW = NT / 64;
+    __shared__ double red_s[NW][2];
+    __shared__ float stat_s[2];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int C = P.C0 + P.C1;
+    const int hp = cpg >> 2;                 // 4-channel pieces per pixel in this group (cpg % 4 == 0, C0 % 4 == 0)
+    const int n_q = P.HW * hp;
+    const int c_base = g * cpg;
+    auto src_of = [&](int pix, int c) -> const bf16* {
+        return c < P.C0 ? P.x0 + ((size_t)b * P.HW + pix) * P.C0 + c : P.x1 + ((size_t)b * P.HW + pix) * P.C1 + (c - P.C0);
+    };
+    float s = 0.f, q = 0.f;
+    for (int idx = t; idx < n_q; idx += NT) {
+        const int pix = idx / hp;
+        const int c = c_base + 4 * (idx - pix * hp);
+        const uint2 v = *reinterpret_cast<const uint2*>(src_of(pix, c));
+        const float a0 = __uint_as_float(v.x << 16), a1 = __uint_as_float(v.x & 0xffff0000u);
+        const float a2 = __uint_as_float(v.y << 16), a3 = __uint_as_float(v.y & 0xffff0000u);
+        s += (a0 + a1) + (a2 + a3);
+        q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (lane == 0) { red_s[wave][0] = s; red_s[wave][1] = q; }
+    __syncthreads();
+    if (t == 0) {
+        double ss = 0.0, qq = 0.0;
+        for (int w = 0; w < NW; ++w) { ss += red_s[w][0]; qq += red_s[w][1]; }
+        const double n = (double)P.HW * cpg;
+        const double mean = ss / n;
+        double var = qq / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stat_s[0] = (float)mean;
+        stat_s[1] = (float)(1.0 / sqrt(var + (double)P.eps));
+    }
+    __syncthreads();
+    const float mean = stat_s[0], rstd = stat_s[1];
+    for (int idx = t; idx < n_q; idx += NT) {
+        const int pix = idx / hp;
+        const int c = c_base + 4 * (idx - pix * hp);
+        const uint2 v = *reinterpret_cast<const uint2*>(src_of(pix, c));
+        const float4 gm = *reinterpret_cast<const float4*>(P.gamma + c);
+        const float4 bt = *reinterpret_cast<const float4*>(P.beta + c);
+        float y0 = (__uint_as_float(v.x << 16) - mean) * rstd * gm.x + bt.x;
+        float y1 = (__uint_as_float(v.x & 0xffff0000u) - mean) * rstd * gm.y + bt.y;
+        float y2 = (__uint_as_float(v.y << 16) - mean) * rstd * gm.z + bt.z;
+        float y3 = (__uint_as_float(v.y & 0xffff0000u) - mean) * rstd * gm.w + bt.w;
+        if (P.silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
+        union { uint2 u; bf16 e[4]; } o;
+        o.e[0] = f2bf(y0);
+        o.e[1] = f2bf(y1);
+        o.e[2] = f2bf(y2);
+        o.e[3] = f2bf(y3);
+        *reinterpret_cast<uint2*>(P.y + ((size_t)b * P.HW + pix) * C + c) = o.u;
+    }
+}
+
 int groupnorm_launch(const GNParams& P, hipStream_t stream) {
     const int C = P.C0 + P.C1;
     if (C % 64 != 0 || (P.C1 && P.C0 % 8 != 0)) return set_error(GL_ERR_ARG, "groupnorm: C=%d (C0=%d) unsupported", C, P.C0);
@@ -173,6 +237,12 @@ int groupnorm_launch(const GNParams& P, hipStream_t stream) {
     const int C8 = C / 8;
     if (cpg < 4 || (cpg & 1)) return set_error(GL_ERR_UNSUPPORTED, "groupnorm: %d channels per group (need an even number >= 4)", cpg);
     if (C8 > 1024) return set_error(GL_ERR_ARG, "groupnorm: C=%d too large", C);
+    if (P.HW <= 256 && (P.C0 & 3) == 0 && (cpg & 3) == 0) {
+        if (P.HW * cpg >= 8192) hipLaunchKernelGGL(gn_small_kernel<1024>, dim3(32, P.B), dim3(1024), 0, stream, P, cpg);
+        else hipLaunchKernelGGL(gn_small_kernel<256>, dim3(32, P.B), dim3(256), 0, stream, P, cpg);
+        GL_LAUNCH_CHECK();
+        return GL_OK;
+    }
     const int R = gn_rows(C8);
     const int nsplit = gn_nsplit_c(P.HW, C8);
     const int T = C8 * R;
