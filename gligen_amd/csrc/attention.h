@@ -13,6 +13,7 @@ struct AttnParams {
     int Tq_pad, Tk_pad;  // padded row counts of the q / k,vt buffers (128- / 64-multiples)
     int ldo;             // O row stride in elements
     int o_rows_per_b;    // rows per sample in O
+    int nqb;             // query blocks (128 rows) per (b,h); filled by attn_launch
     float scale_log2e;   // d^-0.5 * log2(e)
 };
 

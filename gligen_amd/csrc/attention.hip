@@ -27,8 +27,16 @@ namespace gl {
 // ONES (DPV > d): the first padding row of V^T (row d) holds 1.0 for every key, so the P V product
 // itself accumulates the softmax denominator in O^T row d (same bf16 P as the numerator) and the
 // per-lane VALU row sum disappears; see attn_vt_ones_launch.
+//
+// BIAS (DP > d, i.e. d = 40): the first padding column of the head dim carries the softmax stabiliser through the MFMA.
+// Q is scaled by scale*log2(e) when its fragments are loaded, Q[:, d] := -m (the running row max, kept bf16-exact) and
+// K[:, d] := 1 as the tile is written to LDS, so K Q^T comes out of the matrix core as s*c - m and the per-element
+// v_fma in front of every v_exp disappears (32 of ~137 VALU instructions per 64-key tile; the kernel is bound by VALU
+// + MFMA issue, which barely overlap here). m only has to be close to the row max, not equal to it: it is moved (and O^T
+// rescaled) when a tile's scores exceed it by more than 2^6, which after the first tiles is rare.
 template <int DP, int DPV, bool ONES>
-__global__ void __launch_bounds__(256) attn_kernel(AttnParams P) {
+__global__ void __launch_bounds__(256, DP == 48 ? 3 : 1) attn_kernel(AttnParams P) {  // d = 40: three workgroups per CU -> a 170-VGPR budget, which also makes hipcc pick the VGPR-destination MFMA form (no v_accvgpr_read per score)
+    constexpr bool BIAS = DP == 48 && ONES;   // d = 40 (column 40 is free)
     constexpr int KS = DP / 16;
     constexpr int DT = DPV / 32;
     constexpr int KROW = DP * 2 + 16;  // LDS row strides (bytes): +16 keeps b128 reads conflict-free
@@ -48,27 +56,43 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams P) {
     const int wave = t >> 6;
     const int lrow = lane & 31;
     const int half = lane >> 5;
-    const int h = blockIdx.y;
-    const int b = blockIdx.z;
-    const size_t bh = (size_t)b * P.H + h;
+    // XCD-aware block order: hardware places block i on XCD i % 8; renumber so that each XCD owns a contiguous range of
+    // (batch, head, query block) -- all query blocks of a head then share one L2 and its K / V^T cross the fabric once
+    int lin = blockIdx.x;
+    {
+        const int total = gridDim.x;
+        if ((total & 7) == 0) lin = (lin & 7) * (total >> 3) + (lin >> 3);
+    }
+    const int qblk = lin % P.nqb;
+    const int bhi = lin / P.nqb;
+    const int h = bhi % P.H;
+    const int b = bhi / P.H;
+    const size_t bh = (size_t)bhi;
 
     const bf16* __restrict__ Qg = P.q + bh * P.Tq_pad * DP;
     const bf16* __restrict__ Kg = P.k + bh * P.Tk_pad * DP;
     const bf16* __restrict__ Vg = P.vt + bh * DPV * P.Tk_pad;
 
-    const int myq = blockIdx.x * 128 + wave * 32 + lrow;
+    const int myq = qblk * 128 + wave * 32 + lrow;
 
     bf16x8 qf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s)
         qf[s] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)myq * DP + 16 * s + 8 * half);
+    if constexpr (BIAS) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[s][e] = f2bf((float)qf[s][e] * P.scale_log2e);
+        if (half == 1) qf[2][0] = f2bf(0.f);   // column 40 = -m, m = 0 until the first tile has been seen
+    }
 
     f32x16 ot[DT];
 #pragma unroll
     for (int i = 0; i < DT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
-    float m_run = -1e30f;  // running max, in scaled (log2) units
+    float m_run = BIAS ? 0.f : -1e30f;  // running max (BIAS: the stabiliser baked into Q column 40), in scaled (log2) units
     float l_run = 0.f;     // this lane's partial denominator (its 16+16 keys per tile)
     const float c = P.scale_log2e;
 
@@ -103,7 +127,9 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams P) {
             if (id < KCH) {
                 int row = id / (DP / 8);
                 int cch = id - row * (DP / 8);
-                *reinterpret_cast<uint4*>(ks + row * KROW + cch * 16) = make_uint4(kreg[4*i],kreg[4*i+1],kreg[4*i+2],kreg[4*i+3]);
+                uint32_t k0 = kreg[4*i];
+                if constexpr (BIAS) k0 = cch == 5 ? ((k0 & 0xffff0000u) | 0x3f80u) : k0;   // K[:, 40] = 1.0
+                *reinterpret_cast<uint4*>(ks + row * KROW + cch * 16) = make_uint4(k0,kreg[4*i+1],kreg[4*i+2],kreg[4*i+3]);
             }
         }
 #pragma unroll
@@ -155,6 +181,34 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams P) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[u][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        bf16x8 pb0, pb1, pb2, pb3;
+        if constexpr (BIAS) {
+            // st already is s*c - m_run
+            const bool move = it == 0 || mx > 6.f;
+            if (__builtin_amdgcn_ballot_w64(move) != 0) {
+                const bf16 mb = f2bf(m_run + mx);
+                const float m_upd = move ? (float)mb : m_run;
+                const float delta = m_upd - m_run;   // exact: both are bf16 values
+                if (it > 0) {                        // O^T is still zero in the first tile (and 2^-delta may overflow there)
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                    for (int i = 0; i < DT; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[u][r] -= delta;
+                m_run = m_upd;
+                const bf16 nb = f2bf(-m_upd);
+                if (half == 1) qf[2][0] = nb;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[u][r] = __builtin_amdgcn_exp2f(st[u][r]);
+        } else {
         const float m_new = fmaxf(m_run, mx * c);
         // the running max stops growing after the first few tiles: rescale O only when some row's did
         if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
@@ -167,7 +221,6 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams P) {
         }
         m_run = m_new;
         float psum = 0.f;
-        bf16x8 pb0, pb1, pb2, pb3;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -176,6 +229,8 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams P) {
                 if constexpr (!ONES) psum += p;
                 st[u][r] = p;
             }
+        if constexpr (!ONES) l_run += psum;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             pb0[e] = f2bf(st[0][e]);
@@ -183,7 +238,6 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams P) {
             pb2[e] = f2bf(st[1][e]);
             pb3[e] = f2bf(st[1][8 + e]);
         }
-        if constexpr (!ONES) l_run += psum;
 
         // ---- O^T += V^T P^T
 #pragma unroll
@@ -247,8 +301,10 @@ static int launch_attn(const AttnParams& P, int B, hipStream_t stream) {
         GL_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    dim3 grid(cdiv(P.Nq, 128), P.H, B);
-    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, stream, P);
+    AttnParams Q = P;
+    Q.nqb = cdiv(P.Nq, 128);
+    dim3 grid(Q.nqb * P.H * B);
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, stream, Q);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }

@@ -588,7 +588,12 @@ void Engine::finalize() {
 void Engine::gemm(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, hipStream_t s) {
     ProfScope ps(this, s, "gemm", 2.0 * M * N * K, 0.0);
     CK(gemm_launch(A, W, M, N, K, E, ws_, ws_bytes_, s));
-    if (profiling_) ps.rename(gemm_last_kernel_name());  // the symbol the tile selection actually launched
+    if (profiling_) {
+        static const bool by_shape = getenv("GL_PROF_SHAPES") != nullptr;  // developer aid: one record per problem, not per symbol
+        std::string nm = gemm_last_kernel_name();  // the symbol the tile selection actually launched
+        if (by_shape) nm += fmt(" M%d N%d K%d", M, N, K);
+        ps.rename(nm);
+    }
     ++n_launches;
 }
 

@@ -463,6 +463,11 @@ struct WorkDesc {
     int splits;
     int kt_per_split;
     int n_items;
+    // XCD partition of the item space. box < 0: contiguous ranges of the linear (tm, tn, z) order. Otherwise the 8 XCDs
+    // form a 2^lgm x 2^lgn x 2^lgz grid over (M tiles, N tiles, K splits), box = lgm | lgn << 4, and each owns an
+    // rm x tiles_n x rz box (tiles_n = N tiles PER BOX then), so that an activation panel is fetched by 2^lgn L2s and a
+    // weight panel by 2^lgm (the K axis duplicates nothing). rz = splits when box < 0.
+    int box, rm, rz;
     int dbg;  // developer ablation (GL_GEMM_DBG): bit 0 = skip the DMA, bit 1 = skip the MFMAs, bit 2 = skip the epilogue (results are garbage), bit 3 = fragment-layout epilogue stores
 };
 
@@ -769,12 +774,22 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0x80000000u, 0x00020000);
 
     auto decode = [&](int w, int& tm, int& tn, int& z) {
-        const int q = wd.n_items >> 3, r = wd.n_items & 7, xcd = w & 7, idx = w >> 3;
-        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        const int tile = id / wd.splits;
-        z = id - tile * wd.splits;
+        const int xcd = w & 7, idx = w >> 3;
+        int id = idx;
+        if (wd.box < 0) {
+            const int q = wd.n_items >> 3, r = wd.n_items & 7;
+            id += xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        }
+        const int tile = id / wd.rz;
+        z = id - tile * wd.rz;
         tm = tile / wd.tiles_n;
         tn = tile - tm * wd.tiles_n;
+        if (wd.box >= 0) {
+            const int lgm = wd.box & 15, lgn = wd.box >> 4;
+            z += (xcd >> (lgm + lgn)) * wd.rz;
+            tn += ((xcd >> lgm) & ((1 << lgn) - 1)) * wd.tiles_n;
+            tm += (xcd & ((1 << lgm) - 1)) * wd.rm;
+        }
     };
 
     // ---- load cursor: (item, K tile) plus, for the conv gather, the filter tap and channel offset of that tile
@@ -1422,10 +1437,11 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
     const bool fits32 = a_rows * (size_t)std::max(A.ld0, A.ld1) * 2 < 0x7fff0000ull && (size_t)N * K * 2 < 0x7fff0000ull;
     const bool use_u = gemm_variant() == 4 && fits32 && !(E.bias2 && E.res);  // v5's epilogue has no bias2 + residual form
     static const int dbg = getenv("GL_GEMM_DBG") ? atoi(getenv("GL_GEMM_DBG")) : 0;
+    static const int xcd_boxes = getenv("GL_GEMM_XCD_BOXES") ? atoi(getenv("GL_GEMM_XCD_BOXES")) : 1;
 
     auto feasible = [&](int c, int& sp) {
         const int tm = kTm[c], tn = kTn[c];
-        if (tm == 8 && !use_u) return false;
+        if (tm == 8) return false;  // not built (see run_cfg)
         if (E.act == ACT_GEGLU && (tn & 1)) return false;
         if (sp > 1 && (!ws || nk / sp < 2 || (size_t)sp * M * N * sizeof(float) > ws_bytes)) return false;
         const int kps = cdiv(nk, sp);
@@ -1440,6 +1456,24 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
         wd.kt_per_split = cdiv(nk, sp);
         wd.splits = cdiv(nk, wd.kt_per_split);
         wd.n_items = cdiv(M, tm * 32) * wd.tiles_n * wd.splits;
+        wd.box = -1; wd.rm = 0; wd.rz = wd.splits;
+        if (use_u && xcd_boxes) {
+            // fabric-side bytes ~ A_bytes * (#N bands) + W_bytes * (#M bands); only exact partitions (all boxes equal)
+            const int tiles_m = cdiv(M, tm * 32), tiles_n = wd.tiles_n;
+            const double a_bytes = (double)a_rows * (A.C0 + A.C1) * 2, w_bytes = (double)N * K * 2;
+            double best = 1e300;
+            for (int lgm = 3; lgm >= 0; --lgm)
+                for (int lgn = 3 - lgm; lgn >= 0; --lgn) {
+                    const int lgz = 3 - lgm - lgn;
+                    if (tiles_m % (1 << lgm) || tiles_n % (1 << lgn) || wd.splits % (1 << lgz)) continue;
+                    const double cost = a_bytes * (1 << lgn) + w_bytes * (1 << lgm);
+                    if (cost < best) {
+                        best = cost;
+                        wd.box = lgm | lgn << 4;
+                        wd.rm = tiles_m >> lgm; wd.tiles_n = tiles_n >> lgn; wd.rz = wd.splits >> lgz;
+                    }
+                }
+        }
         g_last_cfg[0] = tm; g_last_cfg[1] = tn; g_last_cfg[2] = wd.splits;
         if (use_u) snprintf(g_last_name, sizeof g_last_name, "gemm_u_kernel<%d, %d, %d, %d, %d>", tm == 8 ? 4 : 2, tm == 8 ? 4 : tm, tn, A.mode, tm == 8 ? 3 : 2);
         else snprintf(g_last_name, sizeof g_last_name, "gemm_p_kernel<%d, %d, %d>", tm, tn, A.mode);
@@ -1453,8 +1487,9 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
                 case 1: rc = launch_u<2, 4, 4, 2>(A, W, M, N, K, E, ws, wd, stream); break;
                 case 2: rc = launch_u<2, 2, 5, 2>(A, W, M, N, K, E, ws, wd, stream); break;
                 case 3: rc = launch_u<2, 2, 4, 2>(A, W, M, N, K, E, ws, wd, stream); break;
-                case 4: rc = launch_u<4, 4, 5, 3>(A, W, M, N, K, E, ws, wd, stream); break;
-                default: rc = launch_u<4, 4, 4, 3>(A, W, M, N, K, E, ws, wd, stream); break;
+                // candidates 4-5 (WMW = 4: 8 waves, 256-row tile, 3-stage ring, one workgroup per CU) lost every sweep against
+                // two 4-wave workgroups per CU and are no longer instantiated; the kernel template keeps the geometry
+                default: g_force_grid = saved_grid; return set_error(GL_ERR_UNSUPPORTED, "gemm: the 8-wave 256-row tile is not built");
             }
         } else {
             switch (c) {

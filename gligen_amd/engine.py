@@ -161,10 +161,10 @@ class Engine:
         Beff = int(batch or t.shape[0])
         extra = None if inpaint_extra is None else _f32(inpaint_extra, dev)
         out = torch.empty((Beff, self.unet_cfg["out_channels"], x.shape[2], x.shape[3]), device=dev, dtype=torch.float32)
-        recs = (_lib.ProfRec * 64)()
+        recs = (_lib.ProfRec * 512)()
         n = C.c_int(0)
         check(self.lib.gl_unet_profile(self._ctx, Beff, int(x.shape[2]), int(x.shape[3]), _ptr(x), int(x.shape[0]), _ptr(t),
-                                       _ptr(extra), 0 if extra is None else int(extra.shape[0]), _ptr(out), recs, 64, C.byref(n),
+                                       _ptr(extra), 0 if extra is None else int(extra.shape[0]), _ptr(out), recs, 512, C.byref(n),
                                        _stream()))
         return [dict(name=recs[i].name.decode(), calls=recs[i].calls, ms=recs[i].ms, flops=recs[i].flops, bytes=recs[i].bytes)
                 for i in range(n.value)]

@@ -51,7 +51,7 @@ def test_gemm_main_loop_has_no_dma_drain(gemm_asm):
         # DMA must not be wrapped in waterfall loops (descriptor / soffset / m0 proven wave-uniform)
         text = "\n".join(loop)
         assert len(re.findall(r"v_readfirstlane_b32", text)) <= 12, f"{name}: waterfall loops around the LDS-DMA?"
-    assert seen >= 10
+    assert seen >= 8
 
 
 def test_gemm_kernels_do_not_spill(gemm_asm):
