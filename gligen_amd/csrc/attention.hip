@@ -24,6 +24,13 @@
 
 namespace gl {
 
+// max over the two lanes l and l^32 without the LDS round trip of a bpermute (gfx950 v_permlane32_swap)
+__device__ __forceinline__ float max_xor32(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 // ONES (DPV > d): the first padding row of V^T (row d) holds 1.0 for every key, so the P V product
 // itself accumulates the softmax denominator in O^T row d (same bf16 P as the numerator) and the
 // per-lane VALU row sum disappears; see attn_vt_ones_launch.
@@ -180,7 +187,7 @@ __global__ void __launch_bounds__(256, DP == 48 ? 3 : 1) attn_kernel(AttnParams 
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[u][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = max_xor32(mx);
         bf16x8 pb0, pb1, pb2, pb3;
         if constexpr (BIAS) {
             // st already is s*c - m_run
