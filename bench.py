@@ -56,6 +56,30 @@ def cpu_baseline():
             "host_cpus": os.cpu_count()}
 
 
+def pmc_traffic(kernel):
+    """Fabric-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (tools/gpu_traffic.sh -> profiles/<round>/pmc_traffic.csv; counters cannot be collected from inside a timed run).
+    FETCH_SIZE / WRITE_SIZE are KiB summed over the L2 channels; FETCH_SIZE is doubled, the guide's gfx950 correction
+    for 16-B-per-lane streaming reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is taken as reported."""
+    import csv, glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "pmc_traffic.csv")))
+    if not files:
+        return None, None
+    sym = kernel.split(" + ")[0]
+    fetch = write = None
+    with open(files[-1], newline="") as fh:
+        for r in csv.DictReader(fh):
+            if r["kernel"] == sym and r["counter"] == "FETCH_SIZE":
+                fetch = float(r["mean"]) * 1024 * 2
+            if r["kernel"] == sym and r["counter"] == "WRITE_SIZE":
+                write = float(r["mean"]) * 1024
+    if fetch is None or write is None:
+        return None, None
+    return fetch + write, (f"{os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__)))}: mean over the run's launches of this symbol, "
+                           f"2 x FETCH_SIZE ({fetch / 1e6:.1f} MB) + WRITE_SIZE ({write / 1e6:.1f} MB); L2-to-fabric requests, "
+                           "Infinity-Cache hits included, so an upper bound on HBM bytes")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,10 +171,11 @@ def main():
         # same command) lists the same symbol with its average duration over the whole run.
         mm = [p for p in prof if p["flops"] > 0]
         dom = mm[0]
+        traffic, traffic_src = pmc_traffic(dom["name"])
         tot_ms = sum(p["ms"] for p in prof)
         roofline = {"bound": "mfma", "kernel": dom["name"], "achieved": dom["flops"] / (dom["ms"] * 1e-3) / 1e12,
                     "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": dom["flops"] / (dom["ms"] * 1e-3) / PEAK_BF16,
-                    "traffic": None, "launches_per_unet_eval": dom["calls"], "avg_launch_us": dom["ms"] / dom["calls"] * 1e3,
+                    "traffic": traffic, "traffic_src": traffic_src, "launches_per_unet_eval": dom["calls"], "avg_launch_us": dom["ms"] / dom["calls"] * 1e3,
                     "flops_per_launch_avg": dom["flops"] / dom["calls"], "share_of_unet_eval": dom["ms"] / tot_ms,
                     "measured": "HIP events on the launch stream around each launch of one eager UNet evaluation at batch 2B",
                     "unet_eval": {"achieved": unet_tflops, "frac": unet_tflops * 1e12 / PEAK_BF16, "flops_per_launch": 2 * B * F_UNET,

@@ -994,7 +994,12 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
                         const float bgg[4] = {bg[jj].x, bg[jj].y, bg[jj].z, bg[jj].w};
                         float o[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (acc[i][2 * jj][e] + bvv[e]) * gelu_erf_f(acc[i][2 * jj + 1][e] + bgg[e]);
+                        for (int e = 0; e < 4; e += 2) {
+                            const f32x2 r = geglu2(f32x2{acc[i][2 * jj][e] + bvv[e], acc[i][2 * jj][e + 1] + bvv[e + 1]},
+                                                   f32x2{acc[i][2 * jj + 1][e] + bgg[e], acc[i][2 * jj + 1][e + 1] + bgg[e + 1]});
+                            o[e] = r.x;
+                            o[e + 1] = r.y;
+                        }
                         const int j0 = (n0 >> 5) * 16 + (n0 & 15);
                         store_bf16x4(reinterpret_cast<bf16*>(E.out) + (size_t)m * E.ldo + j0, o);
                     }

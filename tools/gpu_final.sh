@@ -19,3 +19,5 @@ rm -rf gpurun_out/prof
 tail -2 gpurun_out/prof.log
 find gpurun_out/prof -name "*kernel_trace*" -delete
 find gpurun_out/prof -name "*kernel_stats*"
+bash tools/gpu_traffic.sh > gpurun_out/traffic.log 2>&1
+tail -3 gpurun_out/traffic.log
