@@ -1111,8 +1111,54 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
     constexpr int EPW = 16 * RS;                   // bytes per wave
     static_assert(WMW * 2 * EPW <= STAGE, "epilogue staging does not fit one ring slot");
     auto epilogue_staged = [&](int tm, int tn, int slot_done) -> bool {
-        if (wd.splits > 1 || E.mode != EPI_ROWMAJOR || E.out_f32 || (N & 7) || E.act == ACT_GEGLU) return false;
+        if (wd.splits > 1 || E.mode != EPI_ROWMAJOR || E.out_f32 || (N & 7) || (E.act == ACT_GEGLU && (TN & 1))) return false;
         unsigned char* ep = smem + slot_done * STAGE + wave * EPW;
+        if constexpr ((TN & 1) == 0) {
+            // value / gate fragments alternate (16 columns each), so a wave's TN*16 accumulator columns become TN*8 output
+            // columns: val * gelu(gate) is formed in the fragment layout and staged, then leaves as 16 B per lane
+            if (E.act == ACT_GEGLU) {
+                constexpr int OW = TN * 8;                 // output columns of the wave
+                constexpr int LPG = OW / 8;                // lanes per staged row
+                constexpr int RSG = OW * 4 + 16;
+                if (E.res || E.bias2 || E.remap_in || ((N >> 1) & 7)) return false;
+                const int mrow = tm * BM + wm * TM * 16;
+                const int ncb = tn * BN + wn * WCOLS;      // first accumulator column (a multiple of 32)
+                const int rr = lane / LPG, cc = lane - rr * LPG;
+                const int ocol = (ncb >> 1) + cc * 8;
+                __builtin_amdgcn_s_barrier();
+                float4 bv[TN / 2], bg[TN / 2];
+#pragma unroll
+                for (int jj = 0; jj < TN / 2; ++jj) {
+                    const int n0 = ncb + jj * 32 + (lane >> 4) * 4;
+                    bv[jj] = bg[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (E.bias && n0 < N) {
+                        bv[jj] = *reinterpret_cast<const float4*>(E.bias + n0);
+                        bg[jj] = *reinterpret_cast<const float4*>(E.bias + n0 + 16);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int jj = 0; jj < TN / 2; ++jj) {
+                        const f32x2 r0 = geglu2(f32x2{acc[i][2 * jj][0] + bv[jj].x, acc[i][2 * jj][1] + bv[jj].y},
+                                                f32x2{acc[i][2 * jj + 1][0] + bg[jj].x, acc[i][2 * jj + 1][1] + bg[jj].y});
+                        const f32x2 r1 = geglu2(f32x2{acc[i][2 * jj][2] + bv[jj].z, acc[i][2 * jj][3] + bv[jj].w},
+                                                f32x2{acc[i][2 * jj + 1][2] + bg[jj].z, acc[i][2 * jj + 1][3] + bg[jj].w});
+                        *reinterpret_cast<float4*>(ep + l15 * RSG + (jj * 16 + (lane >> 4) * 4) * 4) = make_float4(r0.x, r0.y, r1.x, r1.y);
+                    }
+                    const int m = mrow + i * 16 + rr;
+                    if (rr < 16 && m < M && ocol < (N >> 1)) {
+                        const float4 a = *reinterpret_cast<const float4*>(ep + rr * RSG + cc * 32);
+                        const float4 b = *reinterpret_cast<const float4*>(ep + rr * RSG + cc * 32 + 16);
+                        U4BF8 o;
+                        o.e[0] = f2bf(a.x); o.e[1] = f2bf(a.y); o.e[2] = f2bf(a.z); o.e[3] = f2bf(a.w);
+                        o.e[4] = f2bf(b.x); o.e[5] = f2bf(b.y); o.e[6] = f2bf(b.z); o.e[7] = f2bf(b.w);
+                        *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(E.out) + (size_t)m * E.ldo + ocol) = o.u;
+                    }
+                }
+                return true;
+            }
+        }
         const int mrow = tm * BM + wm * TM * 16;               // first row of the wave's sub-tile
         const int ncb = tn * BN + wn * WCOLS;                  // first column
         const int rr = lane / LPR, cc = lane - rr * LPR;       // read side: row inside a read instruction, 8-column group
