@@ -199,7 +199,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
+    gdist.shutdown()
 
 
 if __name__ == "__main__":

@@ -55,3 +55,10 @@ def sum_over_ranks(value: float, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def shutdown() -> None:
+    """Tear the process group down (after a final barrier) so that ranks leave together and RCCL exits quietly."""
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
