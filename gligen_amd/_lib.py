@@ -23,7 +23,7 @@ class UNetConfig(C.Structure):
         ("n_mult", C.c_int), ("channel_mult", C.c_int * 8),
         ("n_attn", C.c_int), ("attention_resolutions", C.c_int * 8),
         ("inpaint_mode", C.c_int), ("grounding_kind", C.c_int),
-        ("gr_in_dim", C.c_int), ("gr_out_dim", C.c_int), ("max_persons", C.c_int),
+        ("gr_in_dim", C.c_int), ("gr_out_dim", C.c_int), ("max_persons", C.c_int), ("fuser_kind", C.c_int),
     ]
 
 

@@ -68,7 +68,8 @@ struct STW {
     SelfAttnW a1, fa;
     CrossAttnW a2;
     FFW ff, fff;
-    LinW flin;  // fuser.linear (context_dim -> C)
+    LinW flin;  // fuser.linear (context_dim -> C), gatedSA
+    CrossAttnW fca;  // fuser.attn of gatedCA (keys / values = grounding tokens)
 };
 
 enum LayerKind { L_CONV_IN, L_RES, L_ST, L_DOWN, L_UP };
@@ -202,8 +203,10 @@ class Engine {
 
     // ---- conditioning cache
     struct Cond {
-        int Beff = 0, Ng = 0, ctx_T = 0, ctx_Tpad = 0;
+        int Beff = 0, Ng = 0, ctx_T = 0, ctx_Tpad = 0, obj_Tpad = 0;
         std::vector<bf16*> objs;    // per transformer: [Beff*Ng][C]
+        std::vector<bf16*> obj_k;   // gatedCA, per transformer: [Beff*H][obj_Tpad][DP]   (K of the grounding tokens)
+        std::vector<bf16*> obj_vt;  // gatedCA, per transformer: [Beff*H][DPV][obj_Tpad]
         std::vector<bf16*> ctx_k;   // per transformer: [Beff*H][ctx_Tpad][DP]
         std::vector<bf16*> ctx_vt;  // per transformer: [Beff*H][DPV][ctx_Tpad]
         std::vector<void*> allocs;

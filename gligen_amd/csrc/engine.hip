@@ -154,6 +154,8 @@ const RawTensor& Engine::raw(const std::string& key) const {
 void Engine::configure_unet(const gl_unet_config& c) {
     if (c.n_mult < 1 || c.n_mult > 8 || c.n_attn < 0 || c.n_attn > 8) throw GlError(GL_ERR_ARG, "bad unet config");
     if (c.model_channels % 64 != 0) throw GlError(GL_ERR_UNSUPPORTED, "model_channels must be a multiple of 64");
+    if (c.fuser_kind != 0 && c.fuser_kind != 2)
+        throw GlError(GL_ERR_UNSUPPORTED, "fuser_kind: 0 (gatedSA) and 2 (gatedCA) are implemented; gatedSA2 (spatial-map modalities) is not");
     ucfg_ = c;
     has_unet_ = true;
 }
@@ -332,14 +334,24 @@ void Engine::build_unet() {
         t.a2.ctx_dim = (int)raw(tb + ".attn2.to_k.weight").shape[1];
         t.a2.out = linear(tb + ".attn2.to_out.0");
         t.ff = ffw(tb + ".ff", C);
-        if (!has(tb + ".fuser.linear.weight"))
-            throw GlError(GL_ERR_UNSUPPORTED, "only fuser_type gatedSA (GatedSelfAttentionDense) is supported");
-        t.flin = linear(tb + ".fuser.linear");
+        if (has(tb + ".fuser.linear.weight") != (c.fuser_kind == 0))
+            throw GlError(GL_ERR_ARG, "fuser weights do not match fuser_kind (gatedSA has fuser.linear, gatedCA does not)");
         t.fn1 = norm(tb + ".fuser.norm1");
         t.fn2 = norm(tb + ".fuser.norm2");
-        t.fa.wqk = cast_rows({tb + ".fuser.attn.to_q.weight", tb + ".fuser.attn.to_k.weight"});
-        t.fa.wv = cast_rows({tb + ".fuser.attn.to_v.weight"});
-        t.fa.out = linear(tb + ".fuser.attn.to_out.0");
+        if (c.fuser_kind == 0) {
+            t.flin = linear(tb + ".fuser.linear");
+            t.fa.wqk = cast_rows({tb + ".fuser.attn.to_q.weight", tb + ".fuser.attn.to_k.weight"});
+            t.fa.wv = cast_rows({tb + ".fuser.attn.to_v.weight"});
+            t.fa.out = linear(tb + ".fuser.attn.to_out.0");
+        } else {  // gatedCA: CrossAttention(query_dim, key_dim = value_dim = grounding-token dim) -- attention.py:194
+            t.fca.q = linear(tb + ".fuser.attn.to_q", false);
+            t.fca.wk = cast_rows({tb + ".fuser.attn.to_k.weight"});
+            t.fca.wv = cast_rows({tb + ".fuser.attn.to_v.weight"});
+            t.fca.ctx_dim = (int)raw(tb + ".fuser.attn.to_k.weight").shape[1];
+            if (t.fca.ctx_dim != c.gr_out_dim || (int)raw(tb + ".fuser.attn.to_v.weight").shape[1] != c.gr_out_dim)
+                throw GlError(GL_ERR_ARG, "gatedCA: fuser.attn key / value dim must equal the grounding-token dim");
+            t.fca.out = linear(tb + ".fuser.attn.to_out.0");
+        }
         t.fff = ffw(tb + ".fuser.ff", C);
         raw(tb + ".fuser.alpha_attn");
         raw(tb + ".fuser.alpha_dense");
@@ -786,20 +798,47 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
     self_attention(t.a1, ln, B, Tp, HW, HW, C, d, o, s);
     bf16* t1 = linear_rows(o, M, t.a1.out, ACT_NONE, t0, nullptr, s);
 
-    // fuser: x = x + scale*tanh(alpha_attn) * attn(norm1([x ; linear(objs)]))[:, :N]
     const int Ng = cond_.Ng;
-    const int Tf = round_up(HW + Ng, 64);
-    bf16* lnc = arena_.get<bf16>((size_t)B * Tf * C);
-    {
-        LNParams P{};
-        P.x = t1; P.x2 = cond_.objs[t.idx]; P.B = B; P.N1 = HW; P.N2 = Ng; P.Tpad = Tf; P.C = C; P.eps = 1e-5f;
-        P.gamma = t.fn1.g; P.beta = t.fn1.b; P.y = lnc;
-        ProfScope ps(this, s, "ln_kernel", 0.0, 2.0 * B * (HW + Ng) * (double)C * 2);
-        CK(layernorm_launch(P, s));
+    bf16* t2;
+    if (ucfg_.fuser_kind == 0) {
+        // fuser (gatedSA): x = x + scale*tanh(alpha_attn) * attn(norm1([x ; linear(objs)]))[:, :N]
+        const int Tf = round_up(HW + Ng, 64);
+        bf16* lnc = arena_.get<bf16>((size_t)B * Tf * C);
+        {
+            LNParams P{};
+            P.x = t1; P.x2 = cond_.objs[t.idx]; P.B = B; P.N1 = HW; P.N2 = Ng; P.Tpad = Tf; P.C = C; P.eps = 1e-5f;
+            P.gamma = t.fn1.g; P.beta = t.fn1.b; P.y = lnc;
+            ProfScope ps(this, s, "ln_kernel", 0.0, 2.0 * B * (HW + Ng) * (double)C * 2);
+            CK(layernorm_launch(P, s));
+            ++n_launches;
+        }
+        self_attention(t.fa, lnc, B, Tf, HW, HW + Ng, C, d, o, s);
+        t2 = linear_rows(o, M, t.fa.out, ACT_NONE, t1, gates_ + 2 * t.idx, s);
+    } else {
+        // fuser (gatedCA, attention.py:207-212): x = x + scale*tanh(alpha_attn) * attn(norm1(x), objs, objs)
+        ln = layernorm(t1, B, HW, C, t.fn1, true, s);
+        int dp, dpv;
+        CK(attn_dims(d, &dp, &dpv));
+        AttnBufs& bufs = attn_bufs(B, heads, d, Tp, cond_.obj_Tpad);
+        AOperand A;
+        aoperand_rows(A, ln, C, C);
+        Epilogue E;
+        epilogue_defaults(E);
+        E.mode = EPI_QK_HEADS;
+        E.q = bufs.q; E.k = nullptr; E.C = C; E.H = heads; E.d = d; E.DP = dp; E.T = Tp; E.Tpad_q = bufs.Tq_pad; E.Tpad_k = 0;
+        gemm(A, t.fca.q.w, B * Tp, C, C, E, s);
+        AttnParams P{};
+        P.q = bufs.q; P.k = cond_.obj_k[t.idx]; P.vt = cond_.obj_vt[t.idx]; P.o = o;
+        P.H = heads; P.d = d; P.Nq = HW; P.Nk = Ng; P.Tq_pad = bufs.Tq_pad; P.Tk_pad = cond_.obj_Tpad;
+        P.ldo = C; P.o_rows_per_b = HW;
+        P.scale_log2e = (float)(1.4426950408889634 / std::sqrt((double)d));
+        {
+            ProfScope ps(this, s, attn_kernel_name(d), 4.0 * B * heads * (double)HW * Ng * d, 0.0);
+            CK(attn_launch(P, B, s));
+        }
         ++n_launches;
+        t2 = linear_rows(o, M, t.fca.out, ACT_NONE, t1, gates_ + 2 * t.idx, s);
     }
-    self_attention(t.fa, lnc, B, Tf, HW, HW + Ng, C, d, o, s);
-    bf16* t2 = linear_rows(o, M, t.fa.out, ACT_NONE, t1, gates_ + 2 * t.idx, s);
     //        x = x + scale*tanh(alpha_dense) * ff(norm2(x))
     ln = layernorm(t2, B, HW, C, t.fn2, false, s);
     bf16* t3 = feedforward(t.fff, ln, M, t2, gates_ + 2 * t.idx + 1, s);
@@ -870,6 +909,9 @@ void Engine::set_cond(int Beff, const float* context, int n_ctx, const gl_ground
     const int Ng = gkind_ == 1 ? 2 * g.n : g.n;
     const int ctx_Tpad = round_up(n_ctx, 64);
     const int heads = c.num_heads;
+    const bool ca = c.fuser_kind == 2;
+    const int obj_Tpad = round_up(Ng, 64);
+    const int obj_stride = ca ? obj_Tpad : Ng;   // rows per sample of the grounding-token matrix (gatedCA pads to the key tile)
     if (cond_.Beff != Beff || cond_.Ng != Ng || cond_.ctx_Tpad != ctx_Tpad) {
         HIPCK(hipStreamSynchronize(s));
         sampler_release_graph();
@@ -885,7 +927,14 @@ void Engine::set_cond(int Beff, const float* context, int n_ctx, const gl_ground
         for (const STW& t : st_) {
             int dp, dpv;
             CK(attn_dims(t.d, &dp, &dpv));
-            cond_.objs.push_back(reinterpret_cast<bf16*>(palloc((size_t)Beff * Ng * t.C * sizeof(bf16))));
+            if (ca) {
+                cond_.objs.push_back(nullptr);
+                cond_.obj_k.push_back(reinterpret_cast<bf16*>(palloc((size_t)Beff * heads * obj_Tpad * dp * sizeof(bf16))));
+                cond_.obj_vt.push_back(reinterpret_cast<bf16*>(palloc((size_t)Beff * heads * dpv * obj_Tpad * sizeof(bf16))));
+                CK(attn_vt_ones_launch(cond_.obj_vt.back(), Beff * heads, t.d, obj_Tpad, 0));
+            } else {
+                cond_.objs.push_back(reinterpret_cast<bf16*>(palloc((size_t)Beff * Ng * t.C * sizeof(bf16))));
+            }
             cond_.ctx_k.push_back(reinterpret_cast<bf16*>(palloc((size_t)Beff * heads * ctx_Tpad * dp * sizeof(bf16))));
             cond_.ctx_vt.push_back(reinterpret_cast<bf16*>(palloc((size_t)Beff * heads * dpv * ctx_Tpad * sizeof(bf16))));
             CK(attn_vt_ones_launch(cond_.ctx_vt.back(), Beff * heads, t.d, ctx_Tpad, 0));
@@ -894,13 +943,15 @@ void Engine::set_cond(int Beff, const float* context, int n_ctx, const gl_ground
         cond_.Beff = Beff;
         cond_.Ng = Ng;
         cond_.ctx_Tpad = ctx_Tpad;
+        cond_.obj_Tpad = obj_Tpad;
     }
     cond_.ctx_T = n_ctx;
     arena_.reset();
 
     // ---- grounding tokens: objs = position_net(**grounding_input)  -> [Beff][Ng][out_dim]
     const int out_dim = c.gr_out_dim;
-    bf16* objs = arena_.get<bf16>((size_t)Beff * Ng * out_dim);
+    bf16* objs = arena_.get<bf16>((size_t)Beff * obj_stride * out_dim);
+    if (ca) HIPCK(hipMemsetAsync(objs, 0, (size_t)Beff * obj_stride * out_dim * sizeof(bf16), s));  // key-tile padding rows
     const int rows = Beff * g.n;
     auto mlp = [&](int which, const PosNetIn& pin_in, int remap_off) {
         PosNetIn pin = pin_in;
@@ -916,7 +967,7 @@ void Engine::set_cond(int Beff, const float* context, int n_ctx, const gl_ground
         Epilogue E;
         epilogue_defaults(E);
         E.out = objs; E.ldo = out_dim; E.bias = pn_[which][2].b;
-        E.remap_in = g.n; E.remap_out = Ng; E.remap_off = remap_off;
+        E.remap_in = g.n; E.remap_out = obj_stride; E.remap_off = remap_off;
         gemm(A, pn_[which][2].w, rows, out_dim, pn_[which][2].K, E, s);
     };
     PosNetIn pin{};
@@ -947,13 +998,30 @@ void Engine::set_cond(int Beff, const float* context, int n_ctx, const gl_ground
     for (const STW& t : st_) {
         int dp, dpv;
         CK(attn_dims(t.d, &dp, &dpv));
-        {
+        if (!ca) {
             AOperand A;
             aoperand_rows(A, objs, t.flin.K, t.flin.K);
             Epilogue E;
             epilogue_defaults(E);
             E.out = cond_.objs[t.idx]; E.ldo = t.C; E.bias = t.flin.b;
             gemm(A, t.flin.w, Beff * Ng, t.C, t.flin.K, E, s);
+        } else {  // gatedCA: fuser.attn.to_k / to_v of the grounding tokens, head layouts of the attention kernel
+            {
+                AOperand A;
+                aoperand_rows(A, objs, t.fca.ctx_dim, t.fca.ctx_dim);
+                Epilogue E;
+                epilogue_defaults(E);
+                E.mode = EPI_QK_HEADS;
+                E.q = cond_.obj_k[t.idx]; E.C = t.C; E.H = heads; E.d = t.d; E.DP = dp; E.T = obj_Tpad; E.Tpad_q = obj_Tpad;
+                gemm(A, t.fca.wk, Beff * obj_Tpad, t.C, t.fca.ctx_dim, E, s);
+            }
+            {
+                Epilogue E;
+                epilogue_defaults(E);
+                E.mode = EPI_VT_HEADS;
+                E.out = cond_.obj_vt[t.idx]; E.H = heads; E.d = t.d; E.DPV = dpv; E.T = obj_Tpad; E.Tpad_k = obj_Tpad;
+                CK(gemm_launch_t(t.fca.wv, t.C, objs, Beff * obj_Tpad, t.fca.ctx_dim, E, s));
+            }
         }
         {
             AOperand A;

@@ -59,7 +59,7 @@ class Engine:
     # ---- configuration / weights -------------------------------------------------
     def configure_unet(self, *, in_channels, out_channels, model_channels, num_res_blocks, num_heads, context_dim,
                        channel_mult: Sequence[int], attention_resolutions: Sequence[int], inpaint_mode=False,
-                       grounding_kind="text", gr_in_dim=768, gr_out_dim=768, max_persons=0) -> None:
+                       grounding_kind="text", gr_in_dim=768, gr_out_dim=768, max_persons=0, fuser_type="gatedSA") -> None:
         cfg = UNetConfig()
         cfg.in_channels, cfg.out_channels, cfg.model_channels = in_channels, out_channels, model_channels
         cfg.num_res_blocks, cfg.num_heads, cfg.context_dim = num_res_blocks, num_heads, context_dim
@@ -72,6 +72,7 @@ class Engine:
         cfg.inpaint_mode = int(bool(inpaint_mode))
         cfg.grounding_kind = GROUNDING_KINDS[grounding_kind]
         cfg.gr_in_dim, cfg.gr_out_dim, cfg.max_persons = gr_in_dim, gr_out_dim, max_persons
+        cfg.fuser_kind = {"gatedSA": 0, "gatedSA2": 1, "gatedCA": 2}[fuser_type or "gatedSA"]
         check(self.lib.gl_unet_configure(self._ctx, C.byref(cfg)))
         self.unet_cfg = dict(in_channels=in_channels, out_channels=out_channels, inpaint_mode=bool(inpaint_mode),
                              grounding_kind=grounding_kind, context_dim=context_dim)

@@ -47,7 +47,7 @@ def build_unet_engine(model, arena_gb: float = 12.0) -> Engine:
         channel_mult=list(model.channel_mult), attention_resolutions=list(model.attention_resolutions),
         inpaint_mode=model.inpaint_mode, grounding_kind=kind,
         gr_in_dim=getattr(pn, "in_dim", pn.out_dim), gr_out_dim=pn.out_dim,
-        max_persons=getattr(pn, "max_persons_per_image", 0))
+        max_persons=getattr(pn, "max_persons_per_image", 0), fuser_type=model.fuser_type)
     eng.upload("unet", model.state_dict())
     eng.finalize()
     return eng

@@ -87,8 +87,9 @@ class _GatedBase(_EngineOnly):
 
 
 class GatedCrossAttentionDense(_GatedBase):
-    """fuser_type 'gatedCA' (reference attention.py:190-212). Kept for type checks in
-    set_alpha_scale; not used by any shipped GLIGEN config and not implemented by the engine."""
+    """fuser_type 'gatedCA' (reference attention.py:190-212): x += s*tanh(a1)*CA(LN(x), objs, objs); x += s*tanh(a2)*FF(LN(x)).
+    No shipped GLIGEN config uses it; the engine runs it with the same kernels as attn2 (K / V of the grounding tokens
+    are projected once per prompt)."""
 
     def __init__(self, query_dim, key_dim, value_dim, n_heads, d_head):
         super().__init__()
@@ -118,8 +119,11 @@ class BasicTransformerBlock(_EngineOnly):
         self.use_checkpoint = use_checkpoint  # inert at inference, as in the reference
         if fuser_type == "gatedSA":
             self.fuser = GatedSelfAttentionDense(query_dim, key_dim, n_heads, d_head)
-        elif fuser_type in ("gatedSA2", "gatedCA"):
-            raise NotImplementedError(f"fuser_type {fuser_type!r}: only 'gatedSA' (all shipped GLIGEN configs) is implemented on MI355X")
+        elif fuser_type == "gatedCA":
+            self.fuser = GatedCrossAttentionDense(query_dim, key_dim, value_dim, n_heads, d_head)
+        elif fuser_type == "gatedSA2":
+            raise NotImplementedError("fuser_type 'gatedSA2' (spatial-map modalities: square grounding-token grids, bicubic "
+                                      "resize) is not implemented on MI355X; 'gatedSA' (all shipped configs) and 'gatedCA' are")
         else:
             raise AssertionError(fuser_type)
 

@@ -136,10 +136,23 @@ def gated_self_attention(sd: SD, p: str, x: torch.Tensor, objs: torch.Tensor, he
     return x
 
 
+def gated_cross_attention(sd: SD, p: str, x: torch.Tensor, objs: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    """GatedCrossAttentionDense.forward (fuser_type 'gatedCA') — attention.py:207-212."""
+    a = cross_attention(sd, p + ".attn", _ln(sd, p + ".norm1", x), objs, heads)
+    x = x + scale * torch.tanh(sd[p + ".alpha_attn"]) * a
+    x = x + scale * torch.tanh(sd[p + ".alpha_dense"]) * feed_forward(sd, p + ".ff", _ln(sd, p + ".norm2", x))
+    return x
+
+
 def transformer_block(sd: SD, p: str, x, ctx, objs, heads: int, scale: float) -> torch.Tensor:
-    """BasicTransformerBlock._forward — attention.py:333-338."""
+    """BasicTransformerBlock._forward — attention.py:333-338. The fuser variant is read off the state_dict: gatedSA has
+    fuser.linear (attention.py:219), gatedCA does not (attention.py:190-205); gatedSA2 shares gatedSA's keys and is
+    not covered."""
     x = self_attention(sd, p + ".attn1", _ln(sd, p + ".norm1", x), heads) + x
-    x = gated_self_attention(sd, p + ".fuser", x, objs, heads, scale)
+    if p + ".fuser.linear.weight" in sd:
+        x = gated_self_attention(sd, p + ".fuser", x, objs, heads, scale)
+    else:
+        x = gated_cross_attention(sd, p + ".fuser", x, objs, heads, scale)
     x = cross_attention(sd, p + ".attn2", _ln(sd, p + ".norm2", x), ctx, heads) + x
     x = feed_forward(sd, p + ".ff", _ln(sd, p + ".norm3", x)) + x
     return x

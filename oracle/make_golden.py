@@ -40,7 +40,7 @@ from ldm.models.autoencoder import AutoencoderKL  # noqa: E402  (reference)
 from ldm.models.diffusion.ldm import LatentDiffusion  # noqa: E402
 from ldm.models.diffusion.plms import PLMSSampler  # noqa: E402
 from ldm.models.diffusion.ddim import DDIMSampler  # noqa: E402
-from ldm.modules.attention import GatedSelfAttentionDense  # noqa: E402
+from ldm.modules.attention import GatedCrossAttentionDense, GatedSelfAttentionDense  # noqa: E402
 from ldm.modules.diffusionmodules.openaimodel import UNetModel  # noqa: E402
 from ldm.util import instantiate_from_config  # noqa: E402
 
@@ -70,7 +70,7 @@ ref_draw_masks = _extract_function(os.path.join(REF, "inpaint_mask_func.py"), "d
 
 def set_alpha_scale(model, alpha_scale):  # reference gligen_inference.py:24-28
     for module in model.modules():
-        if type(module) == GatedSelfAttentionDense:
+        if type(module) == GatedCrossAttentionDense or type(module) == GatedSelfAttentionDense:
             module.scale = alpha_scale
 
 
@@ -246,6 +246,7 @@ CASES = {
     "unet_small_text_image": lambda: unet_case("unet_small_text_image", syn.UNET_CFG_SMALL, "text_image", 2, 16),
     "unet_small_keypoint": lambda: unet_case("unet_small_keypoint", syn.UNET_CFG_SMALL, "keypoint", 2, 16),
     "unet_small_inpaint": lambda: unet_case("unet_small_inpaint", syn.UNET_CFG_SMALL, "text", 2, 16, inpaint=True),
+    "unet_small_gatedca": lambda: unet_case("unet_small_gatedca", dict(syn.UNET_CFG_SMALL, fuser_type="gatedCA"), "text", 2, 16),
     "unet_full_text": lambda: unet_case("unet_full_text", syn.UNET_CFG, "text", 1, 16),
     "vae_small": lambda: vae_case("vae_small", syn.VAE_DDCONFIG_SMALL, 2, 16),
     "vae_full": lambda: vae_case("vae_full", syn.VAE_DDCONFIG, 1, 8),

@@ -60,6 +60,19 @@ def test_unet_state_dict_contract(name, kind, inpaint):
     assert m.in_channels == 4 and m.image_size == 64 and m.first_conv_restorable == (not inpaint)
 
 
+def test_fuser_variants():
+    """gatedCA (attention.py:190-212) keeps the reference's keys; gatedSA2 (spatial-map modalities) is refused loudly."""
+    from ldm.modules.attention import GatedCrossAttentionDense
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    cfg = dict(syn.UNET_CFG_SMALL, grounding_tokenizer=syn.GROUNDING_TOKENIZERS["text"])
+    m = UNetModel(**dict(cfg, fuser_type="gatedCA"))
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == golden_shapes("unet_small_gatedca")
+    assert any(type(x) is GatedCrossAttentionDense for x in m.modules())
+    assert not any(k.endswith("fuser.linear.weight") for k in m.state_dict())
+    with pytest.raises(NotImplementedError, match="gatedSA2"):
+        UNetModel(**dict(cfg, fuser_type="gatedSA2"))
+
+
 def test_full_model_contracts_on_meta_device():
     from ldm.models.autoencoder import AutoencoderKL
     from ldm.modules.diffusionmodules.openaimodel import UNetModel

@@ -11,7 +11,7 @@ from oracle import gligen_oracle as orc
 FP32_TOL = 1e-9  # MSE between two fp32 evaluations of the same graph
 
 
-@pytest.mark.parametrize("name", ["unet_small_text", "unet_small_text_image", "unet_small_keypoint", "unet_small_inpaint"])
+@pytest.mark.parametrize("name", ["unet_small_text", "unet_small_text_image", "unet_small_keypoint", "unet_small_inpaint", "unet_small_gatedca"])
 def test_unet_small(name):
     g = load_golden(name)
     meta = g["meta"]

@@ -42,7 +42,7 @@ def _to(d, dev):
     return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items()}
 
 
-@pytest.mark.parametrize("name", ["unet_small_text", "unet_small_text_image", "unet_small_keypoint", "unet_small_inpaint"])
+@pytest.mark.parametrize("name", ["unet_small_text", "unet_small_text_image", "unet_small_keypoint", "unet_small_inpaint", "unet_small_gatedca"])
 def test_unet_small_vs_reference(name):
     dev = _dev()
     g = load_golden(name)
