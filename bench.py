@@ -107,7 +107,9 @@ def main():
     import gligen_inference as gi
     from gligen_amd import synthetic as syn
     from gligen_amd.build import build_native
-    build_native()
+    if local_rank == 0:
+        build_native()       # no-op when the in-tree library is newer than its sources; one rank per node may compile
+    gdist.barrier()
     gi.device = dev
     B = args.batch
     # random-init weights of the shipped architecture, generated on the device (fast), same statistics as the test fixture

@@ -38,11 +38,11 @@ __device__ __forceinline__ float max_xor32(float x) {
 // BIAS (DP > d, i.e. d = 40): the first padding column of the head dim carries the softmax stabiliser through the MFMA.
 // Q is scaled by scale*log2(e) when its fragments are loaded, Q[:, d] := -m (the running row max, kept bf16-exact) and
 // K[:, d] := 1 as the tile is written to LDS, so K Q^T comes out of the matrix core as s*c - m and the per-element
-// v_fma in front of every v_exp disappears (32 of ~137 VALU instructions per 64-key tile; the kernel is bound by VALU
+// v_fma in front of every v_exp disappears (32 of ~105 VALU instructions per 64-key tile; the kernel is bound by VALU
 // + MFMA issue, which barely overlap here). m only has to be close to the row max, not equal to it: it is moved (and O^T
 // rescaled) when a tile's scores exceed it by more than 2^6, which after the first tiles is rare.
 template <int DP, int DPV, bool ONES>
-__global__ void __launch_bounds__(256, DP == 48 ? 3 : 1) attn_kernel(AttnParams P) {  // d = 40: three workgroups per CU -> a 170-VGPR budget, which also makes hipcc pick the VGPR-destination MFMA form (no v_accvgpr_read per score)
+__global__ void __launch_bounds__(256, DP == 48 ? 3 : 1) attn_kernel(AttnParams P) {  // d = 40: the bound trims the kernel to 124 VGPRs = four waves per SIMD
     constexpr bool BIAS = DP == 48 && ONES;   // d = 40 (column 40 is free)
     constexpr int KS = DP / 16;
     constexpr int DT = DPV / 32;
