@@ -154,8 +154,7 @@ const RawTensor& Engine::raw(const std::string& key) const {
 void Engine::configure_unet(const gl_unet_config& c) {
     if (c.n_mult < 1 || c.n_mult > 8 || c.n_attn < 0 || c.n_attn > 8) throw GlError(GL_ERR_ARG, "bad unet config");
     if (c.model_channels % 64 != 0) throw GlError(GL_ERR_UNSUPPORTED, "model_channels must be a multiple of 64");
-    if (c.fuser_kind != 0 && c.fuser_kind != 2)
-        throw GlError(GL_ERR_UNSUPPORTED, "fuser_kind: 0 (gatedSA) and 2 (gatedCA) are implemented; gatedSA2 (spatial-map modalities) is not");
+    if (c.fuser_kind < 0 || c.fuser_kind > 2) throw GlError(GL_ERR_ARG, "fuser_kind: 0 gatedSA, 1 gatedSA2, 2 gatedCA");
     ucfg_ = c;
     has_unet_ = true;
 }
@@ -334,11 +333,11 @@ void Engine::build_unet() {
         t.a2.ctx_dim = (int)raw(tb + ".attn2.to_k.weight").shape[1];
         t.a2.out = linear(tb + ".attn2.to_out.0");
         t.ff = ffw(tb + ".ff", C);
-        if (has(tb + ".fuser.linear.weight") != (c.fuser_kind == 0))
+        if (has(tb + ".fuser.linear.weight") != (c.fuser_kind != 2))
             throw GlError(GL_ERR_ARG, "fuser weights do not match fuser_kind (gatedSA has fuser.linear, gatedCA does not)");
         t.fn1 = norm(tb + ".fuser.norm1");
         t.fn2 = norm(tb + ".fuser.norm2");
-        if (c.fuser_kind == 0) {
+        if (c.fuser_kind != 2) {  // gatedSA and gatedSA2 hold the same parameters
             t.flin = linear(tb + ".fuser.linear");
             t.fa.wqk = cast_rows({tb + ".fuser.attn.to_q.weight", tb + ".fuser.attn.to_k.weight"});
             t.fa.wv = cast_rows({tb + ".fuser.attn.to_v.weight"});
@@ -800,7 +799,30 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
 
     const int Ng = cond_.Ng;
     bf16* t2;
-    if (ucfg_.fuser_kind == 0) {
+    if (ucfg_.fuser_kind == 1) {
+        // fuser (gatedSA2, attention.py:271-297): the attention outputs AT the grounding tokens (an sg x sg grid) are
+        // projected, resized bicubically to the visual grid and added as the gated residual
+        int sg = 0;
+        while (sg * sg < Ng) ++sg;
+        if (sg * sg != Ng || H != W) throw GlError(GL_ERR_ARG, fmt("gatedSA2 needs square token grids (visual %dx%d, %d grounding tokens)", H, W, Ng));
+        const int Ta = HW + Ng;
+        const int Tf = round_up(Ta, 64);
+        bf16* lnc = arena_.get<bf16>((size_t)B * Tf * C);
+        {
+            LNParams P{};
+            P.x = t1; P.x2 = cond_.objs[t.idx]; P.B = B; P.N1 = HW; P.N2 = Ng; P.Tpad = Tf; P.C = C; P.eps = 1e-5f;
+            P.gamma = t.fn1.g; P.beta = t.fn1.b; P.y = lnc;
+            ProfScope ps(this, s, "ln_kernel", 0.0, 2.0 * B * Ta * (double)C * 2);
+            CK(layernorm_launch(P, s));
+            ++n_launches;
+        }
+        bf16* oa = arena_.get<bf16>((size_t)B * Ta * C);
+        self_attention(t.fa, lnc, B, Tf, Ta, Ta, C, d, oa, s);                 // every token is a query here
+        bf16* pr = linear_rows(oa, B * Ta, t.fa.out, ACT_NONE, nullptr, nullptr, s);  // [B][HW + Ng][C]
+        t2 = arena_.get<bf16>((size_t)M * C);
+        CK(fuser_resize_launch(pr, t1, gates_ + 2 * t.idx, t2, B, Ta, HW, sg, H, C, s));
+        ++n_launches;
+    } else if (ucfg_.fuser_kind == 0) {
         // fuser (gatedSA): x = x + scale*tanh(alpha_attn) * attn(norm1([x ; linear(objs)]))[:, :N]
         const int Tf = round_up(HW + Ng, 64);
         bf16* lnc = arena_.get<bf16>((size_t)B * Tf * C);

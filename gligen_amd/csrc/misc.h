@@ -74,6 +74,8 @@ struct PlmsParams {
 int plms_update_launch(const PlmsParams& p, hipStream_t stream);
 
 // img = (sqrt_ac x0 + sqrt_1mac noise) * mask + (1 - mask) * img   (reference plms.py:96-100)
+int fuser_resize_launch(const bf16* tok, const bf16* x, const float* gate, bf16* y, int B, int row_stride, int grid_off, int sg, int sv,
+                        int C, hipStream_t stream);
 int inpaint_blend_launch(float* img, const float* x0, const float* noise, const float* mask,
                          float sqrt_ac, float sqrt_1mac, int B, int C, int HW, hipStream_t stream);
 

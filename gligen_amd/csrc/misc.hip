@@ -283,6 +283,66 @@ int inpaint_blend_launch(float* img, const float* x0, const float* noise, const 
     return GL_OK;
 }
 
+// GatedSelfAttentionDense2 residual (reference attention.py:289-295): the projected attention outputs at the sg x sg
+// grid of grounding tokens, resized to the sv x sv visual grid by torch's bicubic (F.interpolate mode='bicubic',
+// align_corners=False: src = (dst + 0.5) * sg / sv - 0.5, cubic convolution with A = -0.75, taps clamped to the grid),
+// then y = x + gate * residual.  tok: [B][row_stride][C] with the grid at rows [grid_off, grid_off + sg*sg);  x, y: [B][sv*sv][C].
+__device__ __forceinline__ void cubic_taps(float t, float w[4]) {
+    const float A = -0.75f;
+    const float a = t + 1.f, b = 1.f - t, c = 2.f - t;
+    w[0] = ((A * a - 5.f * A) * a + 8.f * A) * a - 4.f * A;
+    w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+    w[2] = ((A + 2.f) * b - (A + 3.f)) * b * b + 1.f;
+    w[3] = ((A * c - 5.f * A) * c + 8.f * A) * c - 4.f * A;
+}
+__global__ void fuser_resize_kernel(const bf16* __restrict__ tok, const bf16* __restrict__ x, const float* __restrict__ gate,
+                                    bf16* __restrict__ y, int B, int row_stride, int grid_off, int sg, int sv, int C) {
+    const int C2 = C >> 1;
+    const int64_t total = (int64_t)B * sv * sv * C2;
+    const float g = *gate;
+    const float sc = (float)sg / (float)sv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C2) * 2;
+        const int64_t r = i / C2;
+        const int pix = (int)(r % (sv * sv));
+        const int b = (int)(r / (sv * sv));
+        const int oy = pix / sv, ox = pix - oy * sv;
+        const float fy = sc * (oy + 0.5f) - 0.5f, fx = sc * (ox + 0.5f) - 0.5f;
+        const float fly = floorf(fy), flx = floorf(fx);
+        float wy[4], wx[4];
+        cubic_taps(fy - fly, wy);
+        cubic_taps(fx - flx, wx);
+        const int iy = (int)fly, ix = (int)flx;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int yy = min(max(iy - 1 + p, 0), sg - 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int xx = min(max(ix - 1 + q, 0), sg - 1);
+                const uint32_t v = *reinterpret_cast<const uint32_t*>(tok + ((size_t)b * row_stride + grid_off + yy * sg + xx) * C + c);
+                const float w = wy[p] * wx[q];
+                a0 += w * __uint_as_float(v << 16);
+                a1 += w * __uint_as_float(v & 0xffff0000u);
+            }
+        }
+        const size_t o = ((size_t)b * sv * sv + pix) * C + c;
+        const uint32_t xv = *reinterpret_cast<const uint32_t*>(x + o);
+        union { uint32_t u; bf16 e[2]; } out;
+        out.e[0] = f2bf(__uint_as_float(xv << 16) + g * a0);
+        out.e[1] = f2bf(__uint_as_float(xv & 0xffff0000u) + g * a1);
+        *reinterpret_cast<uint32_t*>(y + o) = out.u;
+    }
+}
+int fuser_resize_launch(const bf16* tok, const bf16* x, const float* gate, bf16* y, int B, int row_stride, int grid_off, int sg, int sv,
+                        int C, hipStream_t stream) {
+    if (C & 1) return set_error(GL_ERR_ARG, "fuser_resize: odd channel count");
+    hipLaunchKernelGGL(fuser_resize_kernel, dim3(grid_for((int64_t)B * sv * sv * (C >> 1))), dim3(256), 0, stream, tok, x, gate, y, B,
+                       row_stride, grid_off, sg, sv, C);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
 __global__ void to_uint8_kernel(const float* __restrict__ s, uint8_t* __restrict__ d, int B, int C, int HW) {
     const int64_t total = (int64_t)B * HW * C;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {

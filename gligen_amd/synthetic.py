@@ -113,17 +113,18 @@ def make_embeddings(B: int, n_valid: int, max_objs: int = 30, dim: int = 768, se
     return e
 
 
-def make_batch(kind: str, B: int, n_valid: int = 8, seed: int = 0) -> Dict[str, torch.Tensor]:
+def make_batch(kind: str, B: int, n_valid: int = 8, seed: int = 0, max_objs: int = 30) -> Dict[str, torch.Tensor]:
     """A dataset-style batch dict (the input of GroundingNetInput.prepare)."""
     if kind == "keypoint":
         g = torch.Generator().manual_seed(3000 + seed)
         pts = torch.zeros(B, 8 * 17, 2)
         pts[:, : 2 * 17] = torch.rand(B, 2 * 17, 2, generator=g)
         return dict(points=pts, masks=(pts.mean(dim=2) != 0).float())
-    boxes, masks = make_boxes(B, n_valid, seed=seed)
-    batch = dict(boxes=boxes, masks=masks, text_embeddings=make_embeddings(B, n_valid, seed=seed))
+    boxes, masks = make_boxes(B, n_valid, max_objs=max_objs, seed=seed)
+    batch = dict(boxes=boxes, masks=masks, text_embeddings=make_embeddings(B, n_valid, max_objs=max_objs, seed=seed))
     if kind == "text_image":
-        batch.update(text_masks=masks.clone(), image_masks=masks.clone(), image_embeddings=make_embeddings(B, n_valid, seed=seed + 7))
+        batch.update(text_masks=masks.clone(), image_masks=masks.clone(),
+                     image_embeddings=make_embeddings(B, n_valid, max_objs=max_objs, seed=seed + 7))
     return batch
 
 

@@ -41,8 +41,8 @@ typedef struct gl_unet_config {
     int gr_in_dim;        /* PositionNet in_dim (768) */
     int gr_out_dim;       /* PositionNet out_dim (768) */
     int max_persons;      /* keypoint only */
-    int fuser_kind;       /* BasicTransformerBlock fuser (attention.py:312-322): 0 gatedSA (every shipped config),
-                             2 gatedCA; 1 = gatedSA2 (spatial-map modalities) is rejected by gl_unet_configure */
+    int fuser_kind;       /* BasicTransformerBlock fuser (attention.py:312-322): 0 gatedSA (every shipped discrete-token
+                             config), 1 gatedSA2 (square grounding-token grid, bicubic resize), 2 gatedCA */
 } gl_unet_config;
 
 /* AutoencoderKL ddconfig (reference ldm/modules/diffusionmodules/model.py:462-533). */

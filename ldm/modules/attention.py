@@ -107,6 +107,19 @@ class GatedSelfAttentionDense(_GatedBase):
         self._gates(query_dim)
 
 
+class GatedSelfAttentionDense2(_GatedBase):
+    """fuser_type 'gatedSA2' (reference attention.py:251-297; the spatial-map modalities): same parameters as
+    GatedSelfAttentionDense, but the residual is the attention output AT the grounding tokens (a square grid), resized
+    bicubically to the visual grid. NB the reference's set_alpha_scale never touches this class (exact-type match on the
+    other two, gligen_inference.py:24-28), so `scale` stays 1 unless set by hand."""
+
+    def __init__(self, query_dim, context_dim, n_heads, d_head):
+        super().__init__()
+        self.linear = nn.Linear(context_dim, query_dim)
+        self.attn = SelfAttention(query_dim=query_dim, heads=n_heads, dim_head=d_head)
+        self._gates(query_dim)
+
+
 class BasicTransformerBlock(_EngineOnly):
     def __init__(self, query_dim, key_dim, value_dim, n_heads, d_head, fuser_type, use_checkpoint=True):
         super().__init__()
@@ -122,8 +135,7 @@ class BasicTransformerBlock(_EngineOnly):
         elif fuser_type == "gatedCA":
             self.fuser = GatedCrossAttentionDense(query_dim, key_dim, value_dim, n_heads, d_head)
         elif fuser_type == "gatedSA2":
-            raise NotImplementedError("fuser_type 'gatedSA2' (spatial-map modalities: square grounding-token grids, bicubic "
-                                      "resize) is not implemented on MI355X; 'gatedSA' (all shipped configs) and 'gatedCA' are")
+            self.fuser = GatedSelfAttentionDense2(query_dim, key_dim, n_heads, d_head)
         else:
             raise AssertionError(fuser_type)
 

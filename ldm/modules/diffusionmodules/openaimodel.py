@@ -157,8 +157,9 @@ class UNetModel(nn.Module):
         return self._engine
 
     def fuser_scale(self):
-        from ldm.modules.attention import GatedCrossAttentionDense, GatedSelfAttentionDense
-        scales = {float(m.scale) for m in self.modules() if type(m) in (GatedSelfAttentionDense, GatedCrossAttentionDense)}
+        from ldm.modules.attention import GatedCrossAttentionDense, GatedSelfAttentionDense, GatedSelfAttentionDense2
+        kinds = (GatedSelfAttentionDense, GatedSelfAttentionDense2, GatedCrossAttentionDense)
+        scales = {float(m.scale) for m in self.modules() if type(m) in kinds}
         if len(scales) != 1:
             raise NotImplementedError(f"per-layer fuser scales {sorted(scales)}: the engine applies one scale to all fusers")
         return scales.pop()

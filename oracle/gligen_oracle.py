@@ -136,6 +136,23 @@ def gated_self_attention(sd: SD, p: str, x: torch.Tensor, objs: torch.Tensor, he
     return x
 
 
+def gated_self_attention2(sd: SD, p: str, x: torch.Tensor, objs: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    """GatedSelfAttentionDense2.forward (fuser_type 'gatedSA2') — attention.py:271-297: the attention outputs AT the
+    grounding tokens (a size_g x size_g grid) are resized bicubically to the visual grid and added as the residual."""
+    B, n, _ = x.shape
+    ng = objs.shape[1]
+    sv, sg = int(round(n ** 0.5)), int(round(ng ** 0.5))
+    assert sv * sv == n and sg * sg == ng, "visual / grounding tokens must be square rootable (attention.py:279-283)"
+    o = _lin(sd, p + ".linear", objs)
+    out = self_attention(sd, p + ".attn", _ln(sd, p + ".norm1", torch.cat([x, o], dim=1)), heads)[:, n:]
+    out = out.permute(0, 2, 1).reshape(B, -1, sg, sg)
+    out = F.interpolate(out, (sv, sv), mode="bicubic")
+    residual = out.reshape(B, -1, n).permute(0, 2, 1)
+    x = x + scale * torch.tanh(sd[p + ".alpha_attn"]) * residual
+    x = x + scale * torch.tanh(sd[p + ".alpha_dense"]) * feed_forward(sd, p + ".ff", _ln(sd, p + ".norm2", x))
+    return x
+
+
 def gated_cross_attention(sd: SD, p: str, x: torch.Tensor, objs: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
     """GatedCrossAttentionDense.forward (fuser_type 'gatedCA') — attention.py:207-212."""
     a = cross_attention(sd, p + ".attn", _ln(sd, p + ".norm1", x), objs, heads)
@@ -144,12 +161,13 @@ def gated_cross_attention(sd: SD, p: str, x: torch.Tensor, objs: torch.Tensor, h
     return x
 
 
-def transformer_block(sd: SD, p: str, x, ctx, objs, heads: int, scale: float) -> torch.Tensor:
+def transformer_block(sd: SD, p: str, x, ctx, objs, heads: int, scale: float, fuser_type: Optional[str] = None) -> torch.Tensor:
     """BasicTransformerBlock._forward — attention.py:333-338. The fuser variant is read off the state_dict: gatedSA has
-    fuser.linear (attention.py:219), gatedCA does not (attention.py:190-205); gatedSA2 shares gatedSA's keys and is
-    not covered."""
+    fuser.linear (attention.py:219), gatedCA does not (attention.py:190-205); gatedSA2 shares gatedSA's keys and is selected by `fuser_type`."""
     x = self_attention(sd, p + ".attn1", _ln(sd, p + ".norm1", x), heads) + x
-    if p + ".fuser.linear.weight" in sd:
+    if fuser_type == "gatedSA2":
+        x = gated_self_attention2(sd, p + ".fuser", x, objs, heads, scale)
+    elif p + ".fuser.linear.weight" in sd:
         x = gated_self_attention(sd, p + ".fuser", x, objs, heads, scale)
     else:
         x = gated_cross_attention(sd, p + ".fuser", x, objs, heads, scale)
@@ -158,13 +176,13 @@ def transformer_block(sd: SD, p: str, x, ctx, objs, heads: int, scale: float) ->
     return x
 
 
-def spatial_transformer(sd: SD, p: str, x, ctx, objs, heads: int, scale: float) -> torch.Tensor:
+def spatial_transformer(sd: SD, p: str, x, ctx, objs, heads: int, scale: float, fuser_type: Optional[str] = None) -> torch.Tensor:
     """SpatialTransformer.forward (GroupNorm eps 1e-6, 1x1 in/out projections) — attention.py:366-376."""
     B, C, H, W = x.shape
     h = _gn(sd, p + ".norm", x, 1e-6)
     h = F.conv2d(h, sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"])
     h = h.flatten(2).transpose(1, 2)
-    h = transformer_block(sd, p + ".transformer_blocks.0", h, ctx, objs, heads, scale)
+    h = transformer_block(sd, p + ".transformer_blocks.0", h, ctx, objs, heads, scale, fuser_type)
     h = h.transpose(1, 2).reshape(B, C, H, W)
     h = F.conv2d(h, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"])
     return h + x
@@ -208,7 +226,7 @@ def unet_forward(sd: SD, cfg: Mapping, inp: Mapping, fuser_scale: float = 1.0) -
         for _ in range(cfg["num_res_blocks"]):
             h = unet_resblock(sd, f"input_blocks.{n}.0", h, emb)
             if attn_here(ds):
-                h = spatial_transformer(sd, f"input_blocks.{n}.1", h, ctx, objs, heads, fuser_scale)
+                h = spatial_transformer(sd, f"input_blocks.{n}.1", h, ctx, objs, heads, fuser_scale, cfg.get("fuser_type"))
             hs.append(h)
             n += 1
         if level != len(mults) - 1:
@@ -217,7 +235,7 @@ def unet_forward(sd: SD, cfg: Mapping, inp: Mapping, fuser_scale: float = 1.0) -
             n += 1
             ds *= 2
     h = unet_resblock(sd, "middle_block.0", h, emb)
-    h = spatial_transformer(sd, "middle_block.1", h, ctx, objs, heads, fuser_scale)
+    h = spatial_transformer(sd, "middle_block.1", h, ctx, objs, heads, fuser_scale, cfg.get("fuser_type"))
     h = unet_resblock(sd, "middle_block.2", h, emb)
     n = 0
     for level in reversed(range(len(mults))):
@@ -226,7 +244,7 @@ def unet_forward(sd: SD, cfg: Mapping, inp: Mapping, fuser_scale: float = 1.0) -
             h = unet_resblock(sd, f"output_blocks.{n}.0", h, emb)
             j = 1
             if attn_here(ds):
-                h = spatial_transformer(sd, f"output_blocks.{n}.1", h, ctx, objs, heads, fuser_scale)
+                h = spatial_transformer(sd, f"output_blocks.{n}.1", h, ctx, objs, heads, fuser_scale, cfg.get("fuser_type"))
                 j = 2
             if level and i == cfg["num_res_blocks"]:
                 h = F.interpolate(h, scale_factor=2, mode="nearest")

@@ -82,10 +82,10 @@ def build_unet(cfg, kind, inpaint=False, seed=1234):
     return model
 
 
-def unet_case(name, cfg, kind, B, hw, inpaint=False, n_valid=3):
+def unet_case(name, cfg, kind, B, hw, inpaint=False, n_valid=3, max_objs=30):
     t0 = time.time()
     model = build_unet(cfg, kind, inpaint)
-    batch = syn.make_batch(kind, B, n_valid=n_valid, seed=1)
+    batch = syn.make_batch(kind, B, n_valid=n_valid, seed=1, max_objs=max_objs)
     g = model.grounding_tokenizer_input.prepare(batch)
     x = syn.make_latent(B, 4, hw, hw, seed=1)
     ctx = syn.make_context(B, seed=1)
@@ -105,7 +105,7 @@ def unet_case(name, cfg, kind, B, hw, inpaint=False, n_valid=3):
         out["eps_scale03"] = model(inp).numpy()
         set_alpha_scale(model, 1)
         out["objs"] = model.position_net(**g).numpy()
-    meta = dict(cfg=cfg, kind=kind, B=B, hw=hw, inpaint=inpaint, n_valid=n_valid, weight_seed=1234,
+    meta = dict(cfg=cfg, kind=kind, B=B, hw=hw, inpaint=inpaint, n_valid=n_valid, max_objs=max_objs, weight_seed=1234,
                 n_keys=len(model.state_dict()), n_params=int(sum(p.numel() for p in model.parameters())))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), meta=json.dumps(meta), **out)
     shapes = {k: list(v.shape) for k, v in model.state_dict().items()}
@@ -247,6 +247,9 @@ CASES = {
     "unet_small_keypoint": lambda: unet_case("unet_small_keypoint", syn.UNET_CFG_SMALL, "keypoint", 2, 16),
     "unet_small_inpaint": lambda: unet_case("unet_small_inpaint", syn.UNET_CFG_SMALL, "text", 2, 16, inpaint=True),
     "unet_small_gatedca": lambda: unet_case("unet_small_gatedca", dict(syn.UNET_CFG_SMALL, fuser_type="gatedCA"), "text", 2, 16),
+    # gatedSA2 needs a square grid of grounding tokens (attention.py:279-283): 16 box slots = 4 x 4
+    "unet_small_gatedsa2": lambda: unet_case("unet_small_gatedsa2", dict(syn.UNET_CFG_SMALL, fuser_type="gatedSA2"), "text", 2, 16,
+                                             max_objs=16),
     "unet_full_text": lambda: unet_case("unet_full_text", syn.UNET_CFG, "text", 1, 16),
     "vae_small": lambda: vae_case("vae_small", syn.VAE_DDCONFIG_SMALL, 2, 16),
     "vae_full": lambda: vae_case("vae_full", syn.VAE_DDCONFIG, 1, 8),

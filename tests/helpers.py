@@ -34,13 +34,14 @@ def golden_shapes(name):
 
 def oracle_cfg(cfg, kind):
     return dict(model_channels=cfg["model_channels"], channel_mult=cfg["channel_mult"], num_res_blocks=cfg["num_res_blocks"],
-                attention_resolutions=cfg["attention_resolutions"], num_heads=cfg["num_heads"], grounding_kind=kind)
+                attention_resolutions=cfg["attention_resolutions"], num_heads=cfg["num_heads"], grounding_kind=kind,
+                fuser_type=cfg.get("fuser_type", "gatedSA"))
 
 
 def unet_inputs(meta):
     """The exact inputs oracle/make_golden.py:unet_case fed to the reference."""
     B, hw, kind = meta["B"], meta["hw"], meta["kind"]
-    batch = syn.make_batch(kind, B, n_valid=meta["n_valid"], seed=1)
+    batch = syn.make_batch(kind, B, n_valid=meta["n_valid"], seed=1, max_objs=meta.get("max_objs", 30))
     x = syn.make_latent(B, 4, hw, hw, seed=1)
     ctx = syn.make_context(B, seed=1)
     t = torch.tensor([981, 441][:B] if B <= 2 else [981] * B, dtype=torch.long)

@@ -61,7 +61,7 @@ def test_unet_state_dict_contract(name, kind, inpaint):
 
 
 def test_fuser_variants():
-    """gatedCA (attention.py:190-212) keeps the reference's keys; gatedSA2 (spatial-map modalities) is refused loudly."""
+    """gatedCA (attention.py:190-212) and gatedSA2 (attention.py:251-297) keep the reference's keys and scale semantics."""
     from ldm.modules.attention import GatedCrossAttentionDense
     from ldm.modules.diffusionmodules.openaimodel import UNetModel
     cfg = dict(syn.UNET_CFG_SMALL, grounding_tokenizer=syn.GROUNDING_TOKENIZERS["text"])
@@ -69,8 +69,14 @@ def test_fuser_variants():
     assert {k: list(v.shape) for k, v in m.state_dict().items()} == golden_shapes("unet_small_gatedca")
     assert any(type(x) is GatedCrossAttentionDense for x in m.modules())
     assert not any(k.endswith("fuser.linear.weight") for k in m.state_dict())
-    with pytest.raises(NotImplementedError, match="gatedSA2"):
-        UNetModel(**dict(cfg, fuser_type="gatedSA2"))
+    m2 = UNetModel(**dict(cfg, fuser_type="gatedSA2"))
+    assert {k: list(v.shape) for k, v in m2.state_dict().items()} == golden_shapes("unet_small_gatedsa2")
+    # the reference's set_alpha_scale matches the other two classes by exact type and leaves GatedSelfAttentionDense2 alone
+    from gligen_inference import set_alpha_scale
+    set_alpha_scale(m2, 0.3)
+    assert m2.fuser_scale() == 1.0
+    set_alpha_scale(m, 0.3)
+    assert m.fuser_scale() == 0.3
 
 
 def test_full_model_contracts_on_meta_device():

@@ -11,7 +11,8 @@ from oracle import gligen_oracle as orc
 FP32_TOL = 1e-9  # MSE between two fp32 evaluations of the same graph
 
 
-@pytest.mark.parametrize("name", ["unet_small_text", "unet_small_text_image", "unet_small_keypoint", "unet_small_inpaint", "unet_small_gatedca"])
+@pytest.mark.parametrize("name", ["unet_small_text", "unet_small_text_image", "unet_small_keypoint", "unet_small_inpaint", "unet_small_gatedca",
+                                  "unet_small_gatedsa2"])
 def test_unet_small(name):
     g = load_golden(name)
     meta = g["meta"]
@@ -25,9 +26,15 @@ def test_unet_small(name):
         assert mse(orc.unet_forward(sd, cfg, inp), g["eps"]) < FP32_TOL
         inp_null = dict(inp, grounding_input=orc.null_grounding(meta["kind"], gk))
         assert mse(orc.unet_forward(sd, cfg, inp_null), g["eps_null"]) < FP32_TOL
-        assert mse(orc.unet_forward(sd, cfg, inp, fuser_scale=0.3), g["eps_scale03"]) < FP32_TOL
+        # the reference's set_alpha_scale matches GatedSelfAttentionDense / GatedCrossAttentionDense by exact type
+        # (gligen_inference.py:24-28) and therefore never reaches a GatedSelfAttentionDense2: its scale stays 1
+        sa2 = cfg["fuser_type"] == "gatedSA2"
+        assert mse(orc.unet_forward(sd, cfg, inp, fuser_scale=1.0 if sa2 else 0.3), g["eps_scale03"]) < FP32_TOL
     # the fixture is not vacuous: grounding and the gate scale change eps measurably
-    assert mse(g["eps"], g["eps_scale03"]) > 1e-4
+    if sa2:
+        assert np.array_equal(g["eps"], g["eps_scale03"]) and mse(g["eps"], g["eps_null"]) > 1e-4
+    else:
+        assert mse(g["eps"], g["eps_scale03"]) > 1e-4
     assert g["eps"].std() > 0.1
 
 

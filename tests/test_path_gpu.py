@@ -42,7 +42,8 @@ def _to(d, dev):
     return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items()}
 
 
-@pytest.mark.parametrize("name", ["unet_small_text", "unet_small_text_image", "unet_small_keypoint", "unet_small_inpaint", "unet_small_gatedca"])
+@pytest.mark.parametrize("name", ["unet_small_text", "unet_small_text_image", "unet_small_keypoint", "unet_small_inpaint", "unet_small_gatedca",
+                                  "unet_small_gatedsa2"])
 def test_unet_small_vs_reference(name):
     dev = _dev()
     g = load_golden(name)
@@ -62,13 +63,22 @@ def test_unet_small_vs_reference(name):
     r = dict(eps=mse(eps, g["eps"]), eps_null=mse(eps_null, g["eps_null"]), eps_scale03=mse(eps_s, g["eps_scale03"]),
              eps_var=float(g["eps"].var()))
     # the grounding / gate effects themselves must be reproduced, not just the bulk of eps
-    d_ref = torch.from_numpy(g["eps"] - g["eps_scale03"])
-    d_hip = (eps - eps_s).float().cpu()
+    if meta["cfg"].get("fuser_type") == "gatedSA2":
+        # reference quirk: set_alpha_scale never reaches GatedSelfAttentionDense2 (exact-type match, gligen_inference.py:24-28);
+        # the grounding effect is checked instead
+        assert torch.equal(eps_s, eps) and np.array_equal(g["eps"], g["eps_scale03"])
+        d_ref = torch.from_numpy(g["eps"] - g["eps_null"])
+        d_hip = (eps - eps_null).float().cpu()
+    else:
+        d_ref = torch.from_numpy(g["eps"] - g["eps_scale03"])
+        d_hip = (eps - eps_s).float().cpu()
     r["gate_effect_rel_err"] = float(((d_hip - d_ref) ** 2).mean() / (d_ref ** 2).mean())
     REPORT[name] = r
     assert eps.shape == tuple(g["eps"].shape) and eps.dtype == torch.float32 and eps.device.type == "cuda"
     assert r["eps"] < EPS_MSE_TOL and r["eps_null"] < EPS_MSE_TOL and r["eps_scale03"] < EPS_MSE_TOL, r
-    assert r["gate_effect_rel_err"] < 0.05, r
+    # (gatedSA2: the effect checked is eps - eps_null, an order of magnitude smaller than the gate-scale effect of the
+    #  other fixtures, so bf16 noise weighs more against it)
+    assert r["gate_effect_rel_err"] < (0.15 if meta["cfg"].get("fuser_type") == "gatedSA2" else 0.05), r
     # determinism: same inputs -> bit-identical eps
     assert torch.equal(model(inp), eps)
 
