@@ -59,3 +59,35 @@ def test_gemm_kernels_do_not_spill(gemm_asm):
         assert int(m.group(1)) == 0
     for m in re.finditer(r"\.private_segment_fixed_size:\s*(\d+)", gemm_asm):
         assert int(m.group(1)) == 0
+
+
+@pytest.fixture(scope="module")
+def attn_asm(tmp_path_factory):
+    from gligen_amd.build import EXTRA_FLAGS
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = tmp_path_factory.mktemp("isa") / "attention.s"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", *EXTRA_FLAGS.get("attention.hip", []), "-I", str(ROOT / "include"),
+           "--offload-device-only", "-S", str(ROOT / "gligen_amd" / "csrc" / "attention.hip"), "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return out.read_text()
+
+
+def test_attention_d40_loop_is_lean(attn_asm):
+    """The d = 40 attention kernel is bound by VALU + MFMA issue (they barely overlap on gfx950), so its 64-key loop must
+    stay free of per-score work that the design removed: no v_fma in front of the exps (the stabiliser rides through the
+    MFMA), no AGPR traffic (VGPR-destination MFMAs), no LDS bpermute for the row max, and <= 128 VGPRs (four waves per SIMD)."""
+    name = re.search(r"^(_ZN2gl11attn_kernelILi48ELi64ELb1EE[^:\s]*):", attn_asm, re.M).group(1)
+    a = attn_asm.index(name + ":")
+    body = attn_asm[a:attn_asm.index(".Lfunc_end", a)]
+    meta = attn_asm[attn_asm.index(".name:           " + name):]
+    assert int(re.search(r"\.vgpr_count:\s*(\d+)", meta).group(1)) <= 128
+    assert int(re.search(r"\.vgpr_spill_count:\s*(\d+)", meta).group(1)) == 0
+    ops = [l.split()[0] for l in body.split("\n") if l.strip() and not l.strip().startswith((";", "."))]
+    count = lambda op: sum(1 for o in ops if o.startswith(op))
+    assert count("v_accvgpr") == 0
+    assert count("ds_bpermute") <= 1 and count("v_permlane32_swap") >= 1   # one shuffle is left after the loop (denominator row)
+    # peeled first tile + loop: 64 exps and 28 MFMAs, and only the handful of fmas of the rare paths
+    assert count("v_mfma_f32_32x32x16_bf16") == 28
+    assert 64 <= count("v_exp_f32") <= 70
+    assert count("v_fma_f32") <= 8
