@@ -201,3 +201,37 @@ def test_vae_encode(name):
         z = orc.vae_encode(sd, dict(ch_mult=dd["ch_mult"], num_res_blocks=dd["num_res_blocks"], scale_factor=0.18215), x,
                            torch.from_numpy(g["noise"]))
     assert mse(z, g["z"]) / float(g["z"].var()) < 1e-9
+
+
+def test_bicubic_taps_of_the_resize_kernel():
+    """The arithmetic of misc.hip:fuser_resize_kernel (source index, cubic-convolution taps with A = -0.75, clamped taps),
+    restated in numpy, against torch's F.interpolate(mode='bicubic') which the reference calls (attention.py:291)."""
+    import torch.nn.functional as F
+
+    def taps(t, A=-0.75):
+        a, b, c = t + 1.0, 1.0 - t, 2.0 - t
+        return [((A * a - 5 * A) * a + 8 * A) * a - 4 * A, ((A + 2) * t - (A + 3)) * t * t + 1,
+                ((A + 2) * b - (A + 3)) * b * b + 1, ((A * c - 5 * A) * c + 8 * A) * c - 4 * A]
+
+    def resize(inp, so):
+        si = inp.shape[-1]
+        out = np.zeros(inp.shape[:2] + (so, so), np.float32)
+        sc = si / so
+        for y in range(so):
+            fy = sc * (y + 0.5) - 0.5
+            iy = int(np.floor(fy))
+            wy = taps(fy - iy)
+            for x in range(so):
+                fx = sc * (x + 0.5) - 0.5
+                ix = int(np.floor(fx))
+                wx = taps(fx - ix)
+                for p in range(4):
+                    yy = min(max(iy - 1 + p, 0), si - 1)
+                    for q in range(4):
+                        xx = min(max(ix - 1 + q, 0), si - 1)
+                        out[:, :, y, x] += wy[p] * wx[q] * inp[:, :, yy, xx]
+        return out
+
+    x = torch.randn(2, 3, 4, 4, generator=torch.Generator().manual_seed(0))
+    for so in (2, 4, 8, 16, 64):
+        assert np.abs(F.interpolate(x, (so, so), mode="bicubic").numpy() - resize(x.numpy(), so)).max() < 2e-6
