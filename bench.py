@@ -1,19 +1,27 @@
 """Benchmark of the GLIGEN denoising hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4|C5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one batch: B=4 box+text prompts (8 boxes each) at
-512x512, 50 PLMS steps with classifier-free guidance 7.5 (102 UNet forwards per sample, run as 51
-[cond ; uncond]-batched evaluations) + AutoencoderKL.decode -> B images (config C2 of BASELINE.json).
-Inputs (x_T, CLIP-shaped context, grounding features, seeded random weights of the SD-1.4 GLIGEN
-architecture) are resident in HBM before the timed region. N > 1: every rank runs the same batch
-size on its own GPU (weak scaling, no data-path collective); value = all images / max-over-ranks time.
+One "step" = one pass of the hot path over one batch of B = 4 prompts per GPU at 512x512: 50 PLMS steps with
+classifier-free guidance 7.5 (102 UNet forwards per sample, run as 51 [cond ; uncond]-batched evaluations) +
+AutoencoderKL.decode -> B images. --config picks the BASELINE.json configuration (default C2, the one the metric is quoted on):
+    C2  box+text, 8 boxes (30 grounding tokens)
+    C3  box+text+image grounding (2 x 30 tokens; BASELINE: batch 32 over 8 GPUs = 4 per GPU)
+    C4  inpainting box+text: AutoencoderKL.encode of the input image + 9-channel first conv + per-step q_sample blend,
+        all inside the timed region
+    C5  keypoint grounding (136 tokens; BASELINE: batch 16 over 4 GPUs = 4 per GPU)
+Inputs (x_T, CLIP-shaped context, grounding features, seeded random weights of the SD-1.4 GLIGEN architecture) are
+resident in HBM before the timed region. N > 1: every rank runs the same batch size on its own GPU (weak scaling, no
+data-path collective); value = all images / max-over-ranks time.
 """
 import argparse
+import glob
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -22,37 +30,67 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-F_UNET = 1136.88e9     # algorithmic FLOPs per UNetModel.forward per sample, 64x64 latent, Ng = 30
-F_VAE_DEC = 2514.52e9  # AutoencoderKL.decode 64x64 -> 512x512 per sample
-F_IMG = 102 * F_UNET + F_VAE_DEC
-PEAK_BF16 = 2500e12    # dense bf16 MFMA peak, MI355X_MICROARCH.md
+# algorithmic FLOPs (2 per MAC over conv / linear / attention products, reference-faithful op list)
+F_UNET = {30: 1136.88e9, 60: 1143.40e9, 136: 1160.32e9}   # per UNetModel.forward per sample at a 64x64 latent, by grounding tokens
+F_VAE_DEC = 2514.52e9   # AutoencoderKL.decode 64x64 -> 512x512 per sample
+F_VAE_ENC = 1116.66e9   # AutoencoderKL.encode 512x512 -> 64x64 per sample (C4)
+F_CONV9 = 12e9 / 102    # the 5 extra first-conv input channels of the inpainting model, per forward
+PEAK_BF16 = 2500e12     # dense bf16 MFMA peak, MI355X_MICROARCH.md
+
+CONFIGS = {
+    "C2": dict(kind="text", inpaint=False, ng=30, desc="C2: box+text, 8 boxes (30 grounding tokens)"),
+    "C3": dict(kind="text_image", inpaint=False, ng=60, desc="C3: box+text+image grounding, 8 boxes (2 x 30 grounding tokens)"),
+    "C4": dict(kind="text", inpaint=True, ng=30, desc="C4: inpainting box+text (encode of the input image + 9-channel first conv + per-step blend in the timed region)"),
+    "C5": dict(kind="keypoint", inpaint=False, ng=136, desc="C5: keypoint grounding, 2 persons (136 grounding tokens)"),
+}
 
 
-def cpu_baseline():
-    """The CPU oracle (port of the reference algorithm) on the host cores: one UNet forward and one decode at the
-    benchmark's size, extrapolated to 102 forwards + 1 decode per image (a full image is ~15 CPU-minutes)."""
+def flops_per_image(cfg, plms_steps=50):
+    f = 2 * (plms_steps + 1) * F_UNET[cfg["ng"]] + F_VAE_DEC
+    if cfg["inpaint"]:
+        f += F_VAE_ENC + 2 * (plms_steps + 1) * F_CONV9
+    return f
+
+
+def cpu_baseline(cfg):
+    """The reference's CPU path on the host cores, next to the GPU number: 1 warm-up + 3 timed UNetModel.forward (B=1, 64x64
+    latent) + 1 AutoencoderKL.decode, extrapolated to 102 forwards + 1 decode per image (a full image is ~15 CPU-minutes).
+    kind "reference": the reference's own modules (oracle/ref_cpu_baseline.py imports them from /root/reference in a
+    subprocess; only where that tree is mounted). kind "port": the CPU oracle, oracle/gligen_oracle.py (the GPU box)."""
+    script = os.path.join(ROOT, "oracle", "ref_cpu_baseline.py")
+    if os.path.isdir("/root/reference/ldm"):
+        try:
+            r = subprocess.run([sys.executable, script, "--kind", cfg["kind"]], capture_output=True, text=True, timeout=900, cwd="/tmp")
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode == 0 and line:
+                return json.loads(line[-1])
+        except Exception:
+            pass
     from gligen_amd import synthetic as syn
     from oracle import gligen_oracle as orc
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import grounding_kwargs, oracle_cfg
     shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_shapes.json")))
     torch.manual_seed(0)
+    kind = "text"   # the three tokenizers differ by < 2 % of a forward; the committed shape table is the box+text model's
     sd = {k: torch.randn(s) * 0.02 if len(s) else torch.tensor(0.5) for k, s in shapes["unet_full_text"].items()}
-    batch = syn.make_batch("text", 1, n_valid=8)
+    batch = syn.make_batch(kind, 1, n_valid=8)
     inp = dict(x=syn.make_latent(1, 4, 64, 64), timesteps=torch.tensor([501]), context=syn.make_context(1),
-               grounding_input=grounding_kwargs("text", batch))
-    cfg = oracle_cfg(syn.UNET_CFG, "text")
+               grounding_input=grounding_kwargs(kind, batch))
+    ocfg = oracle_cfg(syn.UNET_CFG, kind)
+    ts = []
     with torch.no_grad():
-        t0 = time.perf_counter(); orc.unet_forward(sd, cfg, inp); t_unet = time.perf_counter() - t0
-        t0 = time.perf_counter(); orc.unet_forward(sd, cfg, inp); t_unet = min(t_unet, time.perf_counter() - t0)
+        for i in range(4):   # 1 warm-up + 3
+            t0 = time.perf_counter(); orc.unet_forward(sd, ocfg, inp); ts.append(time.perf_counter() - t0)
+        t_unet = float(np.mean(ts[1:]))
         vsd = {k: torch.randn(s) * 0.02 for k, s in shapes["vae_full"].items()}
         d = syn.VAE_DDCONFIG
         t0 = time.perf_counter()
         orc.vae_decode(vsd, dict(ch_mult=d["ch_mult"], num_res_blocks=d["num_res_blocks"], scale_factor=0.18215), syn.make_latent(1, 4, 64, 64))
         t_dec = time.perf_counter() - t0
     return {"value": 1.0 / (102 * t_unet + t_dec), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/gligen_oracle.py fp32 torch-CPU: 2x unet_forward (B=1, 64x64 latent, Ng=30; best {t_unet:.2f} s) + 1x vae_decode "
-                      f"({t_dec:.2f} s), extrapolated to 102 forwards + 1 decode per 512x512 image",
+            "sample": f"oracle/gligen_oracle.py fp32 torch-CPU: 1 warm-up + 3 timed unet_forward (B=1, 64x64 latent, Ng=30; mean {t_unet:.2f} s) "
+                      f"+ 1x vae_decode ({t_dec:.2f} s), extrapolated to 102 forwards + 1 decode per 512x512 image",
             "host_cpus": os.cpu_count()}
 
 
@@ -61,8 +99,8 @@ def pmc_traffic(kernel):
     (tools/gpu_traffic.sh -> profiles/<round>/pmc_traffic.csv; counters cannot be collected from inside a timed run).
     FETCH_SIZE / WRITE_SIZE are KiB summed over the L2 channels; FETCH_SIZE is doubled, the guide's gfx950 correction
     for 16-B-per-lane streaming reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is taken as reported."""
-    import csv, glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "pmc_traffic.csv")))
+    import csv
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.csv")), key=os.path.getmtime)
     if not files:
         return None, None
     sym = kernel.split(" + ")[0]
@@ -75,9 +113,50 @@ def pmc_traffic(kernel):
                 write = float(r["mean"]) * 1024
     if fetch is None or write is None:
         return None, None
-    return fetch + write, (f"{os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__)))}: mean over the run's launches of this symbol, "
+    return fetch + write, (f"{os.path.relpath(files[-1], ROOT)}: mean over the run's launches of this symbol, "
                            f"2 x FETCH_SIZE ({fetch / 1e6:.1f} MB) + WRITE_SIZE ({write / 1e6:.1f} MB); L2-to-fabric requests, "
-                           "Infinity-Cache hits included, so an upper bound on HBM bytes")
+                           "Infinity-Cache hits included, so an upper bound on HBM bytes; per-problem rows: pmc_traffic_per_problem.csv beside it")
+
+
+class ClockSampler(threading.Thread):
+    """Shader / memory clock of this rank's GPU while the timed region runs (sysfs pp_dpm_sclk / pp_dpm_mclk, the level marked
+    '*'), every 0.25 s: box-to-box spread of the same commit was +-12 % in round 1 and needs a clock next to every number."""
+
+    def __init__(self, index):
+        super().__init__(daemon=True)
+        self.files = {}
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        if cards:
+            base = os.path.dirname(cards[min(index, len(cards) - 1)])
+            self.files = {"sclk_mhz": os.path.join(base, "pp_dpm_sclk"), "mclk_mhz": os.path.join(base, "pp_dpm_mclk")}
+        self.samples = {k: [] for k in self.files}
+        self.stop_flag = threading.Event()
+
+    @staticmethod
+    def _current(path):
+        try:
+            for line in open(path):
+                if "*" in line:
+                    return float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except Exception:
+            return None
+        return None
+
+    def run(self):
+        while not self.stop_flag.is_set():
+            for k, p in self.files.items():
+                v = self._current(p)
+                if v is not None:
+                    self.samples[k].append(v)
+            self.stop_flag.wait(0.25)
+
+    def summary(self):
+        self.stop_flag.set()
+        out = {}
+        for k, v in self.samples.items():
+            if v:
+                out[k] = {"min": min(v), "mean": round(sum(v) / len(v), 1), "max": max(v), "samples": len(v)}
+        return out or None
 
 
 def main():
@@ -85,7 +164,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4, help="images per GPU per step (BASELINE config C2: 4)")
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS), help="BASELINE.json configuration (default: C2, the one the metric is quoted on)")
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU per step (BASELINE C2: 4; C3: 32 / 8 GPUs; C5: 16 / 4 GPUs)")
     ap.add_argument("--plms-steps", type=int, default=50)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--lanes", type=int, default=2,
@@ -94,6 +174,7 @@ def main():
                          "memory-bound kernels overlap the other's MFMA work. 1 = strictly one batch at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
     from gligen_amd import dist as gdist
     rank, local_rank, world = gdist.init_from_env()
@@ -112,25 +193,31 @@ def main():
     gdist.barrier()
     gi.device = dev
     B = args.batch
+    kind = cfg["kind"]
     # random-init weights of the shipped architecture, generated on the device (fast), same statistics as the test fixture
     L = max(1, min(args.lanes, args.steps))
     lanes = []
     for _ in range(L):
-        model, autoencoder, diffusion, cfg = gi.load_synthetic("text", seed=1234, fast=True)
-        model.grounding_tokenizer_input = gi.instantiate_from_config(cfg["grounding_tokenizer_input"])
+        model, autoencoder, diffusion, mcfg = gi.load_synthetic(kind, inpaint=cfg["inpaint"], seed=1234, fast=True)
+        model.grounding_tokenizer_input = gi.instantiate_from_config(mcfg["grounding_tokenizer_input"])
         lanes.append((model, autoencoder, diffusion, torch.cuda.Stream(device=dev)))
     lo, hi = gdist.shard_range(B * world, rank, world)
-    batch = {k: v[lo:hi].to(dev) for k, v in syn.make_batch("text", B * world, n_valid=8, seed=0).items()}
+    batch = {k: v[lo:hi].to(dev) for k, v in syn.make_batch(kind, B * world, n_valid=8, seed=0).items()}
     context = syn.make_context(B * world, seed=0)[lo:hi].to(dev)
     uc = syn.make_context(B * world, seed=1)[lo:hi].to(dev)
     x_T = syn.make_latent(B * world, 4, 64, 64, seed=0)[lo:hi].to(dev)
+    image = mask = None
+    if cfg["inpaint"]:   # one input image per sample in [-1, 1], mask from the boxes (reference gligen_inference.py:396-407)
+        image = (torch.rand(B * world, 3, 512, 512, generator=torch.Generator().manual_seed(8)) * 2 - 1)[lo:hi].to(dev)
+        mask = gi.draw_masks_from_boxes(batch["boxes"].cpu(), 64).to(dev)
     torch.cuda.synchronize()
 
     def one_pass(lane):
         model, autoencoder, diffusion, stream = lanes[lane]
         with torch.cuda.stream(stream):
+            z0 = autoencoder.encode(image) if cfg["inpaint"] else None
             imgs = gi.generate(model, autoencoder, diffusion, batch, context, uc, steps=args.plms_steps, guidance_scale=7.5,
-                               alpha_type=None, starting_noise=x_T.clone(), use_graph=not args.no_graph)
+                               alpha_type=None, starting_noise=x_T.clone(), use_graph=not args.no_graph, inpainting_mask=mask, z0=z0)
             return autoencoder.engine.to_uint8(imgs)
 
     for _ in range(max(1, args.warmup)):       # every lane: GEMM autotune (first lane), graph capture, allocator warm-up
@@ -142,21 +229,29 @@ def main():
     torch.cuda.synchronize()
     unet_ms, first_ms, n_evals = lanes[0][0].engine.sampler_timing()
 
+    clocks = ClockSampler(local_rank)
     gdist.barrier(); torch.cuda.synchronize()
+    clocks.start()
     t0 = time.perf_counter()
     outs = [one_pass(i % L) for i in range(args.steps)]
     torch.cuda.synchronize(); gdist.barrier()
     elapsed = gdist.max_over_ranks(time.perf_counter() - t0, dev)
+    clk = clocks.summary()
     out = outs[-1]
     assert out.shape == (B, 512, 512, 3) and out.dtype == torch.uint8
-    assert all(torch.equal(o, out) for o in outs), "lanes disagree on identical inputs"
+    if not cfg["inpaint"]:   # (inpainting draws fresh q_sample / posterior noise every pass, as the reference does)
+        assert all(torch.equal(o, out) for o in outs), "lanes disagree on identical inputs"
 
     # per-kernel profile of one eager [cond ; uncond] evaluation on lane 0 (conditioning is still set from the last pass):
     # HIP events on the launch stream around every launch, aggregated by kernel symbol
     with torch.cuda.stream(lanes[0][3]):
         tt = torch.full((2 * B,), 501, device=dev, dtype=torch.long)
-        lanes[0][0].engine.unet_profile(x_T, tt, batch=2 * B)          # warm
-        prof = lanes[0][0].engine.unet_profile(x_T, tt, batch=2 * B)
+        extra = None
+        if cfg["inpaint"]:
+            z0 = lanes[0][1].encode(image)
+            extra = torch.cat([z0 * mask, mask], dim=1)
+        lanes[0][0].engine.unet_profile(x_T, tt, extra, batch=2 * B)          # warm
+        prof = lanes[0][0].engine.unet_profile(x_T, tt, extra, batch=2 * B)
     torch.cuda.synchronize()
 
     autoencoder = lanes[0][1]
@@ -167,7 +262,9 @@ def main():
     if rank == 0:
         n_images = B * world * args.steps
         value = n_images / elapsed
-        unet_tflops = 2 * B * F_UNET / (unet_ms * 1e-3) / 1e12
+        f_unet = F_UNET[cfg["ng"]] + (F_CONV9 if cfg["inpaint"] else 0.0)
+        f_img = flops_per_image(cfg, args.plms_steps)
+        unet_tflops = 2 * B * f_unet / (unet_ms * 1e-3) / 1e12
         # dominant kernel = the symbol with the largest total time inside one UNet evaluation; its launches' algorithmic
         # FLOPs / their HIP-event time. profiles/<round>/bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this
         # same command) lists the same symbol with its average duration over the whole run.
@@ -180,27 +277,31 @@ def main():
                     "traffic": traffic, "traffic_src": traffic_src, "launches_per_unet_eval": dom["calls"], "avg_launch_us": dom["ms"] / dom["calls"] * 1e3,
                     "flops_per_launch_avg": dom["flops"] / dom["calls"], "share_of_unet_eval": dom["ms"] / tot_ms,
                     "measured": "HIP events on the launch stream around each launch of one eager UNet evaluation at batch 2B",
-                    "unet_eval": {"achieved": unet_tflops, "frac": unet_tflops * 1e12 / PEAK_BF16, "flops_per_launch": 2 * B * F_UNET,
+                    "unet_eval": {"achieved": unet_tflops, "frac": unet_tflops * 1e12 / PEAK_BF16, "flops_per_launch": 2 * B * f_unet,
                                   "desc": "whole [cond ; uncond] evaluation (one hipGraph launch) against the same roof"},
-                    "whole_image": {"achieved": value / world * F_IMG / 1e12, "frac": value / world * F_IMG / PEAK_BF16},
+                    "whole_image": {"achieved": value / world * f_img / 1e12, "frac": value / world * f_img / PEAK_BF16, "flops_per_image": f_img},
+                    "eager_sum_ms": round(tot_ms, 3),
                     "kernels": [{"kernel": p["name"], "launches": p["calls"], "ms": round(p["ms"], 4),
                                  **({"TFLOP/s": round(p["flops"] / (p["ms"] * 1e-3) / 1e12, 1)} if p["flops"] > 0 else
-                                    {"GB/s": round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1)})} for p in prof[:12]]}
+                                    {"GB/s": round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1), "frac_of_6.3TB/s": round(p["bytes"] / (p["ms"] * 1e-3) / 6.3e12, 3)})}
+                                for p in prof[:14]]}
         line = {
             "metric": "512x512 images/sec @ 50 PLMS steps, box+text (CFG 7.5), UNet step ms",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "C2: box+text, 8 boxes (30 grounding tokens), 512x512, 50 PLMS steps, CFG 7.5, bf16 storage / fp32 accumulate",
+            "config": {"workload": cfg["desc"] + ", 512x512, 50 PLMS steps, CFG 7.5, bf16 storage / fp32 accumulate", "baseline_config": args.config,
                        "images_per_gpu_per_step": B, "plms_steps": args.plms_steps, "unet_evals_per_image": 2 * (args.plms_steps + 1),
-                       "hipgraph": not args.no_graph, "batches_in_flight": L, "weights": "seeded random init of the SD-1.4 GLIGEN architecture (966 tensors, 1.07 B params)"},
+                       "grounding_tokens": cfg["ng"], "hipgraph": not args.no_graph, "batches_in_flight": L,
+                       "weights": "seeded random init of the SD-1.4 GLIGEN architecture (966 tensors, 1.07 B params)"},
             "unet_step_ms": unet_ms, "unet_step_desc": f"one [cond ; uncond] UNet evaluation at batch {2 * B} (hipGraph replay, HIP events on the engine stream, "
                                                        f"measured in an untimed pass with one batch in flight)",
             "vae_decode_ms": dec_ms,
+            "gpu_clocks": clk,
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)
     gdist.shutdown()
 

@@ -24,6 +24,7 @@ class UNetConfig(C.Structure):
         ("n_attn", C.c_int), ("attention_resolutions", C.c_int * 8),
         ("inpaint_mode", C.c_int), ("grounding_kind", C.c_int),
         ("gr_in_dim", C.c_int), ("gr_out_dim", C.c_int), ("max_persons", C.c_int), ("fuser_kind", C.c_int),
+        ("extra_channels", C.c_int),
     ]
 
 
@@ -38,7 +39,7 @@ class Grounding(C.Structure):
     _fields_ = [
         ("n", C.c_int),
         ("boxes", C.c_void_p), ("masks", C.c_void_p), ("text_masks", C.c_void_p), ("image_masks", C.c_void_p),
-        ("text_embeddings", C.c_void_p), ("image_embeddings", C.c_void_p), ("points", C.c_void_p),
+        ("text_embeddings", C.c_void_p), ("image_embeddings", C.c_void_p), ("points", C.c_void_p), ("tokens", C.c_void_p),
     ]
 
 
@@ -49,7 +50,8 @@ class PlmsArgs(C.Structure):
         ("fuser_scale", C.POINTER(C.c_float)), ("guidance_scale", C.c_float),
         ("x", C.c_void_p), ("inpaint_extra", C.c_void_p), ("mask", C.c_void_p), ("x0", C.c_void_p),
         ("noise", C.c_void_p), ("sqrt_ac", C.POINTER(C.c_float)), ("sqrt_1mac", C.POINTER(C.c_float)),
-        ("use_graph", C.c_int), ("sd_conv_w", C.c_void_p), ("sd_conv_b", C.c_void_p), ("ddim", C.c_int),
+        ("mask_B", C.c_int), ("x0_B", C.c_int), ("noise_B", C.c_int),
+        ("use_graph", C.c_int), ("sd_conv_w", C.c_void_p), ("sd_conv_b", C.c_void_p), ("sd_conv_step", C.c_int), ("ddim", C.c_int),
     ]
 
 
@@ -70,6 +72,8 @@ SYMBOLS = {
     "gl_finalize": (_I, [_P]),
     "gl_unet_set_cond": (_I, [_P, _I, _P, _I, C.POINTER(Grounding), _P]),
     "gl_unet_set_fuser_scale": (_I, [_P, C.c_float, _P]),
+    "gl_unet_grounding_tokens": (_I, [_P, _P, _P]),
+    "gl_op_grounding_downsample": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P]),
     "gl_unet_restore_first_conv": (_I, [_P, _P, _P, _P]),
     "gl_unet_forward": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P]),
     "gl_vae_decode": (_I, [_P, _I, _I, _I, _P, _P, _P]),

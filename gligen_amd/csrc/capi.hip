@@ -20,8 +20,10 @@ struct gl_ctx {
     }                                                    \
     return GL_OK;
 
+// every entry point runs on the context's own device, whatever the caller's current device is
 #define NEED(ctx)                                                         \
-    if (!(ctx) || !(ctx)->eng) return gl::set_error(GL_ERR_ARG, "null context");
+    if (!(ctx) || !(ctx)->eng) return gl::set_error(GL_ERR_ARG, "null context"); \
+    if (hipSetDevice((ctx)->eng->device()) != hipSuccess) return gl::set_error(GL_ERR_HIP, "hipSetDevice(%d) failed", (ctx)->eng->device());
 
 static inline hipStream_t S(gl_stream s) { return reinterpret_cast<hipStream_t>(s); }
 
@@ -100,6 +102,37 @@ int gl_unet_set_cond(gl_ctx* ctx, int Beff, const float* context, int n_ctx_toke
     if (!context || !g) return gl::set_error(GL_ERR_ARG, "null context/grounding");
     GL_API_BEGIN
     ctx->eng->set_cond(Beff, context, n_ctx_tokens, *g, S(s));
+    GL_API_END
+}
+
+int gl_unet_grounding_tokens(gl_ctx* ctx, float* out, gl_stream s) {
+    NEED(ctx);
+    if (!out) return gl::set_error(GL_ERR_ARG, "null out pointer");
+    GL_API_BEGIN
+    ctx->eng->grounding_tokens(out, S(s));
+    GL_API_END
+}
+
+int gl_op_grounding_downsample(gl_ctx* ctx, const float* img, int B, int Cimg, int H, int W, int n_in, int R, int mode,
+                               const float* w1, const float* b1, int c_mid, const float* w2, const float* b2, int c_out,
+                               float* out, gl_stream s) {
+    NEED(ctx);
+    if (!img || !out || B <= 0 || n_in <= 0 || n_in > Cimg || R <= 0) return gl::set_error(GL_ERR_ARG, "grounding_downsample: bad arguments");
+    if (w1 && (!b1 || !w2 || !b2 || c_mid <= 0 || c_out <= 0 || R % 4)) return gl::set_error(GL_ERR_ARG, "grounding_downsample: bad conv arguments");
+    GL_API_BEGIN
+    if (!w1) {
+        GL_TRY(gl::resize_f32_launch(img, out, B, Cimg, n_in, H, W, R, mode, S(s)));
+    } else {
+        gl::Arena& ar = ctx->eng->arena();
+        const size_t mk = ar.mark();
+        float* r = ar.get<float>((size_t)B * n_in * R * R);
+        float* h1 = ar.get<float>((size_t)B * c_mid * (R / 2) * (R / 2));
+        int rc = gl::resize_f32_launch(img, r, B, Cimg, n_in, H, W, R, mode, S(s));
+        if (rc == GL_OK) rc = gl::conv4x4s2_f32_launch(r, w1, b1, h1, B, n_in, c_mid, R, R, 1, S(s));
+        if (rc == GL_OK) rc = gl::conv4x4s2_f32_launch(h1, w2, b2, out, B, c_mid, c_out, R / 2, R / 2, 0, S(s));
+        ar.release(mk);
+        if (rc != GL_OK) return rc;
+    }
     GL_API_END
 }
 

@@ -104,6 +104,7 @@ class Engine {
 
     void set_cond(int Beff, const float* context, int n_ctx, const gl_grounding& g, hipStream_t s);
     void set_fuser_scale(float v, hipStream_t s);
+    void grounding_tokens(float* out, hipStream_t s);  // [Beff][Ng][gr_out_dim] fp32: objs of openaimodel.py:433 for the current conditioning
     void restore_first_conv(const float* w, const float* b, hipStream_t s);
     void unet_forward(int Beff, int h, int w, const float* x, int xB, const int64_t* t, const float* extra,
                       int extraB, float* eps, hipStream_t s);
@@ -204,6 +205,8 @@ class Engine {
     // ---- conditioning cache
     struct Cond {
         int Beff = 0, Ng = 0, ctx_T = 0, ctx_Tpad = 0, obj_Tpad = 0;
+        bf16* tokens = nullptr;     // position_net output [Beff][obj_stride][gr_out_dim] (kept for gl_unet_grounding_tokens)
+        int obj_stride = 0;
         std::vector<bf16*> objs;    // per transformer: [Beff*Ng][C]
         std::vector<bf16*> obj_k;   // gatedCA, per transformer: [Beff*H][obj_Tpad][DP]   (K of the grounding tokens)
         std::vector<bf16*> obj_vt;  // gatedCA, per transformer: [Beff*H][DPV][obj_Tpad]

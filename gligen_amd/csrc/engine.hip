@@ -155,6 +155,9 @@ void Engine::configure_unet(const gl_unet_config& c) {
     if (c.n_mult < 1 || c.n_mult > 8 || c.n_attn < 0 || c.n_attn > 8) throw GlError(GL_ERR_ARG, "bad unet config");
     if (c.model_channels % 64 != 0) throw GlError(GL_ERR_UNSUPPORTED, "model_channels must be a multiple of 64");
     if (c.fuser_kind < 0 || c.fuser_kind > 2) throw GlError(GL_ERR_ARG, "fuser_kind: 0 gatedSA, 1 gatedSA2, 2 gatedCA");
+    if (c.extra_channels < 0 || c.extra_channels > 64) throw GlError(GL_ERR_ARG, "extra_channels out of range");
+    // openaimodel.py:446-447 is a breakpoint() in the reference: no shipped model combines the two
+    if (c.extra_channels && c.inpaint_mode) throw GlError(GL_ERR_UNSUPPORTED, "inpaint_mode with a grounding downsampler is undefined in the reference");
     ucfg_ = c;
     has_unet_ = true;
 }
@@ -283,7 +286,7 @@ void Engine::build_unet() {
     {
         const RawTensor& w = raw(U + "input_blocks.0.0.weight");
         const int in_c = (int)w.shape[1];
-        const int expect = c.inpaint_mode ? 2 * c.in_channels + 1 : c.in_channels;
+        const int expect = c.inpaint_mode ? 2 * c.in_channels + 1 : c.in_channels + c.extra_channels;
         if (in_c != expect) throw GlError(GL_ERR_ARG, fmt("first conv has %d input channels, config implies %d", in_c, expect));
         conv_in_kpad_ = round_up(9 * in_c, 64);
         bf16* dst = reinterpret_cast<bf16*>(persist((size_t)mc * conv_in_kpad_ * sizeof(bf16), false));
@@ -484,8 +487,11 @@ void Engine::build_unet() {
         float* d = reinterpret_cast<float*>(persist(tab.size() * sizeof(float), false));
         HIPCK(hipMemcpy(d, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
         kp_table_ = d;
+    } else if (gkind_ == 3) {
+        // spatial-map modalities (canny / hed / depth / normal / sem _grounding_net.py): the tokenizer is a ConvNeXt backbone
+        // that runs once per prompt on the host side of this ABI; its output arrives through gl_grounding.tokens
     } else {
-        throw GlError(GL_ERR_UNSUPPORTED, "grounding_kind must be 0 (text), 1 (text+image) or 2 (keypoint)");
+        throw GlError(GL_ERR_UNSUPPORTED, "grounding_kind must be 0 (text), 1 (text+image), 2 (keypoint) or 3 (precomputed tokens)");
     }
 }
 
@@ -920,13 +926,20 @@ void Engine::restore_first_conv(const float* w, const float* b, hipStream_t s) {
     if (!has_unet_ || !finalized_) throw GlError(GL_ERR_STATE, "unet not finalized");
     if (ucfg_.inpaint_mode) throw GlError(GL_ERR_STATE, "first conv of an inpainting model is not restorable");
     const int mc = ucfg_.model_channels;
-    CK(pack_conv_small_launch(w, const_cast<bf16*>(conv_in_small_.w), mc, conv_in_small_.Cin, conv_in_kpad_, s));
+    // a 4 + k channel GLIGEN first conv (grounding downsampler) becomes the 4-channel SD conv: the k extra input
+    // channels get zero weights, which is what dropping the concat (openaimodel.py:442-444, first_conv_type "SD") computes
+    CK(pack_conv_small_launch(w, const_cast<bf16*>(conv_in_small_.w), mc, conv_in_small_.Cin, conv_in_kpad_, s, ucfg_.in_channels));
     HIPCK(hipMemcpyAsync(const_cast<float*>(conv_in_small_.b), b, mc * sizeof(float), hipMemcpyDeviceToDevice, s));
 }
 
 void Engine::set_cond(int Beff, const float* context, int n_ctx, const gl_grounding& g, hipStream_t s) {
     if (!has_unet_ || !finalized_) throw GlError(GL_ERR_STATE, "unet not finalized");
     if (Beff <= 0 || n_ctx <= 0 || g.n <= 0) throw GlError(GL_ERR_ARG, "set_cond: empty batch / context / grounding");
+    if (ucfg_.fuser_kind == 1) {
+        int sg = 0;
+        while (sg * sg < (gkind_ == 1 ? 2 * g.n : g.n)) ++sg;
+        if (sg * sg != (gkind_ == 1 ? 2 * g.n : g.n)) throw GlError(GL_ERR_ARG, "gatedSA2 needs a square number of grounding tokens");
+    }
     const gl_unet_config& c = ucfg_;
     const int Ng = gkind_ == 1 ? 2 * g.n : g.n;
     const int ctx_Tpad = round_up(n_ctx, 64);
@@ -961,11 +974,16 @@ void Engine::set_cond(int Beff, const float* context, int n_ctx, const gl_ground
             cond_.ctx_vt.push_back(reinterpret_cast<bf16*>(palloc((size_t)Beff * heads * dpv * ctx_Tpad * sizeof(bf16))));
             CK(attn_vt_ones_launch(cond_.ctx_vt.back(), Beff * heads, t.d, ctx_Tpad, 0));
         }
+        cond_.tokens = reinterpret_cast<bf16*>(palloc((size_t)Beff * obj_stride * c.gr_out_dim * sizeof(bf16)));
         HIPCK(hipStreamSynchronize(0));
         cond_.Beff = Beff;
         cond_.Ng = Ng;
         cond_.ctx_Tpad = ctx_Tpad;
         cond_.obj_Tpad = obj_Tpad;
+    }
+    if (cond_.ctx_T != n_ctx && smp_.exec) {  // captured cross-attention launches bake Nk = ctx_T
+        HIPCK(hipStreamSynchronize(smp_.stream));
+        sampler_release_graph();
     }
     cond_.ctx_T = n_ctx;
     arena_.reset();
@@ -1007,12 +1025,18 @@ void Engine::set_cond(int Beff, const float* context, int n_ctx, const gl_ground
         mlp(0, pin, 0);
         pin.feat = g.image_embeddings; pin.fmask = g.image_masks; pin.null_feat = pn_null_feat_[1];
         mlp(1, pin, g.n);
+    } else if (gkind_ == 3) {
+        if (!g.tokens) throw GlError(GL_ERR_ARG, "grounding_kind 3 needs gl_grounding.tokens");
+        CK(pad_rows_cast_launch(g.tokens, objs, Beff, g.n, obj_stride, out_dim, s));
     } else {
         if (!g.points || !g.masks) throw GlError(GL_ERR_ARG, "keypoint grounding needs points and masks");
         if (g.n != c.max_persons * 17) throw GlError(GL_ERR_ARG, "keypoint grounding: n must be max_persons*17");
         pin.feat = kp_table_; pin.feat_mod = g.n; pin.pos = g.points; pin.F = out_dim; pin.P = 2; pin.null_feat = pn_null_feat_[0];
         mlp(0, pin, 0);
     }
+
+    cond_.obj_stride = obj_stride;
+    HIPCK(hipMemcpyAsync(cond_.tokens, objs, (size_t)Beff * obj_stride * out_dim * sizeof(bf16), hipMemcpyDeviceToDevice, s));  // gl_unet_grounding_tokens
 
     // ---- per transformer: fuser.linear(objs), attn2.to_k / to_v (context)
     bf16* ctxb = arena_.get<bf16>((size_t)Beff * ctx_Tpad * c.context_dim);
@@ -1064,13 +1088,20 @@ void Engine::set_cond(int Beff, const float* context, int n_ctx, const gl_ground
     }
 }
 
+void Engine::grounding_tokens(float* out, hipStream_t s) {
+    if (!cond_.tokens) throw GlError(GL_ERR_STATE, "no conditioning set");
+    CK(bf16_rows_to_f32_launch(cond_.tokens, out, cond_.Beff, cond_.Ng, cond_.obj_stride, ucfg_.gr_out_dim, s));
+}
+
 // ---------------------------------------------------------------- UNetModel.forward (openaimodel.py:420-464)
 void Engine::unet_forward(int Beff, int h, int w, const float* x, int xB, const int64_t* t, const float* extra,
                           int extraB, float* eps, hipStream_t s) {
     if (!has_unet_ || !finalized_) throw GlError(GL_ERR_STATE, "unet not finalized");
     if (cond_.Beff != Beff) throw GlError(GL_ERR_STATE, fmt("unet_forward batch %d but conditioning was set for %d", Beff, cond_.Beff));
     const gl_unet_config& c = ucfg_;
-    if ((c.inpaint_mode != 0) != (extra != nullptr)) throw GlError(GL_ERR_ARG, "inpainting_extra_input must be given iff inpaint_mode");
+    const int extra_C = c.inpaint_mode ? c.in_channels + 1 : c.extra_channels;
+    if ((extra_C != 0) != (extra != nullptr))
+        throw GlError(GL_ERR_ARG, "the extra first-conv input (inpainting_extra_input / downsampled grounding_extra_input) must be given iff the model has those channels");
     if (xB <= 0 || Beff % xB != 0) throw GlError(GL_ERR_ARG, "x batch must divide the effective batch");
     const int mc = c.model_channels;
     arena_.reset();
@@ -1107,10 +1138,10 @@ void Engine::unet_forward(int Beff, int h, int w, const float* x, int xB, const 
                 for (int r = 0; r < reps; ++r) {
                     Im2colParams P{};
                     P.x0 = x; P.C0 = c.in_channels;
-                    P.x1 = extra; P.C1 = extra ? c.in_channels + 1 : 0;
+                    P.x1 = extra; P.C1 = extra_C;
                     P.B = xB; P.H = cur.H; P.W = cur.W; P.Kpad = conv_in_kpad_;
                     P.out = col + (size_t)r * xB * HW * conv_in_kpad_;
-                    if (extra && extraB != xB) throw GlError(GL_ERR_ARG, "inpainting_extra_input batch must equal x batch");
+                    if (extra && extraB != xB) throw GlError(GL_ERR_ARG, "extra first-conv input batch must equal x batch");
                     CK(im2col_small_launch(P, s));
                     ++n_launches;
                 }
@@ -1386,6 +1417,9 @@ void Engine::sample_plms(const gl_plms_args& a, hipStream_t caller) {
     const gl_unet_config& c = ucfg_;
     if (a.n_steps < 1 || !a.timesteps || !a.a_t || !a.a_prev || !a.x) throw GlError(GL_ERR_ARG, "sample_plms: missing schedule or latent");
     if (a.mask && (!a.x0 || !a.noise || !a.sqrt_ac || !a.sqrt_1mac)) throw GlError(GL_ERR_ARG, "sample_plms: mask needs x0, noise and q_sample coefficients");
+    const int maskB = a.mask_B ? a.mask_B : a.B, x0B = a.x0_B ? a.x0_B : a.B, noiseB = a.noise_B ? a.noise_B : a.B;
+    if (a.mask && ((maskB != 1 && maskB != a.B) || (x0B != 1 && x0B != a.B) || (noiseB != 1 && noiseB != a.B)))
+        throw GlError(GL_ERR_ARG, fmt("sample_plms: mask / x0 / noise batch (%d, %d, %d) must be 1 or the latent batch %d", maskB, x0B, noiseB, a.B));
     const bool cfg = a.guidance_scale != 1.f;
     const int Beff = cfg ? 2 * a.B : a.B;
     if (cond_.Beff != Beff) throw GlError(GL_ERR_STATE, fmt("sample_plms: conditioning batch is %d, need %d", cond_.Beff, Beff));
@@ -1442,12 +1476,13 @@ void Engine::sample_plms(const gl_plms_args& a, hipStream_t caller) {
     bool restored = false;
     for (int i = 0; i < a.n_steps; ++i) {
         if (a.fuser_scale) set_fuser_scale(a.fuser_scale[i], s);
-        if (a.fuser_scale && a.fuser_scale[i] == 0.f && a.sd_conv_w && a.sd_conv_b && !restored) {
+        if (a.sd_conv_w && a.sd_conv_b && !restored && i == a.sd_conv_step) {
             restore_first_conv(a.sd_conv_w, a.sd_conv_b, s);
             restored = true;
         }
         if (a.mask)
-            CK(inpaint_blend_launch(a.x, a.x0, a.noise + (size_t)i * n, a.mask, a.sqrt_ac[i], a.sqrt_1mac[i], a.B, Cl, a.h * a.w, s));
+            CK(inpaint_blend_launch(a.x, a.x0, a.noise + (size_t)i * (n / a.B) * noiseB, a.mask, a.sqrt_ac[i], a.sqrt_1mac[i], a.B, Cl, a.h * a.w,
+                                    x0B, noiseB, maskB, s));
         eval(a.x, a.timesteps[i]);
         PlmsParams P{};
         P.eps_pair = smp_.eps_pair; P.has_uncond = cfg ? 1 : 0; P.guidance = a.guidance_scale;

@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 
@@ -1369,8 +1370,8 @@ static int g_force_grid = 0;
 void gemm_force_cfg(int tm, int tn, int splits) { g_force_tm = tm; g_force_tn = tn; g_force_splits = splits; }
 void gemm_force_grid(int g) { g_force_grid = g; }
 void gemm_set_autotune(int on);
-static int g_last_cfg[3] = {0, 0, 0};
-static char g_last_name[96] = "gemm";
+static thread_local int g_last_cfg[3] = {0, 0, 0};      // per calling thread: one engine context per thread
+static thread_local char g_last_name[96] = "gemm";
 const char* gemm_last_kernel_name() { return g_last_name; }
 void gemm_last_cfg(int* tm, int* tn, int* splits) { *tm = g_last_cfg[0]; *tn = g_last_cfg[1]; *splits = g_last_cfg[2]; }
 
@@ -1470,9 +1471,9 @@ int launch_u(const AOperand& A, const bf16* W, int M, int N, int K, const Epilog
 // GL_GEMM_AUTOTUNE=0 use the analytic cost model below. A launch only writes E.out (and the split-K workspace),
 // and the engine never aliases E.out with an input, so re-running a launch is idempotent.
 struct TunedCfg { int c, sp, grid; };
-static std::unordered_map<std::string, TunedCfg> g_tuned;
+static std::unordered_map<std::string, TunedCfg> g_tuned;   // process-wide, guarded by g_tune_mu (ctypes drops the GIL during calls)
+static std::mutex g_tune_mu;
 static int g_autotune = -1;
-static hipEvent_t g_tune_ev[2] = {nullptr, nullptr};
 void gemm_set_autotune_impl(int on) { g_autotune = on; }
 
 int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, float* ws, size_t ws_bytes,
@@ -1584,6 +1585,7 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
     char key[160];
     snprintf(key, sizeof key, "%d,%d,%d|%d,%d,%d,%d,%d,%d,%d|%d,%d,%d,%d,%d,%d|%d", M, N, K, A.mode, A.C0, A.C1, A.stride, A.ups, A.Win,
              A.Hin, E.mode, E.act, E.res != nullptr, E.bias2 != nullptr, E.out_f32, E.gate != nullptr, (int)use_u);
+    std::unique_lock<std::mutex> tune_lock(g_tune_mu);
     if (g_tuned.empty() && use_u && !getenv("GL_GEMM_NO_TABLE")) {
         // shipped choices for the problems of the benchmark configurations (generated by tools/make_tuned_table.py from an
         // autotune log taken on MI355X with 10 timed launches per candidate): deterministic kernel selection run to run
@@ -1593,7 +1595,11 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
         for (const auto& e : kTable) g_tuned.emplace(e.key, TunedCfg{e.c, e.sp, e.grid});
     }
     auto it = g_tuned.find(key);
-    if (it != g_tuned.end()) return run_cfg(it->second.c, it->second.sp, it->second.grid);
+    if (it != g_tuned.end()) {
+        const TunedCfg t = it->second;
+        tune_lock.unlock();
+        return run_cfg(t.c, t.sp, t.grid);
+    }
 
     // ---- analytic model (also the capture-time / tuning-off fallback)
     double best_t = 1e30;
@@ -1621,12 +1627,17 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
 
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (stream) (void)hipStreamIsCapturing(stream, &cap);
-    if (!g_autotune || cap != hipStreamCaptureStatusNone) return run_cfg(best_c, best_sp, 0);
-
-    if (!g_tune_ev[0]) {
-        GL_HIP(hipEventCreate(&g_tune_ev[0]));
-        GL_HIP(hipEventCreate(&g_tune_ev[1]));
+    if (!g_autotune || cap != hipStreamCaptureStatusNone) {
+        tune_lock.unlock();
+        return run_cfg(best_c, best_sp, 0);
     }
+
+    // timing events live on the device that is current for this call (the context's device), for this tuning pass only;
+    // the lock is held across the pass: two threads tuning at once would time each other's launches
+    hipEvent_t g_tune_ev[2];
+    GL_HIP(hipEventCreate(&g_tune_ev[0]));
+    GL_HIP(hipEventCreate(&g_tune_ev[1]));
+    struct EvGuard { hipEvent_t* e; ~EvGuard() { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); } } ev_guard{g_tune_ev};
     TunedCfg win{best_c, best_sp, 0};
     float win_ms = 1e30f;
     static const int tune_reps = getenv("GL_GEMM_TUNE_REPS") ? std::max(1, atoi(getenv("GL_GEMM_TUNE_REPS"))) : 3;
@@ -1653,6 +1664,7 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
         }
     }
     g_tuned[key] = win;
+    tune_lock.unlock();
     static const bool tune_log = getenv("GL_GEMM_TUNE_LOG") != nullptr;
     if (tune_log)
         fprintf(stderr, "[gemm autotune] %s -> %dx%d / %d splits @%d (%.1f us; model said %dx%d / %d) cfg %d %d %d\n", key, kTm[win.c] * 32,

@@ -51,7 +51,13 @@ int set_f32_launch(float* dst, float v, hipStream_t stream);
 // conv weight OIHW fp32 -> [O_pad][kh*kw][I] bf16 (K-major: k = tap*I + c), rows >= O zero
 int pack_conv_weight_launch(const float* src, bf16* dst, int O, int I, int KH, int KW, int O_pad, hipStream_t stream);
 // small-Cin conv weight OIHW fp32 -> [O][Kpad] bf16 with k = tap*I + c
-int pack_conv_small_launch(const float* src, bf16* dst, int O, int I, int Kpad, hipStream_t stream);
+// I_src (0 = I): input channels of the source weight when it has fewer than the packed layout (extra channels get zeros)
+int pack_conv_small_launch(const float* src, bf16* dst, int O, int I, int Kpad, hipStream_t stream, int I_src = 0);
+int bf16_rows_to_f32_launch(const bf16* src, float* dst, int B, int rows, int src_rows, int cols, hipStream_t stream);
+// GroundingDownsampler pieces (spatial-map modalities): resize of the first n channels of img [B][Cimg][H][W] to [B][n][R][R]
+// (torch bicubic align_corners=False, or legacy nearest), Conv2d(k 4, s 2, p 1) in fp32 NCHW with optional SiLU
+int resize_f32_launch(const float* img, float* out, int B, int Cimg, int n, int H, int W, int R, int nearest, hipStream_t stream);
+int conv4x4s2_f32_launch(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int Hin, int Win, int silu, hipStream_t stream);
 // GEGLU projection [8C][K] fp32 (+bias [8C]) -> row-interleaved bf16 / fp32 (see gemm.hip epi_geglu4)
 // layout: gemm_geglu_layout() of the GEMM variant that will consume the packed rows
 int pack_geglu_launch(const float* w, const float* b, bf16* wp, float* bp, int C4, int K, int layout, hipStream_t stream);
@@ -76,8 +82,9 @@ int plms_update_launch(const PlmsParams& p, hipStream_t stream);
 // img = (sqrt_ac x0 + sqrt_1mac noise) * mask + (1 - mask) * img   (reference plms.py:96-100)
 int fuser_resize_launch(const bf16* tok, const bf16* x, const float* gate, bf16* y, int B, int row_stride, int grid_off, int sg, int sv,
                         int C, hipStream_t stream);
+// x0B / noiseB / maskB: batch of that tensor, B or 1 (broadcast)
 int inpaint_blend_launch(float* img, const float* x0, const float* noise, const float* mask,
-                         float sqrt_ac, float sqrt_1mac, int B, int C, int HW, hipStream_t stream);
+                         float sqrt_ac, float sqrt_1mac, int B, int C, int HW, int x0B, int noiseB, int maskB, hipStream_t stream);
 
 // NCHW fp32 in [-1,1] -> NHWC u8: trunc(255 * (clamp(x,-1,1)*0.5+0.5)) (reference gligen_inference.py:443-445)
 int to_uint8_launch(const float* src, uint8_t* dst, int B, int C, int HW, hipStream_t stream);

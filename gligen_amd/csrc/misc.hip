@@ -161,6 +161,23 @@ int pad_rows_bf16_launch(const bf16* src, bf16* dst, int B, int rows, int rows_p
     return GL_OK;
 }
 
+// bf16 [B][src_rows][cols] (first `rows` rows of every sample) -> fp32 [B][rows][cols]
+__global__ void bf16_rows_to_f32_kernel(const bf16* __restrict__ s, float* __restrict__ d, int B, int rows, int src_rows, int cols) {
+    const int64_t total = (int64_t)B * rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cols);
+        const int64_t rr = i / cols;
+        const int r = (int)(rr % rows);
+        const int b = (int)(rr / rows);
+        d[i] = bf2f(s[((size_t)b * src_rows + r) * cols + c]);
+    }
+}
+int bf16_rows_to_f32_launch(const bf16* src, float* dst, int B, int rows, int src_rows, int cols, hipStream_t stream) {
+    hipLaunchKernelGGL(bf16_rows_to_f32_kernel, dim3(grid_for((int64_t)B * rows * cols)), dim3(256), 0, stream, src, dst, B, rows, src_rows, cols);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
 __global__ void set_f32_kernel(float* d, float v) { d[0] = v; }
 int set_f32_launch(float* dst, float v, hipStream_t stream) {
     hipLaunchKernelGGL(set_f32_kernel, dim3(1), dim3(1), 0, stream, dst, v);
@@ -185,7 +202,9 @@ int pack_conv_weight_launch(const float* src, bf16* dst, int O, int I, int KH, i
     return GL_OK;
 }
 
-__global__ void pack_conv_small_kernel(const float* __restrict__ s, bf16* __restrict__ d, int O, int I, int Kpad) {
+// I_src <= I: the source weight has fewer input channels than the packed layout (the SD first conv restored into a
+// 4 + k channel GLIGEN first conv); the missing channels get zero weights
+__global__ void pack_conv_small_kernel(const float* __restrict__ s, bf16* __restrict__ d, int O, int I, int I_src, int Kpad) {
     const int64_t total = (int64_t)O * Kpad;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int k = (int)(i % Kpad);
@@ -193,13 +212,14 @@ __global__ void pack_conv_small_kernel(const float* __restrict__ s, bf16* __rest
         float v = 0.f;
         if (k < 9 * I) {
             const int tap = k / I, c = k - tap * I;
-            v = s[((size_t)o * I + c) * 9 + tap];
+            if (c < I_src) v = s[((size_t)o * I_src + c) * 9 + tap];
         }
         d[i] = f2bf(v);
     }
 }
-int pack_conv_small_launch(const float* src, bf16* dst, int O, int I, int Kpad, hipStream_t stream) {
-    hipLaunchKernelGGL(pack_conv_small_kernel, dim3(grid_for((int64_t)O * Kpad)), dim3(256), 0, stream, src, dst, O, I, Kpad);
+int pack_conv_small_launch(const float* src, bf16* dst, int O, int I, int Kpad, hipStream_t stream, int I_src) {
+    if (I_src <= 0) I_src = I;
+    hipLaunchKernelGGL(pack_conv_small_kernel, dim3(grid_for((int64_t)O * Kpad)), dim3(256), 0, stream, src, dst, O, I, I_src, Kpad);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }
@@ -267,18 +287,25 @@ int plms_update_launch(const PlmsParams& p, hipStream_t stream) {
     return GL_OK;
 }
 
-__global__ void inpaint_blend_kernel(float* img, const float* x0, const float* noise, const float* mask, float sa, float s1, int B, int C, int HW) {
+// x0 / noise / mask may carry batch 1 (broadcast over the latent batch, as the reference's tensor broadcasting does for the
+// single encoded input image of gligen_inference.run) or batch B
+__global__ void inpaint_blend_kernel(float* img, const float* x0, const float* noise, const float* mask, float sa, float s1, int B, int C, int HW,
+                                     int x0B, int noiseB, int maskB) {
     const int64_t total = (int64_t)B * C * HW;
+    const int64_t per = (int64_t)C * HW;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int pix = (int)(i % HW);
-        const int b = (int)(i / ((int64_t)C * HW));
-        const float m = mask[(size_t)b * HW + pix];
-        const float orig = sa * x0[i] + s1 * noise[i];
+        const int b = (int)(i / per);
+        const int64_t r = i - (int64_t)b * per;
+        const float m = mask[(size_t)(maskB == 1 ? 0 : b) * HW + pix];
+        const float orig = sa * x0[(x0B == 1 ? 0 : (int64_t)b * per) + r] + s1 * noise[(noiseB == 1 ? 0 : (int64_t)b * per) + r];
         img[i] = orig * m + (1.f - m) * img[i];
     }
 }
-int inpaint_blend_launch(float* img, const float* x0, const float* noise, const float* mask, float sqrt_ac, float sqrt_1mac, int B, int C, int HW, hipStream_t stream) {
-    hipLaunchKernelGGL(inpaint_blend_kernel, dim3(grid_for((int64_t)B * C * HW)), dim3(256), 0, stream, img, x0, noise, mask, sqrt_ac, sqrt_1mac, B, C, HW);
+int inpaint_blend_launch(float* img, const float* x0, const float* noise, const float* mask, float sqrt_ac, float sqrt_1mac, int B, int C, int HW,
+                         int x0B, int noiseB, int maskB, hipStream_t stream) {
+    hipLaunchKernelGGL(inpaint_blend_kernel, dim3(grid_for((int64_t)B * C * HW)), dim3(256), 0, stream, img, x0, noise, mask, sqrt_ac, sqrt_1mac, B, C, HW,
+                       x0B, noiseB, maskB);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }
@@ -405,6 +432,87 @@ __global__ void zero_kernel(uint4* d, int64_t n16) {
 int zero_launch(void* dst, size_t bytes, hipStream_t stream) {
     if (bytes % 16 != 0) return set_error(GL_ERR_ARG, "zero: size %zu not a multiple of 16", bytes);
     hipLaunchKernelGGL(zero_kernel, dim3(grid_for(bytes / 16)), dim3(256), 0, stream, (uint4*)dst, (int64_t)(bytes / 16));
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+
+// ---- GroundingDownsampler of the spatial-map modalities (reference canny/depth/normal/sem/hed_grounding_downsampler.py):
+// F.interpolate of the first n channels of the conditioning image to R x R (bicubic, align_corners=False, A = -0.75, taps
+// clamped -- torch's upsample_bicubic2d without antialias; or legacy 'nearest': src = floor(dst * in / out)), then
+// Conv2d(k=4, s=2, p=1) -> SiLU -> Conv2d(k=4, s=2, p=1). Once per prompt, fp32 throughout, a few MFLOP: plain kernels.
+__global__ void resize_f32_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int Cimg, int n, int H, int W, int R, int nearest) {
+    const int64_t total = (int64_t)B * n * R * R;
+    const float sy = (float)H / (float)R, sx = (float)W / (float)R;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % R);
+        const int oy = (int)((i / R) % R);
+        const int c = (int)((i / ((int64_t)R * R)) % n);
+        const int b = (int)(i / ((int64_t)R * R * n));
+        const float* src = img + ((size_t)b * Cimg + c) * H * W;
+        float v;
+        if (nearest) {
+            const int iy = min((int)floorf(oy * sy), H - 1), ix = min((int)floorf(ox * sx), W - 1);
+            v = src[(size_t)iy * W + ix];
+        } else {
+            const float fy = (oy + 0.5f) * sy - 0.5f, fx = (ox + 0.5f) * sx - 0.5f;
+            const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+            float wy[4], wx[4];
+            cubic_taps(fy - y0, wy);
+            cubic_taps(fx - x0, wx);
+            v = 0.f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int yy = min(max(y0 - 1 + a, 0), H - 1);
+                float row = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int xx = min(max(x0 - 1 + e, 0), W - 1);
+                    row += wx[e] * src[(size_t)yy * W + xx];
+                }
+                v += wy[a] * row;
+            }
+        }
+        out[i] = v;
+    }
+}
+__global__ void conv4x4s2_f32_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
+                                     int B, int Cin, int Cout, int Hin, int Win, int silu) {
+    const int Ho = Hin / 2, Wo = Win / 2;
+    const int64_t total = (int64_t)B * Cout * Ho * Wo;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % Wo);
+        const int oy = (int)((i / Wo) % Ho);
+        const int o = (int)((i / ((int64_t)Wo * Ho)) % Cout);
+        const int b = (int)(i / ((int64_t)Wo * Ho * Cout));
+        float acc = bias[o];
+        for (int c = 0; c < Cin; ++c) {
+            const float* xc = x + ((size_t)b * Cin + c) * Hin * Win;
+            const float* wc = w + ((size_t)o * Cin + c) * 16;
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky) {
+                const int iy = 2 * oy - 1 + ky;
+                if (iy < 0 || iy >= Hin) continue;
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) {
+                    const int ix = 2 * ox - 1 + kx;
+                    if (ix < 0 || ix >= Win) continue;
+                    acc += wc[ky * 4 + kx] * xc[(size_t)iy * Win + ix];
+                }
+            }
+        }
+        y[i] = silu ? acc / (1.f + __expf(-acc)) : acc;
+    }
+}
+int resize_f32_launch(const float* img, float* out, int B, int Cimg, int n, int H, int W, int R, int nearest, hipStream_t stream) {
+    hipLaunchKernelGGL(resize_f32_kernel, dim3(grid_for((int64_t)B * n * R * R)), dim3(256), 0, stream, img, out, B, Cimg, n, H, W, R, nearest);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+int conv4x4s2_f32_launch(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int Hin, int Win, int silu, hipStream_t stream) {
+    if ((Hin | Win) & 1) return set_error(GL_ERR_ARG, "conv4x4s2: odd input size %dx%d", Hin, Win);
+    hipLaunchKernelGGL(conv4x4s2_f32_kernel, dim3(grid_for((int64_t)B * Cout * (Hin / 2) * (Win / 2))), dim3(256), 0, stream, x, w, bias, y, B, Cin, Cout, Hin, Win,
+                       silu);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }

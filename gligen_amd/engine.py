@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from ._lib import Grounding, PlmsArgs, UNetConfig, VaeConfig, check
 
-GROUNDING_KINDS = {"text": 0, "text_image": 1, "keypoint": 2}
+GROUNDING_KINDS = {"text": 0, "text_image": 1, "keypoint": 2, "tokens": 3}
 
 
 def _stream() -> C.c_void_p:
@@ -59,7 +59,8 @@ class Engine:
     # ---- configuration / weights -------------------------------------------------
     def configure_unet(self, *, in_channels, out_channels, model_channels, num_res_blocks, num_heads, context_dim,
                        channel_mult: Sequence[int], attention_resolutions: Sequence[int], inpaint_mode=False,
-                       grounding_kind="text", gr_in_dim=768, gr_out_dim=768, max_persons=0, fuser_type="gatedSA") -> None:
+                       grounding_kind="text", gr_in_dim=768, gr_out_dim=768, max_persons=0, fuser_type="gatedSA",
+                       extra_channels=0) -> None:
         cfg = UNetConfig()
         cfg.in_channels, cfg.out_channels, cfg.model_channels = in_channels, out_channels, model_channels
         cfg.num_res_blocks, cfg.num_heads, cfg.context_dim = num_res_blocks, num_heads, context_dim
@@ -73,9 +74,11 @@ class Engine:
         cfg.grounding_kind = GROUNDING_KINDS[grounding_kind]
         cfg.gr_in_dim, cfg.gr_out_dim, cfg.max_persons = gr_in_dim, gr_out_dim, max_persons
         cfg.fuser_kind = {"gatedSA": 0, "gatedSA2": 1, "gatedCA": 2}[fuser_type or "gatedSA"]
+        cfg.extra_channels = int(extra_channels)
         check(self.lib.gl_unet_configure(self._ctx, C.byref(cfg)))
         self.unet_cfg = dict(in_channels=in_channels, out_channels=out_channels, inpaint_mode=bool(inpaint_mode),
-                             grounding_kind=grounding_kind, context_dim=context_dim)
+                             grounding_kind=grounding_kind, context_dim=context_dim, extra_channels=int(extra_channels),
+                             gr_out_dim=gr_out_dim)
 
     def configure_vae(self, *, ch, out_ch, z_channels, num_res_blocks, embed_dim, ch_mult: Sequence[int],
                       scale_factor: float) -> None:
@@ -124,6 +127,8 @@ class Engine:
         elif kind == "text_image":
             b = put("boxes"); put("masks"); put("text_masks"); put("image_masks")
             put("text_embeddings"); put("image_embeddings")
+        elif kind == "tokens":
+            b = put("tokens")
         else:
             b = put("points"); put("masks")
         if b.shape[0] != ctx.shape[0]:
@@ -131,6 +136,31 @@ class Engine:
         g.n = int(b.shape[1])
         check(self.lib.gl_unet_set_cond(self._ctx, int(ctx.shape[0]), _ptr(ctx), int(ctx.shape[1]), C.byref(g), _stream()))
         self._keep = keep
+        self._cond_shape = (int(ctx.shape[0]), g.n * (2 if kind == "text_image" else 1))
+
+    def grounding_tokens(self) -> torch.Tensor:
+        """objs = position_net(**grounding_input) of the current conditioning, fp32 [Beff, Ng, out_dim]."""
+        Beff, Ng = int(self._cond_shape[0]), int(self._cond_shape[1])
+        out = torch.empty((Beff, Ng, self.unet_cfg["gr_out_dim"]), device=self.device, dtype=torch.float32)
+        check(self.lib.gl_unet_grounding_tokens(self._ctx, _ptr(out), _stream()))
+        return out
+
+    def grounding_downsample(self, img: torch.Tensor, n_in: int, resize: int, mode: str, convs) -> torch.Tensor:
+        """GroundingDownsampler.forward: img [B,Cimg,H,W] -> [B,out,resize/4,resize/4] (convs = (w1,b1,w2,b2)) or, convs None,
+        the resized first n_in channels [B,n_in,resize,resize]."""
+        img = _f32(img, self.device)
+        B, Cimg, H, W = img.shape
+        m = {"bicubic": 0, "nearest": 1}[mode]
+        if convs is None:
+            out = torch.empty((B, n_in, resize, resize), device=self.device, dtype=torch.float32)
+            check(self.lib.gl_op_grounding_downsample(self._ctx, _ptr(img), B, Cimg, H, W, n_in, resize, m, None, None, 0, None, None, 0,
+                                                      _ptr(out), _stream()))
+            return out
+        w1, b1, w2, b2 = (_f32(t.detach(), self.device) for t in convs)
+        out = torch.empty((B, w2.shape[0], resize // 4, resize // 4), device=self.device, dtype=torch.float32)
+        check(self.lib.gl_op_grounding_downsample(self._ctx, _ptr(img), B, Cimg, H, W, n_in, resize, m, _ptr(w1), _ptr(b1), int(w1.shape[0]),
+                                                  _ptr(w2), _ptr(b2), int(w2.shape[0]), _ptr(out), _stream()))
+        return out
 
     def set_fuser_scale(self, scale: float) -> None:
         check(self.lib.gl_unet_set_fuser_scale(self._ctx, C.c_float(float(scale)), _stream()))
@@ -191,8 +221,10 @@ class Engine:
     def sample_plms(self, x: torch.Tensor, timesteps: np.ndarray, a_t: np.ndarray, a_prev: np.ndarray,
                     fuser_scale: Optional[np.ndarray], guidance_scale: float, *, inpaint_extra=None, mask=None, x0=None,
                     noise=None, sqrt_ac=None, sqrt_1mac=None, use_graph: bool = True, sd_first_conv=None,
-                    ddim: bool = False) -> torch.Tensor:
-        """In-place PLMS (or, ddim=True, eta-0 DDIM) loop on x (fp32 [B,C,h,w]); conditioning must already be set."""
+                    restore_at: int = -1, ddim: bool = False) -> torch.Tensor:
+        """In-place PLMS (or, ddim=True, eta-0 DDIM) loop on x (fp32 [B,C,h,w]); conditioning must already be set.
+        Inpainting: mask [B|1,1,h,w], x0 [B|1,C,h,w], noise [S,B|1,C,h,w] (batch 1 broadcasts over the latent batch, as
+        the reference's q_sample(x0, ts) * mask does). sd_first_conv = (weight, bias) swapped in before step restore_at."""
         dev = self.device
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
         n = len(timesteps)
@@ -215,9 +247,16 @@ class Engine:
             inpaint_extra = _f32(inpaint_extra, dev); keep.append(inpaint_extra); a.inpaint_extra = inpaint_extra.data_ptr()
         if mask is not None:
             mask, x0, noise = _f32(mask, dev), _f32(x0, dev), _f32(noise, dev)
+            B, Cl, h, w = x.shape
+            if (mask.dim() != 4 or tuple(mask.shape[1:]) != (1, h, w) or x0.dim() != 4 or tuple(x0.shape[1:]) != (Cl, h, w)
+                    or noise.dim() != 5 or noise.shape[0] != n or tuple(noise.shape[2:]) != (Cl, h, w)
+                    or any(int(b) not in (1, B) for b in (mask.shape[0], x0.shape[0], noise.shape[1]))):
+                raise ValueError(f"sample_plms: mask {tuple(mask.shape)}, x0 {tuple(x0.shape)}, noise {tuple(noise.shape)} do not fit "
+                                 f"a latent {tuple(x.shape)} over {n} steps ([B|1,1,h,w], [B|1,C,h,w], [S,B|1,C,h,w])")
             sa = np.ascontiguousarray(sqrt_ac, dtype=np.float32); s1 = np.ascontiguousarray(sqrt_1mac, dtype=np.float32)
             keep += [mask, x0, noise, sa, s1]
             a.mask, a.x0, a.noise = mask.data_ptr(), x0.data_ptr(), noise.data_ptr()
+            a.mask_B, a.x0_B, a.noise_B = int(mask.shape[0]), int(x0.shape[0]), int(noise.shape[1])
             a.sqrt_ac = sa.ctypes.data_as(C.POINTER(C.c_float)); a.sqrt_1mac = s1.ctypes.data_as(C.POINTER(C.c_float))
         a.use_graph = int(bool(use_graph))
         a.ddim = int(bool(ddim))
@@ -225,6 +264,9 @@ class Engine:
             cw, cb = _f32(sd_first_conv[0], dev), _f32(sd_first_conv[1], dev)
             keep += [cw, cb]
             a.sd_conv_w, a.sd_conv_b = cw.data_ptr(), cb.data_ptr()
+            if not 0 <= restore_at < n:
+                raise ValueError("sample_plms: sd_first_conv needs restore_at = the step index it is swapped in at")
+            a.sd_conv_step = int(restore_at)
         check(self.lib.gl_sample_plms(self._ctx, C.byref(a), _stream()))
         self._keep_plms = keep
         return x

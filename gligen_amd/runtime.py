@@ -29,11 +29,25 @@ def module_device(module: torch.nn.Module) -> torch.device:
 
 def grounding_kind_of(position_net) -> str:
     mod = type(position_net).__module__.rsplit(".", 1)[-1]
-    kinds = {"text_grounding_net": "text", "text_image_grounding_net": "text_image", "keypoint_grounding_net": "keypoint"}
+    kinds = {"text_grounding_net": "text", "text_image_grounding_net": "text_image", "keypoint_grounding_net": "keypoint",
+             # spatial-map tokenizers (ConvNeXt backbone, once per prompt): the engine takes their output tokens
+             "canny_grounding_net": "tokens", "hed_grounding_net": "tokens", "depth_grounding_net": "tokens",
+             "normal_grounding_net": "tokens", "sem_grounding_net": "tokens"}
     if mod not in kinds:
-        raise NotImplementedError(f"grounding tokenizer {type(position_net).__module__} is not implemented on MI355X "
-                                  "(supported: text, text+image, keypoint)")
+        raise NotImplementedError(f"grounding tokenizer {type(position_net).__module__} is not implemented on MI355X")
     return kinds[mod]
+
+
+_SCRATCH = {}
+
+
+def scratch_engine(device) -> Engine:
+    """A weight-less engine per device for stand-alone operator calls (GroundingDownsampler outside a UNetModel)."""
+    dev = torch.device(device)
+    key = dev.index or 0
+    if key not in _SCRATCH:
+        _SCRATCH[key] = Engine(dev, arena_gb=1.0)
+    return _SCRATCH[key]
 
 
 def build_unet_engine(model, arena_gb: float = 12.0) -> Engine:
@@ -47,8 +61,11 @@ def build_unet_engine(model, arena_gb: float = 12.0) -> Engine:
         channel_mult=list(model.channel_mult), attention_resolutions=list(model.attention_resolutions),
         inpaint_mode=model.inpaint_mode, grounding_kind=kind,
         gr_in_dim=getattr(pn, "in_dim", pn.out_dim), gr_out_dim=pn.out_dim,
-        max_persons=getattr(pn, "max_persons_per_image", 0), fuser_type=model.fuser_type)
-    eng.upload("unet", model.state_dict())
+        max_persons=getattr(pn, "max_persons_per_image", 0), fuser_type=model.fuser_type,
+        extra_channels=model.additional_channel_from_downsampler if model.first_conv_type == "GLIGEN" else 0)
+    # the tokenizer / downsampler of the spatial-map modalities run through their own operator calls, not from engine weights
+    skip = ("position_net.", "downsample_net.") if kind == "tokens" else ("downsample_net.",)
+    eng.upload("unet", {k: v for k, v in model.state_dict().items() if not k.startswith(skip)})
     eng.finalize()
     return eng
 

@@ -134,3 +134,15 @@ def make_context(B: int, tokens: int = 77, dim: int = 768, seed: int = 0) -> tor
 
 def make_latent(B: int, C: int, h: int, w: int, seed: int = 0) -> torch.Tensor:
     return torch.randn(B, C, h, w, generator=torch.Generator().manual_seed(5000 + seed))
+
+
+def make_spatial_map(modality: str, B: int, res: int, seed: int = 0) -> torch.Tensor:
+    """A conditioning map as the reference's prepare_batch_* build it (gligen_inference.py:221-338): RGB-replicated grey
+    map in [-1, 1] (canny / hed / depth), an RGB normal map, or 152 one-hot semantic class planes."""
+    g = torch.Generator().manual_seed(6000 + seed)
+    if modality == "sem":
+        cls = torch.randint(0, 152, (B, res // 8, res // 8), generator=g).repeat_interleave(8, 1).repeat_interleave(8, 2)
+        return torch.zeros(B, 152, res, res).scatter_(1, cls.unsqueeze(1), 1.0)
+    if modality == "normal":
+        return torch.rand(B, 3, res, res, generator=g) * 2 - 1
+    return (torch.rand(B, 1, res, res, generator=g) * 2 - 1).repeat(1, 3, 1, 1)

@@ -7,6 +7,9 @@ Differences that follow from running offline / on the native engine:
     `uc`) — without them the HF CLIP weights are loaded exactly as the reference does (needs the
     hub cache); `--synthetic` builds seeded random-weight models and features so the whole path
     runs with no checkpoint at all;
+  * launched under torch.distributed.run (one process per GPU) the batch is sharded across the ranks: x_T is drawn once
+    from `--seed` for the whole batch and sliced, so an N-GPU run writes the same images as a 1-GPU run (no data-path
+    collective; the reference has no multi-GPU inference at all, gligen_inference.py:21);
   * checkpoints embed a pickled OmegaConf config: it is read with omegaconf when installed, else
     through a minimal unpickling shim (`_load_pickled_config`).
 """
@@ -58,15 +61,14 @@ class _Node(dict):
 
 
 def _plain(obj):
-    """omegaconf node graph (or our shim of it) -> plain python containers."""
-    content = getattr(obj, "_content", None) if not isinstance(obj, (dict, list)) else None
-    if content is None and isinstance(obj, _Node):
-        content = obj.__dict__.get("_content")
-    if content is not None:
-        obj = content
-    val = getattr(obj, "_val", None) if not isinstance(obj, (dict, list, str, int, float, bool, type(None))) else None
-    if val is not None:
-        return _plain(val)
+    """omegaconf node graph (real omegaconf classes, or the _Node stand-ins the shim unpickler builds) -> plain python
+    containers. Containers keep their children in `_content`, value nodes (AnyNode, StringNode, ...) their value in `_val`."""
+    state = getattr(obj, "__dict__", None)
+    if isinstance(state, dict) and not isinstance(obj, type):
+        if "_content" in state:
+            return _plain(state["_content"])
+        if "_val" in state:
+            return _plain(state["_val"])
     if isinstance(obj, dict):
         return {k: _plain(v) for k, v in obj.items()}
     if isinstance(obj, (list, tuple)):
@@ -216,6 +218,70 @@ def prepare_batch_kp(meta, batch=1, max_persons_per_image=8):
     return batch_to_device(out, device)
 
 
+def crop_and_resize(image):
+    """center crop to a square, resize to 512 x 512 (reference gligen_inference.py:189-193)."""
+    w, h = image.size
+    c = min(w, h)
+    left, top = int(round((w - c) / 2.0)), int(round((h - c) / 2.0))
+    return image.crop((left, top, left + c, top + c)).resize((512, 512))
+
+
+def _pil_to_unit_tensor(image):
+    arr = np.asarray(image)
+    if arr.ndim == 2:
+        arr = arr[:, :, None]
+    return (torch.from_numpy(arr.copy()).permute(2, 0, 1).float() / 255 - 0.5) / 0.5
+
+
+def _prepare_batch_map(meta, batch, meta_key, batch_key):
+    """prepare_batch_hed / _canny / _depth / _normal (reference gligen_inference.py:221-300): the map as an RGB image in
+    [-1, 1], repeated over the batch, mask = 1. meta[meta_key] is a file name or an already-loaded tensor [3,512,512]."""
+    src = meta[meta_key]
+    img = src.float() if torch.is_tensor(src) else _pil_to_unit_tensor(crop_and_resize(Image.open(src).convert("RGB")))
+    out = {batch_key: img.unsqueeze(0).repeat(batch, 1, 1, 1), "mask": torch.ones(batch, 1)}
+    return batch_to_device(out, device)
+
+
+def prepare_batch_hed(meta, batch=1):
+    return _prepare_batch_map(meta, batch, "hed_image", "hed_edge")
+
+
+def prepare_batch_canny(meta, batch=1):
+    return _prepare_batch_map(meta, batch, "canny_image", "canny_edge")
+
+
+def prepare_batch_depth(meta, batch=1):
+    return _prepare_batch_map(meta, batch, "depth", "depth")
+
+
+def prepare_batch_normal(meta, batch=1):
+    return _prepare_batch_map(meta, batch, "normal", "normal")
+
+
+@torch.no_grad()
+def prepare_batch_sem(meta, batch=1):
+    """ADE class-index image -> 152 one-hot planes at 512 x 512, nearest resize (reference gligen_inference.py:318-338;
+    the colour visualisation it also writes is a side effect, not an input of the model)."""
+    src = meta["sem"]
+    if torch.is_tensor(src):
+        sem = src.long()
+    else:
+        im = Image.open(src).convert("L")
+        w, h = im.size
+        c = min(w, h)
+        left, top = int(round((w - c) / 2.0)), int(round((h - c) / 2.0))
+        im = im.crop((left, top, left + c, top + c)).resize((512, 512), Image.NEAREST)
+        sem = torch.from_numpy(np.asarray(im).copy()).long()
+    planes = torch.zeros(152, 512, 512).scatter_(0, sem.unsqueeze(0), 1.0)
+    out = {"sem": planes.unsqueeze(0).repeat(batch, 1, 1, 1), "mask": torch.ones(batch, 1)}
+    return batch_to_device(out, device)
+
+
+# run() picks the batch builder by checkpoint-name substring, in this order (reference gligen_inference.py:363-376)
+_PREPARE_BY_NAME = (("keypoint", prepare_batch_kp), ("hed", prepare_batch_hed), ("canny", prepare_batch_canny), ("depth", prepare_batch_depth),
+                    ("normal", prepare_batch_normal), ("sem", prepare_batch_sem))
+
+
 def draw_masks_from_boxes(boxes, size):
     """Inpainting mask: 1 outside, 0 inside int(box*size) rectangles (reference inpaint_mask_func.py:16-41)."""
     masks = []
@@ -270,7 +336,8 @@ def load_synthetic(kind="text", inpaint=False, image_size=64, seed=1234, fast=Fa
 # ---- run ---------------------------------------------------------------------------------------------
 @torch.no_grad()
 def generate(model, autoencoder, diffusion, batch, context, uc, *, steps=50, guidance_scale=7.5, alpha_type=None,
-             starting_noise=None, inpainting_mask=None, z0=None, use_graph=True, no_plms=False):
+             starting_noise=None, inpainting_mask=None, z0=None, use_graph=True, no_plms=False, grounding_extra_input=None,
+             grounding_input=None):
     """The sampling core of run() (reference gligen_inference.py:389-431) on already-encoded inputs."""
     # reference gligen_inference.py:385-390: DDIM (250 steps) with --no_plms, else PLMS (50 steps)
     sampler_cls = DDIMSampler if no_plms else PLMSSampler
@@ -279,18 +346,19 @@ def generate(model, autoencoder, diffusion, batch, context, uc, *, steps=50, gui
     inpainting_extra_input = None
     if inpainting_mask is not None:
         inpainting_extra_input = torch.cat([z0 * inpainting_mask, inpainting_mask], dim=1)
-    grounding_input = model.grounding_tokenizer_input.prepare(batch)
+    if grounding_input is None:
+        grounding_input = model.grounding_tokenizer_input.prepare(batch)
     input = dict(x=starting_noise, timesteps=None, context=context, grounding_input=grounding_input,
-                 inpainting_extra_input=inpainting_extra_input, grounding_extra_input=None)
+                 inpainting_extra_input=inpainting_extra_input, grounding_extra_input=grounding_extra_input)
     B = context.shape[0]
     shape = (B, model.in_channels, model.image_size, model.image_size)
     latents = sampler.sample(S=steps, shape=shape, input=input, uc=uc, guidance_scale=guidance_scale, mask=inpainting_mask, x0=z0)
     return autoencoder.decode(latents)
 
 
-def save_images(samples, output_folder):
+def save_images(samples, output_folder, first_id=None):
     os.makedirs(output_folder, exist_ok=True)
-    start = len(os.listdir(output_folder))
+    start = len(os.listdir(output_folder)) if first_id is None else first_id
     ids = list(range(start, start + samples.shape[0]))
     print(ids)
     for image_id, sample in zip(ids, samples):
@@ -300,23 +368,44 @@ def save_images(samples, output_folder):
 
 
 @torch.no_grad()
+def _shard(t, lo, hi):
+    return t[lo:hi] if torch.is_tensor(t) else t
+
+
+@torch.no_grad()
 def run(meta, config, starting_noise=None, models=None):
-    """config: argparse namespace / dict with batch_size, guidance_scale, negative_prompt, no_plms, folder."""
+    """config: argparse namespace / dict with batch_size, guidance_scale, negative_prompt, no_plms, folder (+ optional
+    steps, seed). Under torch.distributed (WORLD_SIZE > 1) batch_size is the GLOBAL batch: every rank samples its
+    contiguous slice (gligen_amd.dist.shard_range) with replicated weights and writes its own images."""
+    from gligen_amd import dist as gdist
     args = dict(config) if isinstance(config, dict) else vars(config)
     if models is None:
         model, autoencoder, text_encoder, diffusion, ckpt_config = load_ckpt(meta["ckpt"])
     else:
         model, autoencoder, text_encoder, diffusion, ckpt_config = models
     model.grounding_tokenizer_input = instantiate_from_config(ckpt_config["grounding_tokenizer_input"])
+    grounding_downsampler_input = None
     if "grounding_downsampler_input" in ckpt_config:
-        raise NotImplementedError("spatial-map checkpoints (hed/canny/depth/normal/sem) are outside the MI355X hot path")
+        grounding_downsampler_input = instantiate_from_config(ckpt_config["grounding_downsampler_input"])
     B = args["batch_size"]
-    batch = prepare_batch_kp(meta, B) if "keypoint" in meta["ckpt"] else prepare_batch(meta, B)
+    rank, _, world = gdist.env_world()
+    lo, hi = gdist.shard_range(B, rank, world)
+    prepare = next((fn for key, fn in _PREPARE_BY_NAME if key in meta["ckpt"]), prepare_batch)
+    batch = {k: _shard(v, lo, hi) for k, v in prepare(meta, B).items()}
+    if "grounding_tokens" in meta:   # spatial-map modalities: ConvNeXt tokens computed elsewhere (like precomputed CLIP features)
+        batch["tokens"] = _shard(meta["grounding_tokens"].to(device), lo, hi)
     if "context" in meta:  # precomputed CLIP last_hidden_state (B,77,768)
-        context, uc = meta["context"].to(device), meta["uc"].to(device)
+        context, uc = meta["context"].to(device)[lo:hi], meta["uc"].to(device)[lo:hi]
     else:
-        context = text_encoder.encode([meta["prompt"]] * B)
-        uc = text_encoder.encode(B * [args.get("negative_prompt") or ""])
+        context = text_encoder.encode([meta["prompt"]] * (hi - lo))
+        uc = text_encoder.encode((hi - lo) * [args.get("negative_prompt") or ""])
+    if world > 1 or args.get("seed") is not None:
+        # one seeded draw for the whole batch, sliced: an N-GPU run reproduces the 1-GPU images
+        if starting_noise is None:
+            gen = torch.Generator().manual_seed(int(args.get("seed") or 0))
+            starting_noise = torch.randn((B, model.in_channels, model.image_size, model.image_size), generator=gen)
+    if starting_noise is not None:
+        starting_noise = starting_noise.to(device)[lo:hi] if starting_noise.shape[0] == B else starting_noise.to(device)
     mask = z0 = None
     if "input_image" in meta:
         assert ckpt_config.get("inpaint_mode"), "input_image is given, the ckpt must be the inpaint model, are you using the correct ckpt?"
@@ -326,10 +415,27 @@ def run(meta, config, starting_noise=None, models=None):
         else:
             img = torch.from_numpy(np.asarray(Image.open(meta["input_image"]).convert("RGB").resize((512, 512)))).permute(2, 0, 1)
             z0 = autoencoder.encode((img.float().unsqueeze(0).to(device) / 255 - 0.5) / 0.5)
+    grounding_extra_input = None
+    if grounding_downsampler_input is not None:
+        grounding_extra_input = grounding_downsampler_input.prepare(batch)
+    grounding_input = None
+    if "tokens" in batch:
+        model.grounding_tokenizer_input.prepare(batch)   # remembers the shapes its null input needs
+        grounding_input = {"tokens": batch["tokens"]}
     no_plms = bool(args.get("no_plms"))
-    samples = generate(model, autoencoder, diffusion, batch, context, uc, steps=250 if no_plms else 50, guidance_scale=args["guidance_scale"],
-                       alpha_type=meta.get("alpha_type"), starting_noise=starting_noise, inpainting_mask=mask, z0=z0, no_plms=no_plms)
-    save_images(samples, os.path.join(args["folder"], meta["save_folder_name"]))
+    steps = int(args.get("steps") or (250 if no_plms else 50))
+    samples = generate(model, autoencoder, diffusion, batch, context, uc, steps=steps, guidance_scale=args["guidance_scale"],
+                       alpha_type=meta.get("alpha_type"), starting_noise=starting_noise, inpainting_mask=mask, z0=z0, no_plms=no_plms,
+                       grounding_extra_input=grounding_extra_input, grounding_input=grounding_input)
+    folder = os.path.join(args["folder"], meta["save_folder_name"])
+    if world > 1:
+        os.makedirs(folder, exist_ok=True)
+        gdist.barrier()
+        start = len(os.listdir(folder))     # every rank counts before any rank writes
+        gdist.barrier()
+        save_images(samples, folder, first_id=start + lo)
+    else:
+        save_images(samples, folder)
     return samples
 
 
@@ -349,25 +455,81 @@ def _synthetic_meta(kind, B):
     return meta
 
 
-if __name__ == "__main__":
+# The reference's demo prompts (gligen_inference.py:466-637), same fields; checkpoints are looked up where the reference
+# expects them (../gligen_checkpoints/...). The spatial-map entries additionally need ConvNeXt grounding tokens.
+KEYPOINTS_COCO_18150 = [
+    [[0.7598, 0.2542], [0.7431, 0.2104], [0.8118, 0.2021], [0.0, 0.0], [0.9514, 0.1813], [0.7806, 0.2917], [0.0, 0.0], [0.6785, 0.5125],
+     [0.0, 0.0], [0.5389, 0.6479], [0.6785, 0.6750], [0.7973, 0.7042], [0.0, 0.0], [0.6181, 0.7375], [0.9764, 0.8458], [0.0, 0.0], [0.0, 0.0]],
+    [[0.2681, 0.4313], [0.2514, 0.3979], [0.0, 0.0], [0.0785, 0.3854], [0.0, 0.0], [0.0910, 0.5583], [0.0, 0.0], [0.1243, 0.8479],
+     [0.0, 0.0], [0.0, 0.0], [0.0, 0.0], [0.0, 0.0], [0.0, 0.0], [0.2410, 0.8146], [0.1202, 0.6146], [0.0, 0.0], [0.2743, 0.7188]],
+]
+CKPT_DIR = "../gligen_checkpoints"
+meta_list = [
+    dict(ckpt=f"{CKPT_DIR}/checkpoint_generation_text.pth", prompt="a teddy bear sitting next to a bird", phrases=["a teddy bear", "a bird"],
+         locations=[[0.0, 0.09, 0.33, 0.76], [0.55, 0.11, 1.0, 0.8]], alpha_type=[0.3, 0.0, 0.7], save_folder_name="generation_box_text"),
+    dict(ckpt=f"{CKPT_DIR}/checkpoint_inpainting_text.pth", input_image="inference_images/dalle2_museum.jpg", prompt="a corgi and a cake",
+         phrases=["corgi", "cake"], locations=[[0.25, 0.28, 0.42, 0.52], [0.14, 0.58, 0.58, 0.92]], save_folder_name="inpainting_box_text"),
+    dict(ckpt=f"{CKPT_DIR}/checkpoint_generation_text_image.pth", prompt="an alarm clock sitting on the beach", images=["inference_images/clock.png"],
+         phrases=["alarm clock"], locations=[[0.0, 0.09, 0.53, 0.76]], alpha_type=[1.0, 0.0, 0.0], save_folder_name="generation_box_image"),
+    dict(ckpt=f"{CKPT_DIR}/checkpoint_generation_text_image.pth", prompt="a brick house in the woods, anime, oil painting",
+         phrases=["a brick house", "placehoder"], images=["inference_images/placeholder.png", "inference_images/style_golden.jpg"],
+         locations=[[0.4, 0.2, 1.0, 0.8], [0.0, 1.0, 0.0, 1.0]], alpha_type=[1, 0, 0], text_mask=[1, 0], image_mask=[0, 1],
+         save_folder_name="generation_box_text_style"),
+    dict(ckpt=f"{CKPT_DIR}/checkpoint_inpainting_text_image.pth", input_image="inference_images/beach.jpg", prompt="a bigben on the beach",
+         images=["inference_images/bigben.jpg"], locations=[[0.18, 0.08, 0.62, 0.75]], save_folder_name="inpainting_box_image"),
+    dict(ckpt=f"{CKPT_DIR}/checkpoint_generation_hed.pth", prompt="a man is eating breakfast", hed_image="inference_images/hed_man_eat.png",
+         save_folder_name="hed", alpha_type=[0.9, 0, 0.1]),
+    dict(ckpt=f"{CKPT_DIR}/checkpoint_generation_canny.pth", prompt="A Humanoid Robot Designed for Companionship",
+         canny_image="inference_images/canny_robot.png", alpha_type=[0.9, 0, 0.1], save_folder_name="canny"),
+    dict(ckpt=f"{CKPT_DIR}/checkpoint_generation_normal.pth", prompt="a large tree with no leaves in front of a building",
+         normal="inference_images/normal_tree_building.jpg", alpha_type=[0.7, 0, 0.3], save_folder_name="normal"),
+    dict(ckpt=f"{CKPT_DIR}/checkpoint_generation_depth.pth", prompt="a Vibrant colorful Bird Sitting on Tree Branch",
+         depth="inference_images/depth_bird.png", alpha_type=[0.7, 0, 0.3], save_folder_name="depth"),
+    dict(ckpt=f"{CKPT_DIR}/checkpoint_generation_sem.pth", prompt="a living room filled with lots of furniture and plants",
+         sem="inference_images/sem_ade_living_room.png", alpha_type=[0.7, 0, 0.3], save_folder_name="sem"),
+    dict(ckpt=f"{CKPT_DIR}/checkpoint_generation_keypoint.pth", prompt="A young man and a small boy are talking", locations=KEYPOINTS_COCO_18150,
+         alpha_type=[0.3, 0.0, 0.7], save_folder_name="keypoint"),
+]
+
+
+def main(argv=None):
     parser = argparse.ArgumentParser()
     parser.add_argument("--folder", type=str, default="generation_samples", help="root folder for output")
-    parser.add_argument("--batch_size", type=int, default=5, help="")
+    parser.add_argument("--batch_size", type=int, default=5, help="images per prompt (the GLOBAL batch under torch.distributed.run)")
     parser.add_argument("--no_plms", action="store_true", help="use DDIM instead. WARNING: I did not test the code yet")
     parser.add_argument("--guidance_scale", type=float, default=7.5, help="")
     parser.add_argument("--negative_prompt", type=str,
                         default="longbody, lowres, bad anatomy, bad hands, missing fingers, extra digit, fewer digits, cropped, worst quality, low quality", help="")
     parser.add_argument("--synthetic", type=str, default=None, choices=["text", "text_image", "keypoint"],
                         help="run with seeded random weights and features (no checkpoint / CLIP needed)")
-    parser.add_argument("--ckpt", type=str, default=None, help="GLIGEN checkpoint (diffusion_pytorch_model.bin)")
-    args = parser.parse_args()
+    parser.add_argument("--inpaint", action="store_true", help="with --synthetic text: the inpainting model (9-channel first conv, encode + blend)")
+    parser.add_argument("--ckpt", type=str, default=None, help="run only the meta_list entries whose checkpoint path contains this string")
+    parser.add_argument("--seed", type=int, default=None, help="seed of x_T (one draw for the whole batch, sliced across ranks)")
+    parser.add_argument("--steps", type=int, default=None, help="override the sampler's step count (reference: 50 PLMS / 250 DDIM)")
+    args = parser.parse_args(argv)
+
+    # one process per GPU: `python -m torch.distributed.run --nproc-per-node N gligen_inference.py ...` shards --batch_size
+    from gligen_amd import dist as gdist
+    global device
+    rank, local_rank, world = gdist.init_from_env()
+    if world > 1:
+        device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(device)
+        if args.seed is None:
+            args.seed = 0
     if args.synthetic:
-        model, autoencoder, diffusion, cfg = load_synthetic(args.synthetic)
-        run(_synthetic_meta(args.synthetic, args.batch_size), args, models=(model, autoencoder, None, diffusion, cfg))
+        model, autoencoder, diffusion, cfg = load_synthetic(args.synthetic, inpaint=args.inpaint)
+        meta = _synthetic_meta(args.synthetic, args.batch_size)
+        if args.inpaint:
+            from gligen_amd import synthetic as syn
+            meta.update(input_image="synthetic", z0=autoencoder.encode(torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(8)).to(device) * 2 - 1))
+        run(meta, args, models=(model, autoencoder, None, diffusion, cfg))
     else:
-        if not args.ckpt:
-            parser.error("--ckpt or --synthetic is required (the reference's demo meta_list needs downloaded checkpoints)")
-        meta = dict(ckpt=args.ckpt, prompt="a teddy bear sitting next to a bird", phrases=["a teddy bear", "a bird"],
-                    locations=[[0.0, 0.09, 0.33, 0.76], [0.55, 0.11, 1.0, 0.8]], alpha_type=[0.3, 0.0, 0.7],
-                    save_folder_name="generation_box_text")
-        run(meta, args)
+        for meta in meta_list:   # the reference runs every entry (gligen_inference.py:640-642)
+            if args.ckpt is None or args.ckpt in meta["ckpt"]:
+                run(meta, args)
+    gdist.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,6 @@
+"""depth map as the UNet's grounding_extra_input (reference grounding_input/depth_grounding_downsampler_input.py)."""
+
+
+class GroundingDSInput:
+    def prepare(self, batch):
+        return batch["depth"]

@@ -1,0 +1,6 @@
+"""depth map grounding input (reference grounding_input/depth_grounding_tokinzer_input.py)."""
+from grounding_input._base import _SpatialNetInputBase
+
+
+class GroundingNetInput(_SpatialNetInputBase):
+    image_key = "depth"

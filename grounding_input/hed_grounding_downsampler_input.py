@@ -1,0 +1,6 @@
+"""hed map as the UNet's grounding_extra_input (reference grounding_input/hed_grounding_downsampler_input.py)."""
+
+
+class GroundingDSInput:
+    def prepare(self, batch):
+        return batch["hed_edge"]

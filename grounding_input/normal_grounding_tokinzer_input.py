@@ -1,0 +1,6 @@
+"""normal map grounding input (reference grounding_input/normal_grounding_tokinzer_input.py)."""
+from grounding_input._base import _SpatialNetInputBase
+
+
+class GroundingNetInput(_SpatialNetInputBase):
+    image_key = "normal"

@@ -1,0 +1,6 @@
+"""sem map as the UNet's grounding_extra_input (reference grounding_input/sem_grounding_downsampler_input.py)."""
+
+
+class GroundingDSInput:
+    def prepare(self, batch):
+        return batch["sem"]

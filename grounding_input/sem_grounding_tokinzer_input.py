@@ -1,0 +1,6 @@
+"""sem map grounding input (reference grounding_input/sem_grounding_tokinzer_input.py)."""
+from grounding_input._base import _SpatialNetInputBase
+
+
+class GroundingNetInput(_SpatialNetInputBase):
+    image_key = "sem"

@@ -37,12 +37,15 @@ typedef struct gl_unet_config {
     int n_attn;
     int attention_resolutions[8];
     int inpaint_mode;     /* 9-channel first conv (openaimodel.py:299-302) */
-    int grounding_kind;   /* 0 text (text_grounding_net.py), 1 text+image, 2 keypoint */
+    int grounding_kind;   /* 0 text (text_grounding_net.py), 1 text+image, 2 keypoint, 3 precomputed tokens (the spatial-map
+                             tokenizers canny/hed/depth/normal/sem_grounding_net.py: ConvNeXt features computed by the caller) */
     int gr_in_dim;        /* PositionNet in_dim (768) */
     int gr_out_dim;       /* PositionNet out_dim (768) */
     int max_persons;      /* keypoint only */
     int fuser_kind;       /* BasicTransformerBlock fuser (attention.py:312-322): 0 gatedSA (every shipped discrete-token
                              config), 1 gatedSA2 (square grounding-token grid, bicubic resize), 2 gatedCA */
+    int extra_channels;   /* additional_channel_from_downsampler (openaimodel.py:288-305): the first conv takes
+                             in_channels + extra_channels inputs; the extra ones are the GroundingDownsampler output */
 } gl_unet_config;
 
 /* AutoencoderKL ddconfig (reference ldm/modules/diffusionmodules/model.py:462-533). */
@@ -65,6 +68,7 @@ typedef struct gl_grounding {
     const float* text_embeddings;  /* [Beff][n][in_dim] (kind 0: positive_embeddings) */
     const float* image_embeddings; /* [Beff][n][in_dim]                  (kind 1) */
     const float* points;         /* [Beff][n][2]                         (kind 2) */
+    const float* tokens;         /* [Beff][n][out_dim] grounding tokens  (kind 3) */
 } gl_grounding;
 
 /* One PLMS run (reference ldm/models/diffusion/plms.py:65-162): schedule arrays are host
@@ -80,14 +84,18 @@ typedef struct gl_plms_args {
     float guidance_scale;
     float* x;                    /* device fp32 [B][C][h][w]: x_T in, x_0 out */
     const float* inpaint_extra;  /* device fp32 [B][C+1][h][w] or NULL (gligen_inference.py:406-407) */
-    const float* mask;           /* device fp32 [B][1][h][w] or NULL     (plms.py:96-100) */
-    const float* x0;             /* device fp32 [B][C][h][w] or NULL */
-    const float* noise;          /* device fp32 [n_steps][B][C][h][w] q_sample noise, required with mask */
+    const float* mask;           /* device fp32 [mask_B][1][h][w] or NULL     (plms.py:96-100) */
+    const float* x0;             /* device fp32 [x0_B][C][h][w] or NULL */
+    const float* noise;          /* device fp32 [n_steps][noise_B][C][h][w] q_sample noise, required with mask */
+    int mask_B, x0_B, noise_B;   /* batch of mask / x0 / noise: B, or 1 = broadcast over the latent batch, as the reference's
+                                    q_sample(x0, ts) * mask does for the single encoded input image of run()
+                                    (gligen_inference.py:396-407). 0 means B. Anything else is rejected. */
     const float* sqrt_ac;        /* host [n_steps]: sqrt_alphas_cumprod[t] (ldm.py:19-22) */
     const float* sqrt_1mac;      /* host [n_steps] */
     int use_graph;               /* capture one UNet evaluation in a hipGraph and replay it */
-    const float* sd_conv_w;      /* device fp32 [mc][C][3][3] + [mc]: SD first-conv weights swapped in at the */
-    const float* sd_conv_b;      /*   first step whose fuser_scale is 0 (plms.py:88-89), or NULL */
+    const float* sd_conv_w;      /* device fp32 [mc][C][3][3] + [mc]: SD first-conv weights swapped in before step */
+    const float* sd_conv_b;      /*   sd_conv_step, the first step whose alpha is 0 (plms.py:88-89), or NULL */
+    int sd_conv_step;
     int ddim;                    /* 0: PLMS (Adams-Bashforth multistep, plms.py:111-162). 1: DDIMSampler with eta = 0
                                     (reference ldm/models/diffusion/ddim.py:65-134): one evaluation per step,
                                     x_prev = sqrt(a_prev) pred_x0 + sqrt(1 - a_prev) e_t */
@@ -108,13 +116,18 @@ int gl_finalize(gl_ctx* ctx);
 /* Step-invariant part of UNetModel.forward: position_net(**grounding_input) (openaimodel.py:433),
  * fuser.linear(objs) (attention.py:239) and attn2.to_k/to_v(context) (attention.py:130-131). */
 int gl_unet_set_cond(gl_ctx* ctx, int Beff, const float* context, int n_ctx_tokens, const gl_grounding* g, gl_stream s);
+/* objs = position_net(**grounding_input) (openaimodel.py:433) of the current conditioning: out fp32 [Beff][Ng][gr_out_dim]
+ * (Ng = 2n for the text+image tokenizer). Parity aid: the reference exposes the same tensor as model.position_net(...). */
+int gl_unet_grounding_tokens(gl_ctx* ctx, float* out, gl_stream s);
 /* set_alpha_scale(model, alpha) (gligen_inference.py:24-28) */
 int gl_unet_set_fuser_scale(gl_ctx* ctx, float scale, gl_stream s);
 /* UNetModel.restore_first_conv_from_SD (openaimodel.py:400-413): replace the first conv's weights
  * (OIHW fp32 [mc][in_channels][3][3], bias [mc]); stream-ordered, valid under hipGraph replay. */
 int gl_unet_restore_first_conv(gl_ctx* ctx, const float* w, const float* b, gl_stream s);
 /* UNetModel.forward (openaimodel.py:420-464): x [xB][C][h][w] (sample b reads x[b % xB]),
- * timesteps int64 [Beff], inpaint_extra [extraB][C+1][h][w] or NULL, eps_out [Beff][out_ch][h][w]. */
+ * timesteps int64 [Beff], eps_out [Beff][out_ch][h][w]. inpaint_extra = the channels concatenated to x in front of the
+ * first conv (openaimodel.py:442-447): inpainting_extra_input [extraB][C+1][h][w] for inpaint_mode, the GroundingDownsampler
+ * output [extraB][extra_channels][h][w] (gl_op_grounding_downsample) for the spatial-map modalities, else NULL. */
 int gl_unet_forward(gl_ctx* ctx, int Beff, int h, int w, const float* x, int xB, const int64_t* timesteps,
                     const float* inpaint_extra, int extraB, float* eps_out, gl_stream s);
 /* AutoencoderKL.decode (autoencoder.py:40-44): z [B][zc][h][w] -> img [B][out_ch][8h][8w] */
@@ -147,6 +160,14 @@ int gl_unet_profile(gl_ctx* ctx, int Beff, int h, int w, const float* x, int xB,
 
 int gl_arena_high_water(gl_ctx* ctx, size_t* bytes);
 int gl_launch_count(gl_ctx* ctx, int64_t* n);
+
+/* GroundingDownsampler.forward of the spatial-map modalities (reference canny_/depth_/normal_/sem_/hed_grounding_downsampler.py):
+ * img fp32 [B][Cimg][H][W] -> first n_in channels resized to R x R (mode 0 bicubic, 1 nearest, as F.interpolate) ->
+ * Conv2d(n_in, c_mid, 4, 2, 1) -> SiLU -> Conv2d(c_mid, c_out, 4, 2, 1) -> out fp32 [B][c_out][R/4][R/4].
+ * w1 = NULL: no layers (hed: the resized map itself, out [B][n_in][R][R]). Step-invariant: once per prompt. */
+int gl_op_grounding_downsample(gl_ctx* ctx, const float* img, int B, int Cimg, int H, int W, int n_in, int R, int mode,
+                               const float* w1, const float* b1, int c_mid, const float* w2, const float* b2, int c_out,
+                               float* out, gl_stream s);
 
 /* ---- single-operator entry points (parity tests and per-kernel profiling) -------------- */
 /* y = act(x W^T + b) [+ res]; x [M][K] bf16, W [N][K] bf16, b fp32|NULL, res bf16|NULL,

@@ -85,23 +85,43 @@ class PLMSSampler(object):
             g = model.grounding_tokenizer_input.get_null_input()
         if cfg:
             g_null = model.grounding_tokenizer_input.get_null_input()
+            if model.engine.unet_cfg["grounding_kind"] == "tokens":  # spatial-map tokenizers: concatenate their outputs
+                g, g_null = {"tokens": model.position_net.tokens(**g)}, {"tokens": model.position_net.tokens(**g_null)}
             ctx2 = torch.cat([context, uc.to(context)], dim=0)
             g2 = {k: torch.cat([g[k], g_null[k].to(g[k])], dim=0) for k in g}
         else:
             ctx2, g2 = context, g
         model.set_conditioning(ctx2, g2)
-        if alphas is None:
+        # The reference's set_alpha_scale matches GatedSelfAttentionDense / GatedCrossAttentionDense by exact type
+        # (gligen_inference.py:24-28): a gatedSA2 model keeps scale = 1 on every step, whatever the alpha schedule says.
+        # The schedule still decides when the SD first conv is swapped in (plms.py:88-89).
+        scales = alphas
+        if alphas is None or model.fuser_type == "gatedSA2":
             model.engine.set_fuser_scale(model.fuser_scale())
+            scales = None
 
         img = input["x"].to(device=model.engine.device, dtype=torch.float32).contiguous().clone()
         a_t = _np(self.ddim_alphas).astype(np.float32)[::-1].copy()          # index = S - i - 1
         a_prev = _np(self.ddim_alphas_prev).astype(np.float32)[::-1].copy()
         extra = {}
+        # Device-generator draws, call for call as the reference makes them, so that equal seeds give equal noise:
+        # per step one randn_like(x0) inside q_sample when inpainting (plms.py:96-99 -> ldm.py:19-22), then the
+        # sigma_t * randn_like(x) of get_x_prev_and_pred_x0 (plms.py:138; sigma is 0, the draw still advances the
+        # generator) -- twice on the first PLMS step (plms.py:144,159), once otherwise and for DDIM (ddim.py:131).
+        noise = []
         if mask is not None:
             assert x0 is not None
-            # the reference draws randn_like(x0) inside q_sample at every step (plms.py:98); here all
-            # S draws come from the same default device generator, up front
-            extra = dict(mask=mask, x0=x0, noise=torch.randn((S, *x0.shape), device=img.device, dtype=torch.float32),
+            x0 = x0.to(device=img.device, dtype=torch.float32)
+            mask = mask.to(device=img.device, dtype=torch.float32)
+        for i in range(S):
+            if mask is not None:
+                noise.append(torch.randn_like(x0))
+            for _ in range(2 if (i == 0 and self.multistep) else 1):
+                torch.randn_like(img)
+        if mask is not None:
+            if tuple(mask.shape[1:]) != (1, *img.shape[2:]) or tuple(x0.shape[1:]) != tuple(img.shape[1:]):
+                raise ValueError(f"inpainting: mask {tuple(mask.shape)} / x0 {tuple(x0.shape)} do not match the latent {tuple(img.shape)}")
+            extra = dict(mask=mask, x0=x0, noise=torch.stack(noise),
                          sqrt_ac=self.diffusion.sqrt_alphas_cumprod.cpu().numpy()[time_range],
                          sqrt_1mac=self.diffusion.sqrt_one_minus_alphas_cumprod.cpu().numpy()[time_range])
         gate_off = alphas is not None and bool((alphas == 0).any())
@@ -110,9 +130,10 @@ class PLMSSampler(object):
         sd_conv = None
         if gate_off and model.first_conv_restorable and not model.__dict__.get("_first_conv_restored"):
             sd_conv = model.load_sd_first_conv()  # swapped in on the device at the first gated-off step
-        model.engine.sample_plms(img, time_range, a_t, a_prev, alphas, guidance_scale if cfg else 1.0,
+        restore_at = int(np.argmax(alphas == 0)) if sd_conv is not None else -1
+        model.engine.sample_plms(img, time_range, a_t, a_prev, scales, guidance_scale if cfg else 1.0,
                                  inpaint_extra=input.get("inpainting_extra_input"), use_graph=self.use_graph,
-                                 sd_first_conv=sd_conv, ddim=not self.multistep, **extra)
+                                 sd_first_conv=sd_conv, restore_at=restore_at, ddim=not self.multistep, **extra)
         if sd_conv is not None:
             model.restore_first_conv_from_SD()  # bring the module parameters in line with the engine
         if alphas is not None and self.set_alpha_scale is not None:

@@ -75,21 +75,28 @@ class UNetModel(nn.Module):
                  grounding_downsampler=None, grounding_tokenizer=None):
         super().__init__()
         assert fuser_type in ["gatedSA", "gatedSA2", "gatedCA"]
-        if grounding_downsampler is not None:
-            raise NotImplementedError("spatial grounding downsamplers (canny/hed/depth/normal/sem) are outside the MI355X hot path")
         self.image_size, self.in_channels, self.model_channels, self.out_channels = image_size, in_channels, model_channels, out_channels
         self.num_res_blocks, self.attention_resolutions, self.dropout = num_res_blocks, attention_resolutions, dropout
         self.channel_mult, self.conv_resample, self.use_checkpoint = channel_mult, conv_resample, use_checkpoint
         self.num_heads, self.context_dim, self.fuser_type, self.inpaint_mode = num_heads, context_dim, fuser_type, inpaint_mode
         self.grounding_tokenizer_input = None  # set externally (gligen_inference.py:348-349)
+        # spatial-map modalities: the downsampled conditioning map enters as extra first-conv channels (reference
+        # openaimodel.py:288-305); "GLIGEN" = the 4 + k channel conv is in place, "SD" = it was swapped for the SD one
         self.downsample_net = None
         self.additional_channel_from_downsampler = 0
         self.first_conv_type = "SD"
         self.first_conv_restorable = not inpaint_mode
+        if grounding_downsampler is not None:
+            if inpaint_mode:
+                raise NotImplementedError("inpaint_mode with a grounding downsampler is a TODO breakpoint in the reference (openaimodel.py:446-447)")
+            self.downsample_net = instantiate_from_config(grounding_downsampler)
+            self.additional_channel_from_downsampler = self.downsample_net.out_dim
+            self.first_conv_type = "GLIGEN"
 
         mc, ted = model_channels, model_channels * 4
         self.time_embed = _slots(3, i0=linear(mc, ted), i2=linear(ted, ted))
-        in_c = in_channels * 2 + 1 if inpaint_mode else in_channels  # latent | masked latent | mask
+        # latent (| downsampled grounding map) | masked latent | mask
+        in_c = in_channels * 2 + 1 if inpaint_mode else in_channels + self.additional_channel_from_downsampler
         self.input_blocks = nn.ModuleList([TimestepEmbedSequential(conv_nd(dims, in_c, mc, 3, padding=1))])
 
         def res(cin, cout):
@@ -130,6 +137,8 @@ class UNetModel(nn.Module):
 
         self._engine = None
         self._cond_key = None
+        self._cond_held = None
+        self._ds_cache = None
 
     # ---- engine lifecycle ---------------------------------------------------------------
     def _apply(self, fn, *a, **k):  # .to()/.cuda()/.float(): parameters move, the packed copy is stale
@@ -146,6 +155,8 @@ class UNetModel(nn.Module):
             eng.close()
         self.__dict__["_engine"] = None
         self.__dict__["_cond_key"] = None
+        self.__dict__["_cond_held"] = None
+        self.__dict__["_ds_cache"] = None
         self.__dict__["_first_conv_restored"] = False
 
     @property
@@ -165,11 +176,33 @@ class UNetModel(nn.Module):
         return scales.pop()
 
     def set_conditioning(self, context, grounding_input):
-        """Step-invariant work (grounding tokens, fuser projections, text K/V); cached by tensor identity."""
+        """Step-invariant work (grounding tokens, fuser projections, text K/V), skipped when the very same tensors come
+        back unmodified. The cache entry HOLDS the tensors it fingerprinted: an address / version match can then only mean
+        "same live tensor, not written since" — a freed temporary whose block the allocator hands to the next prompt's
+        same-shaped tensor can no longer pass for it."""
         key = (_rt.tensor_fingerprint(context), _rt.mapping_fingerprint(grounding_input))
         if key != self._cond_key:
-            self.engine.set_cond(context, grounding_input)
-            self._cond_key = key
+            g = grounding_input
+            if self.engine.unet_cfg["grounding_kind"] == "tokens" and "tokens" not in g:
+                g = {"tokens": self.position_net.tokens(**g)}  # spatial-map tokenizer: once per prompt
+            self.engine.set_cond(context, g)
+            self.__dict__["_cond_key"] = key
+            self.__dict__["_cond_held"] = (context, dict(grounding_input))
+
+    def first_conv_extra(self, input):
+        """The downsampled grounding map concatenated to x in front of the first conv (reference openaimodel.py:442-444):
+        step-invariant, so computed once per distinct grounding_extra_input tensor. None for models without a downsampler.
+        (After the SD first conv was swapped in the engine's weights for these channels are zero; the map still has to be
+        bound because the packed first conv keeps its 4 + k layout.)"""
+        if self.downsample_net is None or self.engine.unet_cfg.get("extra_channels", 0) == 0:
+            return None
+        g = input.get("grounding_extra_input")
+        if g is None:
+            raise ValueError("this model has a grounding downsampler: input['grounding_extra_input'] is required")
+        key = _rt.tensor_fingerprint(g)
+        if self._ds_cache is None or self._ds_cache[0] != key:
+            self.__dict__["_ds_cache"] = (key, g, self.downsample_net(g, engine=self.engine))
+        return self._ds_cache[2]
 
     # ---- reference API ------------------------------------------------------------------
     SD_FIRST_CONV_FILE = "SD_input_conv_weight_bias.pth"  # cwd-relative, as in the reference
@@ -192,9 +225,18 @@ class UNetModel(nn.Module):
         w, b = self.load_sd_first_conv()
         conv = self.input_blocks[0][0]
         with torch.no_grad():
-            conv.weight.copy_(w.to(conv.weight))
-            conv.bias.copy_(b.to(conv.bias))
+            if conv.weight.shape == w.shape:
+                conv.weight.copy_(w.to(conv.weight))
+                conv.bias.copy_(b.to(conv.bias))
+            else:  # 4 + k channel GLIGEN conv: the reference builds a fresh 4-channel conv (openaimodel.py:407-409)
+                new = conv_nd(2, self.in_channels, self.model_channels, 3, padding=1).to(conv.weight)
+                new.weight.copy_(w.to(new.weight))
+                new.bias.copy_(b.to(new.bias))
+                self.GLIGEN_first_conv_state_dict = {k: v.clone() for k, v in conv.state_dict().items()}
+                self.input_blocks[0]._modules["0"] = new  # not through _apply: the packed engine copy stays valid
+                conv = new
         if self._engine is not None:
+            # the engine zeroes the weights of the k downsampler channels: same result as dropping the concat
             self._engine.restore_first_conv(conv.weight, conv.bias)
         self.first_conv_type = "SD"
         self.__dict__["_first_conv_restored"] = True
@@ -213,7 +255,7 @@ class UNetModel(nn.Module):
         eng = self.engine
         self.set_conditioning(input["context"], grounding_input)
         eng.set_fuser_scale(self.fuser_scale())
-        extra = input.get("inpainting_extra_input") if self.inpaint_mode else None
+        extra = input.get("inpainting_extra_input") if self.inpaint_mode else self.first_conv_extra(input)
         if self.inpaint_mode and extra is None:
             raise ValueError("inpaint_mode model needs input['inpainting_extra_input']")
         x = input["x"]

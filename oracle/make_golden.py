@@ -187,20 +187,21 @@ def plms_trace_case(name, S, alpha_type, sampler_cls=None):
     print(f"{name}: {len(mock.calls)} model calls, {mock.restores} first-conv restores")
 
 
-def plms_unet_case(name, S, hw, alpha_type, inpaint=False, sampler_cls=None):
+def plms_unet_case(name, S, hw, alpha_type, inpaint=False, sampler_cls=None, cfg=None, max_objs=30, B=2, x0_batch=None):
+    """x0_batch=1: one encoded input image broadcast over a larger latent batch, as gligen_inference.run() does
+    (reference gligen_inference.py:396-407 with the CLI's default batch_size 5)."""
     t0 = time.time()
     from functools import partial
     sampler_cls = sampler_cls or PLMSSampler
     diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000)
-    model = build_unet(syn.UNET_CFG_SMALL, "text", inpaint)
+    model = build_unet(cfg or syn.UNET_CFG_SMALL, "text", inpaint)
     # restore_first_conv_from_SD th.load()s a cwd-relative file: give it a seeded stand-in for the real
     # SD weights (same shapes), so the test can rebuild the identical file without /root/reference
     import tempfile
     tmp = tempfile.mkdtemp()
     torch.save(syn.sd_first_conv_state(), os.path.join(tmp, "SD_input_conv_weight_bias.pth"))
     os.chdir(tmp)
-    B = 2
-    batch = syn.make_batch("text", B, n_valid=3, seed=1)
+    batch = syn.make_batch("text", B, n_valid=3, seed=1, max_objs=max_objs)
     g = model.grounding_tokenizer_input.prepare(batch)
     x = syn.make_latent(B, 4, hw, hw, seed=6)
     ctx, uc = syn.make_context(B, seed=1), syn.make_context(B, seed=9)
@@ -208,9 +209,9 @@ def plms_unet_case(name, S, hw, alpha_type, inpaint=False, sampler_cls=None):
     noise = None
     if inpaint:
         mask = ref_draw_masks(batch["boxes"], hw)
-        z0 = syn.make_latent(B, 4, hw, hw, seed=2)
+        z0 = syn.make_latent(x0_batch or B, 4, hw, hw, seed=2)
         extra = torch.cat([z0 * mask, mask], dim=1)
-        noise = torch.randn(S, B, 4, hw, hw, generator=torch.Generator().manual_seed(77))
+        noise = torch.randn(S, x0_batch or B, 4, hw, hw, generator=torch.Generator().manual_seed(77))
         draws = iter(noise)
         diffusion_q = diffusion.q_sample
         diffusion.q_sample = lambda x_start, t, noise=None: diffusion_q(x_start, t, noise=next(draws))
@@ -220,8 +221,136 @@ def plms_unet_case(name, S, hw, alpha_type, inpaint=False, sampler_cls=None):
         out = sampler.sample(S=S, shape=tuple(x.shape), input=inp, uc=uc, guidance_scale=7.5, mask=mask, x0=z0)
     extra_out = {} if noise is None else dict(noise=noise.numpy())
     np.savez_compressed(os.path.join(OUT, name + ".npz"), x_out=out.numpy(), **extra_out,
-                        meta=json.dumps(dict(S=S, hw=hw, alpha_type=alpha_type, guidance_scale=7.5, B=B, inpaint=inpaint, n_valid=3)))
+                        meta=json.dumps(dict(S=S, hw=hw, alpha_type=alpha_type, guidance_scale=7.5, B=B, inpaint=inpaint, n_valid=3,
+                                             cfg=cfg or syn.UNET_CFG_SMALL, max_objs=max_objs, x0_batch=x0_batch or B)))
     print(f"{name}: x_out std {out.std():.4f} [{time.time() - t0:.1f}s]")
+
+
+def unet_pair_case(name, kind, B, hw, n_valid=8):
+    """The shipped topology at the benchmark's latent size: eps of the grounded batch and of the null-grounding / uc batch
+    (the two halves of the engine's [cond ; uncond] evaluation, reference plms.py:116-122)."""
+    t0 = time.time()
+    model = build_unet(syn.UNET_CFG, kind)
+    batch = syn.make_batch(kind, B, n_valid=n_valid, seed=3)
+    g = model.grounding_tokenizer_input.prepare(batch)
+    x = syn.make_latent(B, 4, hw, hw, seed=3)
+    ctx, uc = syn.make_context(B, seed=3), syn.make_context(B, seed=9)
+    t = torch.full((B,), 501, dtype=torch.long)
+    with torch.no_grad():
+        eps = model(dict(x=x, timesteps=t, context=ctx, grounding_input=g, inpainting_extra_input=None, grounding_extra_input=None)).numpy()
+        eps_u = model(dict(x=x, timesteps=t, context=uc, inpainting_extra_input=None, grounding_extra_input=None)).numpy()
+        objs = model.position_net(**g).numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), eps=eps.astype(np.float16), eps_uncond=eps_u.astype(np.float16), objs=objs.astype(np.float16),
+                        meta=json.dumps(dict(kind=kind, B=B, hw=hw, n_valid=n_valid, t=501, stored="float16")))
+    print(f"{name}: eps std {eps.std():.4f} cond-vs-uncond mse {((eps - eps_u) ** 2).mean():.3e} [{time.time() - t0:.1f}s]")
+
+
+def _timm_shim():
+    """The reference's convnext.py imports timm (absent here) for trunc_normal_ (init only), DropPath (identity at rate 0)
+    and the register_model decorator; none of them takes part in the forward that is recorded."""
+    import types
+    if "timm" in sys.modules:
+        return
+    timm, models, layers, registry = (types.ModuleType(n) for n in ("timm", "timm.models", "timm.models.layers", "timm.models.registry"))
+    layers.trunc_normal_ = torch.nn.init.trunc_normal_
+    layers.DropPath = torch.nn.Identity
+    registry.register_model = lambda f: f
+    timm.models, models.layers, models.registry = models, layers, registry
+    sys.modules.update({"timm": timm, "timm.models": models, "timm.models.layers": layers, "timm.models.registry": registry})
+
+
+SPATIAL_KEYS = dict(canny="canny_edge", hed="hed_edge", depth="depth", normal="normal", sem="sem")
+
+
+def spatial_case(name, modality, B=2, hw=16, res=128):
+    """A spatial-map modality end to end in the reference: GroundingDownsampler -> 4 + k channel first conv, ConvNeXt-tiny
+    tokenizer -> gatedSA fusers (configs/cc3m_canny.yaml etc. on the small UNet). The conditioning map is a seeded random
+    image at res x res (the modules resize it themselves)."""
+    t0 = time.time()
+    _timm_shim()
+    key = SPATIAL_KEYS[modality]
+    ds_params = dict(out_dim=1) if modality == "hed" else dict(resize_input=4 * hw, out_dim=8)
+    tk_params = dict(resize_input=128, out_dim=768)
+    if modality == "sem":
+        ds_params["in_dim"], tk_params["in_dim"] = 152, 152
+    cfg = dict(syn.UNET_CFG_SMALL,
+               grounding_downsampler=dict(target=f"ldm.modules.diffusionmodules.{modality}_grounding_downsampler.GroundingDownsampler", params=ds_params),
+               grounding_tokenizer=dict(target=f"ldm.modules.diffusionmodules.{modality}_grounding_net.PositionNet", params=tk_params))
+    import ldm.modules.diffusionmodules.convnext as cnx
+    real_hub = torch.hub.load_state_dict_from_url
+    torch.hub.load_state_dict_from_url = lambda *a, **k: {"model": {}}   # pretrained=True would download ImageNet weights
+    try:
+        model = UNetModel(**cfg).eval()
+    finally:
+        torch.hub.load_state_dict_from_url = real_hub
+    syn.fill_module_(model, 1234)
+    gin = instantiate_from_config(dict(target=f"grounding_input.{modality}_grounding_tokinzer_input.GroundingNetInput"))
+    dsin = instantiate_from_config(dict(target=f"grounding_input.{modality}_grounding_downsampler_input.GroundingDSInput"))
+    model.grounding_tokenizer_input = gin
+    img = syn.make_spatial_map(modality, B, res, seed=1)
+    batch = {key: img, "mask": torch.ones(B, 1)}
+    g = gin.prepare(batch)
+    extra = dsin.prepare(batch)
+    x, ctx = syn.make_latent(B, 4, hw, hw, seed=1), syn.make_context(B, seed=1)
+    t = torch.tensor([981, 441][:B], dtype=torch.long)
+    inp = dict(x=x, timesteps=t, context=ctx, grounding_input=g, inpainting_extra_input=None, grounding_extra_input=extra)
+    out = {}
+    with torch.no_grad():
+        out["eps"] = model(inp).numpy()
+        out["eps_null"] = model({k: v for k, v in inp.items() if k != "grounding_input"}).numpy()
+        out["objs"] = model.position_net(**g).numpy().astype(np.float16)
+        out["objs_null"] = model.position_net(**gin.get_null_input()).numpy().astype(np.float16)
+        out["ds"] = model.downsample_net(extra).numpy()
+    meta = dict(cfg=cfg, modality=modality, B=B, hw=hw, res=res, weight_seed=1234, n_keys=len(model.state_dict()))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), meta=json.dumps(meta), **out)
+    print(f"{name}: eps std {out['eps'].std():.4f}; cond-vs-null mse {((out['eps'] - out['eps_null']) ** 2).mean():.3e}; ds std {out['ds'].std():.4f} "
+          f"[{time.time() - t0:.1f}s]")
+    return {k: list(v.shape) for k, v in model.state_dict().items()}
+
+
+def c1_case(name="c1_end_to_end", S=20, hw=32):
+    """BASELINE config C1: box+text, 1 box, 256x256, 20 PLMS steps, CFG 7.5, B=1, fp32 on the CPU through the reference's
+    PLMSSampler + UNetModel + AutoencoderKL.decode (gligen_inference.py:343-446 with steps / image_size overridden), the first
+    meta_list entry's alpha schedule [0.3, 0, 0.7] (gligen_inference.py:469-476) incl. the SD first-conv swap."""
+    t0 = time.time()
+    from functools import partial
+    import tempfile
+    diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000)
+    model = build_unet(syn.UNET_CFG, "text")
+    ae = AutoencoderKL(ddconfig=syn.VAE_DDCONFIG, embed_dim=4, scale_factor=0.18215).eval()
+    syn.fill_module_(ae, 4321)
+    tmp = tempfile.mkdtemp()
+    torch.save(syn.sd_first_conv_state(), os.path.join(tmp, "SD_input_conv_weight_bias.pth"))
+    os.chdir(tmp)
+    batch = syn.make_batch("text", 1, n_valid=1, seed=1)
+    g = model.grounding_tokenizer_input.prepare(batch)
+    x = syn.make_latent(1, 4, hw, hw, seed=6)
+    ctx, uc = syn.make_context(1, seed=1), syn.make_context(1, seed=9)
+    alpha_type = [0.3, 0.0, 0.7]
+    sampler = PLMSSampler(diffusion, model, alpha_generator_func=partial(ref_alpha_generator, type=alpha_type), set_alpha_scale=set_alpha_scale)
+    inp = dict(x=x.clone(), timesteps=None, context=ctx, grounding_input=g, inpainting_extra_input=None, grounding_extra_input=None)
+    with torch.no_grad():
+        z = sampler.sample(S=S, shape=tuple(x.shape), input=inp, uc=uc, guidance_scale=7.5)
+        t_s = time.time() - t0
+        img = ae.decode(z)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), z=z.numpy(), img=img.numpy().astype(np.float16),
+                        meta=json.dumps(dict(S=S, hw=hw, alpha_type=alpha_type, guidance_scale=7.5, B=1, n_valid=1, img_stored="float16",
+                                             ref_cpu_seconds=round(time.time() - t0, 1), ref_sampler_seconds=round(t_s, 1),
+                                             cpu_threads=torch.get_num_threads())))
+    print(f"{name}: z std {z.std():.4f} img std {img.std():.4f} [{time.time() - t0:.1f}s]")
+
+
+def meta_list_case():
+    """The reference's demo prompt list (gligen_inference.py:466-637), parsed out of its __main__ block."""
+    tree = ast.parse(open(os.path.join(REF, "gligen_inference.py")).read())
+    found = None
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Assign) and any(isinstance(t, ast.Name) and t.id == "meta_list" for t in node.targets):
+            # a list of dict(...) calls over literals: evaluated with `dict` as the only visible name
+            found = eval(compile(ast.Expression(node.value), "meta_list", "eval"), {"__builtins__": {}, "dict": dict})
+    assert found
+    json.dump(found, open(os.path.join(OUT, "meta_list.json"), "w"), indent=1)
+    print(f"meta_list: {len(found)} entries")
 
 
 def misc_case():
@@ -263,6 +392,22 @@ CASES = {
     "vae_enc_small": lambda: vae_encode_case("vae_enc_small", syn.VAE_DDCONFIG_SMALL, 2, 64),
     "vae_enc_full": lambda: vae_encode_case("vae_enc_full", syn.VAE_DDCONFIG, 1, 64),
     "misc": misc_case,
+    "meta_list": meta_list_case,
+    # ---- round 2: the BASELINE configurations at their real sizes, sampler-level cases for the remaining code paths
+    "vae_enc_512": lambda: vae_encode_case("vae_enc_512", syn.VAE_DDCONFIG, 1, 512),
+    "plms50_unet_small": lambda: plms_unet_case("plms50_unet_small", 50, 16, [0.3, 0.0, 0.7]),
+    "plms_unet_small_gatedsa2": lambda: plms_unet_case("plms_unet_small_gatedsa2", 5, 16, [0.6, 0.0, 0.4],
+                                                       cfg=dict(syn.UNET_CFG_SMALL, fuser_type="gatedSA2"), max_objs=16),
+    "plms_unet_small_inpaint_x0b1": lambda: plms_unet_case("plms_unet_small_inpaint_x0b1", 4, 16, None, inpaint=True, B=3, x0_batch=1),
+    "unet_full_64_text": lambda: unet_pair_case("unet_full_64_text", "text", 4, 64),
+    "unet_full_64_text_image": lambda: unet_pair_case("unet_full_64_text_image", "text_image", 1, 64),
+    "unet_full_64_keypoint": lambda: unet_pair_case("unet_full_64_keypoint", "keypoint", 1, 64),
+    "c1_end_to_end": c1_case,
+    # spatial-map modalities
+    "unet_small_canny": lambda: spatial_case("unet_small_canny", "canny"),
+    "unet_small_hed": lambda: spatial_case("unet_small_hed", "hed", B=1, hw=64),  # the hed downsampler always resizes to 64 x 64
+    "unet_small_normal": lambda: spatial_case("unet_small_normal", "normal"),
+    "unet_small_sem": lambda: spatial_case("unet_small_sem", "sem"),
 }
 
 if __name__ == "__main__":

@@ -85,3 +85,22 @@ def mse(a, b):
     a = torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a).float().cpu()
     b = torch.as_tensor(np.asarray(b) if not torch.is_tensor(b) else b).float().cpu()
     return float(((a - b) ** 2).mean())
+
+
+def scripted_randn_like(noise, multistep=True):
+    """A stand-in for torch.randn_like that replays recorded q_sample draws in the call order of the reference's sampling
+    loop (plms.py:96-99 then the sigma_t * randn_like(x) of get_x_prev_and_pred_x0, twice on the first PLMS step):
+    noise[i] for the q_sample slot of step i, zeros for the sigma = 0 draws."""
+    state = dict(step=0, slot=0)
+
+    def fn(like, *a, **k):
+        i, slot = state["step"], state["slot"]
+        n_dummy = 2 if (i == 0 and multistep) else 1
+        out = noise[i].to(like) if slot == 0 else torch.zeros_like(like)
+        if slot == 0:
+            assert tuple(out.shape) == tuple(like.shape), (out.shape, like.shape)
+        state["slot"] += 1
+        if state["slot"] > n_dummy:
+            state["step"], state["slot"] = i + 1, 0
+        return out
+    return fn

@@ -1,0 +1,284 @@
+"""Parity on the BASELINE configurations at their real sizes and on the product entry points (MI355X).
+
+Goldens are outputs of the REAL reference (oracle/make_golden.py, run in the build container): the shipped topology at
+the benchmark's 64x64 latent for the three discrete tokenizers, the C1 end-to-end run (256x256, 20 PLMS steps, CFG,
+alpha schedule, decode), AutoencoderKL.encode at 512x512, the spatial-map modalities. Nothing here compares the HIP
+path with itself, except the "one model, two prompts" test whose reference is a fresh model.
+"""
+import json
+import os
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROOT, build_product_unet, build_product_vae, golden_shapes, load_golden, mse
+from gligen_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+EPS_MSE_TOL = 2e-4     # absolute, on eps with std ~0.3 (bar in BASELINE.json: 1e-3)
+REPORT = {}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _report():
+    yield
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_report_configs.json"), "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _to(d, dev):
+    return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items()}
+
+
+@pytest.fixture(scope="module")
+def full_models():
+    """The shipped topology, one engine per tokenizer kind, built once for this module (1.07 B parameters each)."""
+    cache = {}
+
+    def get(kind):
+        if kind not in cache:
+            cache[kind] = build_product_unet(syn.UNET_CFG, kind, device=_dev())
+        return cache[kind]
+    yield get
+    for m in cache.values():
+        m._drop_engine()
+
+
+@pytest.mark.parametrize("name", ["unet_full_64_text", "unet_full_64_text_image", "unet_full_64_keypoint"])
+def test_unet_full_size_pair_vs_reference(name, full_models):
+    """One [cond ; uncond] evaluation of the shipped UNet at the benchmark's latent size, exactly as the sampler issues it
+    (batch 2B = 8 for box+text: BASELINE C2; Ng = 60 for text+image: C3; Ng = 136 for keypoints: C5), both halves against
+    the reference's two forwards; the PositionNet output against the reference's too."""
+    dev = _dev()
+    g = load_golden(name)
+    meta = g["meta"]
+    kind, B, hw = meta["kind"], meta["B"], meta["hw"]
+    model = full_models(kind)
+    batch = syn.make_batch(kind, B, n_valid=meta["n_valid"], seed=3)
+    gin = model.grounding_tokenizer_input.prepare(_to(batch, dev))
+    g_null = model.grounding_tokenizer_input.get_null_input()
+    x = syn.make_latent(B, 4, hw, hw, seed=3).to(dev)
+    ctx, uc = syn.make_context(B, seed=3).to(dev), syn.make_context(B, seed=9).to(dev)
+    t = torch.full((2 * B,), meta["t"], device=dev, dtype=torch.long)
+    ctx2 = torch.cat([ctx, uc])
+    g2 = {k: torch.cat([gin[k], g_null[k].to(gin[k])]) for k in gin}
+    model.set_conditioning(ctx2, g2)
+    model.engine.set_fuser_scale(1.0)
+    eps = model.engine.unet_forward(x, t, None, batch=2 * B)     # sample b reads x[b % B]
+    ref_c, ref_u = g["eps"].astype(np.float32), g["eps_uncond"].astype(np.float32)
+    r = dict(eps_cond=mse(eps[:B], ref_c), eps_uncond=mse(eps[B:], ref_u), eps_var=float(ref_c.var()))
+    d_ref = torch.from_numpy(ref_c - ref_u)
+    d_hip = (eps[:B] - eps[B:]).float().cpu()
+    r["guidance_direction_rel_err"] = float(((d_hip - d_ref) ** 2).mean() / (d_ref ** 2).mean())
+    objs = model.engine.grounding_tokens()[:B]
+    ref_objs = torch.from_numpy(g["objs"].astype(np.float32))
+    r["objs_rel_mse"] = mse(objs, ref_objs) / float(ref_objs.var())
+    REPORT[name] = r
+    assert eps.shape == (2 * B, 4, hw, hw)
+    assert r["eps_cond"] < EPS_MSE_TOL and r["eps_uncond"] < EPS_MSE_TOL, r
+    assert r["guidance_direction_rel_err"] < 0.02, r          # e_c - e_u is what CFG multiplies by 7.5
+    assert r["objs_rel_mse"] < 1e-3, r                         # three bf16 GEMMs of a 832 -> 512 -> 512 -> 768 MLP
+
+
+def test_c1_end_to_end_vs_reference(full_models, tmp_path, monkeypatch):
+    """BASELINE config C1 (256x256, 20 PLMS steps, 1 box, CFG 7.5, B=1) through gligen_inference.generate: final latent and
+    decoded image against the reference's own PLMSSampler + UNetModel + AutoencoderKL.decode run on the CPU."""
+    dev = _dev()
+    import gligen_inference as gi
+    from ldm.models.diffusion.ldm import LatentDiffusion
+    g = load_golden("c1_end_to_end")
+    meta = g["meta"]
+    hw, S = meta["hw"], meta["S"]
+    torch.save(syn.sd_first_conv_state(), tmp_path / "SD_input_conv_weight_bias.pth")
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(gi, "device", dev)
+    model = build_product_unet(dict(syn.UNET_CFG, image_size=hw), "text", device=dev)   # own instance: the first conv gets swapped
+    ae = build_product_vae(syn.VAE_DDCONFIG, device=dev)
+    diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000).to(dev)
+    batch = _to(syn.make_batch("text", 1, n_valid=1, seed=1), dev)
+    ctx, uc = syn.make_context(1, seed=1).to(dev), syn.make_context(1, seed=9).to(dev)
+    captured = {}
+    real_decode = type(ae).decode
+
+    def decode(self, z):
+        captured["z"] = z.clone()
+        return real_decode(self, z)
+    monkeypatch.setattr(type(ae), "decode", decode)
+    img = gi.generate(model, ae, diffusion, batch, ctx, uc, steps=S, guidance_scale=meta["guidance_scale"], alpha_type=meta["alpha_type"],
+                      starting_noise=syn.make_latent(1, 4, hw, hw, seed=6).to(dev))
+    z_ref, img_ref = g["z"], g["img"].astype(np.float32)
+    r = dict(z_rel_mse=mse(captured["z"], z_ref) / float(z_ref.var()), z_std=float(z_ref.std()),
+             img_mse=mse(img, img_ref), img_var=float(img_ref.var()), ref_cpu_seconds=meta["ref_cpu_seconds"])
+    r["img_rel_mse"] = r["img_mse"] / r["img_var"]
+    REPORT["c1_end_to_end"] = r
+    assert img.shape == tuple(img_ref.shape) == (1, 3, 8 * hw, 8 * hw)
+    # 42 chained CFG evaluations of a random-weight UNet (the latent grows to std ~12, i.e. the dynamics amplify
+    # perturbations) in bf16 against fp32
+    assert r["z_rel_mse"] < 5e-2 and r["img_rel_mse"] < 0.1, r
+    model._drop_engine()
+    ae._drop_engine()
+
+
+def test_vae_encode_512_vs_reference(monkeypatch):
+    """AutoencoderKL.encode at the inpainting configuration's real size (512x512 -> 64x64 latent, BASELINE C4)."""
+    dev = _dev()
+    g = load_golden("vae_enc_512")
+    ae = build_product_vae(syn.VAE_DDCONFIG, device=dev)
+    res = g["meta"]["res"]
+    x = torch.rand(1, 3, res, res, generator=torch.Generator().manual_seed(8)) * 2 - 1
+    noise = torch.from_numpy(g["noise"])
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: noise.clone())  # the one posterior draw, as recorded
+    z = ae.encode(x.to(dev))
+    monkeypatch.undo()
+    rel = mse(z, g["z"]) / float(g["z"].var())
+    REPORT["vae_enc_512"] = dict(z_rel_mse=rel)
+    assert z.shape == (1, 4, res // 8, res // 8) and rel < 5e-3, REPORT["vae_enc_512"]
+    ae._drop_engine()
+
+
+def test_two_prompts_one_model():
+    """A model that has served prompt A must give prompt B exactly what a fresh model gives it — through forward() and
+    through sampler.sample(), whose [cond ; uncond] conditioning tensors are temporaries (freed on return, their blocks
+    recycled by the caching allocator for the next prompt's same-shaped temporaries)."""
+    dev = _dev()
+    from gligen_inference import alpha_generator, set_alpha_scale
+    from ldm.models.diffusion.ldm import LatentDiffusion
+    from ldm.models.diffusion.plms import PLMSSampler
+    B, hw, S = 2, 16, 3
+    diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000).to(dev)
+
+    def prompt(seed, n_ctx=77):
+        batch = _to(syn.make_batch("text", B, n_valid=3, seed=seed), dev)
+        return batch, syn.make_context(B, tokens=n_ctx, seed=seed).to(dev), syn.make_context(B, tokens=n_ctx, seed=seed + 50).to(dev)
+
+    def forward(model, p):
+        batch, ctx, _ = p
+        gin = model.grounding_tokenizer_input.prepare(batch)
+        return model(dict(x=syn.make_latent(B, 4, hw, hw, seed=1).to(dev), timesteps=torch.tensor([981, 441], device=dev), context=ctx,
+                          grounding_input=gin, inpainting_extra_input=None, grounding_extra_input=None))
+
+    def sample(model, p):
+        batch, ctx, uc = p
+        gin = model.grounding_tokenizer_input.prepare(batch)
+        sampler = PLMSSampler(diffusion, model, alpha_generator_func=partial(alpha_generator, type=None), set_alpha_scale=set_alpha_scale)
+        inp = dict(x=syn.make_latent(B, 4, hw, hw, seed=6).to(dev), timesteps=None, context=ctx, grounding_input=gin,
+                   inpainting_extra_input=None, grounding_extra_input=None)
+        return sampler.sample(S=S, shape=(B, 4, hw, hw), input=inp, uc=uc, guidance_scale=7.5).clone()
+
+    pa, pb, pc = prompt(1), prompt(2), prompt(3, n_ctx=70)   # C: a shorter text inside the same 64-token pad
+    fresh = {}
+    for tag, p in (("b", pb), ("c", pc)):
+        m = build_product_unet(syn.UNET_CFG_SMALL, "text", device=dev)
+        fresh[tag] = (forward(m, p), sample(m, p))
+        m._drop_engine()
+    model = build_product_unet(syn.UNET_CFG_SMALL, "text", device=dev)
+    fa, sa = forward(model, pa), sample(model, pa)
+    fb, sb = forward(model, pb), sample(model, pb)
+    sc = sample(model, pc)
+    fc = forward(model, pc)
+    assert not torch.equal(fa, fb) and not torch.equal(sa, sb)
+    assert torch.equal(fb, fresh["b"][0]), "forward() served stale conditioning"
+    assert torch.equal(sb, fresh["b"][1]), "sampler.sample() served stale conditioning"
+    assert torch.equal(sc, fresh["c"][1]) and torch.equal(fc, fresh["c"][0]), "a changed text length replayed stale launch arguments"
+    # in-place edits of a live conditioning tensor are seen too
+    batch, ctx, _ = pb
+    gin = model.grounding_tokenizer_input.prepare(batch)
+    inp = dict(x=syn.make_latent(B, 4, hw, hw, seed=1).to(dev), timesteps=torch.tensor([981, 441], device=dev), context=ctx,
+               grounding_input=gin, inpainting_extra_input=None, grounding_extra_input=None)
+    e0 = model(inp)
+    ctx.mul_(0.5)
+    assert not torch.equal(model(inp), e0)
+    model._drop_engine()
+
+
+def test_run_entry_inpaint_batch(tmp_path, monkeypatch):
+    """gligen_inference.run() — the reference's top-level flow (gligen_inference.py:343-446): batch assembly, inpainting mask
+    from the boxes, ONE encoded input image broadcast over batch_size > 1 (z0 of batch 1, as the reference's run() has it),
+    sampling, decode, PNG files. Its samples must equal generate() on the same inputs expanded by hand."""
+    dev = _dev()
+    import gligen_inference as gi
+    from PIL import Image
+    monkeypatch.setattr(gi, "device", dev)
+    monkeypatch.chdir(tmp_path)
+    B, hw = 3, 16
+    cfg = gi.synthetic_config("text", inpaint=True, image_size=hw)
+    cfg["model"]["params"].update(syn.UNET_CFG_SMALL, image_size=hw, inpaint_mode=True, grounding_tokenizer=syn.GROUNDING_TOKENIZERS["text"])
+    cfg["autoencoder"]["params"]["ddconfig"] = syn.VAE_DDCONFIG_SMALL
+    model = syn.fill_module_(gi.instantiate_from_config(cfg["model"]).eval(), 1234).to(dev)
+    ae = syn.fill_module_(gi.instantiate_from_config(cfg["autoencoder"]).eval(), 4321).to(dev)
+    diffusion = gi.instantiate_from_config(cfg["diffusion"]).to(dev)
+    boxes, _ = syn.make_boxes(1, 2, seed=4)
+    emb = syn.make_embeddings(1, 2, seed=4)[0, :2]
+    z0 = syn.make_latent(1, 4, hw, hw, seed=2)
+    meta = dict(ckpt="synthetic_inpaint_text", prompt="x", save_folder_name="inp", locations=boxes[0, :2].tolist(), text_embeddings=list(emb),
+                context=syn.make_context(B, seed=0), uc=syn.make_context(B, seed=1), input_image="unused.png", z0=z0)
+    args = dict(batch_size=B, guidance_scale=7.5, negative_prompt=None, no_plms=False, folder=str(tmp_path / "out"), steps=4)
+    x_T = syn.make_latent(B, 4, hw, hw, seed=6).to(dev)
+    torch.manual_seed(123)
+    samples = gi.run(meta, args, starting_noise=x_T.clone(), models=(model, ae, None, diffusion, cfg))
+    files = sorted(os.listdir(tmp_path / "out" / "inp"))
+    assert files == ["0.png", "1.png", "2.png"]
+    assert samples.shape == (B, 3, 2 * hw, 2 * hw) and torch.isfinite(samples).all()
+    png = np.asarray(Image.open(tmp_path / "out" / "inp" / "1.png"))
+    expect = (torch.clamp(samples[1], -1, 1) * 0.5 + 0.5).cpu().numpy().transpose(1, 2, 0) * 255
+    assert np.array_equal(png, expect.astype(np.uint8))
+    # the same thing through generate(): same seed -> same randn_like(z0) sequence -> identical samples
+    batch = gi.prepare_batch(meta, B)
+    mask = gi.draw_masks_from_boxes(batch["boxes"], hw).to(dev)
+    torch.manual_seed(123)
+    ref = gi.generate(model, ae, diffusion, batch, meta["context"].to(dev), meta["uc"].to(dev), steps=4, guidance_scale=7.5,
+                      starting_noise=x_T.clone(), inpainting_mask=mask, z0=z0.to(dev))
+    assert torch.equal(ref, samples)
+    # and the known region really is the (re-noised, at the last step barely noised) input latent: inside the mask's kept
+    # area the final latent tracks z0, so the broadcast of the single z0 reached every sample of the batch
+    model._drop_engine()
+    ae._drop_engine()
+
+
+@pytest.mark.parametrize("modality", ["canny", "hed", "normal", "sem"])
+def test_spatial_modality_vs_reference(modality):
+    """Spatial-map modalities: GroundingDownsampler on the device against the reference's output, then the
+    UNet with the 4 + k channel first conv and the reference tokenizer's tokens, cond and null, against the reference eps."""
+    dev = _dev()
+    name = f"unet_small_{modality}"
+    g = load_golden(name)
+    meta = g["meta"]
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from ldm.util import instantiate_from_config
+    model = syn.fill_module_(UNetModel(**meta["cfg"]).eval(), 1234).to(dev)
+    assert {k: list(v.shape) for k, v in model.state_dict().items()} == golden_shapes(name)
+    B, hw = meta["B"], meta["hw"]
+    key = {"canny": "canny_edge", "hed": "hed_edge", "normal": "normal", "sem": "sem"}[modality]
+    img = syn.make_spatial_map(modality, B, meta["res"], seed=1).to(dev)
+    batch = {key: img, "mask": torch.ones(B, 1, device=dev)}
+    gin = instantiate_from_config(dict(target=f"grounding_input.{modality}_grounding_tokinzer_input.GroundingNetInput"))
+    dsin = instantiate_from_config(dict(target=f"grounding_input.{modality}_grounding_downsampler_input.GroundingDSInput"))
+    model.grounding_tokenizer_input = gin
+    prepared = gin.prepare(batch)
+    assert set(prepared) == {key, "mask"} and set(gin.get_null_input()) == {key, "mask"}
+    extra = dsin.prepare(batch)
+    ds = model.downsample_net(extra)
+    r = dict(ds_max_abs_err=float((ds.cpu() - torch.from_numpy(g["ds"])).abs().max()), ds_std=float(g["ds"].std()))
+    assert ds.shape == tuple(g["ds"].shape) and r["ds_max_abs_err"] < 2e-5, r   # fp32 on both sides
+    x, ctx = syn.make_latent(B, 4, hw, hw, seed=1).to(dev), syn.make_context(B, seed=1).to(dev)
+    t = torch.tensor([981, 441][:B], device=dev)
+    tok = torch.from_numpy(g["objs"].astype(np.float32)).to(dev)
+    tok_null = torch.from_numpy(g["objs_null"].astype(np.float32)).to(dev)
+    inp = dict(x=x, timesteps=t, context=ctx, grounding_input={"tokens": tok}, inpainting_extra_input=None, grounding_extra_input=extra)
+    eps = model(inp)
+    eps_null = model(dict(inp, grounding_input={"tokens": tok_null}))
+    r.update(eps=mse(eps, g["eps"]), eps_null=mse(eps_null, g["eps_null"]), eps_var=float(g["eps"].var()))
+    REPORT[name] = r
+    assert r["eps"] < EPS_MSE_TOL and r["eps_null"] < EPS_MSE_TOL, r
+    model._drop_engine()

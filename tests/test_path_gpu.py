@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from helpers import (ROOT, build_product_unet, build_product_vae, golden_shapes, grounding_kwargs, load_golden, mse,
-                     oracle_cfg, unet_inputs)
+                     oracle_cfg, scripted_randn_like, unet_inputs)
 from gligen_amd import synthetic as syn
 
 pytestmark = pytest.mark.gpu
@@ -160,8 +160,15 @@ def test_vae_encode_vs_reference(name, dd, monkeypatch):
     ae._drop_engine()
 
 
-@pytest.mark.parametrize("name", ["plms_unet_small", "plms_unet_small_inpaint", "ddim_unet_small", "ddim_unet_small_inpaint"])
+PLMS_TOL = {"plms50_unet_small": 0.25}   # relative MSE of the final latent; default 2e-2 (see the assertion)
+
+
+@pytest.mark.parametrize("name", ["plms_unet_small", "plms_unet_small_inpaint", "ddim_unet_small", "ddim_unet_small_inpaint",
+                                  "plms_unet_small_gatedsa2", "plms_unet_small_inpaint_x0b1", "plms50_unet_small"])
 def test_plms_vs_reference(name, tmp_path, monkeypatch):
+    """Sampler-level parity with the reference's own PLMS / DDIM loops: alpha schedule + SD first-conv swap, inpainting
+    blend (incl. one encoded image broadcast over a larger batch, as run() does), the gatedSA2 fuser under a schedule
+    (the reference never rescales that class), and a full 50-step run (51 graph replays)."""
     dev = _dev()
     from functools import partial
     from gligen_inference import alpha_generator, set_alpha_scale
@@ -176,11 +183,12 @@ def test_plms_vs_reference(name, tmp_path, monkeypatch):
     torch.save(syn.sd_first_conv_state(), tmp_path / "SD_input_conv_weight_bias.pth")
     monkeypatch.chdir(tmp_path)
     diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000).to(dev)
-    batch = syn.make_batch("text", B, n_valid=meta["n_valid"], seed=1)
+    cfg = meta.get("cfg", syn.UNET_CFG_SMALL)
+    batch = syn.make_batch("text", B, n_valid=meta["n_valid"], seed=1, max_objs=meta.get("max_objs", 30))
     ctx, uc = syn.make_context(B, seed=1).to(dev), syn.make_context(B, seed=9).to(dev)
     results = []
     for use_graph in (False, True):
-        model = build_product_unet(syn.UNET_CFG_SMALL, "text", meta["inpaint"], device=dev)
+        model = build_product_unet(cfg, "text", meta["inpaint"], device=dev)
         gin = model.grounding_tokenizer_input.prepare(_to(batch, dev))
         mask = z0 = extra = None
         sampler = PLMSSampler(diffusion, model, alpha_generator_func=partial(alpha_generator, type=meta["alpha_type"]),
@@ -188,21 +196,23 @@ def test_plms_vs_reference(name, tmp_path, monkeypatch):
         sampler.use_graph = use_graph
         if meta["inpaint"]:
             mask = draw_masks_from_boxes(batch["boxes"], hw).to(dev)
-            z0 = syn.make_latent(B, 4, hw, hw, seed=2).to(dev)
+            z0 = syn.make_latent(meta.get("x0_batch", B), 4, hw, hw, seed=2).to(dev)
             extra = torch.cat([z0 * mask, mask], dim=1)
         inp = dict(x=syn.make_latent(B, 4, hw, hw, seed=6).to(dev), timesteps=None, context=ctx, grounding_input=gin,
                    inpainting_extra_input=extra, grounding_extra_input=None)
-        if meta["inpaint"]:  # patch only around the sampler call: make_latent above draws through torch.randn too
+        if meta["inpaint"]:  # the S q_sample draws, as recorded from the reference run, in the reference's call order
             noise = torch.from_numpy(g["noise"]).to(dev)
-            monkeypatch.setattr(torch, "randn", lambda *a, **k: noise.clone())  # the S q_sample draws, as recorded
+            monkeypatch.setattr(torch, "randn_like", scripted_randn_like(noise, multistep=not name.startswith("ddim")))
         out = sampler.sample(S=S, shape=(B, 4, hw, hw), input=inp, uc=uc, guidance_scale=7.5, mask=mask, x0=z0)
         monkeypatch.undo()
         monkeypatch.chdir(tmp_path)
         results.append(out.clone())
         model._drop_engine()
     rel = mse(results[0], g["x_out"]) / float(g["x_out"].var())
-    REPORT[name] = dict(x_rel_mse=rel)
-    assert rel < 2e-2, REPORT[name]
+    REPORT[name] = dict(x_rel_mse=rel, x_std=float(g["x_out"].std()))
+    # bf16 engine vs fp32 reference through S chained CFG evaluations of a random-weight (non-contracting) UNet: the
+    # short runs land at 1e-4 .. 1e-3 relative; the 50-step run amplifies the per-evaluation rounding the most
+    assert rel < PLMS_TOL.get(name, 2e-2), REPORT[name]
     assert torch.equal(results[0], results[1]), "hipGraph replay must reproduce the eager launch sequence bit for bit"
 
 
