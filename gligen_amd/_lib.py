@@ -49,8 +49,8 @@ class PlmsArgs(C.Structure):
         ("timesteps", C.POINTER(C.c_int64)), ("a_t", C.POINTER(C.c_float)), ("a_prev", C.POINTER(C.c_float)),
         ("fuser_scale", C.POINTER(C.c_float)), ("guidance_scale", C.c_float),
         ("x", C.c_void_p), ("inpaint_extra", C.c_void_p), ("mask", C.c_void_p), ("x0", C.c_void_p),
-        ("noise", C.c_void_p), ("sqrt_ac", C.POINTER(C.c_float)), ("sqrt_1mac", C.POINTER(C.c_float)),
-        ("mask_B", C.c_int), ("x0_B", C.c_int), ("noise_B", C.c_int),
+        ("noise", C.c_void_p), ("mask_B", C.c_int), ("x0_B", C.c_int), ("noise_B", C.c_int),
+        ("sqrt_ac", C.POINTER(C.c_float)), ("sqrt_1mac", C.POINTER(C.c_float)),
         ("use_graph", C.c_int), ("sd_conv_w", C.c_void_p), ("sd_conv_b", C.c_void_p), ("sd_conv_step", C.c_int), ("ddim", C.c_int),
     ]
 

@@ -1,6 +1,8 @@
 // extern "C" surface of libgligen_amd.so (see include/gligen_amd.h). Nothing throws across it.
 #include "engine.h"
 
+#include <cstdlib>
+
 #include <cmath>
 
 using namespace gl;
@@ -347,27 +349,44 @@ int gl_op_attention(gl_ctx* ctx, const void* xq, const void* xkv, int B, int Nq,
     ck(cast_f32_bf16_launch(wv, wvb, (int64_t)C * Ck, S(s)));
     ck(pad_rows_bf16_launch((const bf16*)xq, xqp, B, Nq, Tq, C, S(s)));
     ck(pad_rows_bf16_launch((const bf16*)xkv, xkp, B, Nk, Tk, Ck, S(s)));
-    {
+    // self-attention (same rows for q, k, v): the engine's fused projection, one EPI_QKV_HEADS GEMM (GL_QKV_FUSED=0: off)
+    const bool fused = xq == xkv && C == Ck && Nq == Nk && gemm_supports_qkv() && (2 * C) % 128 == 0 &&
+                       !(getenv("GL_QKV_FUSED") && atoi(getenv("GL_QKV_FUSED")) == 0);
+    if (fused) {
+        bf16* wqkv = ar.get<bf16>((size_t)3 * C * C);
+        ck(cast_f32_bf16_launch(wq, wqkv, (int64_t)C * C, S(s)));
+        ck(cast_f32_bf16_launch(wk, wqkv + (size_t)C * C, (int64_t)C * C, S(s)));
+        ck(cast_f32_bf16_launch(wv, wqkv + (size_t)2 * C * C, (int64_t)C * C, S(s)));
         AOperand A;
         aoperand_rows(A, xqp, C, C);
         Epilogue E;
         epilogue_defaults(E);
-        E.mode = EPI_QK_HEADS; E.q = bufs.q; E.C = C; E.H = H; E.d = d; E.DP = dp; E.T = Tq; E.Tpad_q = bufs.Tq_pad;
-        ck(gemm_launch(A, wqb, B * Tq, C, C, E, eng.splitk_ws(), eng.splitk_ws_bytes(), S(s)));
-    }
-    {
-        AOperand A;
-        aoperand_rows(A, xkp, Ck, Ck);
-        Epilogue E;
-        epilogue_defaults(E);
-        E.mode = EPI_QK_HEADS; E.q = bufs.k; E.C = C; E.H = H; E.d = d; E.DP = dp; E.T = Tk; E.Tpad_q = bufs.Tk_pad;
-        ck(gemm_launch(A, wkb, B * Tk, C, Ck, E, eng.splitk_ws(), eng.splitk_ws_bytes(), S(s)));
-    }
-    {
-        Epilogue E;
-        epilogue_defaults(E);
-        E.mode = EPI_VT_HEADS; E.out = bufs.vt; E.H = H; E.d = d; E.DPV = dpv; E.T = Tk; E.Tpad_k = bufs.Tk_pad;
-        ck(gemm_launch_t(wvb, C, xkp, B * Tk, Ck, E, S(s)));
+        E.mode = EPI_QKV_HEADS; E.q = bufs.q; E.k = bufs.k; E.vt = bufs.vt; E.C = C; E.H = H; E.d = d; E.DP = dp; E.DPV = dpv; E.T = Tq;
+        E.Tpad_q = bufs.Tq_pad; E.Tpad_k = bufs.Tk_pad;
+        ck(gemm_launch(A, wqkv, B * Tq, 3 * C, C, E, nullptr, 0, S(s)));
+    } else {
+        {
+            AOperand A;
+            aoperand_rows(A, xqp, C, C);
+            Epilogue E;
+            epilogue_defaults(E);
+            E.mode = EPI_QK_HEADS; E.q = bufs.q; E.C = C; E.H = H; E.d = d; E.DP = dp; E.T = Tq; E.Tpad_q = bufs.Tq_pad;
+            ck(gemm_launch(A, wqb, B * Tq, C, C, E, eng.splitk_ws(), eng.splitk_ws_bytes(), S(s)));
+        }
+        {
+            AOperand A;
+            aoperand_rows(A, xkp, Ck, Ck);
+            Epilogue E;
+            epilogue_defaults(E);
+            E.mode = EPI_QK_HEADS; E.q = bufs.k; E.C = C; E.H = H; E.d = d; E.DP = dp; E.T = Tk; E.Tpad_q = bufs.Tk_pad;
+            ck(gemm_launch(A, wkb, B * Tk, C, Ck, E, eng.splitk_ws(), eng.splitk_ws_bytes(), S(s)));
+        }
+        {
+            Epilogue E;
+            epilogue_defaults(E);
+            E.mode = EPI_VT_HEADS; E.out = bufs.vt; E.H = H; E.d = d; E.DPV = dpv; E.T = Tk; E.Tpad_k = bufs.Tk_pad;
+            ck(gemm_launch_t(wvb, C, xkp, B * Tk, Ck, E, S(s)));
+        }
     }
     AttnParams P{};
     P.q = bufs.q; P.k = bufs.k; P.vt = bufs.vt; P.o = (bf16*)o; P.H = H; P.d = d; P.Nq = Nq; P.Nk = Nk;

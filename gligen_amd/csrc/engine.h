@@ -57,7 +57,12 @@ struct ResW {
     bool has_skip = false;
     LinW skip;
 };
-struct SelfAttnW { const bf16* wqk = nullptr; const bf16* wv = nullptr; LinW out; };
+struct SelfAttnW {
+    const bf16* wqk = nullptr;   // [to_q ; to_k] rows (wqkv when the fused projection is active: [to_q ; to_k ; to_v])
+    const bf16* wv = nullptr;
+    bool fused = false;          // wqk holds all three: one EPI_QKV_HEADS GEMM instead of q,k + v^T launches
+    LinW out;
+};
 struct CrossAttnW { LinW q; const bf16* wk = nullptr; const bf16* wv = nullptr; LinW out; int ctx_dim = 0; };
 struct FFW { const bf16* w1 = nullptr; const float* b1 = nullptr; LinW w2; int C = 0; int geglu16 = 0; };
 struct STW {

@@ -327,8 +327,22 @@ void Engine::build_unet() {
         t.ln1 = norm(tb + ".norm1");
         t.ln2 = norm(tb + ".norm2");
         t.ln3 = norm(tb + ".norm3");
-        t.a1.wqk = cast_rows({tb + ".attn1.to_q.weight", tb + ".attn1.to_k.weight"});
-        t.a1.wv = cast_rows({tb + ".attn1.to_v.weight"});
+        // q, k and v^T of a self-attention come out of ONE GEMM over the LayerNorm'ed rows (EPI_QKV_HEADS) when the head
+        // count / width allow it; GL_QKV_FUSED=0 keeps the two-launch form (q,k GEMM + operand-swapped v^T GEMM) for A/B runs
+        const bool want_fused = !(getenv("GL_QKV_FUSED") && atoi(getenv("GL_QKV_FUSED")) == 0);
+        const bool fuse_qkv = want_fused && gemm_supports_qkv() && (2 * C) % 128 == 0;
+        auto self_attn_w = [&](const std::string& a) {
+            SelfAttnW w;
+            w.fused = fuse_qkv;
+            if (fuse_qkv) {
+                w.wqk = cast_rows({a + ".to_q.weight", a + ".to_k.weight", a + ".to_v.weight"});
+            } else {
+                w.wqk = cast_rows({a + ".to_q.weight", a + ".to_k.weight"});
+                w.wv = cast_rows({a + ".to_v.weight"});
+            }
+            return w;
+        };
+        t.a1 = self_attn_w(tb + ".attn1");
         t.a1.out = linear(tb + ".attn1.to_out.0");
         t.a2.q = linear(tb + ".attn2.to_q", false);
         t.a2.wk = cast_rows({tb + ".attn2.to_k.weight"});
@@ -342,8 +356,7 @@ void Engine::build_unet() {
         t.fn2 = norm(tb + ".fuser.norm2");
         if (c.fuser_kind != 2) {  // gatedSA and gatedSA2 hold the same parameters
             t.flin = linear(tb + ".fuser.linear");
-            t.fa.wqk = cast_rows({tb + ".fuser.attn.to_q.weight", tb + ".fuser.attn.to_k.weight"});
-            t.fa.wv = cast_rows({tb + ".fuser.attn.to_v.weight"});
+            t.fa = self_attn_w(tb + ".fuser.attn");
             t.fa.out = linear(tb + ".fuser.attn.to_out.0");
         } else {  // gatedCA: CrossAttention(query_dim, key_dim = value_dim = grounding-token dim) -- attention.py:194
             t.fca.q = linear(tb + ".fuser.attn.to_q", false);
@@ -741,7 +754,16 @@ void Engine::self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, in
     int dp, dpv;
     CK(attn_dims(d, &dp, &dpv));
     AttnBufs& bufs = attn_bufs(B, H, d, T, T);
-    {
+    if (a.fused) {
+        AOperand A;
+        aoperand_rows(A, ln, C, C);
+        Epilogue E;
+        epilogue_defaults(E);
+        E.mode = EPI_QKV_HEADS;
+        E.q = bufs.q; E.k = bufs.k; E.vt = bufs.vt; E.C = C; E.H = H; E.d = d; E.DP = dp; E.DPV = dpv; E.T = T;
+        E.Tpad_q = bufs.Tq_pad; E.Tpad_k = bufs.Tk_pad;
+        gemm(A, a.wqk, B * T, 3 * C, C, E, s);
+    } else {
         AOperand A;
         aoperand_rows(A, ln, C, C);
         Epilogue E;
@@ -751,7 +773,7 @@ void Engine::self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, in
         E.Tpad_q = bufs.Tq_pad; E.Tpad_k = bufs.Tk_pad;
         gemm(A, a.wqk, B * T, 2 * C, C, E, s);
     }
-    {
+    if (!a.fused) {
         Epilogue E;
         epilogue_defaults(E);
         E.mode = EPI_VT_HEADS;

@@ -20,7 +20,10 @@ struct AOperand {
     int stride, ups, pad_lo;
 };
 
-enum { EPI_ROWMAJOR = 0, EPI_QK_HEADS = 1, EPI_VT_HEADS = 2, EPI_NCHW_F32 = 3 };
+// EPI_QKV_HEADS: one GEMM over the concatenated [to_q ; to_k ; to_v] rows: columns [0,C) -> q, [C,2C) -> k (as EPI_QK_HEADS),
+// [2C,3C) -> v^T. Work items whose columns lie in the V third run the MFMAs with the operand roles exchanged, so their
+// accumulators hold 4 consecutive TOKENS of one feature per lane -- the v^T store pattern of EPI_VT_HEADS -- at no extra cost.
+enum { EPI_ROWMAJOR = 0, EPI_QK_HEADS = 1, EPI_VT_HEADS = 2, EPI_NCHW_F32 = 3, EPI_QKV_HEADS = 4 };
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GEGLU = 2 };
 
 struct Epilogue {
@@ -41,7 +44,8 @@ struct Epilogue {
     bf16* k;
     int C, H, d, DP, T; // T = rows (tokens) per sample in M (multiple of 64)
     int Tpad_q, Tpad_k;
-    int DPV;            // EPI_VT_HEADS: vt [B*H][DPV][Tpad_k], tokens permuted within groups of 16
+    bf16* vt;           // EPI_QKV_HEADS: v^T destination (EPI_VT_HEADS passes it in `out`)
+    int DPV;            // EPI_VT_HEADS / EPI_QKV_HEADS: vt [B*H][DPV][Tpad_k], tokens permuted within groups of 16
     int n_real;         // EPI_NCHW_F32: number of real output channels (<= N)
     // EPI_ROWMAJOR optional row remap: out row = (m / remap_in) * remap_out + m % remap_in + remap_off
     int remap_in, remap_out, remap_off;
@@ -60,6 +64,8 @@ int gemm_launch_t(const bf16* Wrows, int Mw, const bf16* X, int Nx, int K, const
                   hipStream_t stream);
 
 void epilogue_defaults(Epilogue& E);
+// true when the default main loop (v5) is active: EPI_QKV_HEADS exists only there
+bool gemm_supports_qkv();
 // developer switch (kbench A/B): 1 = one-tile-per-workgroup LDS-DMA kernel (v2), 2 = persistent 16x16-tile kernel (v3),
 // 4 = v5: persistent, buffer-descriptor LDS-DMA, asm fragment reads, staged epilogue (default)
 void gemm_set_variant(int v);

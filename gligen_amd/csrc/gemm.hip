@@ -96,6 +96,7 @@ __device__ __forceinline__ void epi_finish4(const Epilogue& E, int m, int n0, fl
             }
             break;
         }
+        case EPI_QKV_HEADS:
         case EPI_QK_HEADS: {
             int which = n0 >= E.C;
             int c = n0 - which * E.C;
@@ -149,6 +150,7 @@ __device__ __forceinline__ void epi_store4(const Epilogue& E, int m, int n0, flo
             }
             break;
         }
+        case EPI_QKV_HEADS:
         case EPI_QK_HEADS: {
             int which = n0 >= E.C;
             int c = n0 - which * E.C;
@@ -736,7 +738,8 @@ __device__ __forceinline__ void pin_regs(bf16x8 (&d)[N]) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(ldst), 16, \
                                              (int)(voff), (int)(soff), 0, 0)
 
-template <int WMW, int TM, int TN, int AMODE, int NST>
+// QKV (EPI_QKV_HEADS, A_ROWS only): its own instantiations, so that the other kernels' register allocation is untouched
+template <int WMW, int TM, int TN, int AMODE, int NST, bool QKV = false>
 __global__ void __launch_bounds__(WMW * 128, (WMW == 2 && NST > 2) ? 1 : 2)
 gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilogue E, float* __restrict__ ws, WorkDesc wd) {
     constexpr int NT = WMW * 128;               // threads
@@ -922,7 +925,9 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
     const int wrow0 = BM * 128 + wn * TN * 16 * 128;
 
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    auto compute = [&](int slot) {
+    // swapv (wave-uniform, EPI_QKV_HEADS items in the V third): MFMA operand roles exchanged -- lane (l15, q) then holds
+    // feature l15 and tokens 4q .. 4q+3 of every 16x16 tile (the v^T store pattern) instead of token l15, features 4q .. 4q+3
+    auto compute = [&](int slot, bool swapv) {
         const unsigned st = lds0 + slot * STAGE;
         const unsigned ax0 = st + xrow0 + foff0, ax1 = st + xrow0 + foff1;
         const unsigned aw0 = st + wrow0 + foff0, aw1 = st + wrow0 + foff1;
@@ -935,20 +940,87 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
         pin_regs(xa);
         pin_regs(wa);
         __builtin_amdgcn_sched_barrier(0);
+        if (!QKV || !swapv) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xa[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xa[i], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i], wa[j], acc[i][j], 0, 0, 0);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)");
         pin_regs(xb);
         pin_regs(wb);
         __builtin_amdgcn_sched_barrier(0);
+        if (!QKV || !swapv) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xb[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xb[i], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb[i], wb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // q / k scatter of a QKV item outside the V third (the EPI_QK_HEADS store, no bias / residual forms)
+    auto epilogue_qk = [&](int tm, int tn) {
+        const int mrow = tm * BM + wm * TM * 16 + l15;
+        const int ncol = tn * BN + wn * TN * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n0 = ncol + j * 16;
+            if (n0 >= N) continue;
+            const int which = n0 >= E.C;
+            const int cc = n0 - which * E.C;
+            const int h = cc / E.d;
+            const int dd = cc - h * E.d;
+            bf16* base = which ? E.k : E.q;
+            const int tp = which ? E.Tpad_k : E.Tpad_q;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = mrow + i * 16;
+                if (m >= M) continue;
+                const int b = m / E.T;
+                const int t = m - b * E.T;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                store_bf16x4(base + ((size_t)(b * E.H + h) * tp + t) * E.DP + dd, v);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // addresses just in time: hoisting all TM x TN of them costs registers (spills at 4 x 5)
+        }
+    };
+
+    // v^T store of an operand-swapped item (EPI_QKV_HEADS): feature n = column, 4 consecutive tokens per lane
+    auto epilogue_vt = [&](int tm, int tn) {
+        const int nfeat = tn * BN + wn * TN * 16 + l15;
+        const int mtok = tm * BM + wm * TM * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = nfeat + j * 16;
+            if (n >= N) continue;
+            const int cfeat = n - 2 * E.C;
+            const int h = cfeat / E.d;
+            const int dd = cfeat - h * E.d;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m0 = mtok + i * 16;
+                if (m0 >= M) continue;
+                const int b = m0 / E.T;
+                const int t0 = m0 - b * E.T;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                store_bf16x4(E.vt + ((size_t)(b * E.H + h) * E.DPV + dd) * E.Tpad_k + perm_tok4(t0), v);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
 
     // Epilogue: every load (bias, time-embedding bias, residual, gate) of the wave's TM x TN fragments is issued
@@ -1248,6 +1320,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
     setup_load(l_item);
     int c_item = l_item, c_tm, c_tn, c_z;
     decode(c_item, c_tm, c_tn, c_z);
+    bool c_swap = QKV && c_tn * BN >= 2 * E.C;   // BN divides 2C (checked on the host): an item is all V or no V
     int c_left = l_kt_end - l_kt;
     int ahead = 0;       // tiles issued and not yet multiplied (including the one about to be)
     int slot_i = 0;      // ring slot of the next issue
@@ -1288,7 +1361,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
         const bool last = c_left == 1;
         const bool defer = AHEAD >= 2 && last;
         if (!defer && more) issue_one();
-        if (!(wd.dbg & 2)) compute(slot_c);
+        if (!(wd.dbg & 2)) compute(slot_c, c_swap);
         const int slot_done = slot_c;
         slot_c = slot_c == NST - 1 ? 0 : slot_c + 1;
         --ahead;
@@ -1298,13 +1371,19 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
                 landed = min(ahead, AHEAD - 1);
             }
             if (!(wd.dbg & 4)) {
-                if ((wd.dbg & 8) || !epilogue_staged(c_tm, c_tn, slot_done)) epilogue(c_tm, c_tn, c_z);  // dbg 8: fragment-layout stores
+                if constexpr (QKV) {
+                    if (c_swap) epilogue_vt(c_tm, c_tn);
+                    else epilogue_qk(c_tm, c_tn);
+                } else {
+                    if ((wd.dbg & 8) || !epilogue_staged(c_tm, c_tn, slot_done)) epilogue(c_tm, c_tn, c_z);  // dbg 8: fragment-layout stores
+                }
             }
             c_item += gridDim.x;
             if (c_item >= wd.n_items) break;
             if (defer && more) issue_one();
             zero_acc();
             decode(c_item, c_tm, c_tn, c_z);
+            c_swap = QKV && c_tn * BN >= 2 * E.C;
             c_left = min(nk, (c_z + 1) * wd.kt_per_split) - c_z * wd.kt_per_split;
         }
     }
@@ -1364,6 +1443,7 @@ static int gemm_variant() {
 }
 // GEGLU weight-row packing the current main-loop variant expects (pack_geglu_launch layout argument)
 int gemm_geglu_layout() { return gemm_variant() >= 2 ? 1 : 0; }
+bool gemm_supports_qkv() { return gemm_variant() == 4; }
 
 static int g_force_tm = 0, g_force_tn = 0, g_force_splits = 0;  // developer override (kbench sweeps)
 static int g_force_grid = 0;
@@ -1456,7 +1536,11 @@ int launch_u(const AOperand& A, const bf16* W, int M, int N, int K, const Epilog
         }                                                                                                        \
         hipLaunchKernelGGL(kfn, grid, block, lds, stream, A, W, M, N, K, E, ws, wd);                             \
     } while (0)
-    if (A.mode == A_ROWS) GL_LAUNCH_U((gemm_u_kernel<WMW, TM, TN, A_ROWS, NST>));
+    if (E.mode == EPI_QKV_HEADS) {
+        // (the 128 x 160 tile is not built for QKV: with the second MFMA form it needs more than 256 registers)
+        if constexpr (TM == 4 && TN == 5) return set_error(GL_ERR_UNSUPPORTED, "gemm: no 128x160 tile for EPI_QKV_HEADS");
+        else GL_LAUNCH_U((gemm_u_kernel<WMW, TM, TN, A_ROWS, NST, true>));
+    } else if (A.mode == A_ROWS) GL_LAUNCH_U((gemm_u_kernel<WMW, TM, TN, A_ROWS, NST>));
     else GL_LAUNCH_U((gemm_u_kernel<WMW, TM, TN, A_CONV3, NST>));
 #undef GL_LAUNCH_U
     GL_LAUNCH_CHECK();
@@ -1495,6 +1579,7 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
         const int tm = kTm[c], tn = kTn[c];
         if (tm == 8) return false;  // not built (see run_cfg)
         if (E.act == ACT_GEGLU && (tn & 1)) return false;
+        if (E.mode == EPI_QKV_HEADS && (sp > 1 || (2 * E.C) % (tn * 32) || (tm == 4 && tn == 5))) return false;   // an item must not straddle the k | v boundary
         if (sp > 1 && (!ws || nk / sp < 2 || (size_t)sp * M * N * sizeof(float) > ws_bytes)) return false;
         const int kps = cdiv(nk, sp);
         sp = cdiv(nk, kps);
@@ -1527,7 +1612,8 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
                 }
         }
         g_last_cfg[0] = tm; g_last_cfg[1] = tn; g_last_cfg[2] = wd.splits;
-        if (use_u) snprintf(g_last_name, sizeof g_last_name, "gemm_u_kernel<%d, %d, %d, %d, %d>", tm == 8 ? 4 : 2, tm == 8 ? 4 : tm, tn, A.mode, tm == 8 ? 3 : 2);
+        if (use_u && E.mode == EPI_QKV_HEADS) snprintf(g_last_name, sizeof g_last_name, "gemm_u_kernel<2, %d, %d, 0, 2, true>", tm, tn);
+        else if (use_u) snprintf(g_last_name, sizeof g_last_name, "gemm_u_kernel<%d, %d, %d, %d, %d>", tm == 8 ? 4 : 2, tm == 8 ? 4 : tm, tn, A.mode, tm == 8 ? 3 : 2);
         else snprintf(g_last_name, sizeof g_last_name, "gemm_p_kernel<%d, %d, %d>", tm, tn, A.mode);
         if (wd.splits > 1) strncat(g_last_name, " + splitk_reduce_kernel", sizeof g_last_name - strlen(g_last_name) - 1);
         const int saved_grid = g_force_grid;
@@ -1693,6 +1779,13 @@ int gemm_launch(const AOperand& A, const bf16* W, int M, int N, int K, const Epi
         return set_error(GL_ERR_ARG, "gemm: GEGLU epilogue needs packed N %% 32 == 0 (N=%d)", N);
     if (E.act == ACT_GEGLU && E.geglu16 != gemm_geglu_layout())
         return set_error(GL_ERR_STATE, "gemm: GEGLU weights were packed for a different main-loop variant");
+    if (E.mode == EPI_QKV_HEADS) {
+        if (A.mode != A_ROWS || A.C1) return set_error(GL_ERR_ARG, "gemm: EPI_QKV_HEADS takes a single row-major activation operand");
+        const size_t a_bytes = (size_t)M * A.ld0 * 2;
+        if (!gemm_supports_qkv() || a_bytes >= 0x7fff0000ull || (size_t)N * K * 2 >= 0x7fff0000ull || N != 3 * E.C || (2 * E.C) % 128 || !E.vt || !E.q || !E.k ||
+            E.T % 64 || M % E.T)
+            return set_error(GL_ERR_UNSUPPORTED, "gemm: EPI_QKV_HEADS needs the v5 main loop, N = 3C with 2C %% 128 == 0, tokens per sample %% 64 == 0");
+    }
     if (gemm_variant() >= 2 && (N >= 128 || E.act == ACT_GEGLU)) return gemm_p_launch(A, W, M, N, K, E, ws, ws_bytes, stream);
 
     // pick the tile: padding efficiency x relative tile speed x chip fill

@@ -60,7 +60,7 @@ def build_unet_engine(model, arena_gb: float = 12.0) -> Engine:
         num_res_blocks=model.num_res_blocks, num_heads=model.num_heads, context_dim=model.context_dim,
         channel_mult=list(model.channel_mult), attention_resolutions=list(model.attention_resolutions),
         inpaint_mode=model.inpaint_mode, grounding_kind=kind,
-        gr_in_dim=getattr(pn, "in_dim", pn.out_dim), gr_out_dim=pn.out_dim,
+        gr_in_dim=getattr(pn, "in_dim", None) or pn.out_dim, gr_out_dim=pn.out_dim,
         max_persons=getattr(pn, "max_persons_per_image", 0), fuser_type=model.fuser_type,
         extra_channels=model.additional_channel_from_downsampler if model.first_conv_type == "GLIGEN" else 0)
     # the tokenizer / downsampler of the spatial-map modalities run through their own operator calls, not from engine weights

@@ -123,9 +123,9 @@ def test_c1_end_to_end_vs_reference(full_models, tmp_path, monkeypatch):
     r["img_rel_mse"] = r["img_mse"] / r["img_var"]
     REPORT["c1_end_to_end"] = r
     assert img.shape == tuple(img_ref.shape) == (1, 3, 8 * hw, 8 * hw)
-    # 42 chained CFG evaluations of a random-weight UNet (the latent grows to std ~12, i.e. the dynamics amplify
-    # perturbations) in bf16 against fp32
-    assert r["z_rel_mse"] < 5e-2 and r["img_rel_mse"] < 0.1, r
+    # 42 chained CFG evaluations of a random-weight UNet + the decoder, bf16 against fp32 (measured on MI355X: latent 6.6e-5,
+    # image 1.7e-4 relative MSE)
+    assert r["z_rel_mse"] < 2e-3 and r["img_rel_mse"] < 5e-3, r
     model._drop_engine()
     ae._drop_engine()
 
@@ -155,7 +155,7 @@ def test_two_prompts_one_model():
     from gligen_inference import alpha_generator, set_alpha_scale
     from ldm.models.diffusion.ldm import LatentDiffusion
     from ldm.models.diffusion.plms import PLMSSampler
-    B, hw, S = 2, 16, 3
+    B, hw, S = 2, 16, 4
     diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000).to(dev)
 
     def prompt(seed, n_ctx=77):

@@ -141,6 +141,7 @@ def attn_ref(xq, xkv, wq, wk, wv, H):
     (2, 256, 256, 320, 320, 8), (1, 1024, 1054, 320, 320, 8), (2, 256, 77, 320, 768, 8),
     (2, 256, 286, 640, 640, 8), (2, 64, 94, 1280, 1280, 8), (1, 64, 77, 1280, 768, 8),
     (1, 16, 46, 1280, 1280, 8), (1, 4096, 4126, 320, 320, 8),
+    (2, 1024, 1024, 640, 640, 8), (2, 256, 256, 1280, 1280, 8), (1, 4096, 4096, 320, 320, 8),   # self-attention: the fused q,k,v^T projection
 ])
 def test_attention(engine, B, Nq, Nk, C, Ck, H):
     xq = bf(rnd(B, Nq, C, seed=1))
@@ -151,6 +152,24 @@ def test_attention(engine, B, Nq, Nk, C, Ck, H):
     y = engine.op_attention(xq, xkv, wq, wk, wv, H)
     assert rel_err(y, ref) < 2.5e-2
     assert ((y.float() - ref).abs().mean() / ref.abs().mean()).item() < 1e-2
+
+
+@pytest.mark.parametrize("B,N,C", [(2, 4096, 320), (2, 1088, 640), (3, 320, 1280), (1, 64, 1280)])
+def test_fused_qkv_projection_matches_two_launch_form(engine, monkeypatch, B, N, C):
+    """One EPI_QKV_HEADS GEMM (q, k stored as the q,k GEMM stores them; v^T from work items that run their MFMAs with the
+    operand roles exchanged) against the two-launch form it replaces: same products in the same K order -> the same bits,
+    unless the two-launch form's q,k GEMM was split along K by the tuner (K = 1280 at small M; the fused GEMM never splits),
+    which only regroups the fp32 sums."""
+    x = bf(rnd(B, N, C, seed=11))
+    wq, wk, wv = rnd(C, C, scale=C ** -0.5, seed=3), rnd(C, C, scale=C ** -0.5, seed=4), rnd(C, C, scale=C ** -0.5, seed=5)
+    monkeypatch.setenv("GL_QKV_FUSED", "1")
+    y1 = engine.op_attention(x, x, wq, wk, wv, 8)
+    monkeypatch.setenv("GL_QKV_FUSED", "0")
+    y0 = engine.op_attention(x, x, wq, wk, wv, 8)
+    if C <= 640:
+        assert torch.equal(y0, y1)
+    assert rel_err(y1, y0.float()) < 4e-3
+    assert rel_err(y1, attn_ref(x, x, wq, wk, wv, 8)) < 2.5e-2
 
 
 def test_attention_spike(engine):

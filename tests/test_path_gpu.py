@@ -160,7 +160,7 @@ def test_vae_encode_vs_reference(name, dd, monkeypatch):
     ae._drop_engine()
 
 
-PLMS_TOL = {"plms50_unet_small": 0.25}   # relative MSE of the final latent; default 2e-2 (see the assertion)
+PLMS_TOL = 2e-3   # relative MSE of the final latent (measured on MI355X: 3e-5 .. 2.5e-4 over the seven cases)
 
 
 @pytest.mark.parametrize("name", ["plms_unet_small", "plms_unet_small_inpaint", "ddim_unet_small", "ddim_unet_small_inpaint",
@@ -210,9 +210,8 @@ def test_plms_vs_reference(name, tmp_path, monkeypatch):
         model._drop_engine()
     rel = mse(results[0], g["x_out"]) / float(g["x_out"].var())
     REPORT[name] = dict(x_rel_mse=rel, x_std=float(g["x_out"].std()))
-    # bf16 engine vs fp32 reference through S chained CFG evaluations of a random-weight (non-contracting) UNet: the
-    # short runs land at 1e-4 .. 1e-3 relative; the 50-step run amplifies the per-evaluation rounding the most
-    assert rel < PLMS_TOL.get(name, 2e-2), REPORT[name]
+    # bf16 engine vs fp32 reference through S chained CFG evaluations of a random-weight UNet
+    assert rel < PLMS_TOL, REPORT[name]
     assert torch.equal(results[0], results[1]), "hipGraph replay must reproduce the eager launch sequence bit for bit"
 
 
