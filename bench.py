@@ -103,7 +103,7 @@ def pmc_traffic(kernel):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.csv")), key=os.path.getmtime)
     if not files:
         return None, None
-    sym = kernel.split(" + ")[0]
+    sym = kernel.split(" + ")[0].split(" [")[0]
     fetch = write = None
     with open(files[-1], newline="") as fh:
         for r in csv.DictReader(fh):

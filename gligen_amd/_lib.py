@@ -24,7 +24,7 @@ class UNetConfig(C.Structure):
         ("n_attn", C.c_int), ("attention_resolutions", C.c_int * 8),
         ("inpaint_mode", C.c_int), ("grounding_kind", C.c_int),
         ("gr_in_dim", C.c_int), ("gr_out_dim", C.c_int), ("max_persons", C.c_int), ("fuser_kind", C.c_int),
-        ("extra_channels", C.c_int),
+        ("extra_channels", C.c_int), ("tok_resize", C.c_int), ("tok_in_dim", C.c_int),
     ]
 
 
@@ -73,6 +73,7 @@ SYMBOLS = {
     "gl_unet_set_cond": (_I, [_P, _I, _P, _I, C.POINTER(Grounding), _P]),
     "gl_unet_set_fuser_scale": (_I, [_P, C.c_float, _P]),
     "gl_unet_grounding_tokens": (_I, [_P, _P, _P]),
+    "gl_op_spatial_tokens": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "gl_op_grounding_downsample": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P]),
     "gl_unet_restore_first_conv": (_I, [_P, _P, _P, _P]),
     "gl_unet_forward": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P]),

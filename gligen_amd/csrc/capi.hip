@@ -115,6 +115,14 @@ int gl_unet_grounding_tokens(gl_ctx* ctx, float* out, gl_stream s) {
     GL_API_END
 }
 
+int gl_op_spatial_tokens(gl_ctx* ctx, const float* image, int B, int C, int H, int W, const float* mask, float* tokens, gl_stream s) {
+    NEED(ctx);
+    if (!image || !mask || !tokens) return gl::set_error(GL_ERR_ARG, "null pointer");
+    GL_API_BEGIN
+    ctx->eng->spatial_tokens(B, image, C, H, W, mask, tokens, S(s));
+    GL_API_END
+}
+
 int gl_op_grounding_downsample(gl_ctx* ctx, const float* img, int B, int Cimg, int H, int W, int n_in, int R, int mode,
                                const float* w1, const float* b1, int c_mid, const float* w2, const float* b2, int c_out,
                                float* out, gl_stream s) {

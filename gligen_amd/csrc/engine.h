@@ -8,6 +8,7 @@
 
 #include "attention.h"
 #include "common.h"
+#include "convnext.h"
 #include "gemm.h"
 #include "misc.h"
 #include "norm.h"
@@ -86,6 +87,20 @@ struct UNetBlock { std::vector<Layer> layers; };
 
 struct VaeAttnW { NormW gn; LinW q, k, v, proj; };
 
+// ConvNeXt-tiny tokenizer of the spatial-map modalities (reference convnext.py:52-118, canny_grounding_net.py:12-62)
+struct CnxBlock { const float* dw_w = nullptr; const float* dw_b = nullptr; NormW ln; LinW pw1, pw2; };
+struct CnxNet {
+    bool present = false;
+    int resize = 0, in_dim = 0, tokens = 0;
+    const float* inconv_w = nullptr; const float* inconv_b = nullptr;   // sem: Conv2d(in_dim, 3, 3, 1, 1)
+    LinW stem; NormW stem_ln;
+    NormW ds_ln[3]; LinW ds[3];
+    std::vector<CnxBlock> blocks[4];
+    int dims[4] = {0, 0, 0, 0};
+    const float* pos = nullptr; const float* null_feat = nullptr;
+    LinW mlp[3];
+};
+
 struct AttnBufs {  // persistent, zero-initialised head-layout buffers for one attention shape
     bf16* q = nullptr;
     bf16* k = nullptr;
@@ -109,7 +124,10 @@ class Engine {
 
     void set_cond(int Beff, const float* context, int n_ctx, const gl_grounding& g, hipStream_t s);
     void set_fuser_scale(float v, hipStream_t s);
-    void grounding_tokens(float* out, hipStream_t s);  // [Beff][Ng][gr_out_dim] fp32: objs of openaimodel.py:433 for the current conditioning
+    void grounding_tokens(float* out, hipStream_t s);
+    // PositionNet.forward of the spatial-map tokenizers: image [B][C][H][W] fp32, mask [B] -> out fp32 [B][tokens][gr_out_dim]
+    void spatial_tokens(int B, const float* image, int C, int H, int W, const float* mask, float* out, hipStream_t s);
+    int spatial_token_count() const { return cnx_.tokens; }  // [Beff][Ng][gr_out_dim] fp32: objs of openaimodel.py:433 for the current conditioning
     void restore_first_conv(const float* w, const float* b, hipStream_t s);
     void unet_forward(int Beff, int h, int w, const float* x, int xB, const int64_t* t, const float* extra,
                       int extraB, float* eps, hipStream_t s);
@@ -206,6 +224,8 @@ class Engine {
     const float* pn_null_feat_[2] = {nullptr, nullptr};
     const float* pn_null_pos_ = nullptr;
     const float* kp_table_ = nullptr;  // keypoint: person+keypoint embedding table [P*17][out]
+    CnxNet cnx_;
+    void build_convnext(const std::string& PN);
 
     // ---- conditioning cache
     struct Cond {

@@ -501,11 +501,153 @@ void Engine::build_unet() {
         HIPCK(hipMemcpy(d, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
         kp_table_ = d;
     } else if (gkind_ == 3) {
-        // spatial-map modalities (canny / hed / depth / normal / sem _grounding_net.py): the tokenizer is a ConvNeXt backbone
-        // that runs once per prompt on the host side of this ABI; its output arrives through gl_grounding.tokens
+        // spatial-map modalities (canny / hed / depth / normal / sem _grounding_net.py): tokens arrive through
+        // gl_grounding.tokens; they are the output of gl_op_spatial_tokens (the ConvNeXt tokenizer below, built when its
+        // weights were uploaded) or were computed elsewhere
+        if (has(PN + "convnext_tiny_backbone.downsample_layers.0.0.weight")) build_convnext(PN);
     } else {
         throw GlError(GL_ERR_UNSUPPORTED, "grounding_kind must be 0 (text), 1 (text+image), 2 (keypoint) or 3 (precomputed tokens)");
     }
+}
+
+// PositionNet of the spatial-map modalities: ConvNeXt-tiny (depths 3,3,9,3; dims 96..768) + position embedding + 3-layer MLP
+void Engine::build_convnext(const std::string& PN) {
+    CnxNet& n = cnx_;
+    const gl_unet_config& c = ucfg_;
+    if (c.tok_resize <= 0 || c.tok_resize % 32) throw GlError(GL_ERR_ARG, "spatial tokenizer: resize_input must be a positive multiple of 32");
+    n.resize = c.tok_resize;
+    n.in_dim = c.tok_in_dim;
+    n.tokens = (c.tok_resize / 32) * (c.tok_resize / 32);
+    const std::string BB = PN + "convnext_tiny_backbone.";
+    if (n.in_dim) {
+        n.inconv_w = F(PN + "in_conv.weight");
+        n.inconv_b = F(PN + "in_conv.bias");
+    }
+    auto patch_conv = [&](const std::string& p, int k) {
+        const RawTensor& w = raw(p + ".weight");
+        if (w.shape.size() != 4 || w.shape[2] != k || w.shape[3] != k) throw GlError(GL_ERR_ARG, "'" + p + "' is not a " + std::to_string(k) + "x" + std::to_string(k) + " conv");
+        LinW l;
+        l.N = (int)w.shape[0];
+        l.K = round_up(k * k * (int)w.shape[1], 64);
+        bf16* dst = reinterpret_cast<bf16*>(persist((size_t)l.N * l.K * sizeof(bf16), false));
+        CK(pack_patch_weight_launch(w.p, dst, l.N, (int)w.shape[1], k, l.K, 0));
+        l.w = dst;
+        l.b = F(p + ".bias");
+        return l;
+    };
+    n.stem = patch_conv(BB + "downsample_layers.0.0", 4);
+    n.stem_ln = norm(BB + "downsample_layers.0.1");
+    n.dims[0] = n.stem.N;
+    for (int i = 0; i < 3; ++i) {
+        n.ds_ln[i] = norm(BB + fmt("downsample_layers.%d.0", i + 1));
+        n.ds[i] = patch_conv(BB + fmt("downsample_layers.%d.1", i + 1), 2);
+        n.dims[i + 1] = n.ds[i].N;
+    }
+    for (int st = 0; st < 4; ++st) {
+        for (int j = 0;; ++j) {
+            const std::string p = BB + fmt("stages.%d.%d", st, j);
+            if (!has(p + ".dwconv.weight")) break;
+            CnxBlock b;
+            const int C = n.dims[st];
+            if (raw(p + ".dwconv.weight").numel != (int64_t)C * 49) throw GlError(GL_ERR_ARG, "'" + p + ".dwconv' is not a depthwise 7x7 conv");
+            b.dw_w = F(p + ".dwconv.weight");
+            b.dw_b = F(p + ".dwconv.bias");
+            b.ln = norm(p + ".norm");
+            b.pw1 = linear(p + ".pwconv1");
+            if (has(p + ".gamma"))  // layer scale folded into pwconv2: gamma * (W h + b) = (gamma W) h + gamma b
+                CK(scale_rows_launch(raw(p + ".pwconv2.weight").p, raw(p + ".pwconv2.bias").p, F(p + ".gamma"), C, 4 * C, 0));
+            b.pw2 = linear(p + ".pwconv2");
+            n.blocks[st].push_back(b);
+        }
+        if (n.blocks[st].empty()) throw GlError(GL_ERR_MISSING, fmt("ConvNeXt stage %d has no blocks", st));
+    }
+    n.pos = F(PN + "pos_embedding");
+    if (raw(PN + "pos_embedding").numel != (int64_t)n.tokens * n.dims[3])
+        throw GlError(GL_ERR_ARG, "pos_embedding does not match (resize_input / 32)^2 tokens");
+    n.null_feat = F(PN + "null_feature");
+    for (int i = 0; i < 3; ++i) n.mlp[i] = linear(PN + fmt("linears.%d", 2 * i));
+    if (n.mlp[2].N != c.gr_out_dim) throw GlError(GL_ERR_ARG, "spatial tokenizer out_dim does not match gr_out_dim");
+    n.present = true;
+}
+
+void Engine::spatial_tokens(int B, const float* image, int Cimg, int H, int W, const float* mask, float* out, hipStream_t s) {
+    if (!has_unet_ || !finalized_ || !cnx_.present) throw GlError(GL_ERR_STATE, "no spatial-map tokenizer (ConvNeXt weights) in this engine");
+    const CnxNet& n = cnx_;
+    const int Cuse = n.in_dim ? n.in_dim : 3;
+    if (B <= 0 || Cimg < Cuse) throw GlError(GL_ERR_ARG, fmt("spatial_tokens: image has %d channels, the tokenizer reads %d", Cimg, Cuse));
+    const size_t mk = arena_.mark();
+    const int R = n.resize;
+    // F.interpolate(x, resize_input): default mode 'nearest' (canny_grounding_net.py:42, sem: explicit nearest)
+    float* img = arena_.get<float>((size_t)B * Cuse * R * R);
+    CK(resize_f32_launch(image, img, B, Cimg, Cuse, H, W, R, 1, s));
+    if (n.in_dim) {
+        float* img3 = arena_.get<float>((size_t)B * 3 * R * R);
+        CK(conv3x3_f32_launch(img, n.inconv_w, n.inconv_b, img3, B, n.in_dim, 3, R, R, s));
+        img = img3;
+    }
+    auto ln_rows = [&](const bf16* x, int M, int C, int ld, const NormW& w) {
+        bf16* y = arena_.get<bf16>((size_t)M * ld);
+        LNParams P{};
+        P.x = x; P.B = 1; P.N1 = M; P.N2 = 0; P.Tpad = M; P.C = C; P.eps = 1e-6f; P.gamma = w.g; P.beta = w.b; P.y = y; P.ldx = ld; P.ldy = ld;
+        CK(layernorm_launch(P, s));
+        return y;
+    };
+    auto mm = [&](const bf16* a, int M, int K, const LinW& L, int ldo, int act, const bf16* res) {
+        if (L.K != K) throw GlError(GL_ERR_STATE, fmt("spatial_tokens: GEMM K %d against packed weight K %d", K, L.K));
+        bf16* y = arena_.get<bf16>((size_t)M * ldo);
+        AOperand A;
+        aoperand_rows(A, a, K, K);
+        Epilogue E;
+        epilogue_defaults(E);
+        E.out = y; E.ldo = ldo; E.bias = L.b; E.act = act; E.res = res; E.ldres = ldo;
+        gemm(A, L.w, M, L.N, K, E, s);
+        return y;
+    };
+    // stem: Conv2d(3, 96, 4, 4) as patchify + GEMM, LayerNorm over channels (convnext.py:71-74)
+    int Hs = R / 4;
+    int M = B * Hs * Hs;
+    int C = n.dims[0], ld = round_up(C, 64);
+    bf16* col = arena_.get<bf16>((size_t)M * n.stem.K);
+    CK(patchify_f32_launch(img, col, B, 3, R, R, 4, n.stem.K, s));
+    bf16* x = mm(col, M, n.stem.K, n.stem, ld, ACT_NONE, nullptr);
+    x = ln_rows(x, M, C, ld, n.stem_ln);
+    for (int st = 0; st < 4; ++st) {
+        if (st > 0) {  // LayerNorm + Conv2d(C, C', 2, 2) (convnext.py:76-81)
+            bf16* l = ln_rows(x, M, C, ld, n.ds_ln[st - 1]);
+            const int Cn = n.dims[st];
+            bf16* pc = arena_.get<bf16>((size_t)(M / 4) * 4 * C);
+            CK(patchify_bf16_launch(l, pc, B, Hs, Hs, C, ld, 2, s));
+            Hs /= 2; M /= 4;
+            const int ldn = round_up(Cn, 64);
+            if (n.ds[st - 1].K != 4 * C) throw GlError(GL_ERR_STATE, "ConvNeXt downsample weight shape");
+            x = mm(pc, M, 4 * C, n.ds[st - 1], ldn, ACT_NONE, nullptr);
+            C = Cn; ld = ldn;
+        }
+        for (const CnxBlock& b : n.blocks[st]) {  // Block.forward (convnext.py:36-50)
+            bf16* y = arena_.get<bf16>((size_t)M * ld);   // dwconv output; dead after the LayerNorm, then reused for the block output
+            const size_t after_y = arena_.mark();
+            CK(dwconv7_launch(x, b.dw_w, b.dw_b, y, B, Hs, Hs, C, ld, s));
+            bf16* l = ln_rows(y, M, C, ld, b.ln);
+            bf16* h = mm(l, M, ld, b.pw1, 4 * C, ACT_GELU, nullptr);
+            AOperand A;
+            aoperand_rows(A, h, 4 * C, 4 * C);
+            Epilogue E;
+            epilogue_defaults(E);
+            E.out = y; E.ldo = ld; E.bias = b.pw2.b; E.res = x; E.ldres = ld;   // x + gamma * pwconv2(...) (gamma folded at build)
+            gemm(A, b.pw2.w, M, b.pw2.N, 4 * C, E, s);
+            arena_.release(after_y);   // l, h
+            x = y;
+        }
+    }
+    if (Hs * Hs != n.tokens) throw GlError(GL_ERR_STATE, "ConvNeXt output grid does not match the token count");
+    // objs = feat * mask + null * (1 - mask) + pos_embedding -> MLP (canny_grounding_net.py:48-59)
+    bf16* mix = arena_.get<bf16>((size_t)M * C);
+    CK(token_mix_launch(x, ld, mask, n.null_feat, n.pos, mix, B, n.tokens, C, s));
+    bf16* h1 = linear_rows(mix, M, n.mlp[0], ACT_SILU, nullptr, nullptr, s);
+    bf16* h2 = linear_rows(h1, M, n.mlp[1], ACT_SILU, nullptr, nullptr, s);
+    bf16* objs = linear_rows(h2, M, n.mlp[2], ACT_NONE, nullptr, nullptr, s);
+    CK(bf16_rows_to_f32_launch(objs, out, B, n.tokens, n.tokens, n.mlp[2].N, s));
+    arena_.release(mk);
 }
 
 void Engine::build_vae() {

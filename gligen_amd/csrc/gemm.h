@@ -24,7 +24,7 @@ struct AOperand {
 // [2C,3C) -> v^T. Work items whose columns lie in the V third run the MFMAs with the operand roles exchanged, so their
 // accumulators hold 4 consecutive TOKENS of one feature per lane -- the v^T store pattern of EPI_VT_HEADS -- at no extra cost.
 enum { EPI_ROWMAJOR = 0, EPI_QK_HEADS = 1, EPI_VT_HEADS = 2, EPI_NCHW_F32 = 3, EPI_QKV_HEADS = 4 };
-enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GEGLU = 2 };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GEGLU = 2, ACT_GELU = 3 };   // ACT_GELU: erf GELU (nn.GELU(), the ConvNeXt tokenizer's MLPs)
 
 struct Epilogue {
     int mode;

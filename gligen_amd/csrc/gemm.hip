@@ -77,6 +77,9 @@ __device__ __forceinline__ void epi_finish4(const Epilogue& E, int m, int n0, fl
     if (E.act == ACT_SILU) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = silu_f(v[i]);
+    } else if (E.act == ACT_GELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
     }
     switch (E.mode) {
         case EPI_ROWMAJOR: {
@@ -135,10 +138,15 @@ __device__ __forceinline__ void epi_finish4(const Epilogue& E, int m, int n0, fl
 // in-order counter for loads and stores, so a load issued after a store cannot be waited for without
 // waiting for that store: an epilogue that alternates {load bias/residual, store} per fragment pays one
 // memory round trip per fragment (measured: 18 of the 27 us of a 32768 x 320 x 320 GEMM).
+// WITH_GELU = false: the conv instantiations (never followed by a GELU) keep the erf code out of their register allocation
+template <bool WITH_GELU = true>
 __device__ __forceinline__ void epi_store4(const Epilogue& E, int m, int n0, float v[4]) {
     if (E.act == ACT_SILU) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = silu_f(v[i]);
+    } else if (WITH_GELU && E.act == ACT_GELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = gelu_erf_f(v[i]);
     }
     switch (E.mode) {
         case EPI_ROWMAJOR: {
@@ -1116,7 +1124,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
                     if (n0 >= N) continue;
                     float v[4] = {acc[i][j][0] + bj[j].x + b2[i][j].x, acc[i][j][1] + bj[j].y + b2[i][j].y,
                                   acc[i][j][2] + bj[j].z + b2[i][j].z, acc[i][j][3] + bj[j].w + b2[i][j].w};
-                    epi_store4(E, mo[i], n0, v);
+                    epi_store4<AMODE == A_ROWS>(E, mo[i], n0, v);
                 }
             }
         } else if (E.mode == EPI_ROWMAJOR && E.res) {
@@ -1166,7 +1174,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
                     const int n0 = ncol + j * 16;
                     if (n0 >= N) continue;
                     float v[4] = {acc[i][j][0] + bj[j].x, acc[i][j][1] + bj[j].y, acc[i][j][2] + bj[j].z, acc[i][j][3] + bj[j].w};
-                    epi_store4(E, mo[i], n0, v);
+                    epi_store4<AMODE == A_ROWS>(E, mo[i], n0, v);
                 }
             }
         }
@@ -1184,7 +1192,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
     constexpr int EPW = 16 * RS;                   // bytes per wave
     static_assert(WMW * 2 * EPW <= STAGE, "epilogue staging does not fit one ring slot");
     auto epilogue_staged = [&](int tm, int tn, int slot_done) -> bool {
-        if (wd.splits > 1 || E.mode != EPI_ROWMAJOR || E.out_f32 || (N & 7) || (E.act == ACT_GEGLU && (TN & 1))) return false;
+        if (wd.splits > 1 || E.mode != EPI_ROWMAJOR || E.out_f32 || (N & 7) || (E.act == ACT_GEGLU && (TN & 1)) || E.act == ACT_GELU) return false;
         unsigned char* ep = smem + slot_done * STAGE + wave * EPW;
         if constexpr ((TN & 1) == 0) {
             // value / gate fragments alternate (16 columns each), so a wave's TN*16 accumulator columns become TN*8 output
@@ -1775,6 +1783,8 @@ int gemm_launch(const AOperand& A, const bf16* W, int M, int N, int K, const Epi
         if (K != A.C0 + A.C1 || (A.C1 && A.C0 % 64 != 0))
             return set_error(GL_ERR_ARG, "gemm: K=%d does not match operand channels (%d,%d)", K, A.C0, A.C1);
     }
+    if (E.act == ACT_GELU && (E.res || E.bias2 || A.mode != A_ROWS))
+        return set_error(GL_ERR_UNSUPPORTED, "gemm: the GELU epilogue has no residual / broadcast-bias form");
     if (E.act == ACT_GEGLU && (N % 32 != 0 || E.mode != EPI_ROWMAJOR))
         return set_error(GL_ERR_ARG, "gemm: GEGLU epilogue needs packed N %% 32 == 0 (N=%d)", N);
     if (E.act == ACT_GEGLU && E.geglu16 != gemm_geglu_layout())

@@ -211,6 +211,14 @@ int main(int argc, char** argv) {
                     E.out = a2; E.ldo = N; E.bias = bias; E.res = a1; E.ldres = N;
                 } else if (epi == 1) {
                     E.act = ACT_GEGLU; E.geglu16 = gemm_geglu_layout(); E.out = a2; E.ldo = N / 2; E.bias = bias;
+                } else if (epi == 4) {   // fused q, k, v^T projection (N = 3C)
+                    const int H = 8, B = kb_batch, T = M / B;
+                    const int C = K, d = C / H;
+                    int dp, dpv;
+                    GC(attn_dims(d, &dp, &dpv));
+                    bf16* vt = a2 + ((size_t)200 << 20);
+                    E.mode = EPI_QKV_HEADS; E.q = a1; E.k = a2; E.vt = vt; E.C = C; E.H = H; E.d = d; E.DP = dp; E.DPV = dpv; E.T = T;
+                    E.Tpad_q = round_up(T, 128); E.Tpad_k = T;
                 } else {
                     const int H = 8, B = kb_batch, T = M / B;
                     const int C = K, d = C / H;

@@ -32,6 +32,8 @@ struct LNParams {
     const float* gamma;
     const float* beta;
     bf16* y;
+    int ldx, ldy;  // row strides in elements of x / y; 0 = C. ldy > C: columns [C, ldy) of y are written as zeros (K padding
+                   // of the GEMM that consumes y: the 96-channel stage of the ConvNeXt tokenizer)
 };
 int layernorm_launch(const LNParams& P, hipStream_t stream);
 

@@ -266,9 +266,11 @@ __global__ void __launch_bounds__(256) ln_kernel(LNParams P) {
     const int b = (int)(r / P.Tpad);
     const int t = (int)(r - (int64_t)b * P.Tpad);
     const int C8 = P.C >> 3;
-    bf16* dst = P.y + r * P.C;
+    const int ldx = P.ldx ? P.ldx : P.C, ldy = P.ldy ? P.ldy : P.C;
+    bf16* dst = P.y + r * ldy;
+    for (int ch = C8 + lane; ch < (ldy >> 3); ch += 64) *reinterpret_cast<uint4*>(dst + ch * 8) = make_uint4(0, 0, 0, 0);
     const bf16* src;
-    if (t < P.N1) src = P.x + ((size_t)b * P.N1 + t) * P.C;
+    if (t < P.N1) src = P.x + ((size_t)b * P.N1 + t) * ldx;
     else if (t < P.N1 + P.N2) src = P.x2 + ((size_t)b * P.N2 + (t - P.N1)) * P.C;
     else {
         for (int ch = lane; ch < C8; ch += 64) *reinterpret_cast<uint4*>(dst + ch * 8) = make_uint4(0, 0, 0, 0);
@@ -321,6 +323,7 @@ __global__ void __launch_bounds__(256) ln_kernel(LNParams P) {
 int layernorm_launch(const LNParams& P, hipStream_t stream) {
     if (P.C % 8 != 0 || P.C > 1536) return set_error(GL_ERR_ARG, "layernorm: C=%d unsupported", P.C);
     if (P.Tpad < P.N1 + P.N2) return set_error(GL_ERR_ARG, "layernorm: Tpad=%d < %d+%d", P.Tpad, P.N1, P.N2);
+    if ((P.ldx && (P.ldx < P.C || P.ldx % 8)) || (P.ldy && (P.ldy < P.C || P.ldy % 8))) return set_error(GL_ERR_ARG, "layernorm: bad row strides");
     const int64_t rows = (int64_t)P.B * P.Tpad;
     hipLaunchKernelGGL(ln_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, stream, P);
     GL_LAUNCH_CHECK();

@@ -60,7 +60,7 @@ class Engine:
     def configure_unet(self, *, in_channels, out_channels, model_channels, num_res_blocks, num_heads, context_dim,
                        channel_mult: Sequence[int], attention_resolutions: Sequence[int], inpaint_mode=False,
                        grounding_kind="text", gr_in_dim=768, gr_out_dim=768, max_persons=0, fuser_type="gatedSA",
-                       extra_channels=0) -> None:
+                       extra_channels=0, tok_resize=0, tok_in_dim=0) -> None:
         cfg = UNetConfig()
         cfg.in_channels, cfg.out_channels, cfg.model_channels = in_channels, out_channels, model_channels
         cfg.num_res_blocks, cfg.num_heads, cfg.context_dim = num_res_blocks, num_heads, context_dim
@@ -75,10 +75,11 @@ class Engine:
         cfg.gr_in_dim, cfg.gr_out_dim, cfg.max_persons = gr_in_dim, gr_out_dim, max_persons
         cfg.fuser_kind = {"gatedSA": 0, "gatedSA2": 1, "gatedCA": 2}[fuser_type or "gatedSA"]
         cfg.extra_channels = int(extra_channels)
+        cfg.tok_resize, cfg.tok_in_dim = int(tok_resize), int(tok_in_dim)
         check(self.lib.gl_unet_configure(self._ctx, C.byref(cfg)))
         self.unet_cfg = dict(in_channels=in_channels, out_channels=out_channels, inpaint_mode=bool(inpaint_mode),
                              grounding_kind=grounding_kind, context_dim=context_dim, extra_channels=int(extra_channels),
-                             gr_out_dim=gr_out_dim)
+                             gr_out_dim=gr_out_dim, tok_tokens=(int(tok_resize) // 32) ** 2)
 
     def configure_vae(self, *, ch, out_ch, z_channels, num_res_blocks, embed_dim, ch_mult: Sequence[int],
                       scale_factor: float) -> None:
@@ -143,6 +144,18 @@ class Engine:
         Beff, Ng = int(self._cond_shape[0]), int(self._cond_shape[1])
         out = torch.empty((Beff, Ng, self.unet_cfg["gr_out_dim"]), device=self.device, dtype=torch.float32)
         check(self.lib.gl_unet_grounding_tokens(self._ctx, _ptr(out), _stream()))
+        return out
+
+    def spatial_tokens(self, image: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        """PositionNet.forward of the spatial-map tokenizers (ConvNeXt-tiny on the device): image [B,C,H,W], mask [B] or [B,1]
+        -> grounding tokens fp32 [B, (resize_input/32)^2, out_dim]."""
+        image = _f32(image, self.device)
+        mask = _f32(mask.reshape(-1), self.device)
+        B, Cc, H, W = image.shape
+        if mask.shape[0] != B:
+            raise ValueError("spatial_tokens: one mask value per image")
+        out = torch.empty((B, self.unet_cfg["tok_tokens"], self.unet_cfg["gr_out_dim"]), device=self.device, dtype=torch.float32)
+        check(self.lib.gl_op_spatial_tokens(self._ctx, _ptr(image), int(B), int(Cc), int(H), int(W), _ptr(mask), _ptr(out), _stream()))
         return out
 
     def grounding_downsample(self, img: torch.Tensor, n_in: int, resize: int, mode: str, convs) -> torch.Tensor:

@@ -62,10 +62,11 @@ def build_unet_engine(model, arena_gb: float = 12.0) -> Engine:
         inpaint_mode=model.inpaint_mode, grounding_kind=kind,
         gr_in_dim=getattr(pn, "in_dim", None) or pn.out_dim, gr_out_dim=pn.out_dim,
         max_persons=getattr(pn, "max_persons_per_image", 0), fuser_type=model.fuser_type,
-        extra_channels=model.additional_channel_from_downsampler if model.first_conv_type == "GLIGEN" else 0)
-    # the tokenizer / downsampler of the spatial-map modalities run through their own operator calls, not from engine weights
-    skip = ("position_net.", "downsample_net.") if kind == "tokens" else ("downsample_net.",)
-    eng.upload("unet", {k: v for k, v in model.state_dict().items() if not k.startswith(skip)})
+        extra_channels=model.additional_channel_from_downsampler if model.first_conv_type == "GLIGEN" else 0,
+        tok_resize=getattr(pn, "resize_input", 0) if kind == "tokens" else 0,
+        tok_in_dim=(getattr(pn, "in_dim", None) or 0) if kind == "tokens" else 0)
+    # (the GroundingDownsampler runs through its own operator call with its weights passed along: gl_op_grounding_downsample)
+    eng.upload("unet", {k: v for k, v in model.state_dict().items() if not k.startswith("downsample_net.")})
     eng.finalize()
     return eng
 

@@ -46,6 +46,8 @@ typedef struct gl_unet_config {
                              config), 1 gatedSA2 (square grounding-token grid, bicubic resize), 2 gatedCA */
     int extra_channels;   /* additional_channel_from_downsampler (openaimodel.py:288-305): the first conv takes
                              in_channels + extra_channels inputs; the extra ones are the GroundingDownsampler output */
+    int tok_resize;       /* grounding_kind 3: PositionNet resize_input (canny_grounding_net.py:13-22), a multiple of 32 */
+    int tok_in_dim;       /* grounding_kind 3: channels of a semantic map (sem_grounding_net.py:13,21), 0 for 3-channel maps */
 } gl_unet_config;
 
 /* AutoencoderKL ddconfig (reference ldm/modules/diffusionmodules/model.py:462-533). */
@@ -161,6 +163,12 @@ int gl_unet_profile(gl_ctx* ctx, int Beff, int h, int w, const float* x, int xB,
 int gl_arena_high_water(gl_ctx* ctx, size_t* bytes);
 int gl_launch_count(gl_ctx* ctx, int64_t* n);
 
+/* PositionNet.forward of the spatial-map modalities (reference canny_/hed_/depth_/normal_/sem_grounding_net.py:38-62):
+ * image fp32 [B][C][H][W] (the map as RGB in [-1,1], or in_dim one-hot planes), mask fp32 [B] -> nearest resize to
+ * resize_input -> (sem: Conv2d(in_dim,3,3,1,1)) -> ConvNeXt-tiny (convnext.py) -> null-feature mixing, + pos_embedding,
+ * 3-layer SiLU MLP -> tokens fp32 [B][(resize_input/32)^2][gr_out_dim], the gl_grounding.tokens of gl_unet_set_cond.
+ * Needs the position_net.* weights uploaded; once per prompt. */
+int gl_op_spatial_tokens(gl_ctx* ctx, const float* image, int B, int C, int H, int W, const float* mask, float* tokens, gl_stream s);
 /* GroundingDownsampler.forward of the spatial-map modalities (reference canny_/depth_/normal_/sem_/hed_grounding_downsampler.py):
  * img fp32 [B][Cimg][H][W] -> first n_in channels resized to R x R (mode 0 bicubic, 1 nearest, as F.interpolate) ->
  * Conv2d(n_in, c_mid, 4, 2, 1) -> SiLU -> Conv2d(c_mid, c_out, 4, 2, 1) -> out fp32 [B][c_out][R/4][R/4].

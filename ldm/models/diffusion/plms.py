@@ -86,7 +86,8 @@ class PLMSSampler(object):
         if cfg:
             g_null = model.grounding_tokenizer_input.get_null_input()
             if model.engine.unet_cfg["grounding_kind"] == "tokens":  # spatial-map tokenizers: concatenate their outputs
-                g, g_null = {"tokens": model.position_net.tokens(**g)}, {"tokens": model.position_net.tokens(**g_null)}
+                tok = lambda kw: model.position_net.tokens(engine=model.engine, **kw)
+                g, g_null = {"tokens": tok(g)}, {"tokens": tok(g_null)}
             ctx2 = torch.cat([context, uc.to(context)], dim=0)
             g2 = {k: torch.cat([g[k], g_null[k].to(g[k])], dim=0) for k in g}
         else:

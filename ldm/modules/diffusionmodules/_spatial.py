@@ -32,14 +32,14 @@ class SpatialPositionNet(_EngineOnly):
         self.linears = _slots(5, i0=nn.Linear(feat, 512), i2=nn.Linear(512, 512), i4=nn.Linear(512, out_dim))
         self.null_feature = nn.Parameter(torch.zeros([feat]))
 
-    def tokens(self, **grounding_input):
-        """Grounding tokens [B, num_tokens, out_dim] for PositionNet.forward's kwargs. Precomputed tokens pass through
-        (`tokens=`: features extracted elsewhere, like the precomputed CLIP features gligen_inference accepts)."""
+    def tokens(self, engine=None, **grounding_input):
+        """PositionNet.forward(<image>, mask) -> grounding tokens [B, num_tokens, out_dim], computed by the engine that holds
+        this model's weights (gl_op_spatial_tokens: ConvNeXt on the device). Precomputed tokens (`tokens=`) pass through."""
         if "tokens" in grounding_input:
             return grounding_input["tokens"]
-        raise NotImplementedError(
-            f"{type(self).__module__}: the ConvNeXt-tiny backbone is not implemented on MI355X yet; pass precomputed "
-            "grounding tokens as grounding_input={'tokens': [B, num_tokens, out_dim]}")
+        if engine is None:
+            raise RuntimeError(f"{type(self).__module__}.PositionNet runs inside UNetModel on the MI355X engine (no CPU implementation)")
+        return engine.spatial_tokens(grounding_input[self.image_key], grounding_input["mask"])
 
 
 class SpatialDownsampler(nn.Module):

@@ -184,7 +184,7 @@ class UNetModel(nn.Module):
         if key != self._cond_key:
             g = grounding_input
             if self.engine.unet_cfg["grounding_kind"] == "tokens" and "tokens" not in g:
-                g = {"tokens": self.position_net.tokens(**g)}  # spatial-map tokenizer: once per prompt
+                g = {"tokens": self.position_net.tokens(engine=self.engine, **g)}  # spatial-map tokenizer: once per prompt
             self.engine.set_cond(context, g)
             self.__dict__["_cond_key"] = key
             self.__dict__["_cond_held"] = (context, dict(grounding_input))

@@ -82,6 +82,63 @@ def position_net(sd: SD, p: str, kind: str, g: Mapping[str, torch.Tensor]) -> to
     raise ValueError(kind)
 
 
+# --------------------------------------------------------------------------- spatial-map modalities
+def _ln_channels_first(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    """LayerNorm(data_format="channels_first") — reference convnext.py:141-146 (biased variance over C)."""
+    u = x.mean(1, keepdim=True)
+    s = (x - u).pow(2).mean(1, keepdim=True)
+    return w[:, None, None] * ((x - u) / torch.sqrt(s + eps)) + b[:, None, None]
+
+
+def convnext_features(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """ConvNeXt.forward_features without head — reference convnext.py:108-112, Block.forward :36-50 (depths read off the keys)."""
+    for i in range(4):
+        d = f"{p}.downsample_layers.{i}"
+        if i == 0:
+            x = F.conv2d(x, sd[d + ".0.weight"], sd[d + ".0.bias"], stride=4)
+            x = _ln_channels_first(x, sd[d + ".1.weight"], sd[d + ".1.bias"])
+        else:
+            x = _ln_channels_first(x, sd[d + ".0.weight"], sd[d + ".0.bias"])
+            x = F.conv2d(x, sd[d + ".1.weight"], sd[d + ".1.bias"], stride=2)
+        j = 0
+        while f"{p}.stages.{i}.{j}.dwconv.weight" in sd:
+            b = f"{p}.stages.{i}.{j}"
+            C = x.shape[1]
+            h = F.conv2d(x, sd[b + ".dwconv.weight"], sd[b + ".dwconv.bias"], padding=3, groups=C).permute(0, 2, 3, 1)
+            h = F.layer_norm(h, (C,), sd[b + ".norm.weight"], sd[b + ".norm.bias"], 1e-6)
+            h = F.linear(F.gelu(F.linear(h, sd[b + ".pwconv1.weight"], sd[b + ".pwconv1.bias"])), sd[b + ".pwconv2.weight"], sd[b + ".pwconv2.bias"])
+            if b + ".gamma" in sd:
+                h = sd[b + ".gamma"] * h
+            x = x + h.permute(0, 3, 1, 2)
+            j += 1
+    return x
+
+
+def spatial_position_net(sd: SD, p: str, image: torch.Tensor, mask: torch.Tensor, resize_input: int) -> torch.Tensor:
+    """PositionNet.forward of the canny / hed / depth / normal / sem tokenizers — reference canny_grounding_net.py:38-62
+    (sem_grounding_net.py:40-65 adds the nearest resize + in_conv in front)."""
+    B = image.shape[0]
+    x = F.interpolate(image, resize_input)  # default mode 'nearest' (sem passes it explicitly)
+    if p + ".in_conv.weight" in sd:
+        x = F.conv2d(x, sd[p + ".in_conv.weight"], sd[p + ".in_conv.bias"], padding=1)
+    feat = convnext_features(sd, p + ".convnext_tiny_backbone", x)
+    T = feat.shape[2] * feat.shape[3]
+    objs = feat.reshape(B, -1, T).permute(0, 2, 1)
+    m = mask.view(-1, 1, 1)
+    objs = objs * m + sd[p + ".null_feature"].view(1, 1, -1) * (1 - m) + sd[p + ".pos_embedding"]
+    return _mlp3(sd, p + ".linears", objs)
+
+
+def grounding_downsampler(sd: SD, p: str, x: torch.Tensor, n_in: int, resize: int, mode: str = "bicubic") -> torch.Tensor:
+    """GroundingDownsampler.forward — reference canny_grounding_downsampler.py:23-29 (hed: no layers, resize 64, :16-22;
+    sem: all planes, nearest, sem_grounding_downsampler.py:23-28)."""
+    out = F.interpolate(x[:, :n_in], (resize, resize), mode=mode)
+    if p + ".layers.0.weight" in sd:
+        out = F.conv2d(out, sd[p + ".layers.0.weight"], sd[p + ".layers.0.bias"], stride=2, padding=1)
+        out = F.conv2d(F.silu(out), sd[p + ".layers.2.weight"], sd[p + ".layers.2.bias"], stride=2, padding=1)
+    return out
+
+
 def null_grounding(kind: str, g: Mapping[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """get_null_input(): all-zero tensors of the prepared shapes —
     grounding_input/text_grounding_tokinzer_input.py:29-45 (and the text_image / keypoint twins)."""
@@ -207,9 +264,16 @@ def unet_forward(sd: SD, cfg: Mapping, inp: Mapping, fuser_scale: float = 1.0) -
     A missing grounding_input is the caller's job (pass null_grounding(...)), as in openaimodel.py:422-426.
     """
     mc, heads = cfg["model_channels"], cfg["num_heads"]
-    objs = position_net(sd, "position_net", cfg.get("grounding_kind", "text"), inp["grounding_input"])
+    if cfg.get("grounding_kind") == "spatial":  # canny / hed / depth / normal / sem: {"image", "mask"} (or precomputed "tokens")
+        gi = inp["grounding_input"]
+        objs = gi["tokens"] if "tokens" in gi else spatial_position_net(sd, "position_net", gi["image"], gi["mask"], cfg["tok_resize"])
+    else:
+        objs = position_net(sd, "position_net", cfg.get("grounding_kind", "text"), inp["grounding_input"])
     emb = _lin(sd, "time_embed.2", F.silu(_lin(sd, "time_embed.0", timestep_embedding(inp["timesteps"], mc))))
     h = inp["x"]
+    if inp.get("grounding_extra_input") is not None:  # downsampled conditioning map in front of the first conv — openaimodel.py:442-444
+        ds_cfg = cfg["downsampler"]
+        h = torch.cat([h, grounding_downsampler(sd, "downsample_net", inp["grounding_extra_input"], ds_cfg["n_in"], ds_cfg["resize"], ds_cfg["mode"])], dim=1)
     if inp.get("inpainting_extra_input") is not None:
         h = torch.cat([h, inp["inpainting_extra_input"]], dim=1)
     ctx = inp["context"]

@@ -279,6 +279,17 @@ def test_spatial_modality_vs_reference(modality):
     eps = model(inp)
     eps_null = model(dict(inp, grounding_input={"tokens": tok_null}))
     r.update(eps=mse(eps, g["eps"]), eps_null=mse(eps_null, g["eps_null"]), eps_var=float(g["eps"].var()))
+    # the tokenizer itself on the device (ConvNeXt-tiny: patchify GEMMs, depthwise 7x7, LayerNorm, GELU MLPs) ...
+    tok_hip = model.position_net.tokens(engine=model.engine, **prepared)
+    tok_null_hip = model.position_net.tokens(engine=model.engine, **gin.get_null_input())
+    r["tokens_rel_mse"] = mse(tok_hip, tok) / float(tok.var())
+    r["tokens_null_rel_mse"] = mse(tok_null_hip, tok_null) / float(tok_null.var())
+    # ... and the whole modality as the reference runs it: conditioning map in, eps out
+    eps_e2e = model(dict(inp, grounding_input=prepared))
+    eps_null_e2e = model({k: v for k, v in inp.items() if k != "grounding_input"})
+    r.update(eps_e2e=mse(eps_e2e, g["eps"]), eps_null_e2e=mse(eps_null_e2e, g["eps_null"]))
     REPORT[name] = r
     assert r["eps"] < EPS_MSE_TOL and r["eps_null"] < EPS_MSE_TOL, r
+    assert r["tokens_rel_mse"] < 3e-3 and r["tokens_null_rel_mse"] < 3e-3, r      # 18 bf16 blocks + 3 MLP layers against fp32
+    assert r["eps_e2e"] < EPS_MSE_TOL and r["eps_null_e2e"] < EPS_MSE_TOL, r
     model._drop_engine()

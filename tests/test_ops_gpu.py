@@ -168,8 +168,22 @@ def test_fused_qkv_projection_matches_two_launch_form(engine, monkeypatch, B, N,
     y0 = engine.op_attention(x, x, wq, wk, wv, 8)
     if C <= 640:
         assert torch.equal(y0, y1)
-    assert rel_err(y1, y0.float()) < 4e-3
+    assert rel_err(y1, y0.float()) < 8e-3   # (max-norm relative: one bf16 ulp of the largest output is 4e-3)
     assert rel_err(y1, attn_ref(x, x, wq, wk, wv, 8)) < 2.5e-2
+
+
+def test_splitk_is_deterministic(engine):
+    """Long-K small-M problems are split along K into fp32 slabs that a second kernel adds up in slab order: the same bits
+    on every run, and the right ones."""
+    for M, N, K in ((512, 1280, 11520), (2048, 1280, 5120), (512, 1280, 2560)):
+        x, w, b = bf(rnd(M, K, seed=1)), rnd(N, K, scale=K ** -0.5, seed=2), rnd(N, seed=3)
+        res = bf(rnd(M, N, seed=4))
+        wb = bf(w)
+        ref = x.float() @ wb.float().t() + b + res.float()
+        y0 = engine.op_linear(x, wb, b, res)
+        assert rel_err(y0, ref) < 2e-2
+        for _ in range(40):
+            assert torch.equal(engine.op_linear(x, wb, b, res), y0)
 
 
 def test_attention_spike(engine):

@@ -235,3 +235,36 @@ def test_bicubic_taps_of_the_resize_kernel():
     x = torch.randn(2, 3, 4, 4, generator=torch.Generator().manual_seed(0))
     for so in (2, 4, 8, 16, 64):
         assert np.abs(F.interpolate(x, (so, so), mode="bicubic").numpy() - resize(x.numpy(), so)).max() < 2e-6
+
+
+DOWNSAMPLER = {"canny": dict(n_in=1, mode="bicubic"), "hed": dict(n_in=1, mode="bicubic"), "normal": dict(n_in=3, mode="bicubic"),
+               "sem": dict(n_in=152, mode="nearest")}
+
+
+@pytest.mark.parametrize("modality", ["canny", "hed", "normal", "sem"])
+def test_spatial_modalities(modality):
+    """ConvNeXt tokenizer, GroundingDownsampler and the 4 + k channel first conv of the spatial-map modalities against the
+    reference's outputs (oracle/make_golden.py:spatial_case)."""
+    name = f"unet_small_{modality}"
+    g = load_golden(name)
+    meta = g["meta"]
+    sd = syn.seeded_state_dict(golden_shapes(name), meta["weight_seed"])
+    B, hw = meta["B"], meta["hw"]
+    img = syn.make_spatial_map(modality, B, meta["res"], seed=1)
+    tk, dsp = meta["cfg"]["grounding_tokenizer"]["params"], meta["cfg"]["grounding_downsampler"]["params"]
+    ds_cfg = dict(DOWNSAMPLER[modality], resize=dsp.get("resize_input", 64))
+    cfg = dict(oracle_cfg(meta["cfg"], "spatial"), tok_resize=tk["resize_input"], downsampler=ds_cfg)
+    x, ctx = syn.make_latent(B, 4, hw, hw, seed=1), syn.make_context(B, seed=1)
+    t = torch.tensor([981, 441][:B], dtype=torch.long)
+    with torch.no_grad():
+        objs = orc.spatial_position_net(sd, "position_net", img, torch.ones(B, 1), tk["resize_input"])
+        assert mse(objs, g["objs"].astype(np.float32)) < 1e-6          # golden tokens are stored as float16
+        objs_null = orc.spatial_position_net(sd, "position_net", torch.zeros_like(img), torch.zeros(B), tk["resize_input"])
+        assert mse(objs_null, g["objs_null"].astype(np.float32)) < 1e-6
+        ds = orc.grounding_downsampler(sd, "downsample_net", img, ds_cfg["n_in"], ds_cfg["resize"], ds_cfg["mode"])
+        assert mse(ds, g["ds"]) < FP32_TOL
+        inp = dict(x=x, timesteps=t, context=ctx, grounding_input=dict(image=img, mask=torch.ones(B, 1)), grounding_extra_input=img)
+        assert mse(orc.unet_forward(sd, cfg, inp), g["eps"]) < FP32_TOL
+        inp_null = dict(inp, grounding_input=dict(image=torch.zeros_like(img), mask=torch.zeros(B)))
+        assert mse(orc.unet_forward(sd, cfg, inp_null), g["eps_null"]) < FP32_TOL
+    assert mse(g["eps"], g["eps_null"]) > 1e-5

@@ -2,7 +2,7 @@
 schedules them (gligen_amd/csrc/engine.hip), grouped by distinct shape, for gligen_amd/build/kbench.
 
 Line formats (count = launches per forward):
-  gemm  M N K epi count        epi: 0 plain+bias(+res)  1 GEGLU  2 qk-heads  3 vt-heads (transposed launch)
+  gemm  M N K epi count        epi: 0 plain+bias(+res)  1 GEGLU  2 qk-heads  3 vt-heads (transposed launch)  4 fused q,k,v^T heads
   conv  B H W C0 C1 Cout stride ups count
   attn  B H d Nq Nk count
   gn    B HW C0 C1 silu count
@@ -50,13 +50,11 @@ def unet(B=8, hw=64, Ng=30, mc=320, mult=(1, 2, 4, 4), nres=2, attn_res=(4, 2, 1
         r.add("gn", B, HW, C, 0, 0)
         r.add("gemm", M, C, C, 0)                 # proj_in
         r.add("ln", B, HW, 0, Tp, C)
-        r.add("gemm", B * Tp, 2 * C, C, 2)        # attn1 q,k
-        r.add("gemm", C, B * Tp, C, 3)            # attn1 v^T
+        r.add("gemm", B * Tp, 3 * C, C, 4)        # attn1 q, k, v^T (one EPI_QKV_HEADS launch)
         r.add("attn", B, heads, d, HW, HW)
         r.add("gemm", M, C, C, 0)                 # attn1 out + res
         r.add("ln", B, HW, Ng, Tf, C)
-        r.add("gemm", B * Tf, 2 * C, C, 2)
-        r.add("gemm", C, B * Tf, C, 3)
+        r.add("gemm", B * Tf, 3 * C, C, 4)        # fuser q, k, v^T
         r.add("attn", B, heads, d, HW, HW + Ng)
         r.add("gemm", M, C, C, 0)
         r.add("ln", B, HW, 0, HW, C)
