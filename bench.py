@@ -125,12 +125,27 @@ class ClockSampler(threading.Thread):
     def __init__(self, index):
         super().__init__(daemon=True)
         self.files = {}
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
-        if cards:
-            base = os.path.dirname(cards[min(index, len(cards) - 1)])
+        base = self._sysfs_of(index)
+        if base:
             self.files = {"sclk_mhz": os.path.join(base, "pp_dpm_sclk"), "mclk_mhz": os.path.join(base, "pp_dpm_mclk")}
         self.samples = {k: [] for k in self.files}
         self.stop_flag = threading.Event()
+
+    @staticmethod
+    def _sysfs_of(index):
+        """sysfs directory of HIP device `index`, by PCI bus id (the node's other GPUs are in /sys too, idle at ~130 MHz)."""
+        try:
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(index)) == 0:
+                d = os.path.join("/sys/bus/pci/devices", buf.value.decode().lower())
+                if os.path.exists(os.path.join(d, "pp_dpm_sclk")):
+                    return d
+        except Exception:
+            pass
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        return os.path.dirname(cards[0]) if len(cards) == 1 else None
 
     @staticmethod
     def _current(path):

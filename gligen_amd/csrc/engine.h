@@ -4,6 +4,7 @@
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "attention.h"
@@ -170,6 +171,9 @@ class Engine {
     const RawTensor& raw(const std::string& key) const;
     bool has(const std::string& key) const { return raw_.count(key) != 0; }
     const float* F(const std::string& key) const { return raw(key).p; }
+    // a >= 2-D tensor that is used in fp32 as uploaded: finalize() must not drop it with the packed matrices' staging copies
+    const float* FK(const std::string& key) { keep_raw_.insert(key); return raw(key).p; }
+    std::unordered_set<std::string> keep_raw_;
     NormW norm(const std::string& prefix);
     LinW linear(const std::string& prefix, bool bias = true);
     ConvW conv3(const std::string& prefix, int Npad = 0);

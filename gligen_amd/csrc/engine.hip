@@ -520,7 +520,7 @@ void Engine::build_convnext(const std::string& PN) {
     n.tokens = (c.tok_resize / 32) * (c.tok_resize / 32);
     const std::string BB = PN + "convnext_tiny_backbone.";
     if (n.in_dim) {
-        n.inconv_w = F(PN + "in_conv.weight");
+        n.inconv_w = FK(PN + "in_conv.weight");
         n.inconv_b = F(PN + "in_conv.bias");
     }
     auto patch_conv = [&](const std::string& p, int k) {
@@ -550,7 +550,7 @@ void Engine::build_convnext(const std::string& PN) {
             CnxBlock b;
             const int C = n.dims[st];
             if (raw(p + ".dwconv.weight").numel != (int64_t)C * 49) throw GlError(GL_ERR_ARG, "'" + p + ".dwconv' is not a depthwise 7x7 conv");
-            b.dw_w = F(p + ".dwconv.weight");
+            b.dw_w = FK(p + ".dwconv.weight");
             b.dw_b = F(p + ".dwconv.bias");
             b.ln = norm(p + ".norm");
             b.pw1 = linear(p + ".pwconv1");
@@ -561,7 +561,7 @@ void Engine::build_convnext(const std::string& PN) {
         }
         if (n.blocks[st].empty()) throw GlError(GL_ERR_MISSING, fmt("ConvNeXt stage %d has no blocks", st));
     }
-    n.pos = F(PN + "pos_embedding");
+    n.pos = FK(PN + "pos_embedding");
     if (raw(PN + "pos_embedding").numel != (int64_t)n.tokens * n.dims[3])
         throw GlError(GL_ERR_ARG, "pos_embedding does not match (resize_input / 32)^2 tokens");
     n.null_feat = F(PN + "null_feature");
@@ -746,7 +746,7 @@ void Engine::finalize() {
     HIPCK(hipDeviceSynchronize());
     // matrices now live packed in bf16: drop their fp32 staging copies (vectors stay, they are used as is)
     for (auto it = raw_.begin(); it != raw_.end();) {
-        if (it->second.shape.size() >= 2 && it->first.find("quant_conv") == std::string::npos) {
+        if (it->second.shape.size() >= 2 && it->first.find("quant_conv") == std::string::npos && !keep_raw_.count(it->first)) {
             (void)hipFree(it->second.p);
             it = raw_.erase(it);
         } else {
@@ -765,6 +765,16 @@ void Engine::gemm(const AOperand& A, const bf16* W, int M, int N, int K, const E
         std::string nm = gemm_last_kernel_name();  // the symbol the tile selection actually launched
         if (by_shape) nm += fmt(" M%d N%d K%d", M, N, K);
         ps.rename(nm);
+    }
+    // developer aid (tools/gpu_traffic.sh): one line per GEMM / conv launch, in launch order, to join rocprofv3's per-dispatch
+    // counter rows (which carry the kernel symbol but not the problem) with their shapes
+    static FILE* launch_log = getenv("GL_LAUNCH_LOG") ? fopen(getenv("GL_LAUNCH_LOG"), "w") : nullptr;
+    if (launch_log) {
+        const double a_rows = A.mode == A_CONV3 ? (double)(M / (A.Ho * A.Wo)) * A.Hin * A.Win : (double)M;
+        const double out_b = E.mode == EPI_NCHW_F32 ? 4.0 * M * E.n_real : (E.act == ACT_GEGLU ? 1.0 : 2.0) * M * (double)N * (E.out_f32 ? 2 : 1);
+        const double bytes = a_rows * (A.C0 + A.C1) * 2 + (double)N * K * 2 + out_b + (E.res ? 2.0 * M * N : 0.0);
+        fprintf(launch_log, "%s|%d|%d|%d|%d|%.0f\n", gemm_last_kernel_name(), M, N, K, A.mode, bytes);
+        fflush(launch_log);
     }
     ++n_launches;
 }

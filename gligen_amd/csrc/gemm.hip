@@ -1546,7 +1546,7 @@ int launch_u(const AOperand& A, const bf16* W, int M, int N, int K, const Epilog
     } while (0)
     if (E.mode == EPI_QKV_HEADS) {
         // (the 128 x 160 tile is not built for QKV: with the second MFMA form it needs more than 256 registers)
-        if constexpr (TM == 4 && TN == 5) return set_error(GL_ERR_UNSUPPORTED, "gemm: no 128x160 tile for EPI_QKV_HEADS");
+        if constexpr ((TM == 4 && TN == 5) || NST != 2) return set_error(GL_ERR_UNSUPPORTED, "gemm: no 128x160 / deep-ring tile for EPI_QKV_HEADS");
         else GL_LAUNCH_U((gemm_u_kernel<WMW, TM, TN, A_ROWS, NST, true>));
     } else if (A.mode == A_ROWS) GL_LAUNCH_U((gemm_u_kernel<WMW, TM, TN, A_ROWS, NST>));
     else GL_LAUNCH_U((gemm_u_kernel<WMW, TM, TN, A_CONV3, NST>));
@@ -1570,10 +1570,11 @@ void gemm_set_autotune_impl(int on) { g_autotune = on; }
 
 int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, float* ws, size_t ws_bytes,
                   hipStream_t stream) {
-    // candidates 0-3: 4 waves, two (or three) workgroups per CU; 4-5: v5 wide (8 waves, 256-row tile, one workgroup per CU)
-    // (the 4-wave tiles on a 4-stage ring with one workgroup per CU -- three K tiles in flight -- were tried for the
-    //  latency-chain small-M problems and never won a sweep against two workgroups per CU; dropped)
-    static const int kTm[6] = {4, 4, 2, 2, 8, 8}, kTn[6] = {5, 4, 5, 4, 5, 4};
+    // candidates 0-3: 4 waves on a 2-stage ring, two (or three) workgroups per CU.
+    // Measured and dropped (twice: round 1 sweeps, round 2 on-device autotune over all 107 problems of the benchmark, 0 wins):
+    // the same tiles on a 4-stage ring (three K tiles in flight) with ONE workgroup per CU for the <= 256-item problems of the
+    // 16x16 / 8x8 UNet levels; and (round 1) an 8-wave 256-row tile on a 3-stage ring.
+    static const int kTm[4] = {4, 4, 2, 2}, kTn[4] = {5, 4, 5, 4};
     static const int kSp[10] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
     const int nk = K / 64;
     // v5 addresses both operands through 32-bit buffer offsets: every operand must be < 2 GiB
@@ -1585,7 +1586,6 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
 
     auto feasible = [&](int c, int& sp) {
         const int tm = kTm[c], tn = kTn[c];
-        if (tm == 8) return false;  // not built (see run_cfg)
         if (E.act == ACT_GEGLU && (tn & 1)) return false;
         if (E.mode == EPI_QKV_HEADS && (sp > 1 || (2 * E.C) % (tn * 32) || (tm == 4 && tn == 5))) return false;   // an item must not straddle the k | v boundary
         if (sp > 1 && (!ws || nk / sp < 2 || (size_t)sp * M * N * sizeof(float) > ws_bytes)) return false;
@@ -1621,7 +1621,7 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
         }
         g_last_cfg[0] = tm; g_last_cfg[1] = tn; g_last_cfg[2] = wd.splits;
         if (use_u && E.mode == EPI_QKV_HEADS) snprintf(g_last_name, sizeof g_last_name, "gemm_u_kernel<2, %d, %d, 0, 2, true>", tm, tn);
-        else if (use_u) snprintf(g_last_name, sizeof g_last_name, "gemm_u_kernel<%d, %d, %d, %d, %d>", tm == 8 ? 4 : 2, tm == 8 ? 4 : tm, tn, A.mode, tm == 8 ? 3 : 2);
+        else if (use_u) snprintf(g_last_name, sizeof g_last_name, "gemm_u_kernel<2, %d, %d, %d, 2, false>", tm, tn, A.mode);
         else snprintf(g_last_name, sizeof g_last_name, "gemm_p_kernel<%d, %d, %d>", tm, tn, A.mode);
         if (wd.splits > 1) strncat(g_last_name, " + splitk_reduce_kernel", sizeof g_last_name - strlen(g_last_name) - 1);
         const int saved_grid = g_force_grid;
@@ -1633,9 +1633,7 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
                 case 1: rc = launch_u<2, 4, 4, 2>(A, W, M, N, K, E, ws, wd, stream); break;
                 case 2: rc = launch_u<2, 2, 5, 2>(A, W, M, N, K, E, ws, wd, stream); break;
                 case 3: rc = launch_u<2, 2, 4, 2>(A, W, M, N, K, E, ws, wd, stream); break;
-                // candidates 4-5 (WMW = 4: 8 waves, 256-row tile, 3-stage ring, one workgroup per CU) lost every sweep against
-                // two 4-wave workgroups per CU and are no longer instantiated; the kernel template keeps the geometry
-                default: g_force_grid = saved_grid; return set_error(GL_ERR_UNSUPPORTED, "gemm: the 8-wave 256-row tile is not built");
+                default: g_force_grid = saved_grid; return set_error(GL_ERR_UNSUPPORTED, "gemm: unknown tile candidate");
             }
         } else {
             switch (c) {
@@ -1658,7 +1656,7 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
 
     // ---- developer override (kbench sweeps): exactly this tile / split if it fits the problem
     if (g_force_tm) {
-        for (int c = 0; c < 6; ++c) {
+        for (int c = 0; c < 4; ++c) {
             if (kTm[c] != g_force_tm || kTn[c] != g_force_tn) continue;
             for (int si = 0; si < 10; ++si) {
                 int sp = kSp[si];
@@ -1735,7 +1733,7 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
     TunedCfg win{best_c, best_sp, 0};
     float win_ms = 1e30f;
     static const int tune_reps = getenv("GL_GEMM_TUNE_REPS") ? std::max(1, atoi(getenv("GL_GEMM_TUNE_REPS"))) : 3;
-    for (int c = 0; c < 4; ++c) {  // (the 8-wave tiles 4, 5 never won a sweep)
+    for (int c = 0; c < 4; ++c) {
         const int tiles = cdiv(M, kTm[c] * 32) * cdiv(N, kTn[c] * 32);
         int last_sp = -1;
         for (int si = 0; si < 10; ++si) {

@@ -290,6 +290,6 @@ def test_spatial_modality_vs_reference(modality):
     r.update(eps_e2e=mse(eps_e2e, g["eps"]), eps_null_e2e=mse(eps_null_e2e, g["eps_null"]))
     REPORT[name] = r
     assert r["eps"] < EPS_MSE_TOL and r["eps_null"] < EPS_MSE_TOL, r
-    assert r["tokens_rel_mse"] < 3e-3 and r["tokens_null_rel_mse"] < 3e-3, r      # 18 bf16 blocks + 3 MLP layers against fp32
+    assert r["tokens_rel_mse"] < 3e-4 and r["tokens_null_rel_mse"] < 3e-4, r      # 18 bf16 blocks + 3 MLP layers against fp32 (measured 1.2e-5 / 1.8e-5)
     assert r["eps_e2e"] < EPS_MSE_TOL and r["eps_null_e2e"] < EPS_MSE_TOL, r
     model._drop_engine()
