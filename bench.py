@@ -188,7 +188,11 @@ def main():
                          "contexts (own weights copy, arena, hipGraph, HIP stream), so one batch's kernel tails, launch gaps and "
                          "memory-bound kernels overlap the other's MFMA work. 1 = strictly one batch at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--alpha-type", default=None,
+                    help="gate schedule 'on,decay,off' (fractions of the steps), e.g. 0.3,0,0.7 as in the reference's demo prompts; default: "
+                         "None = fusers on at every step, the configuration the metric is quoted on (and the one with the most work)")
     args = ap.parse_args()
+    alpha_type = [float(v) for v in args.alpha_type.split(",")] if args.alpha_type else None
     cfg = CONFIGS[args.config]
 
     from gligen_amd import dist as gdist
@@ -225,6 +229,11 @@ def main():
     if cfg["inpaint"]:   # one input image per sample in [-1, 1], mask from the boxes (reference gligen_inference.py:396-407)
         image = (torch.rand(B * world, 3, 512, 512, generator=torch.Generator().manual_seed(8)) * 2 - 1)[lo:hi].to(dev)
         mask = gi.draw_masks_from_boxes(batch["boxes"].cpu(), 64).to(dev)
+    if alpha_type is not None and not cfg["inpaint"]:
+        # restore_first_conv_from_SD reads a cwd-relative file (reference openaimodel.py:404): a seeded stand-in of the same shapes
+        import tempfile
+        os.chdir(tempfile.mkdtemp())
+        torch.save(syn.sd_first_conv_state(), "SD_input_conv_weight_bias.pth")
     torch.cuda.synchronize()
 
     def one_pass(lane):
@@ -232,7 +241,7 @@ def main():
         with torch.cuda.stream(stream):
             z0 = autoencoder.encode(image) if cfg["inpaint"] else None
             imgs = gi.generate(model, autoencoder, diffusion, batch, context, uc, steps=args.plms_steps, guidance_scale=7.5,
-                               alpha_type=None, starting_noise=x_T.clone(), use_graph=not args.no_graph, inpainting_mask=mask, z0=z0)
+                               alpha_type=alpha_type, starting_noise=x_T.clone(), use_graph=not args.no_graph, inpainting_mask=mask, z0=z0)
             return autoencoder.engine.to_uint8(imgs)
 
     for _ in range(max(1, args.warmup)):       # every lane: GEMM autotune (first lane), graph capture, allocator warm-up
@@ -307,7 +316,7 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": cfg["desc"] + ", 512x512, 50 PLMS steps, CFG 7.5, bf16 storage / fp32 accumulate", "baseline_config": args.config,
                        "images_per_gpu_per_step": B, "plms_steps": args.plms_steps, "unet_evals_per_image": 2 * (args.plms_steps + 1),
-                       "grounding_tokens": cfg["ng"], "hipgraph": not args.no_graph, "batches_in_flight": L,
+                       "grounding_tokens": cfg["ng"], "alpha_type": alpha_type or [1, 0, 0], "hipgraph": not args.no_graph, "batches_in_flight": L,
                        "weights": "seeded random init of the SD-1.4 GLIGEN architecture (966 tensors, 1.07 B params)"},
             "unet_step_ms": unet_ms, "unet_step_desc": f"one [cond ; uncond] UNet evaluation at batch {2 * B} (hipGraph replay, HIP events on the engine stream, "
                                                        f"measured in an untimed pass with one batch in flight)",

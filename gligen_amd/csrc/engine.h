@@ -222,6 +222,7 @@ class Engine {
     const float* const* alpha_ptrs_ = nullptr;  // device array [2*n_st]
     float* gates_ = nullptr;                    // device [2*n_st]: (attn, dense) per transformer
     float* fuser_scale_ = nullptr;              // device scalar
+    bool fuser_off_ = false;                    // host mirror of "scale == 0": the fuser branches are then skipped outright
     // grounding tokenizer
     int gkind_ = 0;
     LinW pn_[2][3];
@@ -281,8 +282,9 @@ class Engine {
         float* hist[4] = {nullptr, nullptr, nullptr, nullptr};
         float* x_tmp = nullptr;
         int64_t* t_dev = nullptr;
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
+        // one captured [cond ; uncond] evaluation per fuser state: [0] fusers on, [1] fusers skipped (gate scale 0)
+        hipGraph_t graph[2] = {nullptr, nullptr};
+        hipGraphExec_t exec[2] = {nullptr, nullptr};
         hipStream_t stream = nullptr;  // engine-owned capture/replay stream
         hipEvent_t ev_in = nullptr, ev_out = nullptr;
         std::vector<hipEvent_t> tev;  // (start, stop) per UNet evaluation of the last run

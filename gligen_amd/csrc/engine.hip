@@ -979,6 +979,10 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
 
     const int Ng = cond_.Ng;
     bf16* t2;
+    bf16* t3;
+    if (fuser_off_) {
+        t3 = t1;
+    } else {
     if (ucfg_.fuser_kind == 1) {
         // fuser (gatedSA2, attention.py:271-297): the attention outputs AT the grounding tokens (an sg x sg grid) are
         // projected, resized bicubically to the visual grid and added as the gated residual
@@ -1043,7 +1047,8 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
     }
     //        x = x + scale*tanh(alpha_dense) * ff(norm2(x))
     ln = layernorm(t2, B, HW, C, t.fn2, false, s);
-    bf16* t3 = feedforward(t.fff, ln, M, t2, gates_ + 2 * t.idx + 1, s);
+    t3 = feedforward(t.fff, ln, M, t2, gates_ + 2 * t.idx + 1, s);
+    }
 
     // x = attn2(norm2(x), context) + x
     ln = layernorm(t3, B, HW, C, t.ln2, true, s);
@@ -1092,6 +1097,10 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
 void Engine::set_fuser_scale(float v, hipStream_t s) {
     if (!has_unet_ || !finalized_) throw GlError(GL_ERR_STATE, "unet not finalized");
     CK(set_f32_launch(fuser_scale_, v, s));
+    // set_alpha_scale(model, 0) (the tail of the reference's alpha schedules, gligen_inference.py:31-66): every gated residual is
+    // x + 0 * f(x) = x, so the fuser's attention and feed-forward are not launched at all (gatedSA2 never gets here with 0: the
+    // reference's set_alpha_scale does not reach it)
+    fuser_off_ = v == 0.f;
 }
 
 // UNetModel.restore_first_conv_from_SD (openaimodel.py:400-413): overwrite the packed first-conv
@@ -1155,7 +1164,7 @@ void Engine::set_cond(int Beff, const float* context, int n_ctx, const gl_ground
         cond_.ctx_Tpad = ctx_Tpad;
         cond_.obj_Tpad = obj_Tpad;
     }
-    if (cond_.ctx_T != n_ctx && smp_.exec) {  // captured cross-attention launches bake Nk = ctx_T
+    if (cond_.ctx_T != n_ctx && (smp_.exec[0] || smp_.exec[1])) {  // captured cross-attention launches bake Nk = ctx_T
         HIPCK(hipStreamSynchronize(smp_.stream));
         sampler_release_graph();
     }
@@ -1570,10 +1579,12 @@ void Engine::sampler_timing(float* avg_ms, float* first_ms, int* n) {
 }
 
 void Engine::sampler_release_graph() {
-    if (smp_.exec) (void)hipGraphExecDestroy(smp_.exec);
-    if (smp_.graph) (void)hipGraphDestroy(smp_.graph);
-    smp_.exec = nullptr;
-    smp_.graph = nullptr;
+    for (int i = 0; i < 2; ++i) {
+        if (smp_.exec[i]) (void)hipGraphExecDestroy(smp_.exec[i]);
+        if (smp_.graph[i]) (void)hipGraphDestroy(smp_.graph[i]);
+        smp_.exec[i] = nullptr;
+        smp_.graph[i] = nullptr;
+    }
 }
 
 void Engine::sample_plms(const gl_plms_args& a, hipStream_t caller) {
@@ -1622,8 +1633,9 @@ void Engine::sample_plms(const gl_plms_args& a, hipStream_t caller) {
             smp_.tev.push_back(e);
         }
         HIPCK(hipEventRecord(smp_.tev[2 * evals], s));
+        const int gi = fuser_off_ ? 1 : 0;
         if (a.use_graph && evals >= 1) {
-            if (!smp_.exec) {
+            if (!smp_.exec[gi]) {
                 HIPCK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
                 try {
                     unet_forward(Beff, a.h, a.w, smp_.x2, a.B, smp_.t_dev, a.inpaint_extra, a.B, smp_.eps_pair, s);
@@ -1633,12 +1645,12 @@ void Engine::sample_plms(const gl_plms_args& a, hipStream_t caller) {
                     if (g) (void)hipGraphDestroy(g);
                     throw;
                 }
-                HIPCK(hipStreamEndCapture(s, &smp_.graph));
-                HIPCK(hipGraphInstantiate(&smp_.exec, smp_.graph, nullptr, nullptr, 0));
+                HIPCK(hipStreamEndCapture(s, &smp_.graph[gi]));
+                HIPCK(hipGraphInstantiate(&smp_.exec[gi], smp_.graph[gi], nullptr, nullptr, 0));
             }
-            HIPCK(hipGraphLaunch(smp_.exec, s));
-        } else if (a.use_graph && smp_.exec) {
-            HIPCK(hipGraphLaunch(smp_.exec, s));
+            HIPCK(hipGraphLaunch(smp_.exec[gi], s));
+        } else if (a.use_graph && smp_.exec[gi]) {
+            HIPCK(hipGraphLaunch(smp_.exec[gi], s));
         } else {
             unet_forward(Beff, a.h, a.w, smp_.x2, a.B, smp_.t_dev, a.inpaint_extra, a.B, smp_.eps_pair, s);
         }
