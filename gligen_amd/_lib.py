@@ -72,6 +72,7 @@ SYMBOLS = {
     "gl_finalize": (_I, [_P]),
     "gl_unet_set_cond": (_I, [_P, _I, _P, _I, C.POINTER(Grounding), _P]),
     "gl_unet_set_fuser_scale": (_I, [_P, C.c_float, _P]),
+    "gl_unet_set_fuser_scales": (_I, [_P, C.POINTER(C.c_float), _I, _P]),
     "gl_unet_grounding_tokens": (_I, [_P, _P, _P]),
     "gl_op_spatial_tokens": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "gl_op_grounding_downsample": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P]),

@@ -107,6 +107,14 @@ int gl_unet_set_cond(gl_ctx* ctx, int Beff, const float* context, int n_ctx_toke
     GL_API_END
 }
 
+int gl_unet_set_fuser_scales(gl_ctx* ctx, const float* scales_host, int n, gl_stream s) {
+    NEED(ctx);
+    if (!scales_host) return gl::set_error(GL_ERR_ARG, "null scales");
+    GL_API_BEGIN
+    ctx->eng->set_fuser_scales(scales_host, n, S(s));
+    GL_API_END
+}
+
 int gl_unet_grounding_tokens(gl_ctx* ctx, float* out, gl_stream s) {
     NEED(ctx);
     if (!out) return gl::set_error(GL_ERR_ARG, "null out pointer");

@@ -125,6 +125,8 @@ class Engine {
 
     void set_cond(int Beff, const float* context, int n_ctx, const gl_grounding& g, hipStream_t s);
     void set_fuser_scale(float v, hipStream_t s);
+    void set_fuser_scales(const float* scales_host, int n, hipStream_t s);
+    int n_fusers() const { return (int)st_.size(); }
     void grounding_tokens(float* out, hipStream_t s);
     // PositionNet.forward of the spatial-map tokenizers: image [B][C][H][W] fp32, mask [B] -> out fp32 [B][tokens][gr_out_dim]
     void spatial_tokens(int B, const float* image, int C, int H, int W, const float* mask, float* out, hipStream_t s);
@@ -221,7 +223,7 @@ class Engine {
     ConvW out_conv_;
     const float* const* alpha_ptrs_ = nullptr;  // device array [2*n_st]
     float* gates_ = nullptr;                    // device [2*n_st]: (attn, dense) per transformer
-    float* fuser_scale_ = nullptr;              // device scalar
+    float* fuser_scale_ = nullptr;              // device [n_st]: the fusers' external gate multipliers
     bool fuser_off_ = false;                    // host mirror of "scale == 0": the fuser branches are then skipped outright
     // grounding tokenizer
     int gkind_ = 0;

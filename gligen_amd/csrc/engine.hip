@@ -463,9 +463,8 @@ void Engine::build_unet() {
         HIPCK(hipMemcpy(d, ptrs.data(), ptrs.size() * sizeof(float*), hipMemcpyHostToDevice));
         alpha_ptrs_ = reinterpret_cast<const float* const*>(d);
         gates_ = reinterpret_cast<float*>(persist(ptrs.size() * sizeof(float), true));
-        fuser_scale_ = reinterpret_cast<float*>(persist(sizeof(float), true));
-        const float one = 1.f;
-        HIPCK(hipMemcpy(fuser_scale_, &one, sizeof(float), hipMemcpyHostToDevice));
+        fuser_scale_ = reinterpret_cast<float*>(persist(st_.size() * sizeof(float), true));   // one scale per fuser
+        CK(fill_f32_launch(fuser_scale_, 1.f, (int)st_.size(), 0));
     }
 
     // grounding tokenizer (position_net)
@@ -1096,7 +1095,7 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
 // ---------------------------------------------------------------- conditioning
 void Engine::set_fuser_scale(float v, hipStream_t s) {
     if (!has_unet_ || !finalized_) throw GlError(GL_ERR_STATE, "unet not finalized");
-    CK(set_f32_launch(fuser_scale_, v, s));
+    CK(fill_f32_launch(fuser_scale_, v, (int)st_.size(), s));
     // set_alpha_scale(model, 0) (the tail of the reference's alpha schedules, gligen_inference.py:31-66): every gated residual is
     // x + 0 * f(x) = x, so the fuser's attention and feed-forward are not launched at all (gatedSA2 never gets here with 0: the
     // reference's set_alpha_scale does not reach it)
@@ -1269,6 +1268,18 @@ void Engine::set_cond(int Beff, const float* context, int n_ctx, const gl_ground
             CK(gemm_launch_t(t.a2.wv, t.C, ctxb, Beff * ctx_Tpad, t.a2.ctx_dim, E, s));
         }
     }
+}
+
+// the `scale` attributes of the fuser modules, one per transformer block in module order (they are plain Python attributes in
+// the reference: set_alpha_scale writes the same value into all of them, anything else may write them individually)
+void Engine::set_fuser_scales(const float* scales, int n, hipStream_t s) {
+    if (!has_unet_ || !finalized_) throw GlError(GL_ERR_STATE, "unet not finalized");
+    if (n != (int)st_.size()) throw GlError(GL_ERR_ARG, fmt("set_fuser_scales: %d values for %d fusers", n, (int)st_.size()));
+    HIPCK(hipMemcpyAsync(fuser_scale_, scales, n * sizeof(float), hipMemcpyHostToDevice, s));
+    HIPCK(hipStreamSynchronize(s));   // `scales` is the caller's host memory
+    bool all_zero = true;
+    for (int i = 0; i < n; ++i) all_zero = all_zero && scales[i] == 0.f;
+    fuser_off_ = all_zero;
 }
 
 void Engine::grounding_tokens(float* out, hipStream_t s) {

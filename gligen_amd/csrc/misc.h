@@ -62,7 +62,8 @@ int conv4x4s2_f32_launch(const float* x, const float* w, const float* bias, floa
 // layout: gemm_geglu_layout() of the GEMM variant that will consume the packed rows
 int pack_geglu_launch(const float* w, const float* b, bf16* wp, float* bp, int C4, int K, int layout, hipStream_t stream);
 
-// gates[i] = scale * tanh(alpha[i])   (reference attention.py:241-242)
+int fill_f32_launch(float* dst, float v, int n, hipStream_t stream);
+// gates[i] = scale[i / 2] * tanh(alpha[i])   (reference attention.py:241-242; one scale per fuser module)
 int gates_launch(const float* const* alpha_ptrs, const float* scale, float* gates, int n, hipStream_t stream);
 
 // e_t = e_u + s (e_c - e_u) ; e' = c0 e_t + c1 o1 + c2 o2 + c3 o3 ;

@@ -255,9 +255,19 @@ int pack_geglu_launch(const float* w, const float* b, bf16* wp, float* bp, int C
     return GL_OK;
 }
 
+// scale: one value per fuser (gates 2i and 2i+1 belong to fuser i)
 __global__ void gates_kernel(const float* const* alpha_ptrs, const float* scale, float* gates, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) gates[i] = scale[0] * tanhf(alpha_ptrs[i][0]);
+    if (i < n) gates[i] = scale[i >> 1] * tanhf(alpha_ptrs[i][0]);
+}
+__global__ void fill_f32_kernel(float* d, float v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = v;
+}
+int fill_f32_launch(float* dst, float v, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(fill_f32_kernel, dim3(cdiv(n, 64)), dim3(64), 0, stream, dst, v, n);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
 }
 int gates_launch(const float* const* alpha_ptrs, const float* scale, float* gates, int n, hipStream_t stream) {
     hipLaunchKernelGGL(gates_kernel, dim3(cdiv(n, 64)), dim3(64), 0, stream, alpha_ptrs, scale, gates, n);

@@ -178,6 +178,11 @@ class Engine:
     def set_fuser_scale(self, scale: float) -> None:
         check(self.lib.gl_unet_set_fuser_scale(self._ctx, C.c_float(float(scale)), _stream()))
 
+    def set_fuser_scales(self, scales) -> None:
+        """One gate multiplier per fuser module, in module order (for models whose fusers carry different `scale` values)."""
+        arr = (C.c_float * len(scales))(*[float(v) for v in scales])
+        check(self.lib.gl_unet_set_fuser_scales(self._ctx, arr, len(scales), _stream()))
+
     def restore_first_conv(self, weight: torch.Tensor, bias: torch.Tensor) -> None:
         w, b = _f32(weight, self.device), _f32(bias, self.device)
         check(self.lib.gl_unet_restore_first_conv(self._ctx, _ptr(w), _ptr(b), _stream()))

@@ -123,6 +123,9 @@ int gl_unet_set_cond(gl_ctx* ctx, int Beff, const float* context, int n_ctx_toke
 int gl_unet_grounding_tokens(gl_ctx* ctx, float* out, gl_stream s);
 /* set_alpha_scale(model, alpha) (gligen_inference.py:24-28) */
 int gl_unet_set_fuser_scale(gl_ctx* ctx, float scale, gl_stream s);
+/* the fuser modules' individual `scale` attributes (attention.py:198,231,262), one host float per transformer block in module
+ * order (input_blocks, middle_block, output_blocks), for callers that set them one by one instead of through set_alpha_scale */
+int gl_unet_set_fuser_scales(gl_ctx* ctx, const float* scales_host, int n, gl_stream s);
 /* UNetModel.restore_first_conv_from_SD (openaimodel.py:400-413): replace the first conv's weights
  * (OIHW fp32 [mc][in_channels][3][3], bias [mc]); stream-ordered, valid under hipGraph replay. */
 int gl_unet_restore_first_conv(gl_ctx* ctx, const float* w, const float* b, gl_stream s);

@@ -98,7 +98,7 @@ class PLMSSampler(object):
         # The schedule still decides when the SD first conv is swapped in (plms.py:88-89).
         scales = alphas
         if alphas is None or model.fuser_type == "gatedSA2":
-            model.engine.set_fuser_scale(model.fuser_scale())
+            model.push_fuser_scales()   # whatever the modules carry (1 unless set by hand), possibly one value per fuser
             scales = None
 
         img = input["x"].to(device=model.engine.device, dtype=torch.float32).contiguous().clone()

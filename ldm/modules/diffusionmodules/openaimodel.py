@@ -167,13 +167,25 @@ class UNetModel(nn.Module):
             self._cond_key = None
         return self._engine
 
-    def fuser_scale(self):
+    def fuser_scales(self):
+        """The fusers' `scale` attributes in module order (= the engine's transformer order)."""
         from ldm.modules.attention import GatedCrossAttentionDense, GatedSelfAttentionDense, GatedSelfAttentionDense2
         kinds = (GatedSelfAttentionDense, GatedSelfAttentionDense2, GatedCrossAttentionDense)
-        scales = {float(m.scale) for m in self.modules() if type(m) in kinds}
+        return [float(m.scale) for m in self.modules() if type(m) in kinds]
+
+    def fuser_scale(self):
+        """The common gate multiplier of all fusers (what set_alpha_scale wrote); ValueError if they differ."""
+        scales = set(self.fuser_scales())
         if len(scales) != 1:
-            raise NotImplementedError(f"per-layer fuser scales {sorted(scales)}: the engine applies one scale to all fusers")
+            raise ValueError(f"the fusers carry different scales {sorted(scales)}: use fuser_scales()")
         return scales.pop()
+
+    def push_fuser_scales(self):
+        scales = self.fuser_scales()
+        if len(set(scales)) == 1:
+            self.engine.set_fuser_scale(scales[0])
+        else:
+            self.engine.set_fuser_scales(scales)
 
     def set_conditioning(self, context, grounding_input):
         """Step-invariant work (grounding tokens, fuser projections, text K/V), skipped when the very same tensors come
@@ -254,7 +266,7 @@ class UNetModel(nn.Module):
             grounding_input = self.grounding_tokenizer_input.get_null_input()
         eng = self.engine
         self.set_conditioning(input["context"], grounding_input)
-        eng.set_fuser_scale(self.fuser_scale())
+        self.push_fuser_scales()
         extra = input.get("inpainting_extra_input") if self.inpaint_mode else self.first_conv_extra(input)
         if self.inpaint_mode and extra is None:
             raise ValueError("inpaint_mode model needs input['inpainting_extra_input']")

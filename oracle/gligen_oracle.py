@@ -264,6 +264,11 @@ def unet_forward(sd: SD, cfg: Mapping, inp: Mapping, fuser_scale: float = 1.0) -
     A missing grounding_input is the caller's job (pass null_grounding(...)), as in openaimodel.py:422-426.
     """
     mc, heads = cfg["model_channels"], cfg["num_heads"]
+    if not isinstance(fuser_scale, (int, float)):   # one `scale` per fuser module, in module order (they are plain attributes)
+        scales = iter(list(fuser_scale))
+    else:
+        scales = None
+    _scale = (lambda: next(scales)) if scales is not None else (lambda: fuser_scale)
     if cfg.get("grounding_kind") == "spatial":  # canny / hed / depth / normal / sem: {"image", "mask"} (or precomputed "tokens")
         gi = inp["grounding_input"]
         objs = gi["tokens"] if "tokens" in gi else spatial_position_net(sd, "position_net", gi["image"], gi["mask"], cfg["tok_resize"])
@@ -290,7 +295,7 @@ def unet_forward(sd: SD, cfg: Mapping, inp: Mapping, fuser_scale: float = 1.0) -
         for _ in range(cfg["num_res_blocks"]):
             h = unet_resblock(sd, f"input_blocks.{n}.0", h, emb)
             if attn_here(ds):
-                h = spatial_transformer(sd, f"input_blocks.{n}.1", h, ctx, objs, heads, fuser_scale, cfg.get("fuser_type"))
+                h = spatial_transformer(sd, f"input_blocks.{n}.1", h, ctx, objs, heads, _scale(), cfg.get("fuser_type"))
             hs.append(h)
             n += 1
         if level != len(mults) - 1:
@@ -299,7 +304,7 @@ def unet_forward(sd: SD, cfg: Mapping, inp: Mapping, fuser_scale: float = 1.0) -
             n += 1
             ds *= 2
     h = unet_resblock(sd, "middle_block.0", h, emb)
-    h = spatial_transformer(sd, "middle_block.1", h, ctx, objs, heads, fuser_scale, cfg.get("fuser_type"))
+    h = spatial_transformer(sd, "middle_block.1", h, ctx, objs, heads, _scale(), cfg.get("fuser_type"))
     h = unet_resblock(sd, "middle_block.2", h, emb)
     n = 0
     for level in reversed(range(len(mults))):
@@ -308,7 +313,7 @@ def unet_forward(sd: SD, cfg: Mapping, inp: Mapping, fuser_scale: float = 1.0) -
             h = unet_resblock(sd, f"output_blocks.{n}.0", h, emb)
             j = 1
             if attn_here(ds):
-                h = spatial_transformer(sd, f"output_blocks.{n}.1", h, ctx, objs, heads, fuser_scale, cfg.get("fuser_type"))
+                h = spatial_transformer(sd, f"output_blocks.{n}.1", h, ctx, objs, heads, _scale(), cfg.get("fuser_type"))
                 j = 2
             if level and i == cfg["num_res_blocks"]:
                 h = F.interpolate(h, scale_factor=2, mode="nearest")

@@ -83,6 +83,46 @@ def test_unet_small_vs_reference(name):
     assert torch.equal(model(inp), eps)
 
 
+def test_per_fuser_scales():
+    """The fusers' `scale` attributes are plain per-module values in the reference (attention.py:231); set individually they
+    reach the engine one by one (gl_unet_set_fuser_scales), a zero among them included."""
+    dev = _dev()
+    from ldm.modules.attention import GatedSelfAttentionDense
+    from oracle import gligen_oracle as orc
+    g = load_golden("unet_small_text")
+    meta = g["meta"]
+    model = build_product_unet(meta["cfg"], "text", device=dev)
+    batch, x, ctx, t, _ = unet_inputs(meta)
+    fusers = [m for m in model.modules() if type(m) is GatedSelfAttentionDense]
+    scales = [0.3, 1.0, 0.0, 0.7, 1.5][:len(fusers)] + [1.0] * max(0, len(fusers) - 5)
+    for m, sc in zip(fusers, scales):
+        m.scale = sc
+    assert model.fuser_scales() == scales
+    with pytest.raises(ValueError):
+        model.fuser_scale()
+    gin = model.grounding_tokenizer_input.prepare(_to(batch, dev))
+    eps = model(dict(x=x.to(dev), timesteps=t.to(dev), context=ctx.to(dev), grounding_input=gin, inpainting_extra_input=None,
+                     grounding_extra_input=None))
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        ref = orc.unet_forward(sd, oracle_cfg(meta["cfg"], "text"), dict(x=x, timesteps=t, context=ctx, grounding_input=grounding_kwargs("text", batch)),
+                               fuser_scale=scales)
+        ref_uniform = orc.unet_forward(sd, oracle_cfg(meta["cfg"], "text"), dict(x=x, timesteps=t, context=ctx,
+                                                                                 grounding_input=grounding_kwargs("text", batch)))
+    REPORT["per_fuser_scales"] = dict(eps=mse(eps, ref), vs_uniform=mse(ref, ref_uniform))
+    assert mse(ref, ref_uniform) > 1e-4          # the individual scales matter
+    assert mse(eps, ref) < EPS_MSE_TOL, REPORT["per_fuser_scales"]
+    # all fusers at 0: the fuser branches are skipped outright, which is exact
+    for m in fusers:
+        m.scale = 0
+    eps0 = model(dict(x=x.to(dev), timesteps=t.to(dev), context=ctx.to(dev), grounding_input=gin, inpainting_extra_input=None,
+                      grounding_extra_input=None))
+    with torch.no_grad():
+        ref0 = orc.unet_forward(sd, oracle_cfg(meta["cfg"], "text"), dict(x=x, timesteps=t, context=ctx, grounding_input=grounding_kwargs("text", batch)),
+                                fuser_scale=0.0)
+    assert mse(eps0, ref0) < EPS_MSE_TOL
+
+
 def test_unet_full_vs_reference():
     """The shipped topology (966 tensors, 1.07 B params) at latent 16x16 against the reference's output."""
     dev = _dev()
