@@ -100,7 +100,7 @@ def pmc_traffic(kernel):
     FETCH_SIZE / WRITE_SIZE are KiB summed over the L2 channels; FETCH_SIZE is doubled, the guide's gfx950 correction
     for 16-B-per-lane streaming reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is taken as reported."""
     import csv
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.csv")), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.csv")))   # rN_final sorts last: the newest round's passes
     if not files:
         return None, None
     sym = kernel.split(" + ")[0].split(" [")[0]

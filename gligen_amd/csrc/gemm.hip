@@ -358,8 +358,8 @@ gemm_glds_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
                 GL_GLDS16(src, xs + i * RPP * 128);
             }
         } else {
-            const int tap = kt % 9;          // K tile = (64-channel chunk, filter tap): chunk major (see gemm_u_kernel)
-            const int c = (kt / 9) << 6;
+            const int tap = k0 / Cin;
+            const int c = k0 - tap * Cin;
             const int ky = tap / 3;
             const int kx = tap - ky * 3;
             const bool first = c < A.C0;
@@ -479,7 +479,7 @@ struct WorkDesc {
     // rm x tiles_n x rz box (tiles_n = N tiles PER BOX then), so that an activation panel is fetched by 2^lgn L2s and a
     // weight panel by 2^lgm (the K axis duplicates nothing). rz = splits when box < 0.
     int box, rm, rz;
-    int dbg;  // developer ablation (GL_GEMM_DBG): bit 0 = skip the DMA, bit 1 = skip the MFMAs, bit 2 = skip the epilogue (results are garbage), bit 3 = fragment-layout epilogue stores, bit 4 = tap-major conv K order (timing A/B of the gather only)
+    int dbg;  // developer ablation (GL_GEMM_DBG): bit 0 = skip the DMA, bit 1 = skip the MFMAs, bit 2 = skip the epilogue (results are garbage), bit 3 = fragment-layout epilogue stores
 };
 
 template <int TM, int TN, int AMODE>
@@ -563,8 +563,8 @@ gemm_p_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
                 GL_GLDS16(src, xs + i * 4096);
             }
         } else {
-            const int tap = kt % 9;          // K tile = (64-channel chunk, filter tap): chunk major (see gemm_u_kernel)
-            const int c = (kt / 9) << 6;
+            const int tap = k0 / Cin;
+            const int c = k0 - tap * Cin;
             const int ky = tap / 3;
             const int kx = tap - ky * 3;
             const bool first = c < A.C0;
@@ -806,10 +806,8 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
 
     // ---- load cursor: (item, K tile) plus, for the conv gather, the filter tap and channel offset of that tile
     int l_item = blockIdx.x, l_kt = 0, l_kt_end = 0;
-    int l_tap = 0, l_cc = 0;     // A_CONV3: K tile = (channel chunk l_cc / 64, filter tap l_tap).   A_ROWS: l_cc = k
-    int xm[XP];                  // A_ROWS: row or -1.  A_CONV3: (sample << 22) | ((y + 1) << 11) | (x + 1) of the top-left tap, y field 2047 = no
-                                 // such row: ONE register per row (B < 1024, H, W < 2046) -- this state lives across the epilogue, and the
-                                 // 128 x 160 conv instantiation has no register to spare
+    int l_tap = 0, l_cc = 0;     // A_CONV3: k = l_tap * Cin + l_cc.   A_ROWS: l_cc = k
+    int xm[XP], xy[XP], xx[XP];  // A_ROWS: xm = row or -1.  A_CONV3: xm = b * Hin, (xy, xx) = top-left tap (xy very negative: no row)
     unsigned va[XP], vw[WP];     // per-lane byte offsets into the current activation source / the weight matrix
 
     // byte offsets of this lane's activation chunks for the current (tap, source)
@@ -824,10 +822,10 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
             const int kx = l_tap - ky * 3;
 #pragma unroll
             for (int i = 0; i < XP; ++i) {
-                const int iy = ((xm[i] >> 11) & 2047) - 1 + ky;
-                const int ix = (xm[i] & 2047) - 1 + kx;
+                const int iy = xy[i] + ky;
+                const int ix = xx[i] + kx;
                 const bool ok = iy >= 0 && iy < Hup && ix >= 0 && ix < Wup;
-                const int pix = (((unsigned)xm[i] >> 22) * A.Hin + (iy >> A.ups)) * A.Win + (ix >> A.ups);
+                const int pix = (xm[i] + (iy >> A.ups)) * A.Win + (ix >> A.ups);
                 va[i] = ok ? (unsigned)(pix * ld) * 2u + chb : SENT;
             }
         }
@@ -844,12 +842,14 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
             const bool ok = m < M;
             if constexpr (AMODE == A_ROWS) {
                 xm[i] = ok ? m : -1;
+                xy[i] = xx[i] = 0;
             } else {
                 const int ox = m % A.Wo;
                 const int tmp = m / A.Wo;
                 const int oy = tmp % A.Ho;
-                const int yf = ok ? oy * A.stride - A.pad_lo + 1 : 2047;
-                xm[i] = (int)(((unsigned)(tmp / A.Ho) << 22) | ((unsigned)yf << 11) | (unsigned)(ox * A.stride - A.pad_lo + 1));
+                xm[i] = (tmp / A.Ho) * A.Hin;
+                xy[i] = ok ? oy * A.stride - A.pad_lo : -(1 << 20);
+                xx[i] = ox * A.stride - A.pad_lo;
             }
         }
 #pragma unroll
@@ -858,16 +858,13 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
             const bool in_tile = !(WREM && i == WP - 1) || wave < WREM / 8;
             vw[i] = (in_tile && n < N) ? (unsigned)(n * K) * 2u + chb : SENT;
         }
+        const int k0 = l_kt << 6;
         if constexpr (AMODE == A_ROWS) {
             l_tap = 0;
-            l_cc = l_kt << 6;
+            l_cc = k0;
         } else {
-            l_cc = (l_kt / 9) << 6;
-            l_tap = l_kt - (l_kt / 9) * 9;
-            if (wd.dbg & 16) {
-                l_tap = (l_kt << 6) / Cin;
-                l_cc = (l_kt << 6) - l_tap * Cin;
-            }
+            l_tap = k0 / Cin;
+            l_cc = k0 - l_tap * Cin;
         }
         a_offsets();
     };
@@ -900,25 +897,20 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
         }
         }
         // advance
+        l_cc += 64;
         if (++l_kt >= l_kt_end) {
             l_item += gridDim.x;
             more = l_item < wd.n_items;
             if (more) setup_load(l_item);
         } else if constexpr (AMODE == A_CONV3) {
-            // K order of the conv gather: 64-channel chunk major, the nine filter taps inside it (k = chunk * 576 + tap * 64 + c).
-            // The nine K tiles of a chunk read the same few image rows shifted by one pixel = one 128-byte line, so taps 1..8 of
-            // every chunk hit the XCD's L2 (with the tap-major order the whole Cin-wide row panel came round again per tap:
-            // 6-11x the algorithmic fabric traffic on the 960 / 1920 / 2560-channel decoder convs, profiles/r2_final).
-            if (wd.dbg & 16) {   // developer A/B (timing only, results are garbage): the old tap-major K order
-                l_cc += 64;
-                if (l_cc == Cin) { l_cc = 0; ++l_tap; }
-            } else if (++l_tap == 9) {
-                l_tap = 0;
-                l_cc += 64;
+            if (l_cc == Cin) {
+                l_cc = 0;
+                ++l_tap;
+                a_offsets();
+            } else if (l_cc == A.C0) {
+                a_offsets();
             }
-            a_offsets();
         } else {
-            l_cc += 64;
             if (A.C1 && l_cc == A.C0) a_offsets();
         }
     };
@@ -1785,9 +1777,6 @@ int gemm_launch(const AOperand& A, const bf16* W, int M, int N, int K, const Epi
     if (A.mode == A_CONV3) {
         if ((A.C0 + A.C1) % 64 != 0 || A.C0 % 64 != 0 || K != 9 * (A.C0 + A.C1))
             return set_error(GL_ERR_ARG, "conv3x3: channels (%d,%d) must be multiples of 64 and K=9*Cin (K=%d)", A.C0, A.C1, K);
-        // the gather keeps (sample, y, x) of a tile row in one register: 10 + 11 + 11 bits
-        if (M / (A.Ho * A.Wo) >= 1024 || (A.Hin << A.ups) >= 2046 || (A.Win << A.ups) >= 2046)
-            return set_error(GL_ERR_UNSUPPORTED, "conv3x3: batch %d / image %dx%d beyond the gather's packed coordinates", M / (A.Ho * A.Wo), A.Hin << A.ups, A.Win << A.ups);
     } else {
         if (K != A.C0 + A.C1 || (A.C1 && A.C0 % 64 != 0))
             return set_error(GL_ERR_ARG, "gemm: K=%d does not match operand channels (%d,%d)", K, A.C0, A.C1);

@@ -48,7 +48,7 @@ int cast_pad_cols_launch(const float* src, bf16* dst, int N, int K, int Kpad, hi
 // bf16 [B][rows][cols] -> [B][rows_pad][cols], zero pad rows
 int pad_rows_bf16_launch(const bf16* src, bf16* dst, int B, int rows, int rows_pad, int cols, hipStream_t stream);
 int set_f32_launch(float* dst, float v, hipStream_t stream);
-// conv weight OIHW fp32 -> [O_pad][I/64][kh*kw][64] bf16 (K order of the conv gather: k = (c/64)*(taps*64) + tap*64 + c%64), rows >= O zero
+// conv weight OIHW fp32 -> [O_pad][kh*kw][I] bf16 (K-major: k = tap*I + c), rows >= O zero
 int pack_conv_weight_launch(const float* src, bf16* dst, int O, int I, int KH, int KW, int O_pad, hipStream_t stream);
 // small-Cin conv weight OIHW fp32 -> [O][Kpad] bf16 with k = tap*I + c
 // I_src (0 = I): input channels of the source weight when it has fewer than the packed layout (extra channels get zeros)

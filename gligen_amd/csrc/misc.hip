@@ -185,22 +185,18 @@ int set_f32_launch(float* dst, float v, hipStream_t stream) {
     return GL_OK;
 }
 
-// K order of the implicit-GEMM conv (gemm.hip): 64-channel chunk major, filter taps inside, channels of the chunk innermost:
-// k = (c / 64) * (taps * 64) + tap * 64 + c % 64   (I % 64 == 0)
 __global__ void pack_conv_weight_kernel(const float* __restrict__ s, bf16* __restrict__ d, int O, int I, int KH, int KW, int O_pad) {
     const int taps = KH * KW;
     const int64_t total = (int64_t)O_pad * taps * I;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int k = (int)(i % ((int64_t)taps * I));
-        const int o = (int)(i / ((int64_t)taps * I));
-        const int chunk = k / (taps * 64);
-        const int tap = (k - chunk * taps * 64) >> 6;
-        const int c = chunk * 64 + (k & 63);
+        const int c = (int)(i % I);
+        const int64_t r = i / I;
+        const int tap = (int)(r % taps);
+        const int o = (int)(r / taps);
         d[i] = o < O ? f2bf(s[((size_t)o * I + c) * taps + tap]) : f2bf(0.f);
     }
 }
 int pack_conv_weight_launch(const float* src, bf16* dst, int O, int I, int KH, int KW, int O_pad, hipStream_t stream) {
-    if (I % 64) return set_error(GL_ERR_ARG, "pack_conv_weight: %d input channels (must be a multiple of 64)", I);
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(grid_for((int64_t)O_pad * KH * KW * I)), dim3(256), 0, stream, src, dst, O, I, KH, KW, O_pad);
     GL_LAUNCH_CHECK();
     return GL_OK;
