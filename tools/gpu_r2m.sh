@@ -1,0 +1,5 @@
+#!/bin/bash
+# round 2, evidence run on the shipped tree: g1 (suite + bench lines of every BASELINE config) then g2 (kbench tables, in-situ,
+# rocprofv3 kernel stats, PMC traffic per symbol / per problem)
+bash tools/gpu_r2g1.sh
+bash tools/gpu_r2g2.sh
