@@ -1440,6 +1440,332 @@ splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, Epi
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// conv3x3 "halo" kernel (stride 1, pad 1, power-of-two images up to 64 wide): 8 waves, ONE workgroup per CU, a 256 x (TN*32)
+// output tile = 256 consecutive pixels (whole image rows / whole small images) x BN output channels.
+// The implicit-GEMM kernel above stages the activation operand once per FILTER TAP (128 rows x 128 B per K tile next to 160
+// weight rows: 36 KB of LDS-DMA per 128x160x64 multiply, and the DMA path -- about 53 GB/s per CU -- bounds it). Here a
+// 64-channel chunk of the tile's input pixels INCLUDING the one-pixel halo is staged once ((R+2) x (W+2) rows of 128 B,
+// 324-400 rows for the shapes below) and the nine taps are walked inside LDS: the fragment read of tap (ky, kx) is the same
+// read shifted by ky (W+2) + kx halo rows. Per 256x160x64 multiply the DMA then brings one 20 KB weight tile plus 1/9 of a
+// halo: 2.5x fewer bytes per FLOP.
+//   LDS: two halo buffers (448 rows each = 7 DMA passes of 64 rows) + two weight slots.
+//   K order inside a work item: chunk major, taps inside (weights stay [O][tap][I]: the tap only moves the SGPR offset).
+//   Per (chunk, tap):  vmcnt(0) -> barrier -> DMA of the next weight tile + ONE pass of the next chunk's halo (taps 0..6)
+//                      -> fragment reads + 40 MFMAs per wave.
+//   Split-K splits by chunks and goes through the same fp32 slabs + splitk_reduce_kernel as the kernel above.
+struct HaloDesc {
+    int tiles_n, splits, chunks_per_split, n_items;
+    int lgW, lgH;   // image width / height (powers of two)
+};
+
+template <int TN, int NW>
+__global__ void __launch_bounds__(NW * 64, 1)
+conv_halo_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilogue E, float* __restrict__ ws, HaloDesc hd) {
+    constexpr int NT = NW * 64;
+    constexpr int RPP = NT / 8;                 // rows per DMA pass (one 128-byte row per 8 lanes)
+    constexpr int TM = 32 / NW;                 // 16-row fragments per wave: NW/2 waves along M, 2 along N
+    constexpr int BM = 256;
+    constexpr int BN = TN * 32;
+    constexpr int HROWS = 448;
+    constexpr int HPASS = HROWS / RPP;          // halo DMA passes
+    constexpr int HPT = (HPASS + 6) / 7;        // halo passes issued with each of the taps 0..6
+    constexpr int HBUF = HROWS * 128;           // bytes per halo buffer
+    constexpr int WSLOT = BN * 128;
+    constexpr int WP = (BN + RPP - 1) / RPP;    // weight DMA passes; the last one is partial when BN % RPP != 0
+    constexpr int WREM = BN % RPP;
+    constexpr unsigned SENT = 0x80000000u;
+    static_assert(HPASS * RPP == HROWS && HPT * 7 >= HPASS && WREM % 8 == 0, "loader geometry");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1;
+    const int wn = wave & 1;
+    const int l15 = lane & 15;
+    const int q = lane >> 4;
+    const int r0 = t >> 3;                                          // row inside a DMA pass
+    const unsigned chb = (((t & 7) ^ ((r0 >> 1) & 7)) * 16);        // byte offset of this lane's (swizzled) source chunk
+    const int Cin = A.C0 + A.C1;
+
+    const int Wd = 1 << hd.lgW, Hd = 1 << hd.lgH;
+    const int R = BM >> hd.lgW;                 // image rows per tile
+    const int lgHB = min(hd.lgH, 8 - hd.lgW);   // rows per halo block: a tile is R / HB whole images, or HB = R rows of one
+    const int HB = 1 << lgHB;
+    const int W2 = Wd + 2;
+    const int blkrows = (HB + 2) * W2;
+    const int NH = (R >> lgHB) * blkrows;       // halo rows in use (<= 400)
+
+    const __amdgpu_buffer_rsrc_t ra0 = __builtin_amdgcn_make_buffer_rsrc((void*)A.p0, 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc((void*)(A.p1 ? A.p1 : A.p0), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0x80000000u, 0x00020000);
+
+    // ---- halo row h = pass * RPP + r0 of a tile  <->  source pixel (first pixel of the tile) + hrel, if it is a real pixel: not a
+    // left / right padding column, not beyond NH, not above / below the image (whole-image blocks: always padding there; a block
+    // of R rows inside an image: padding only when the tile starts at the top / ends at the bottom of its image).
+    // Recomputed per DMA pass (one pass per tile in the steady state) with multiply-shift divisions -- exact for h < 993 with
+    // divisors <= 66 resp. <= 448 -- rather than kept in seven registers that the 256-register budget does not have.
+    const unsigned inv_w2 = (65536u + W2 - 1) / W2, inv_blk = (65536u + blkrows - 1) / blkrows;
+    // fragment rows: pixel p of the tile sits at halo row hr (tap (0,0)); tap (ky, kx) adds ky * W2 + kx. A wave's TM * 16 pixels lie
+    // inside one halo block (a block has >= 64 pixels), so fragment i is fragment 0 plus a wave-uniform number of halo rows:
+    // 16 pixels further along the image row, wrapping into the next halo row(s) every Wd pixels
+    int hr00;
+    {
+        const int p = wm * TM * 16 + l15;
+        const int blk = p >> (lgHB + hd.lgW);
+        const int yl = (p >> hd.lgW) & (HB - 1);
+        const int x = p & (Wd - 1);
+        hr00 = blk * blkrows + yl * W2 + x;
+    }
+    auto hr_delta = [&](int i) -> int {   // halo rows from fragment 0 to fragment i (scalar): the wave's first pixel is a multiple
+        const int px = i * 16;            // of 64, so x + (px mod Wd) never carries into the next image row
+        return (px >> hd.lgW) * W2 + (px & (Wd - 1));
+    };
+    const int foff0 = l15 * 128 + (((q) ^ (l15 >> 1)) << 4);
+    const int foff1 = l15 * 128 + (((q + 4) ^ (l15 >> 1)) << 4);
+    const int wrow0 = wn * TN * 16 * 128;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    // ---- work item state
+    int m0 = 0, c_tn = 0, c_z = 0;
+    bool top_ok = false, bot_ok = false;
+    unsigned vw0 = SENT;              // byte offset of this lane's chunk of weight row (tile's first row + r0); pass i adds i * RPP rows
+    auto setup = [&](int item) {
+        const int tile = item / hd.splits;
+        c_z = item - tile * hd.splits;
+        const int tm = tile / hd.tiles_n;
+        c_tn = tile - tm * hd.tiles_n;
+        m0 = tm * BM;
+        const int y0 = (m0 >> hd.lgW) & (Hd - 1);
+        top_ok = y0 != 0;
+        bot_ok = y0 + HB != Hd;
+        vw0 = (unsigned)((c_tn * BN + r0) * K) * 2u + chb;     // N % BN == 0 (host): every weight row of the tile exists
+    };
+    auto issue_halo = [&](int p, int cc_, int hb_) {     // pass p of the 64-channel chunk at channel cc into halo buffer hb
+        const int cc = __builtin_amdgcn_readfirstlane(cc_);
+        const int hb = __builtin_amdgcn_readfirstlane(hb_);
+        const bool first = cc < A.C0;
+        const unsigned ld2 = (unsigned)(first ? A.ld0 : A.ld1) * 2u;
+        const int soff = (first ? cc : cc - A.C0) * 2;
+        const int h = p * RPP + r0;
+        const int blk = (int)(((unsigned)h * inv_blk) >> 16);
+        const int rem = h - blk * blkrows;
+        const int hy = (int)(((unsigned)rem * inv_w2) >> 16);
+        const int hx = rem - hy * W2;
+        const bool ok = h < NH && hx >= 1 && hx <= Wd && (hy != 0 || top_ok) && (hy != HB + 1 || bot_ok);
+        const int hrel = ((blk << lgHB) + hy - 1) * Wd + hx - 1;
+        const unsigned va = ok ? __umul24((unsigned)(m0 + hrel), ld2) + chb : SENT;
+        unsigned char* dst = smem + hb * HBUF + (p * RPP + wave * 8) * 128;
+        if (first) GL_BLDS16(ra0, dst, va, soff);
+        else GL_BLDS16(ra1, dst, va, soff);
+    };
+    auto issue_w = [&](int tap, int cc_, int ws_) {      // weight tile of (tap, chunk) into weight slot ws
+        const int cc = __builtin_amdgcn_readfirstlane(cc_);
+        const int wsl = __builtin_amdgcn_readfirstlane(ws_);
+        const int soff = (tap * Cin + cc) * 2;
+        unsigned char* dst = smem + 2 * HBUF + wsl * WSLOT + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < WP; ++i) {
+            if (WREM && i == WP - 1 && wave >= WREM / 8) continue;   // wave-uniform
+            GL_BLDS16(rw, dst + i * RPP * 128, vw0, soff + i * RPP * K * 2);
+        }
+    };
+
+    f32x4 acc[TM][TN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+
+    // One (chunk, tap) tile: all 2 x (TM + TN) fragment reads go out at once (every wave of the workgroup reads at the same time and
+    // keeps the LDS port full), the MFMAs of K step 0 start when its fragments are in, and hipcc is left to schedule the rest: it
+    // runs the MFMAs of K step 1 behind the NEXT tile's barrier and DMA issue. Hand-placed alternatives were all slower on
+    // MI355X (profiles/r2_final/halo_schedules.txt): the two wave groups half a tile out of phase (each wave gets one
+    // ds_read_b128 out per ~45 clocks, four waves cannot fill the port), activation fragments of the next tile read ahead with
+    // the reads interleaved between the MFMA rows, and four 128x80 waves (one per SIMD: nothing to issue while one waits).
+    auto compute = [&](int tapoff, int hb, int wsl) {
+        const unsigned hbase = lds0 + hb * HBUF;
+        const unsigned wbase = lds0 + 2 * HBUF + wsl * WSLOT + wrow0;
+        unsigned ax0[TM], ax1[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const unsigned hr = (unsigned)(hr00 + hr_delta(i) + tapoff);
+            ax0[i] = hbase + hr * 128u + (((unsigned)q ^ ((hr >> 1) & 7u)) << 4);
+            ax1[i] = ax0[i] ^ 64u;    // k-step 1 = chunks 4..7: (q + 4) ^ s = (q ^ s) ^ 4
+        }
+        const unsigned aw0 = wbase + foff0, aw1 = wbase + foff1;
+        bf16x8 xa[TM], wa[TN], xb[TM], wb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) lds_rd16<0>(xa[i], ax0[i]);
+        lds_rd16_n<TN, 2048>(wa, aw0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) lds_rd16<0>(xb[i], ax1[i]);
+        lds_rd16_n<TN, 2048>(wb, aw1);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN));  // the k-step 0 fragments have returned
+        pin_regs(xa);
+        pin_regs(wa);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xa[i], acc[i][j], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)");
+        pin_regs(xb);
+        pin_regs(wb);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xb[i], acc[i][j], 0, 0, 0);
+    };
+
+    auto store_row = [&](int m, int n0, float (&v)[4]) {   // EPI_ROWMAJOR only (checked on the host)
+        if (E.act == ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+        }
+        if (E.out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(E.out) + (size_t)m * E.ldo + n0) = make_float4(v[0], v[1], v[2], v[3]);
+        else store_bf16x4(reinterpret_cast<bf16*>(E.out) + (size_t)m * E.ldo + n0, v);
+    };
+    auto epilogue = [&]() {
+        const int mrow = m0 + wm * TM * 16 + l15;
+        const int ncol = c_tn * BN + wn * TN * 16 + q * 4;
+        if (hd.splits > 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = mrow + i * 16;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n0 = ncol + j * 16;
+                    *reinterpret_cast<float4*>(ws + ((size_t)c_z * M + m) * N + n0) =
+                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                }
+            }
+            return;
+        }
+        float4 bj[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bj[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (E.bias) bj[j] = *reinterpret_cast<const float4*>(E.bias + ncol + j * 16);
+        }
+        if (E.bias2) {  // + broadcast per-sample bias (ResBlock time embedding); never combined with a residual
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = mrow + i * 16;
+                const float* b2p = E.bias2 + (size_t)(m / E.rows_per_b) * E.bias2_ld + ncol;
+                float4 b2[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b2[j] = *reinterpret_cast<const float4*>(b2p + j * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float v[4] = {acc[i][j][0] + bj[j].x + b2[j].x, acc[i][j][1] + bj[j].y + b2[j].y,
+                                  acc[i][j][2] + bj[j].z + b2[j].z, acc[i][j][3] + bj[j].w + b2[j].w};
+                    store_row(m, ncol + j * 16, v);
+                }
+            }
+        } else if (E.res) {
+            const float g = E.gate ? *E.gate : 1.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = mrow + i * 16;
+                uint2 rs[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) rs[j] = *reinterpret_cast<const uint2*>(E.res + (size_t)m * E.ldres + ncol + j * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n0 = ncol + j * 16;
+                    U2BF4 r;
+                    r.u = rs[j];
+                    float v[4] = {acc[i][j][0] + bj[j].x, acc[i][j][1] + bj[j].y, acc[i][j][2] + bj[j].z, acc[i][j][3] + bj[j].w};
+                    if (E.act == ACT_SILU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = bf2f(r.e[e]) + g * v[e];
+                    if (E.out_f32) {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(E.out) + (size_t)m * E.ldo + n0) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        store_bf16x4(reinterpret_cast<bf16*>(E.out) + (size_t)m * E.ldo + n0, v);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = mrow + i * 16;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float v[4] = {acc[i][j][0] + bj[j].x, acc[i][j][1] + bj[j].y, acc[i][j][2] + bj[j].z, acc[i][j][3] + bj[j].w};
+                    store_row(m, ncol + j * 16, v);
+                }
+            }
+        }
+    };
+
+    // ---- persistent loop over work items. Per (chunk, tap), one barrier:
+    //   vmcnt(0) -> barrier -> DMA of the next weight tile (+ HPT passes of the next chunk's halo, taps 0..6) -> compute
+    int item = blockIdx.x;
+    if (item >= hd.n_items) return;
+    int hb = 0, wsl = 0;              // halo buffer / weight slot of the tile about to be multiplied
+    int cc = 0, cc_end = 0;
+    auto begin_item = [&](int it) {   // prologue DMA of an item: the whole first halo + the first weight tile
+        setup(it);
+        cc = c_z * hd.chunks_per_split * 64;
+        cc_end = min(Cin, cc + hd.chunks_per_split * 64);
+#pragma unroll
+        for (int p = 0; p < HPASS; ++p) issue_halo(p, cc, hb);
+        issue_w(0, cc, wsl);
+    };
+    begin_item(item);
+    zero_acc();
+    for (;;) {
+        hb = __builtin_amdgcn_readfirstlane(hb);
+        wsl = __builtin_amdgcn_readfirstlane(wsl);
+        cc = __builtin_amdgcn_readfirstlane(cc);
+        cc_end = __builtin_amdgcn_readfirstlane(cc_end);
+        const bool next_chunk = cc + 64 < cc_end;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this tile's weights (tap 0: and the chunk's halo) have landed
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (tap < 8) issue_w(tap + 1, cc, wsl ^ 1);
+            else if (next_chunk) issue_w(0, cc + 64, wsl ^ 1);
+            if (tap < 7 && next_chunk) {
+#pragma unroll
+                for (int pp = 0; pp < HPT; ++pp)
+                    if (tap * HPT + pp < HPASS) issue_halo(tap * HPT + pp, cc + 64, hb ^ 1);
+            }
+            compute((tap / 3) * W2 + tap % 3, hb, wsl);
+            wsl ^= 1;
+        }
+        cc += 64;
+        hb ^= 1;
+        if (cc < cc_end) continue;
+        // item done: start the next item's DMA (into the halo buffer / weight slot not read by the last tile), then store
+        const int done_m0 = m0, done_tn = c_tn, done_z = c_z;
+        item += gridDim.x;
+        const bool more = item < hd.n_items;
+        if (more) begin_item(item);
+        {   // the epilogue addresses the finished item
+            const int nm0 = m0, ntn = c_tn, nz = c_z;
+            m0 = done_m0; c_tn = done_tn; c_z = done_z;
+            epilogue();
+            m0 = nm0; c_tn = ntn; c_z = nz;
+        }
+        if (!more) break;
+        zero_acc();
+    }
+}
+
 static int g_gemm_variant = -1;  // 1: LDS-DMA v2 (one tile per workgroup), 2: persistent v3, 4: v5 buffer-DMA persistent (default)
 void gemm_set_variant(int v) { g_gemm_variant = v; }
 static int gemm_variant() {
@@ -1562,6 +1888,75 @@ int launch_u(const AOperand& A, const bf16* W, int M, int N, int K, const Epilog
 // residency candidates on the device with the caller's own buffers and caches the winner; captured launches and
 // GL_GEMM_AUTOTUNE=0 use the analytic cost model below. A launch only writes E.out (and the split-K workspace),
 // and the engine never aliases E.out with an input, so re-running a launch is idempotent.
+// The halo kernel's problems: 3x3, stride 1, pad 1, power-of-two images up to 64 wide whose 256-pixel tiles are whole rows of one
+// image or whole images, plain row-major epilogue (bias, per-sample bias, residual, SiLU, fp32 slabs for split-K).
+static inline int ilog2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
+bool halo_eligible(const AOperand& A, int M, int N, int K, const Epilogue& E) {
+    if (A.mode != A_CONV3 || A.stride != 1 || A.ups || A.pad_lo != 1 || A.Ho != A.Hin || A.Wo != A.Win) return false;
+    const int lgW = ilog2_exact(A.Win), lgH = ilog2_exact(A.Hin);
+    if (lgW < 3 || lgW > 6 || lgH < 0 || M % 256) return false;
+    const int R = 256 >> lgW, HB = std::min(A.Hin, R);
+    if ((R / HB) * (HB + 2) * (A.Win + 2) > 448) return false;
+    if (A.C0 % 64 || A.C1 % 64 || (N % 160 && N % 128)) return false;   // whole 160- or 128-wide tiles only
+    if (E.mode != EPI_ROWMAJOR || E.remap_in || (E.act != ACT_NONE && E.act != ACT_SILU) || (E.bias2 && E.res)) return false;
+    if (E.bias2 && (E.rows_per_b != A.Hin * A.Win)) return false;
+    const size_t a_rows = (size_t)M;
+    return a_rows * (size_t)std::max(A.ld0, A.ld1) * 2 < 0x7fff0000ull && (size_t)N * K * 2 < 0x7fff0000ull;
+}
+
+int launch_halo(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, float* ws, size_t ws_bytes, int want_splits,
+                hipStream_t stream) {
+    const int tn = N % 160 == 0 ? 5 : 4;
+    const int bn = tn * 32;
+    HaloDesc hd;
+    hd.lgW = ilog2_exact(A.Win);
+    hd.lgH = ilog2_exact(A.Hin);
+    hd.tiles_n = cdiv(N, bn);
+    const int tiles = (M / 256) * hd.tiles_n;
+    const int nch = (A.C0 + A.C1) / 64;
+    int sp = want_splits;
+    if (sp <= 0) {   // one work item per CU where the chunks allow it
+        sp = 1;
+        while (tiles * sp < 200 && nch / (sp * 2) >= 2) sp *= 2;
+    }
+    sp = std::max(1, std::min(sp, nch));
+    if (!ws) sp = 1;
+    while (sp > 1 && (size_t)sp * M * N * sizeof(float) > ws_bytes) --sp;
+    hd.chunks_per_split = cdiv(nch, sp);
+    hd.splits = cdiv(nch, hd.chunks_per_split);
+    hd.n_items = tiles * hd.splits;
+    const int halo_waves = 8;
+    g_last_cfg[0] = 8; g_last_cfg[1] = tn; g_last_cfg[2] = hd.splits;
+    snprintf(g_last_name, sizeof g_last_name, "conv_halo_kernel<%d, %d>%s", tn, halo_waves, hd.splits > 1 ? " + splitk_reduce_kernel" : "");
+    dim3 grid(std::min(hd.n_items, 256)), block(halo_waves * 64);
+    const size_t lds = 2 * 7 * 64 * 128 + 2 * bn * 128;
+#define GL_LAUNCH_HALO(KFN)                                                                                      \
+    do {                                                                                                         \
+        auto kfn = KFN;                                                                                          \
+        static bool attr_done = false;                                                                           \
+        if (!attr_done) {                                                                                        \
+            GL_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            attr_done = true;                                                                                    \
+        }                                                                                                        \
+        hipLaunchKernelGGL(kfn, grid, block, lds, stream, A, W, M, N, K, E, ws, hd);                             \
+    } while (0)
+    if (tn == 5) GL_LAUNCH_HALO((conv_halo_kernel<5, 8>));
+    else GL_LAUNCH_HALO((conv_halo_kernel<4, 8>));
+#undef GL_LAUNCH_HALO
+    GL_LAUNCH_CHECK();
+    if (hd.splits > 1) {
+        int64_t total = (int64_t)M * (N / 4);
+        int blocks = (int)fmin((double)cdiv64(total, 256), 4096.0);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws, hd.splits, M, N, E);
+        GL_LAUNCH_CHECK();
+    }
+    return GL_OK;
+}
+
 struct TunedCfg { int c, sp, grid; };
 static std::unordered_map<std::string, TunedCfg> g_tuned;   // process-wide, guarded by g_tune_mu (ctypes drops the GIL during calls)
 static std::mutex g_tune_mu;
@@ -1582,6 +1977,12 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
     const bool fits32 = a_rows * (size_t)std::max(A.ld0, A.ld1) * 2 < 0x7fff0000ull && (size_t)N * K * 2 < 0x7fff0000ull;
     const bool use_u = gemm_variant() == 4 && fits32 && !(E.bias2 && E.res);  // v5's epilogue has no bias2 + residual form
     static const int dbg = getenv("GL_GEMM_DBG") ? atoi(getenv("GL_GEMM_DBG")) : 0;
+    // eligible 3x3 convs with M >= 256 * GL_CONV_HALO (default 8; 0 = never) go to the halo kernel (GL_CONV_HALO_SPLITS=n forces its
+    // K split): at M = 512 (the 8 x 8 level) its 16 tiles x deep split lose to the 64 x 160 tiles of the kernel above
+    static const int halo = getenv("GL_CONV_HALO") ? atoi(getenv("GL_CONV_HALO")) : 8;
+    static const int halo_splits = getenv("GL_CONV_HALO_SPLITS") ? atoi(getenv("GL_CONV_HALO_SPLITS")) : 0;
+    if (halo && use_u && !g_force_tm && halo_eligible(A, M, N, K, E) && M >= halo * 256)
+        return launch_halo(A, W, M, N, K, E, ws, ws_bytes, halo_splits, stream);
     static const int xcd_boxes = getenv("GL_GEMM_XCD_BOXES") ? atoi(getenv("GL_GEMM_XCD_BOXES")) : 1;
 
     auto feasible = [&](int c, int& sp) {

@@ -71,6 +71,13 @@ def conv_ref(x_nhwc, w, b, stride=1, ups=0, pad_lo=1):
     dict(B=2, H=12, W=20, C0=128, C1=64, Cout=64),
     dict(B=3, H=8, W=8, C0=1280, C1=1280, Cout=1280),
     dict(B=1, H=16, W=16, C0=128, Cout=4),
+    # the halo kernel's shapes (M >= 2048, power-of-two images up to 64 wide, N % 160 or % 128 == 0): two sources, a tile that is
+    # some rows of one image (top / bottom padding depends on the tile), a tile of many whole images, 128-wide tiles + split-K
+    dict(B=2, H=32, W=32, C0=128, C1=64, Cout=320),
+    dict(B=4, H=32, W=16, C0=128, Cout=160),
+    dict(B=32, H=8, W=8, C0=192, Cout=160),
+    dict(B=8, H=16, W=16, C0=256, Cout=256),
+    dict(B=1, H=64, W=64, C0=64, Cout=128),
 ])
 def test_conv3x3(engine, cfg):
     B, H, W, C0, Cout = cfg["B"], cfg["H"], cfg["W"], cfg["C0"], cfg["Cout"]

@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 2, call P: halo kernel with the two wave groups out of phase -- check, timing, ablation
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+K=gligen_amd/build/kbench
+{
+echo "== default"; timeout 200 $K tools/unet_b8.shapes 10 conv | grep "^conv\|^TOTAL conv" | cut -c1-130
+echo "== GL_CONV_HALO=1 check"; GL_CONV_HALO=1 timeout 300 $K tools/unet_b8.shapes 10 conv check | grep "^conv\|^TOTAL conv\|CHECK\|MISMATCH\|mismatch" | cut -c1-160
+echo "== vae GL_CONV_HALO=1 check"; GL_CONV_HALO=1 timeout 300 $K tools/vae_b4.shapes 5 conv check | grep "^conv\|^TOTAL conv\|CHECK\|MISMATCH\|mismatch" | cut -c1-160
+for d in 0 1 2 4 5 3; do
+echo "== GL_CONV_HALO_DBG=$d (1 no DMA, 2 no compute, 4 no MFMA)"; GL_CONV_HALO=1 GL_CONV_HALO_DBG=$d timeout 100 $K tools/halo.shapes 10 conv | grep "^conv" | cut -c1-130
+done
+} > gpurun_out/halo2.txt 2>&1
+grep "==\|TOTAL\|CHECK\|MISM" gpurun_out/halo2.txt
