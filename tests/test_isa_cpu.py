@@ -61,6 +61,28 @@ def test_gemm_kernels_do_not_spill(gemm_asm):
         assert int(m.group(1)) == 0
 
 
+def test_halo_kernel_keeps_its_cross_barrier_pipelining(gemm_asm):
+    """conv_halo_kernel: hipcc runs the MFMAs of a tile's second K step BEHIND the next tile's barrier and DMA issue, in front of the
+    next tile's fragment reads (which then fly under them). That order is worth ~20 % of the kernel (every
+    variant that lost it -- run-time ablation switches, a branch chain in front of the barrier -- fell back to the speed of the
+    implicit-GEMM kernel), and nothing in the source pins it: this test does. Also: no scratch, no spills."""
+    names = re.findall(r"^(_ZN2gl16conv_halo_kernel[^:\s]*):", gemm_asm, re.M)
+    assert len(names) == 2
+    for name in names:
+        a = gemm_asm.index(name + ":")
+        body = gemm_asm[a:gemm_asm.index(".Lfunc_end", a)].split("\n")
+        assert not [l for l in body if "scratch_" in l], name
+        bars = [i for i, l in enumerate(body) if "s_barrier" in l]
+        assert len(bars) == 9, (name, len(bars))          # one barrier per filter tap
+        for k in range(1, 7):                                # taps 1..6 (the last two segments also hold the loop's back edge)
+            seg = [l.strip() for l in body[bars[k]:bars[k + 1]]]
+            first_read = next(i for i, l in enumerate(seg) if l.startswith("ds_read"))
+            ahead = sum(1 for l in seg[:first_read] if l.startswith("v_mfma"))
+            assert ahead >= 16, f"{name}: tap {k}: only {ahead} MFMAs in front of the fragment reads"
+            dma = [i for i, l in enumerate(seg) if l.startswith("buffer_load") and "lds" in l]
+            assert dma and dma[0] < first_read, f"{name}: tap {k}: the DMA must be issued before the fragment reads"
+
+
 @pytest.fixture(scope="module")
 def attn_asm(tmp_path_factory):
     from gligen_amd.build import EXTRA_FLAGS
