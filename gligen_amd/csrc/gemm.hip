@@ -1766,6 +1766,256 @@ conv_halo_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// "Wide" GEMM (A_ROWS, round 2): the geometry of conv_halo_kernel for plain row-major activations. 8 waves, ONE workgroup per CU,
+// 256 x (TN*32) tile, two LDS stages of (256 + BN) x 128 B, one barrier per K tile:
+//     vmcnt(0) -> barrier -> DMA of the next K tile into the other stage -> all fragment reads -> MFMAs
+// (hipcc runs the second K step's MFMAs behind the next barrier, as in the halo kernel). Against gemm_u_kernel's 128-row tiles
+// the weight tile is fetched once per 256 rows: 52 KB of LDS-DMA per 256x160x64 multiply instead of 72 KB. For the long-K,
+// wide-N problems (FF-out, the GEGLU projections of the 32x32 / 16x16 levels); whole tiles only (M % 256 == 0, N % BN == 0).
+struct WideDesc {
+    int tiles_n, splits, kt_per_split, n_items;
+};
+
+template <int TN>
+__global__ void __launch_bounds__(512, 1)
+gemm_wide_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilogue E, float* __restrict__ ws, WideDesc wd) {
+    constexpr int TM = 4;
+    constexpr int BM = 256;
+    constexpr int BN = TN * 32;
+    constexpr int XP = BM / 64;                 // activation DMA passes (64 rows each)
+    constexpr int WP = (BN + 63) / 64;          // weight DMA passes; the last one is partial when BN % 64 != 0
+    constexpr int WREM = BN % 64;
+    constexpr int STAGE = (BM + BN) * 128;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1;
+    const int wn = wave & 1;
+    const int l15 = lane & 15;
+    const int q = lane >> 4;
+    const int r0 = t >> 3;                                          // row inside a DMA pass
+    const unsigned chb = (((t & 7) ^ ((r0 >> 1) & 7)) * 16);        // byte offset of this lane's (swizzled) source chunk
+    const int nk = K >> 6;
+
+    const __amdgpu_buffer_rsrc_t ra0 = __builtin_amdgcn_make_buffer_rsrc((void*)A.p0, 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc((void*)(A.p1 ? A.p1 : A.p0), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0x80000000u, 0x00020000);
+
+    const int foff0 = l15 * 128 + (((q) ^ (l15 >> 1)) << 4);
+    const int foff1 = l15 * 128 + (((q + 4) ^ (l15 >> 1)) << 4);
+    const int xrow0 = wm * TM * 16 * 128;
+    const int wrow0 = BM * 128 + wn * TN * 16 * 128;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    // ---- work item state
+    int m0 = 0, c_tn = 0, c_z = 0;
+    unsigned vx0 = 0, vx1 = 0, vw0 = 0;   // byte offsets of this lane's chunk of row (tile's first row + r0) in p0 / p1 / W; pass i adds 64 rows
+    auto setup = [&](int item) {
+        const int tile = item / wd.splits;
+        c_z = item - tile * wd.splits;
+        const int tm = tile / wd.tiles_n;
+        c_tn = tile - tm * wd.tiles_n;
+        m0 = tm * BM;
+        vx0 = (unsigned)((m0 + r0) * A.ld0) * 2u + chb;
+        vx1 = (unsigned)((m0 + r0) * A.ld1) * 2u + chb;
+        vw0 = (unsigned)((c_tn * BN + r0) * K) * 2u + chb;
+    };
+    auto issue = [&](int kt_, int st_) {     // K tile kt into stage st
+        const int kt = __builtin_amdgcn_readfirstlane(kt_);
+        const int st = __builtin_amdgcn_readfirstlane(st_);
+        const int k0 = kt << 6;
+        const bool first = k0 < A.C0;
+        unsigned char* xs = smem + st * STAGE + wave * 1024;
+        if (first) {
+#pragma unroll
+            for (int i = 0; i < XP; ++i) GL_BLDS16(ra0, xs + i * 64 * 128, vx0, k0 * 2 + i * 64 * A.ld0 * 2);
+        } else {
+#pragma unroll
+            for (int i = 0; i < XP; ++i) GL_BLDS16(ra1, xs + i * 64 * 128, vx1, (k0 - A.C0) * 2 + i * 64 * A.ld1 * 2);
+        }
+        unsigned char* wsm = xs + BM * 128;
+#pragma unroll
+        for (int i = 0; i < WP; ++i) {
+            if (WREM && i == WP - 1 && wave >= WREM / 8) continue;   // wave-uniform
+            GL_BLDS16(rw, wsm + i * 64 * 128, vw0, k0 * 2 + i * 64 * K * 2);
+        }
+    };
+
+    f32x4 acc[TM][TN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    // K step 1 of a tile is multiplied one tile late: its MFMAs go out right behind the next barrier and DMA issue, and the next
+    // tile's fragment reads fly under them (the order hipcc finds by itself in the unrolled halo kernel; this loop is not unrolled)
+    bf16x8 xb[TM], wb[TN];
+    auto step1 = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xb[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto compute = [&](int stg, bool pending) {
+        const unsigned st = lds0 + stg * STAGE;
+        const unsigned ax0 = st + xrow0 + foff0, ax1 = st + xrow0 + foff1;
+        const unsigned aw0 = st + wrow0 + foff0, aw1 = st + wrow0 + foff1;
+        bf16x8 xa[TM], wa[TN];
+        if (pending) step1();
+        lds_rd16_n<TM, 2048>(xa, ax0);
+        lds_rd16_n<TN, 2048>(wa, aw0);
+        lds_rd16_n<TM, 2048>(xb, ax1);
+        lds_rd16_n<TN, 2048>(wb, aw1);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN));  // the k-step 0 fragments have returned
+        pin_regs(xa);
+        pin_regs(wa);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xa[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto finish = [&]() {   // the item's last K step 1
+        asm volatile("s_waitcnt lgkmcnt(0)");
+        pin_regs(xb);
+        pin_regs(wb);
+        __builtin_amdgcn_sched_barrier(0);
+        step1();
+    };
+
+    auto epilogue = [&]() {
+        const int mrow = m0 + wm * TM * 16 + l15;
+        const int ncol = c_tn * BN + wn * TN * 16 + q * 4;
+        if (wd.splits > 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = mrow + i * 16;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    *reinterpret_cast<float4*>(ws + ((size_t)c_z * M + m) * N + ncol + j * 16) =
+                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+            return;
+        }
+        if constexpr (TN % 2 == 0) {
+            if (E.act == ACT_GEGLU) {   // geglu16 weight layout: fragment 2 jj = 16 value features, 2 jj + 1 = their gates
+                float4 bv[TN / 2], bg[TN / 2];
+#pragma unroll
+                for (int jj = 0; jj < TN / 2; ++jj) {
+                    bv[jj] = bg[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (E.bias) {
+                        bv[jj] = *reinterpret_cast<const float4*>(E.bias + ncol + jj * 32);
+                        bg[jj] = *reinterpret_cast<const float4*>(E.bias + ncol + jj * 32 + 16);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int m = mrow + i * 16;
+#pragma unroll
+                    for (int jj = 0; jj < TN / 2; ++jj) {
+                        const int n0 = ncol + jj * 32;
+                        const f32x2 r0 = geglu2(f32x2{acc[i][2 * jj][0] + bv[jj].x, acc[i][2 * jj][1] + bv[jj].y},
+                                                f32x2{acc[i][2 * jj + 1][0] + bg[jj].x, acc[i][2 * jj + 1][1] + bg[jj].y});
+                        const f32x2 r1 = geglu2(f32x2{acc[i][2 * jj][2] + bv[jj].z, acc[i][2 * jj][3] + bv[jj].w},
+                                                f32x2{acc[i][2 * jj + 1][2] + bg[jj].z, acc[i][2 * jj + 1][3] + bg[jj].w});
+                        float o[4] = {r0.x, r0.y, r1.x, r1.y};
+                        const int j0 = (n0 >> 5) * 16 + (n0 & 15);
+                        store_bf16x4(reinterpret_cast<bf16*>(E.out) + (size_t)m * E.ldo + j0, o);
+                    }
+                }
+                return;
+            }
+        }
+        float4 bj[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bj[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (E.bias) bj[j] = *reinterpret_cast<const float4*>(E.bias + ncol + j * 16);
+        }
+        const float g = (E.res && E.gate) ? *E.gate : 1.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = mrow + i * 16;
+            uint2 rs[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                rs[j] = make_uint2(0, 0);
+                if (E.res) rs[j] = *reinterpret_cast<const uint2*>(E.res + (size_t)m * E.ldres + ncol + j * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n0 = ncol + j * 16;
+                float v[4] = {acc[i][j][0] + bj[j].x, acc[i][j][1] + bj[j].y, acc[i][j][2] + bj[j].z, acc[i][j][3] + bj[j].w};
+                if (E.act == ACT_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                }
+                if (E.res) {
+                    U2BF4 r;
+                    r.u = rs[j];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = bf2f(r.e[e]) + g * v[e];
+                }
+                if (E.out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(E.out) + (size_t)m * E.ldo + n0) = make_float4(v[0], v[1], v[2], v[3]);
+                else store_bf16x4(reinterpret_cast<bf16*>(E.out) + (size_t)m * E.ldo + n0, v);
+            }
+        }
+    };
+
+    // ---- persistent loop over work items
+    int item = blockIdx.x;
+    if (item >= wd.n_items) return;
+    int stg = 0;
+    int kt = 0, kt_end = 0;
+    auto begin_item = [&](int it) {
+        setup(it);
+        kt = c_z * wd.kt_per_split;
+        kt_end = min(nk, kt + wd.kt_per_split);
+        issue(kt, stg);
+    };
+    begin_item(item);
+    zero_acc();
+    bool pending = false;             // K step 1 of the previous tile of this item waits in xb / wb
+    for (;;) {
+        stg = __builtin_amdgcn_readfirstlane(stg);
+        kt = __builtin_amdgcn_readfirstlane(kt);
+        kt_end = __builtin_amdgcn_readfirstlane(kt_end);
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this K tile has landed
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 1 < kt_end) issue(kt + 1, stg ^ 1);
+        compute(stg, pending);
+        pending = true;
+        stg ^= 1;
+        if (++kt < kt_end) continue;
+        finish();
+        pending = false;
+        // item done: start the next item's first tile (into the stage the last tile was not read from), then store
+        const int done_m0 = m0, done_tn = c_tn, done_z = c_z;
+        item += gridDim.x;
+        const bool more = item < wd.n_items;
+        if (more) begin_item(item);
+        {
+            const int nm0 = m0, ntn = c_tn, nz = c_z;
+            m0 = done_m0; c_tn = done_tn; c_z = done_z;
+            epilogue();
+            m0 = nm0; c_tn = ntn; c_z = nz;
+        }
+        if (!more) break;
+        zero_acc();
+    }
+}
+
+
 static int g_gemm_variant = -1;  // 1: LDS-DMA v2 (one tile per workgroup), 2: persistent v3, 4: v5 buffer-DMA persistent (default)
 void gemm_set_variant(int v) { g_gemm_variant = v; }
 static int gemm_variant() {
@@ -1957,6 +2207,62 @@ int launch_halo(const AOperand& A, const bf16* W, int M, int N, int K, const Epi
     return GL_OK;
 }
 
+// The wide kernel's problems: row-major activations, whole 256 x BN tiles, plain / residual / SiLU / GEGLU row-major epilogues.
+bool wide_eligible(const AOperand& A, int M, int N, int K, const Epilogue& E) {
+    if (A.mode != A_ROWS || M % 256 || (N % 160 && N % 128)) return false;
+    if (A.C1 && A.C0 % 64) return false;
+    if (E.mode != EPI_ROWMAJOR || E.remap_in || E.bias2) return false;
+    if (E.act == ACT_GEGLU) { if (N % 128 || !E.geglu16 || E.res || E.out_f32) return false; }
+    else if (E.act != ACT_NONE && E.act != ACT_SILU) return false;
+    return (size_t)M * (size_t)std::max(A.ld0, A.ld1) * 2 < 0x7fff0000ull && (size_t)N * K * 2 < 0x7fff0000ull;
+}
+
+int launch_wide(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, float* ws, size_t ws_bytes, int want_splits,
+                hipStream_t stream) {
+    const int tn = (E.act != ACT_GEGLU && N % 160 == 0) ? 5 : 4;
+    const int bn = tn * 32;
+    WideDesc wd;
+    wd.tiles_n = N / bn;
+    const int tiles = (M / 256) * wd.tiles_n;
+    const int nk = K / 64;
+    int sp = want_splits;
+    if (sp <= 0) {
+        sp = 1;
+        while (tiles * sp < 200 && nk / (sp * 2) >= 4) sp *= 2;
+    }
+    sp = std::max(1, std::min(sp, nk));
+    if (!ws || E.act == ACT_GEGLU) sp = 1;
+    while (sp > 1 && (size_t)sp * M * N * sizeof(float) > ws_bytes) --sp;
+    wd.kt_per_split = cdiv(nk, sp);
+    wd.splits = cdiv(nk, wd.kt_per_split);
+    wd.n_items = tiles * wd.splits;
+    g_last_cfg[0] = 8; g_last_cfg[1] = tn; g_last_cfg[2] = wd.splits;
+    snprintf(g_last_name, sizeof g_last_name, "gemm_wide_kernel<%d>%s", tn, wd.splits > 1 ? " + splitk_reduce_kernel" : "");
+    dim3 grid(std::min(wd.n_items, 256)), block(512);
+    const size_t lds = 2 * (256 + bn) * 128;
+#define GL_LAUNCH_WIDE(KFN)                                                                                      \
+    do {                                                                                                         \
+        auto kfn = KFN;                                                                                          \
+        static bool attr_done = false;                                                                           \
+        if (!attr_done) {                                                                                        \
+            GL_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            attr_done = true;                                                                                    \
+        }                                                                                                        \
+        hipLaunchKernelGGL(kfn, grid, block, lds, stream, A, W, M, N, K, E, ws, wd);                             \
+    } while (0)
+    if (tn == 5) GL_LAUNCH_WIDE(gemm_wide_kernel<5>);
+    else GL_LAUNCH_WIDE(gemm_wide_kernel<4>);
+#undef GL_LAUNCH_WIDE
+    GL_LAUNCH_CHECK();
+    if (wd.splits > 1) {
+        int64_t total = (int64_t)M * (N / 4);
+        int blocks = (int)fmin((double)cdiv64(total, 256), 4096.0);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws, wd.splits, M, N, E);
+        GL_LAUNCH_CHECK();
+    }
+    return GL_OK;
+}
+
 struct TunedCfg { int c, sp, grid; };
 static std::unordered_map<std::string, TunedCfg> g_tuned;   // process-wide, guarded by g_tune_mu (ctypes drops the GIL during calls)
 static std::mutex g_tune_mu;
@@ -1983,6 +2289,13 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
     static const int halo_splits = getenv("GL_CONV_HALO_SPLITS") ? atoi(getenv("GL_CONV_HALO_SPLITS")) : 0;
     if (halo && use_u && !g_force_tm && halo_eligible(A, M, N, K, E) && M >= halo * 256)
         return launch_halo(A, W, M, N, K, E, ws, ws_bytes, halo_splits, stream);
+    // The wide kernel takes the GEGLU projections (GL_GEMM_WIDE=1, default): 0.78-0.82x the time of gemm_u_kernel's 128x128 tiles at the
+    // 64x64 / 32x32 levels, even below. Everything else it is eligible for is slower there (narrow N: 256-row tiles leave CUs idle or
+    // need a K split) or within 4 % (FF-out): GL_GEMM_WIDE=2 sends all of it for A/B runs, 0 none. (profiles/r2_final/wide_kbench.txt)
+    static const int wide = getenv("GL_GEMM_WIDE") ? atoi(getenv("GL_GEMM_WIDE")) : 1;
+    static const int wide_splits = getenv("GL_GEMM_WIDE_SPLITS") ? atoi(getenv("GL_GEMM_WIDE_SPLITS")) : 0;
+    if (wide && use_u && !g_force_tm && (wide >= 2 || E.act == ACT_GEGLU) && wide_eligible(A, M, N, K, E))
+        return launch_wide(A, W, M, N, K, E, ws, ws_bytes, wide_splits, stream);
     static const int xcd_boxes = getenv("GL_GEMM_XCD_BOXES") ? atoi(getenv("GL_GEMM_XCD_BOXES")) : 1;
 
     auto feasible = [&](int c, int& sp) {

@@ -38,7 +38,8 @@ def test_linear(engine, M, N, K):
     assert rel_err(engine.op_linear(x, w, b, act=1), F.silu(ref)) < TOL
 
 
-@pytest.mark.parametrize("M,C", [(512, 320), (100, 640), (256, 1280)])
+# M % 256 == 0: the wide kernel (256-row tiles, one workgroup per CU; several tiles per workgroup at M = 4096 x N = 2560); else gemm_u_kernel
+@pytest.mark.parametrize("M,C", [(512, 320), (100, 640), (256, 1280), (4096, 320)])
 def test_geglu(engine, M, C):
     x = bf(rnd(M, C, seed=1))
     w, b = rnd(8 * C, C, scale=C ** -0.5, seed=2), rnd(8 * C, seed=3)
@@ -47,6 +48,44 @@ def test_geglu(engine, M, C):
     val, gate = h.chunk(2, dim=-1)
     ref = val * F.gelu(gate)
     assert rel_err(engine.op_geglu(x, w, b), ref) < TOL
+
+
+_WIDE_SNIPPET = r"""
+import sys, torch, torch.nn.functional as F
+sys.path.insert(0, %r)
+from gligen_amd.engine import Engine
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+bf = lambda t: t.to(torch.bfloat16)
+def rel(y, ref):
+    return ((y.float() - ref).norm() / ref.norm()).item()
+eng = Engine(0, arena_gb=2.0)
+worst = 0.0
+for M, N, K in [(512, 320, 1280), (1024, 640, 640), (256, 1280, 5120), (2048, 1280, 320)]:
+    x, w, b = bf(rnd(M, K, seed=1)), rnd(N, K, scale=K ** -0.5, seed=2), rnd(N, seed=3)
+    ref = x.float() @ bf(w).float().t() + b
+    res = bf(rnd(M, N, seed=4))
+    worst = max(worst, rel(eng.op_linear(x, w, b), ref), rel(eng.op_linear(x, w, b, res=res), ref + res.float()),
+                rel(eng.op_linear(x, w, b, act=1), F.silu(ref)))
+print("WORST", worst)
+"""
+
+
+def test_wide_gemm_other_epilogues():
+    """GL_GEMM_WIDE=2 sends every eligible row-major GEMM (not only the GEGLU projections) through gemm_wide_kernel: plain, residual
+    and SiLU epilogues, split-K included (K = 5120 at 5 tiles). The switch is read once per process, hence the subprocess."""
+    import os
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GL_GEMM_WIDE="2")
+    r = subprocess.run([sys.executable, "-c", _WIDE_SNIPPET % root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    worst = float(r.stdout.strip().split("WORST")[-1])
+    assert worst < TOL, worst
 
 
 def conv_ref(x_nhwc, w, b, stride=1, ups=0, pad_lo=1):
