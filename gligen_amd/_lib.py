@@ -106,6 +106,10 @@ def load() -> C.CDLL:
         raise GligenAmdError(
             f"{LIB_PATH} not found: build it with `python -m gligen_amd.build` "
             "(gligen_amd has no fallback path without its HIP library)")
+    # torch first: its wheel bundles its own libamdhip64.so. Loaded after ours (which resolves /opt/rocm's copy) the process ends up
+    # with two HIP runtimes and the second one finds no device ("no HIP device available" from gl_context_create although
+    # torch.cuda.is_available() is True) -- seen with build() called before the first `import torch` of the process.
+    import torch  # noqa: F401
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

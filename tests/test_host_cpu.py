@@ -416,3 +416,15 @@ def test_sharded_run_slices_one_seeded_batch(monkeypatch):
         lo, hi = shard_range(5, rank, 2)
         assert parts[-1][0] == hi - lo
     assert torch.equal(torch.cat([p[1] for p in parts]), full[1]) and torch.equal(torch.cat([p[2] for p in parts]), full[2])
+
+
+def test_lib_load_imports_torch_first():
+    """The HIP library must be loaded after torch (two HIP runtimes in one process otherwise: gl_context_create then finds no device
+    while torch sees the GPU). _lib.load() pins the order itself; in a fresh interpreter torch must be in sys.modules before the
+    CDLL call returns, whatever the caller imported."""
+    import subprocess
+    import sys
+    code = ("import sys; from gligen_amd import _lib; assert 'torch' not in sys.modules; _lib.load(); "
+            "assert 'torch' in sys.modules; print('ok')")
+    r = subprocess.run([sys.executable, "-c", code], cwd=str(ROOT), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-1500:]
