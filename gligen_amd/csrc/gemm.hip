@@ -1505,9 +1505,10 @@ conv_halo_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
     // ---- halo row h = pass * RPP + r0 of a tile  <->  source pixel (first pixel of the tile) + hrel, if it is a real pixel: not a
     // left / right padding column, not beyond NH, not above / below the image (whole-image blocks: always padding there; a block
     // of R rows inside an image: padding only when the tile starts at the top / ends at the bottom of its image).
-    // Recomputed per DMA pass (one pass per tile in the steady state) with multiply-shift divisions -- exact for h < 993 with
-    // divisors <= 66 resp. <= 448 -- rather than kept in seven registers that the 256-register budget does not have.
-    const unsigned inv_w2 = (65536u + W2 - 1) / W2, inv_blk = (65536u + blkrows - 1) / blkrows;
+    // Recomputed per DMA pass (one pass per tile in the steady state) with multiply-shift divisions -- ceil(2^22 / d) is exact for
+    // h < 2^22 / d, i.e. for every h < 448 with d <= 400 (a 16-bit reciprocal is NOT: 395 * ceil(65536 / 396) >> 16 = 1) -- rather
+    // than kept in seven registers that the 256-register budget does not have. tests/test_host_cpu.py restates this index math.
+    const unsigned inv_w2 = ((1u << 22) + W2 - 1) / W2, inv_blk = ((1u << 22) + blkrows - 1) / blkrows;
     // fragment rows: pixel p of the tile sits at halo row hr (tap (0,0)); tap (ky, kx) adds ky * W2 + kx. A wave's TM * 16 pixels lie
     // inside one halo block (a block has >= 64 pixels), so fragment i is fragment 0 plus a wave-uniform number of halo rows:
     // 16 pixels further along the image row, wrapping into the next halo row(s) every Wd pixels
@@ -1550,9 +1551,9 @@ conv_halo_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
         const unsigned ld2 = (unsigned)(first ? A.ld0 : A.ld1) * 2u;
         const int soff = (first ? cc : cc - A.C0) * 2;
         const int h = p * RPP + r0;
-        const int blk = (int)(((unsigned)h * inv_blk) >> 16);
+        const int blk = (int)(((unsigned)h * inv_blk) >> 22);
         const int rem = h - blk * blkrows;
-        const int hy = (int)(((unsigned)rem * inv_w2) >> 16);
+        const int hy = (int)(((unsigned)rem * inv_w2) >> 22);
         const int hx = rem - hy * W2;
         const bool ok = h < NH && hx >= 1 && hx <= Wd && (hy != 0 || top_ok) && (hy != HB + 1 || bot_ok);
         const int hrel = ((blk << lgHB) + hy - 1) * Wd + hx - 1;

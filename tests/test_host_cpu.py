@@ -428,3 +428,59 @@ def test_lib_load_imports_torch_first():
             "assert 'torch' in sys.modules; print('ok')")
     r = subprocess.run([sys.executable, "-c", code], cwd=str(ROOT), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-1500:]
+
+
+def _halo_geometry_ok(H, W, B):
+    """Python restatement of conv_halo_kernel's index math (gligen_amd/csrc/gemm.hip): the DMA side maps halo row h of a 256-pixel tile
+    to a source pixel or to zero padding; the fragment side reads, for output pixel p and tap (ky, kx), halo row hr. Every such read
+    must find pixel (y + ky - 1, x + kx - 1) of p's own image, or padding outside it."""
+    lgW, lgH = W.bit_length() - 1, H.bit_length() - 1
+    R = 256 >> lgW
+    lgHB = min(lgH, 8 - lgW)
+    HB, W2 = 1 << lgHB, W + 2
+    blkrows = (HB + 2) * W2
+    NH = (R >> lgHB) * blkrows
+    assert NH <= 448
+    inv_w2, inv_blk = ((1 << 22) + W2 - 1) // W2, ((1 << 22) + blkrows - 1) // blkrows
+    M = B * H * W
+    assert M % 256 == 0
+    for m0 in range(0, M, 256):
+        y0 = (m0 >> lgW) & (H - 1)
+        top_ok, bot_ok = y0 != 0, y0 + HB != H
+        halo = {}
+        for h in range(448):                                    # seven DMA passes of 64 rows
+            blk = (h * inv_blk) >> 22                           # the kernel's multiply-shift divisions (exact: h < 2^22 / d)
+            rem = h - blk * blkrows
+            hy = (rem * inv_w2) >> 22
+            hx = rem - hy * W2
+            assert h * inv_blk < 2 ** 32 and rem * inv_w2 < 2 ** 32   # no 32-bit wrap in the kernel's unsigned products
+            if h < NH:
+                assert (blk, hy, hx) == (h // blkrows, (h % blkrows) // W2, (h % blkrows) % W2)
+            ok = h < NH and 1 <= hx <= W and (hy != 0 or top_ok) and (hy != HB + 1 or bot_ok)
+            halo[h] = m0 + ((blk << lgHB) + hy - 1) * W + hx - 1 if ok else None
+        for wm in range(4):
+            for i in range(4):
+                for l15 in range(16):
+                    p0 = wm * 64 + l15
+                    hr00 = (p0 >> (lgHB + lgW)) * blkrows + ((p0 >> lgW) & (HB - 1)) * W2 + (p0 & (W - 1))
+                    px = i * 16
+                    hr_i = hr00 + (px >> lgW) * W2 + (px & (W - 1))      # hr_delta(i)
+                    p = p0 + px
+                    m = m0 + p
+                    b, y, x = m // (H * W), (m // W) % H, m % W
+                    for tap in range(9):
+                        ky, kx = tap // 3, tap % 3
+                        hr = hr_i + ky * W2 + kx
+                        yy, xx = y + ky - 1, x + kx - 1
+                        want = (b * H + yy) * W + xx if 0 <= yy < H and 0 <= xx < W else None
+                        if halo[hr] != want:
+                            return False
+    return True
+
+
+@pytest.mark.parametrize("H,W,B", [(64, 64, 1), (32, 32, 2), (16, 16, 8), (8, 8, 32), (32, 16, 4), (16, 32, 4), (16, 8, 16), (8, 16, 16),
+                                   (64, 32, 2), (32, 64, 2), (4, 64, 2), (128, 64, 1)])
+def test_halo_kernel_geometry(H, W, B):
+    """Every image geometry `halo_eligible` admits (power-of-two H, 8 <= W <= 64, at most 400 halo rows): the halo rows the DMA side
+    fills are the rows the fragment side reads, image borders and tile borders inside an image included."""
+    assert _halo_geometry_ok(H, W, B)
