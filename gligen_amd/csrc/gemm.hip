@@ -1883,6 +1883,12 @@ gemm_wide_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xa[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);   // (keeps K step 0's MFMAs in front of the wait below: they only need the first TM + TN reads)
+        // every fragment read of this stage has RETURNED before the wave reaches the next barrier: behind that barrier the stage is
+        // overwritten by DMA, and K step 1's fragments are consumed (the asm reads are invisible to hipcc's own lgkmcnt tracking)
+        asm volatile("s_waitcnt lgkmcnt(0)");
+        pin_regs(xb);
+        pin_regs(wb);
         __builtin_amdgcn_sched_barrier(0);
     };
     auto finish = [&]() {   // the item's last K step 1

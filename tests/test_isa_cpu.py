@@ -83,6 +83,29 @@ def test_halo_kernel_keeps_its_cross_barrier_pipelining(gemm_asm):
             assert dma and dma[0] < first_read, f"{name}: tap {k}: the DMA must be issued before the fragment reads"
 
 
+def test_wide_gemm_waits_for_its_fragment_reads_before_the_barrier(gemm_asm):
+    """gemm_wide_kernel multiplies K step 1 of a tile behind the NEXT barrier. Its fragment reads are inline asm (invisible to hipcc's
+    lgkmcnt bookkeeping), so the source must wait lgkmcnt(0) itself before the wave reaches that barrier: behind it the LDS stage is
+    overwritten by DMA and the fragments are consumed. Order inside the loop: barrier, DMA issue, deferred MFMAs, all fragment
+    reads, lgkmcnt(TM+TN), K step 0's MFMAs, lgkmcnt(0)."""
+    names = re.findall(r"^(_ZN2gl16gemm_wide_kernel[^:\s]*):", gemm_asm, re.M)
+    assert len(names) == 2
+    for name in names:
+        a = gemm_asm.index(name + ":")
+        body = [l.strip() for l in gemm_asm[a:gemm_asm.index(".Lfunc_end", a)].split("\n")]
+        assert not [l for l in body if l.startswith("scratch_")], name
+        bar = next(i for i, l in enumerate(body) if l.startswith("s_barrier"))
+        ev = []
+        for l in body[bar:]:
+            if l.startswith("ds_read"): ev.append("r")
+            elif l.startswith("v_mfma"): ev.append("M")
+            elif l.startswith("buffer_load") and " lds" in l: ev.append("D")
+            elif l.startswith("s_waitcnt") and "lgkmcnt(0)" in l: ev.append("W")
+            elif l.startswith("s_waitcnt") and "lgkmcnt" in l: ev.append("w")
+        seq = re.sub(r"(.)\1+", r"\1", "".join(ev))          # collapse runs
+        assert seq.startswith("DMrwMW"), f"{name}: loop order is {seq[:12]}"
+
+
 @pytest.fixture(scope="module")
 def attn_asm(tmp_path_factory):
     from gligen_amd.build import EXTRA_FLAGS
