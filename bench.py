@@ -3,6 +3,9 @@
     python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4|C5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment spawns its N ranks itself (re-executes under
+torch.distributed.run on 127.0.0.1 with a free port); rank 0 prints the one JSON line either way.
+
 One "step" = one pass of the hot path over one batch of B = 4 prompts per GPU at 512x512: 50 PLMS steps with
 classifier-free guidance 7.5 (102 UNet forwards per sample, run as 51 [cond ; uncond]-batched evaluations) +
 AutoencoderKL.decode -> B images. --config picks the BASELINE.json configuration (default C2, the one the metric is quoted on):
@@ -88,7 +91,17 @@ def cpu_baseline(cfg):
         t0 = time.perf_counter()
         orc.vae_decode(vsd, dict(ch_mult=d["ch_mult"], num_res_blocks=d["num_res_blocks"], scale_factor=0.18215), syn.make_latent(1, 4, 64, 64))
         t_dec = time.perf_counter() - t0
-    return {"value": 1.0 / (102 * t_unet + t_dec), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+    # /root/reference does not exist on this box, so the stated baseline (the reference's own modules) cannot be timed here:
+    # the line says so and carries the number oracle/ref_cpu_baseline.py measured in the build container beside the port's
+    ref_bc = None
+    try:
+        ref_bc = json.load(open(os.path.join(ROOT, "oracle", "ref_cpu_baseline_build_container.json")))
+    except Exception:
+        pass
+    return {"reference_build_container": ref_bc,
+            "note": "/root/reference is absent on this host: 'value' times the CPU oracle (a port); 'reference_build_container' is the "
+                    "reference's own modules timed by oracle/ref_cpu_baseline.py in the build container (other host CPU, see its 'cores')",
+            "value": 1.0 / (102 * t_unet + t_dec), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"oracle/gligen_oracle.py fp32 torch-CPU: 1 warm-up + 3 timed unet_forward (B=1, 64x64 latent, Ng=30; mean {t_unet:.2f} s) "
                       f"+ 1x vae_decode ({t_dec:.2f} s), extrapolated to 102 forwards + 1 decode per 512x512 image",
             "host_cpus": os.cpu_count()}
@@ -174,6 +187,51 @@ class ClockSampler(threading.Thread):
         return out or None
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` outside a launcher: re-execute under torch.distributed.run, one process per GPU, rendezvous
+    on 127.0.0.1 (the container hostname may not resolve). The children's stdout / stderr pass through (rank 0 prints the
+    JSON line); the exit code is the launcher's."""
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def stub_lanes(L, B):
+    """--stub: the measurement protocol without the engine (CPU test of the N-rank launch path, tests/test_dist_cpu.py):
+    a 'pass' sleeps 20 ms and returns a deterministic uint8 tensor of the real shape."""
+    def one_pass(lane):
+        time.sleep(0.02)
+        return torch.zeros((B, 512, 512, 3), dtype=torch.uint8)
+    return one_pass
+
+
+def stub_main(args, cfg, gdist, rank, world, dist_world, dist_backend):
+    B = args.batch
+    one_pass = stub_lanes(1, B)
+    for _ in range(max(1, args.warmup)):
+        one_pass(0)
+    gdist.barrier()
+    t0 = time.perf_counter()
+    outs = [one_pass(0) for _ in range(args.steps)]
+    gdist.barrier()
+    elapsed = gdist.max_over_ranks(time.perf_counter() - t0)
+    assert outs[-1].shape == (B, 512, 512, 3)
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": B * world * args.steps / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "stub", "config": {"workload": "stub: " + cfg["desc"]},
+                          "collective_world_size": dist_world, "collective_backend": dist_backend}), flush=True)
+    gdist.shutdown()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,15 +249,21 @@ def main():
     ap.add_argument("--alpha-type", default=None,
                     help="gate schedule 'on,decay,off' (fractions of the steps), e.g. 0.3,0,0.7 as in the reference's demo prompts; default: "
                          "None = fusers on at every step, the configuration the metric is quoted on (and the one with the most work)")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # protocol-only run without a GPU (CPU test of the launch path)
     args = ap.parse_args()
     alpha_type = [float(v) for v in args.alpha_type.split(",")] if args.alpha_type else None
     cfg = CONFIGS[args.config]
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     from gligen_amd import dist as gdist
-    rank, local_rank, world = gdist.init_from_env()
+    rank, local_rank, world = gdist.init_from_env(backend="gloo" if args.stub else None)
     if world != args.gpus:
-        if args.gpus != 1 or world != 1:
-            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus must agree")
+    dist_world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    dist_backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else None
+    if args.stub:
+        return stub_main(args, cfg, gdist, rank, world, dist_world, dist_backend)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -275,7 +339,9 @@ def main():
             z0 = lanes[0][1].encode(image)
             extra = torch.cat([z0 * mask, mask], dim=1)
         lanes[0][0].engine.unet_profile(x_T, tt, extra, batch=2 * B)          # warm
+        n0 = lanes[0][0].engine.launch_count()
         prof = lanes[0][0].engine.unet_profile(x_T, tt, extra, batch=2 * B)
+        launches_per_eval = lanes[0][0].engine.launch_count() - n0   # kernel launches of one [cond ; uncond] evaluation (gl_launch_count)
     torch.cuda.synchronize()
 
     autoencoder = lanes[0][1]
@@ -321,6 +387,8 @@ def main():
             "unet_step_ms": unet_ms, "unet_step_desc": f"one [cond ; uncond] UNet evaluation at batch {2 * B} (hipGraph replay, HIP events on the engine stream, "
                                                        f"measured in an untimed pass with one batch in flight)",
             "vae_decode_ms": dec_ms,
+            "launches_per_unet_eval": launches_per_eval,
+            "collective_world_size": dist_world, "collective_backend": dist_backend,   # the RCCL world the barrier / max-over-ranks ran in
             "gpu_clocks": clk,
             "roofline": roofline,
         }

@@ -45,7 +45,7 @@ class Grounding(C.Structure):
 
 class PlmsArgs(C.Structure):
     _fields_ = [
-        ("B", C.c_int), ("h", C.c_int), ("w", C.c_int), ("n_steps", C.c_int),
+        ("struct_size", C.c_uint), ("B", C.c_int), ("h", C.c_int), ("w", C.c_int), ("n_steps", C.c_int),
         ("timesteps", C.POINTER(C.c_int64)), ("a_t", C.POINTER(C.c_float)), ("a_prev", C.POINTER(C.c_float)),
         ("fuser_scale", C.POINTER(C.c_float)), ("guidance_scale", C.c_float),
         ("x", C.c_void_p), ("inpaint_extra", C.c_void_p), ("mask", C.c_void_p), ("x0", C.c_void_p),

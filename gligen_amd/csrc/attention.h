@@ -5,7 +5,7 @@ namespace gl {
 
 struct AttnParams {
     const bf16* q;
-    const bf16* k;
+    const bf16* k;       // key-tile layout
     const bf16* vt;
     bf16* o;
     int H, d;
@@ -23,5 +23,7 @@ int attn_launch(const AttnParams& P, int B, hipStream_t stream);
 const char* attn_kernel_name(int d);  // kernel symbol attn_launch uses for head dim d
 // one-time init of a V^T buffer [BH][DPV][Tk_pad]: padding row d := 1.0 (the softmax denominator row)
 int attn_vt_ones_launch(bf16* vt, int BH, int d, int Tk_pad, hipStream_t stream);
+// one-time init of a K buffer [BH][Tk_pad/64][DP/8][64][8] (key-tile layout, gemm.h ktile_off): d = 40: column 40 := 1.0
+int attn_k_init_launch(bf16* k, int BH, int d, int Tk_pad, hipStream_t stream);
 
 }  // namespace gl

@@ -7,7 +7,8 @@
 //
 // Layouts (written by the projection GEMM epilogues, gemm.hip EPI_QK_HEADS / EPI_VT_HEADS):
 //   q  [B*H][Tq_pad][DP]   head dim zero-padded to DP (48 / 80 / 160)
-//   k  [B*H][Tk_pad][DP]
+//   k  [B*H][Tk_pad/64][DP/8][64][8]   key-tile layout (gemm.h ktile_off): a 64-key tile is one contiguous block, 16-byte
+//                          chunks chunk-major; for d = 40 column 40 holds 1.0 (attn_k_init_launch), see BIAS below
 //   vt [B*H][DPV][Tk_pad]  V transposed, tokens permuted inside groups of 16 as
 //                          [0-3, 8-11, 4-7, 12-15]  (DPV = 64 / 96 / 160)
 //   o  [B][rows][ldo]      token-major, head h at columns [h*d, (h+1)*d)
@@ -21,6 +22,10 @@
 // A 256-thread block (4 waves = 128 query rows) streams 64-key tiles of K and V^T through a
 // 2-stage LDS ring (register-staged: loads of tile t+1 are in flight during the MFMAs of tile t).
 #include "attention.h"
+#include "gemm.h"
+
+#include <cstdlib>
+#include <type_traits>
 
 namespace gl {
 
@@ -132,8 +137,8 @@ __global__ void __launch_bounds__(256, DP == 48 ? 3 : 1) attn_kernel(AttnParams 
         for (int i = 0; i < NKC; ++i) {
             int id = t + i * 256;
             if (id < KCH) {
-                int row = id / (DP / 8);
-                int cch = id - row * (DP / 8);
+                int cch = id >> 6;        // key-tile layout: [DP / 8 chunks][64 keys]
+                int row = id & 63;
                 uint32_t k0 = kreg[4*i];
                 if constexpr (BIAS) k0 = cch == 5 ? ((k0 & 0xffff0000u) | 0x3f80u) : k0;   // K[:, 40] = 1.0
                 *reinterpret_cast<uint4*>(ks + row * KROW + cch * 16) = make_uint4(k0,kreg[4*i+1],kreg[4*i+2],kreg[4*i+3]);
@@ -298,6 +303,356 @@ __global__ void __launch_bounds__(256, DP == 48 ? 3 : 1) attn_kernel(AttnParams 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// v2 (round 3), d = 40 and d = 80: the same products and layouts, software-pipelined across key tiles.
+//
+// The kernel above runs, per 64-key tile and wave, QK^T (MFMA) -> softmax (VALU: 32 v_exp, 16 v_max3, 16 v_cvt_pk per lane) -> PV
+// (MFMA) one after the other; at d = 40 the two halves cost about the same issue time (14 MFMAs = 448 clocks against ~80 VALU
+// instructions) and a wave's own VALU and MFMA segments never overlap -- only other waves of the SIMD fill the gaps, partly
+// (tools/overlapbench.hip: a fine MFMA / VALU interleave inside ONE wave reaches 0.7x the time of the block form). Here every
+// iteration j holds three independent pieces of work in one straight-line region,
+//     S(j) = K(j) Q^T            (MFMA)   into the "next" score registers
+//     P(j-1) = exp2(S(j-1) - m)  (VALU)   from the "current" score registers
+//     O^T += V^T(j-1) P^T(j-1)   (MFMA)   in two halves, each behind the exps that feed it
+// so the matrix pipe runs S(j) under the first half of the exps, the first half of PV under the second half of the exps and the
+// second half of PV under the row maximum of S(j). The rare stabiliser move (a tile's scores exceed the running one by > 2^6)
+// sits at the end of the iteration, after PV(j-1): O^T -- then consistently at the old stabiliser -- and S(j) are rescaled there.
+// K and V^T tiles come by LDS-DMA (buffer_load ... lds) straight from their global layouts: no staging registers, no ds_write
+// pass; stage j of the two-slot ring holds {K(j), V^T(j-1)} and is fetched during iteration j-1. Fragment reads are inline asm
+// (hipcc would drain the DMA in front of a visible LDS load, see gemm.hip) with counted lgkmcnt waits.
+//   K tile   [DP/8 chunks][64 keys][16 B]: ds_read_b128 of chunk c for keys lrow is conflict free as it stands
+//   V^T tile [DPV rows][128 B], 16-byte chunk c of row r at slot c ^ ((r >> 1) & 7) (source-side swizzle of the DMA)
+// Both score register sets alternate roles from one iteration to the next (the loop is unrolled by two), so nothing is copied.
+#define GL_BLDS16(rsrc, ldst, voff, soff)                                                                   \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(ldst), 16, \
+                                             (int)(voff), (int)(soff), 0, 0)
+
+template <int OFF>
+__device__ __forceinline__ void lds_rd16(bf16x8& d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void pin_regs(bf16x8 (&d)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(d[i]));
+}
+
+// kf[2 s + u] <- 16-byte chunk 2 s + half of keys 32 u + lrow: K tile offset s * 2048 + u * 512 from the lane's base
+template <int N, int I = 0, int BASE = 0>
+__device__ __forceinline__ void lds_rd_k(bf16x8 (&d)[N], unsigned a) {
+    if constexpr (I < N) {
+        lds_rd16<((BASE + I) >> 1) * 2048 + ((BASE + I) & 1) * 512>(d[I], a);
+        lds_rd_k<N, I + 1, BASE>(d, a);
+    }
+}
+// vf[2 i + jj] <- V^T rows 32 i + lrow through the lane's two (swizzled) chunk addresses a0 (jj = 0), a1 (jj = 1)
+template <int N, int I = 0>
+__device__ __forceinline__ void lds_rd_v(bf16x8 (&d)[N], unsigned a0, unsigned a1) {
+    if constexpr (I < N) {
+        lds_rd16<(I >> 1) * 4096>(d[I], (I & 1) ? a1 : a0);
+        lds_rd_v<N, I + 1>(d, a0, a1);
+    }
+}
+
+template <int DP, int DPV, bool BIAS, int NW>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn2_kernel(AttnParams P) {
+    constexpr int KS = DP / 16;            // k-steps of S^T = K Q^T
+    constexpr int DT = DPV / 32;           // 32-row tiles of O^T
+    constexpr int KP = DP / 8;             // K tile: 1-KiB DMA pieces (one 16-byte chunk of all 64 keys each)
+    constexpr int VP = DPV / 8;            // V^T tile: 1-KiB DMA pieces (8 rows of 128 B each)
+    constexpr int KBYTES = KP * 1024;
+    constexpr int VBYTES = VP * 1024;
+    constexpr int STAGE = KBYTES + VBYTES;
+    constexpr int KPW = (KP + NW - 1) / NW, VPW = (VP + NW - 1) / NW;   // pieces per wave
+    static_assert(DPV % 32 == 0 && DP % 16 == 0 && DPV > DP - 8, "tile geometry");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lrow = lane & 31;
+    const int half = lane >> 5;
+    int lin = blockIdx.x;
+    {   // XCD-aware block order, as above
+        const int total = gridDim.x;
+        if ((total & 7) == 0) lin = (lin & 7) * (total >> 3) + (lin >> 3);
+    }
+    const int qblk = lin % P.nqb;
+    const int bhi = lin / P.nqb;
+    const int h = bhi % P.H;
+    const int b = bhi / P.H;
+    const size_t bh = (size_t)bhi;
+
+    const bf16* __restrict__ Qg = P.q + bh * P.Tq_pad * DP;
+    const bf16* __restrict__ Kg = P.k + bh * P.Tk_pad * DP;
+    const bf16* __restrict__ Vg = P.vt + bh * DPV * P.Tk_pad;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kg, 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vg, 0, 0x80000000u, 0x00020000);
+
+    const int nt = (P.Nk + 63) >> 6;
+    const int myq = qblk * (NW * 32) + wave * 32 + lrow;
+    const int myq_ld = myq < P.Tq_pad ? myq : P.Tq_pad - 1;     // (NW = 8: a 256-row block may reach past the 128-row padding)
+
+    // ---- DMA of stage jj = {K(jj), V^T(jj-1)} into ring slot jj & 1
+    unsigned vvoff[VPW];
+#pragma unroll
+    for (int i = 0; i < VPW; ++i) {
+        const int r = 8 * (wave + NW * i) + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        vvoff[i] = (unsigned)(r * P.Tk_pad) * 2u + (unsigned)c * 16u;
+    }
+    auto issue = [&](int jj_) {
+        const int jj = __builtin_amdgcn_readfirstlane(jj_);
+        unsigned char* st = smem + (jj & 1) * STAGE;
+        if (jj < nt) {
+#pragma unroll
+            for (int i = 0; i < KPW; ++i) {
+                const int pi = wave + NW * i;
+                if (pi < KP) GL_BLDS16(rk, st + pi * 1024, lane * 16, jj * KBYTES + pi * 1024);
+            }
+        }
+        if (jj >= 1) {
+#pragma unroll
+            for (int i = 0; i < VPW; ++i) {
+                const int pi = wave + NW * i;
+                if (pi < VP) GL_BLDS16(rv, st + KBYTES + pi * 1024, vvoff[i], (jj - 1) * 128);
+            }
+        }
+    };
+    issue(0);
+
+    // ---- Q fragments, pre-multiplied by scale * log2(e) (scores come out of the matrix core in exp2 units)
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)myq_ld * DP + 16 * s + 8 * half);
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[s][e] = f2bf((float)qf[s][e] * P.scale_log2e);
+    if constexpr (BIAS) {
+        if (half == 1) qf[2][0] = f2bf(0.f);   // column 40 = -m, m = 0 until the first tile has been seen
+    }
+
+    f32x16 ot[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
+    float m_run = BIAS ? 0.f : -1e30f;   // BIAS: the stabiliser baked into Q column 40; else subtracted in front of the exps
+
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned k_lane = lds0 + (unsigned)(lrow * 16 + half * 1024);
+    const unsigned v_lane = lds0 + KBYTES + (unsigned)(lrow * 128) + (unsigned)((half ^ ((lrow >> 1) & 7)) << 4);
+
+    // One iteration. SM: softmax + PV of tile j-1 (scores in sc). QK: scores of tile j into sn. TAILCK: tile j may be the partial
+    // last tile (run-time check). FIRSTMOVE: tile j is tile 0 (the stabiliser always moves there).
+    auto iter = [&](int j, f32x16 (&sc)[2], f32x16 (&sn)[2], auto sm_c, auto qk_c, auto tail_c, auto first_c) {
+        constexpr bool SM = decltype(sm_c)::value, QK = decltype(qk_c)::value, TAILCK = decltype(tail_c)::value, FIRSTMOVE = decltype(first_c)::value;
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): stage j has landed (this wave's pieces; the barrier covers the others')
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (j + 1 <= nt) issue(j + 1);        // into the slot every wave finished reading in iteration j-1
+        const unsigned sb = (unsigned)((j & 1) * STAGE);
+        const unsigned ak = k_lane + sb;
+        unsigned av[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) av[jj] = (v_lane + sb) ^ (unsigned)(jj << 5);
+
+        bf16x8 vfa[2 * DT], vfb[2 * DT];
+        constexpr int KA = KS > 3 ? 3 : KS;                // k-steps whose K fragments are read up front (the rest reuse their registers)
+        bf16x8 kfa[2 * KA], kfb[KS > 3 ? 2 * (KS - KA) : 1];
+        if constexpr (QK) lds_rd_k(kfa, ak);
+        if constexpr (SM) lds_rd_v(vfa, av[0], av[1]);     // key sub-tile 0 (keys 0..31 of tile j-1)
+        // ---- region 1: S(j) on the matrix core  ||  exp2 of the first 32 keys of tile j-1
+        if constexpr (QK) {
+            if constexpr (SM) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * DT));
+            else asm volatile("s_waitcnt lgkmcnt(0)");
+            pin_regs(kfa);
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            sn[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[0], qf[0], zero, 0, 0, 0);
+            sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[1], qf[0], zero, 0, 0, 0);
+#pragma unroll
+            for (int s = 1; s < KA; ++s) {
+                sn[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[2 * s], qf[s], sn[0], 0, 0, 0);
+                sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[2 * s + 1], qf[s], sn[1], 0, 0, 0);
+            }
+            if constexpr (KS > KA) {
+                __builtin_amdgcn_sched_barrier(0);
+                lds_rd_k<2 * (KS - KA), 0, 2 * KA>(kfb, ak);
+                asm volatile("s_waitcnt lgkmcnt(0)");
+                pin_regs(kfb);
+#pragma unroll
+                for (int s = KA; s < KS; ++s) {
+                    sn[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfb[2 * (s - KA)], qf[s], sn[0], 0, 0, 0);
+                    sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfb[2 * (s - KA) + 1], qf[s], sn[1], 0, 0, 0);
+                }
+            }
+        }
+        bf16x8 pb0, pb1, pb2, pb3;
+        if constexpr (SM) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pb0[e] = f2bf(__builtin_amdgcn_exp2f(BIAS ? sc[0][e] : sc[0][e] - m_run));
+                pb1[e] = f2bf(__builtin_amdgcn_exp2f(BIAS ? sc[0][8 + e] : sc[0][8 + e] - m_run));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the second sub-tile's V^T fragments (they may take the K fragments' registers: S(j)'s MFMAs are issued)
+            lds_rd_v(vfb, av[2], av[3]);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * DT));   // vfa has arrived
+            pin_regs(vfa);
+            // ---- region 2: first half of O^T += V^T P^T  ||  exp2 of the other 32 keys
+#pragma unroll
+            for (int i = 0; i < DT; ++i) {
+                ot[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfa[2 * i], pb0, ot[i], 0, 0, 0);
+                ot[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfa[2 * i + 1], pb1, ot[i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pb2[e] = f2bf(__builtin_amdgcn_exp2f(BIAS ? sc[1][e] : sc[1][e] - m_run));
+                pb3[e] = f2bf(__builtin_amdgcn_exp2f(BIAS ? sc[1][8 + e] : sc[1][8 + e] - m_run));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)");
+            pin_regs(vfb);
+            // ---- region 3: second half of PV  ||  row maximum of S(j)
+#pragma unroll
+            for (int i = 0; i < DT; ++i) {
+                ot[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfb[2 * i], pb2, ot[i], 0, 0, 0);
+                ot[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfb[2 * i + 1], pb3, ot[i], 0, 0, 0);
+            }
+        }
+        if constexpr (QK) {
+            if constexpr (TAILCK) {
+                const int kv0 = j << 6;
+                if (kv0 + 64 > P.Nk) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int kv = kv0 + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            if (kv >= P.Nk) sn[u][r] = -1e30f;
+                        }
+                }
+            }
+            float mx = sn[0][0];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sn[u][r]);
+            mx = max_xor32(mx);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- stabiliser move (rare after the first tiles). Everything accumulated so far -- O^T, including tile j-1 -- is at the
+            // old stabiliser; S(j) is the only other thing that depends on it.
+            if constexpr (BIAS) {
+                // sn is s * c - m_run (the stabiliser rode through the MFMA in Q column 40)
+                const bool move = FIRSTMOVE || mx > 6.f;
+                if (__builtin_amdgcn_ballot_w64(move) != 0) {
+                    const bf16 mb = f2bf(m_run + mx);
+                    const float m_upd = move ? (float)mb : m_run;
+                    const float delta = m_upd - m_run;   // exact: both are bf16 values
+                    if constexpr (!FIRSTMOVE) {           // O^T is still zero in the first tile (and 2^-delta may overflow there)
+                        const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                        for (int i = 0; i < DT; ++i)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sn[u][r] -= delta;
+                    m_run = m_upd;
+                    const bf16 nb = f2bf(-m_upd);
+                    if (half == 1) qf[2][0] = nb;
+                }
+            } else {
+                // sn is s * c; the exps subtract m_run
+                const bool move = FIRSTMOVE || mx - m_run > 6.f;
+                if (__builtin_amdgcn_ballot_w64(move) != 0) {
+                    const float m_upd = move ? mx : m_run;
+                    if constexpr (!FIRSTMOVE) {
+                        const float alpha = __builtin_amdgcn_exp2f(m_run - m_upd);
+#pragma unroll
+                        for (int i = 0; i < DT; ++i)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
+                    }
+                    m_run = m_upd;
+                }
+            }
+        }
+    };
+
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    f32x16 sa[2], sb2[2];
+    iter(0, sb2, sa, F_{}, T_{}, T_{}, T_{});                      // S(0) -> sa
+    if (nt == 1) {
+        iter(1, sa, sb2, T_{}, F_{}, F_{}, F_{});                  // drain
+    } else {
+        int j = 1;
+        for (; j + 1 <= nt - 2; j += 2) {
+            iter(j, sa, sb2, T_{}, T_{}, F_{}, F_{});
+            iter(j + 1, sb2, sa, T_{}, T_{}, F_{}, F_{});
+        }
+        if (j <= nt - 2) {
+            iter(j, sa, sb2, T_{}, T_{}, F_{}, F_{});
+            ++j;
+            iter(j, sb2, sa, T_{}, T_{}, T_{}, F_{});              // j = nt-1: S(nt-1) -> sa
+            iter(j + 1, sa, sb2, T_{}, F_{}, F_{}, F_{});          // drain
+        } else {
+            iter(j, sa, sb2, T_{}, T_{}, T_{}, F_{});              // j = nt-1: S(nt-1) -> sb2
+            iter(j + 1, sb2, sa, T_{}, F_{}, F_{}, F_{});          // drain
+        }
+    }
+
+    // softmax denominator: O^T row d (the ones row of V^T); tile i = d / 32, offset off -> register ((off>>3)<<2 | off&3) of the half (off>>2)&1
+    const int off = P.d & 31;
+    const int rr = ((off >> 3) << 2) | (off & 3);
+    float cand = 0.f;
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (i == (P.d >> 5) && r == rr) cand = ot[i][r];
+    const float other = __shfl_xor(cand, 32, 64);
+    const float l_tot = (((off >> 2) & 1) == half) ? cand : other;
+    const float inv = 1.f / l_tot;
+    if (myq < P.Nq) {
+        bf16* orow = P.o + ((size_t)b * P.o_rows_per_b + myq) * P.ldo + h * P.d;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                int dd0 = 32 * i + 8 * q4 + 4 * half;
+                if (dd0 < P.d) {
+                    U2BF4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o.e[e] = f2bf(ot[i][4 * q4 + e] * inv);
+                    *reinterpret_cast<uint2*>(orow + dd0) = o.u;
+                }
+            }
+    }
+}
+
+template <int DP, int DPV, bool BIAS, int NW>
+static int launch_attn2(const AttnParams& P, int B, hipStream_t stream) {
+    const size_t lds = 2 * ((DP / 8) * 1024 + (DPV / 8) * 1024);
+    auto kfn = attn2_kernel<DP, DPV, BIAS, NW>;
+    static bool attr_done = false;  // once per instantiation; never inside a stream capture
+    if (!attr_done && lds > 48 * 1024) {
+        GL_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    AttnParams Q = P;
+    Q.nqb = cdiv(P.Nq, NW * 32);
+    dim3 grid(Q.nqb * P.H * B);
+    hipLaunchKernelGGL(kfn, grid, dim3(NW * 64), lds, stream, Q);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
 template <int DP, int DPV, bool ONES>
 static int launch_attn(const AttnParams& P, int B, hipStream_t stream) {
     constexpr int KROW = DP * 2 + 16, VROW = 144;
@@ -340,17 +695,45 @@ int attn_vt_ones_launch(bf16* vt, int BH, int d, int Tk_pad, hipStream_t stream)
     return GL_OK;
 }
 
+// GL_ATTN_V2 (developer A/B): 0 = the unpipelined kernel for every head dim, 1 (default) = attn2_kernel with 4 waves (two
+// workgroups per CU) for d = 40, 2 = attn2_kernel with 8 waves (one workgroup per CU: half the K / V^T DMA per query row)
+static int attn_v2_mode() {
+    static const int m = getenv("GL_ATTN_V2") ? atoi(getenv("GL_ATTN_V2")) : 1;
+    return m;
+}
+
 const char* attn_kernel_name(int d) {
-    return d == 40 ? "attn_kernel<48, 64, true>" : d == 80 ? "attn_kernel<80, 96, true>" : "attn_kernel<160, 160, false>";
+    const int v2 = attn_v2_mode();
+    if (d == 40) return v2 == 0 ? "attn_kernel<48, 64, true>" : v2 == 1 ? "attn2_kernel<48, 64, true, 4>" : "attn2_kernel<48, 64, true, 8>";
+    if (d == 80) return "attn_kernel<80, 96, true>";
+    return "attn_kernel<160, 160, false>";
+}
+
+// One-time init of a K buffer (key-tile layout): for d = 40 column 40 of every key := 1.0, the multiplier of the stabiliser that
+// rides in Q column 40 (BIAS above). The projection epilogues only ever write columns < d. No-op for the other head dims.
+__global__ void k_ones_kernel(bf16* k, int DP, int Tk_pad, int col) {
+    bf16* slab = k + (size_t)blockIdx.x * Tk_pad * DP;
+    for (int t = threadIdx.x; t < Tk_pad; t += blockDim.x) slab[ktile_off(0, Tk_pad, t, col, DP)] = (bf16)1.0f;
+}
+int attn_k_init_launch(bf16* k, int BH, int d, int Tk_pad, hipStream_t stream) {
+    if (d != 40) return GL_OK;
+    hipLaunchKernelGGL(k_ones_kernel, dim3(BH), dim3(256), 0, stream, k, 48, Tk_pad, 40);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
 }
 
 int attn_launch(const AttnParams& P, int B, hipStream_t stream) {
     if (P.Nq <= 0 || P.Nk <= 0) return set_error(GL_ERR_ARG, "attention: empty Nq=%d Nk=%d", P.Nq, P.Nk);
     if (P.Tq_pad % 128 != 0 || P.Tk_pad % 64 != 0 || P.Tq_pad < P.Nq || P.Tk_pad < P.Nk)
         return set_error(GL_ERR_ARG, "attention: bad padding Tq_pad=%d Tk_pad=%d (Nq=%d Nk=%d)", P.Tq_pad, P.Tk_pad, P.Nq, P.Nk);
+    const int v2 = attn_v2_mode();
     switch (P.d) {
-        case 40: return launch_attn<48, 64, true>(P, B, stream);
-        case 80: return launch_attn<80, 96, true>(P, B, stream);
+        case 40:
+            if (v2 == 1) return launch_attn2<48, 64, true, 4>(P, B, stream);
+            if (v2 >= 2) return launch_attn2<48, 64, true, 8>(P, B, stream);
+            return launch_attn<48, 64, true>(P, B, stream);
+        case 80:   // (attn2_kernel<80, 96, false, *> needs ~320 registers: 64 spilled at the 256 of two waves per SIMD; not instantiated)
+            return launch_attn<80, 96, true>(P, B, stream);
         case 160: return launch_attn<160, 160, false>(P, B, stream);
         default: return set_error(GL_ERR_UNSUPPORTED, "attention: head dim %d not supported (40, 80, 160)", P.d);
     }

@@ -22,10 +22,24 @@ struct gl_ctx {
     }                                                    \
     return GL_OK;
 
-// every entry point runs on the context's own device, whatever the caller's current device is
+// every entry point runs on the context's own device, whatever the caller's current device is, and hands the caller's
+// current device back on return (a process may hold engines on several GPUs next to torch's own notion of "current")
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+        else prev = -1;   // nothing to restore
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
 #define NEED(ctx)                                                         \
     if (!(ctx) || !(ctx)->eng) return gl::set_error(GL_ERR_ARG, "null context"); \
-    if (hipSetDevice((ctx)->eng->device()) != hipSuccess) return gl::set_error(GL_ERR_HIP, "hipSetDevice(%d) failed", (ctx)->eng->device());
+    DeviceGuard device_guard_((ctx)->eng->device());                      \
+    if (!device_guard_.ok) return gl::set_error(GL_ERR_HIP, "hipSetDevice(%d) failed", (ctx)->eng->device());
 
 static inline hipStream_t S(gl_stream s) { return reinterpret_cast<hipStream_t>(s); }
 
@@ -189,6 +203,9 @@ int gl_vae_decode(gl_ctx* ctx, int B, int h, int w, const float* z, float* img, 
 int gl_sample_plms(gl_ctx* ctx, const gl_plms_args* args, gl_stream s) {
     NEED(ctx);
     if (!args) return gl::set_error(GL_ERR_ARG, "null args");
+    if (args->struct_size != sizeof(gl_plms_args))
+        return gl::set_error(GL_ERR_ARG, "gl_sample_plms: args->struct_size is %u, this library's gl_plms_args has %zu bytes (set it to sizeof(gl_plms_args))",
+                             args->struct_size, sizeof(gl_plms_args));
     GL_API_BEGIN
     ctx->eng->sample_plms(*args, S(s));
     GL_API_END
@@ -394,7 +411,7 @@ int gl_op_attention(gl_ctx* ctx, const void* xq, const void* xkv, int B, int Nq,
             aoperand_rows(A, xkp, Ck, Ck);
             Epilogue E;
             epilogue_defaults(E);
-            E.mode = EPI_QK_HEADS; E.q = bufs.k; E.C = C; E.H = H; E.d = d; E.DP = dp; E.T = Tk; E.Tpad_q = bufs.Tk_pad;
+            E.mode = EPI_QK_HEADS; E.q = bufs.k; E.q_tiled = 1; E.C = C; E.H = H; E.d = d; E.DP = dp; E.T = Tk; E.Tpad_q = bufs.Tk_pad;
             ck(gemm_launch(A, wkb, B * Tk, C, Ck, E, eng.splitk_ws(), eng.splitk_ws_bytes(), S(s)));
         }
         {

@@ -894,6 +894,7 @@ AttnBufs& Engine::attn_bufs(int B, int H, int d, int Tq, int Tk) {
     b.k = reinterpret_cast<bf16*>(persist((size_t)B * H * Tk_pad * dp * sizeof(bf16), true));
     b.vt = reinterpret_cast<bf16*>(persist((size_t)B * H * dpv * Tk_pad * sizeof(bf16), true));
     CK(attn_vt_ones_launch(b.vt, B * H, d, Tk_pad, 0));  // denominator row (attention.hip), once per buffer
+    CK(attn_k_init_launch(b.k, B * H, d, Tk_pad, 0));     // d = 40: the stabiliser's multiplier column
     HIPCK(hipStreamSynchronize(0));
     return attn_bufs_.emplace(key, b).first->second;
 }
@@ -1149,12 +1150,14 @@ void Engine::set_cond(int Beff, const float* context, int n_ctx, const gl_ground
                 cond_.obj_k.push_back(reinterpret_cast<bf16*>(palloc((size_t)Beff * heads * obj_Tpad * dp * sizeof(bf16))));
                 cond_.obj_vt.push_back(reinterpret_cast<bf16*>(palloc((size_t)Beff * heads * dpv * obj_Tpad * sizeof(bf16))));
                 CK(attn_vt_ones_launch(cond_.obj_vt.back(), Beff * heads, t.d, obj_Tpad, 0));
+                CK(attn_k_init_launch(cond_.obj_k.back(), Beff * heads, t.d, obj_Tpad, 0));
             } else {
                 cond_.objs.push_back(reinterpret_cast<bf16*>(palloc((size_t)Beff * Ng * t.C * sizeof(bf16))));
             }
             cond_.ctx_k.push_back(reinterpret_cast<bf16*>(palloc((size_t)Beff * heads * ctx_Tpad * dp * sizeof(bf16))));
             cond_.ctx_vt.push_back(reinterpret_cast<bf16*>(palloc((size_t)Beff * heads * dpv * ctx_Tpad * sizeof(bf16))));
             CK(attn_vt_ones_launch(cond_.ctx_vt.back(), Beff * heads, t.d, ctx_Tpad, 0));
+            CK(attn_k_init_launch(cond_.ctx_k.back(), Beff * heads, t.d, ctx_Tpad, 0));
         }
         cond_.tokens = reinterpret_cast<bf16*>(palloc((size_t)Beff * obj_stride * c.gr_out_dim * sizeof(bf16)));
         HIPCK(hipStreamSynchronize(0));
@@ -1240,7 +1243,7 @@ void Engine::set_cond(int Beff, const float* context, int n_ctx, const gl_ground
                 Epilogue E;
                 epilogue_defaults(E);
                 E.mode = EPI_QK_HEADS;
-                E.q = cond_.obj_k[t.idx]; E.C = t.C; E.H = heads; E.d = t.d; E.DP = dp; E.T = obj_Tpad; E.Tpad_q = obj_Tpad;
+                E.q = cond_.obj_k[t.idx]; E.q_tiled = 1; E.C = t.C; E.H = heads; E.d = t.d; E.DP = dp; E.T = obj_Tpad; E.Tpad_q = obj_Tpad;
                 gemm(A, t.fca.wk, Beff * obj_Tpad, t.C, t.fca.ctx_dim, E, s);
             }
             {
@@ -1257,7 +1260,7 @@ void Engine::set_cond(int Beff, const float* context, int n_ctx, const gl_ground
             Epilogue E;
             epilogue_defaults(E);
             E.mode = EPI_QK_HEADS;
-            E.q = cond_.ctx_k[t.idx]; E.C = t.C; E.H = heads; E.d = t.d; E.DP = dp; E.T = ctx_Tpad; E.Tpad_q = ctx_Tpad;
+            E.q = cond_.ctx_k[t.idx]; E.q_tiled = 1; E.C = t.C; E.H = heads; E.d = t.d; E.DP = dp; E.T = ctx_Tpad; E.Tpad_q = ctx_Tpad;
             gemm(A, t.a2.wk, Beff * ctx_Tpad, t.C, t.a2.ctx_dim, E, s);
         }
         {
@@ -1670,10 +1673,24 @@ void Engine::sample_plms(const gl_plms_args& a, hipStream_t caller) {
         smp_.n_evals = evals;
     };
 
+    // restore_first_conv_from_SD (plms.py:88-89): at the first step whose gate scale is 0. With a schedule that step is
+    // derived here (a caller-supplied sd_conv_step must agree or be 0); without one the caller names it.
+    int sd_step = -1;
+    if (a.sd_conv_w && a.sd_conv_b) {
+        if (a.fuser_scale) {
+            for (int i = 0; i < a.n_steps && sd_step < 0; ++i)
+                if (a.fuser_scale[i] == 0.f) sd_step = i;
+            if (a.sd_conv_step > 0 && a.sd_conv_step != sd_step)
+                throw GlError(GL_ERR_ARG, fmt("sample_plms: sd_conv_step %d is not the first step with fuser_scale 0 (%d)", a.sd_conv_step, sd_step));
+        } else {
+            sd_step = a.sd_conv_step;
+            if (sd_step >= a.n_steps) throw GlError(GL_ERR_ARG, "sample_plms: sd_conv_step beyond the last step");
+        }
+    }
     bool restored = false;
     for (int i = 0; i < a.n_steps; ++i) {
         if (a.fuser_scale) set_fuser_scale(a.fuser_scale[i], s);
-        if (a.sd_conv_w && a.sd_conv_b && !restored && i == a.sd_conv_step) {
+        if (a.sd_conv_w && a.sd_conv_b && !restored && i == sd_step) {
             restore_first_conv(a.sd_conv_w, a.sd_conv_b, s);
             restored = true;
         }

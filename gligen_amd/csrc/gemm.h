@@ -40,8 +40,9 @@ struct Epilogue {
     int ldres;
     const float* gate;  // optional device scalar: out = res + gate * v
     // attention head layouts
-    bf16* q;            // EPI_QK_HEADS: columns [0,C) -> q, [C,2C) -> k ; each [B*H][Tpad][DP]
+    bf16* q;            // EPI_QK_HEADS: columns [0,C) -> q [B*H][Tpad_q][DP] (row-major), [C,2C) -> k in the key-tile layout (ktile_off)
     bf16* k;
+    int q_tiled;        // the q target is a KEY buffer (cross-attention K of the context / grounding tokens): key-tile layout too
     int C, H, d, DP, T; // T = rows (tokens) per sample in M (multiple of 64)
     int Tpad_q, Tpad_k;
     bf16* vt;           // EPI_QKV_HEADS: v^T destination (EPI_VT_HEADS passes it in `out`)
@@ -51,6 +52,13 @@ struct Epilogue {
     int remap_in, remap_out, remap_off;
     int geglu16;        // ACT_GEGLU: weight rows packed for the 16x16-tile kernel (pack_geglu layout 1)
 };
+
+// Key-tile layout of every attention K buffer: [b*H + h][t / 64][DP / 8][64 keys][8]. A 64-key tile is one contiguous block of
+// 64 * DP elements whose 16-byte chunks are chunk-major, so the attention kernels copy it to LDS verbatim by LDS-DMA (1 KiB
+// contiguous per wave-instruction) and a ds_read_b128 of one chunk of 32 consecutive keys is bank-conflict free.
+__host__ __device__ inline size_t ktile_off(size_t bh, int tpad, int t, int dd, int DP) {
+    return (bh * (size_t)tpad + (size_t)(t & ~63)) * DP + (size_t)(dd >> 3) * 512 + (size_t)(t & 63) * 8 + (dd & 7);
+}
 
 // C[M][N] = A[M][K] * W[N][K]^T (+ epilogue). W is row-major bf16 with leading dim K.
 // ws / ws_bytes: optional fp32 split-K workspace (device); may be null (no split-K then).

@@ -109,7 +109,8 @@ __device__ __forceinline__ void epi_finish4(const Epilogue& E, int m, int n0, fl
             int t = m - b * E.T;
             int tp = which ? E.Tpad_k : E.Tpad_q;
             bf16* base = which ? E.k : E.q;
-            store_bf16x4(base + ((size_t)(b * E.H + h) * tp + t) * E.DP + dd, v);
+            const size_t off = (which || E.q_tiled) ? ktile_off((size_t)(b * E.H + h), tp, t, dd, E.DP) : ((size_t)(b * E.H + h) * tp + t) * E.DP + dd;
+            store_bf16x4(base + off, v);
             break;
         }
         case EPI_VT_HEADS: {  // m = feature, n0 = first of 4 consecutive tokens
@@ -168,7 +169,8 @@ __device__ __forceinline__ void epi_store4(const Epilogue& E, int m, int n0, flo
             int t = m - b * E.T;
             int tp = which ? E.Tpad_k : E.Tpad_q;
             bf16* base = which ? E.k : E.q;
-            store_bf16x4(base + ((size_t)(b * E.H + h) * tp + t) * E.DP + dd, v);
+            const size_t off = (which || E.q_tiled) ? ktile_off((size_t)(b * E.H + h), tp, t, dd, E.DP) : ((size_t)(b * E.H + h) * tp + t) * E.DP + dd;
+            store_bf16x4(base + off, v);
             break;
         }
         case EPI_VT_HEADS: {  // m = feature, n0 = first of 4 consecutive tokens
@@ -994,6 +996,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
             const int dd = cc - h * E.d;
             bf16* base = which ? E.k : E.q;
             const int tp = which ? E.Tpad_k : E.Tpad_q;
+            const bool tiled = which || E.q_tiled;   // keys: key-tile layout (gemm.h ktile_off)
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int m = mrow + i * 16;
@@ -1001,7 +1004,8 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
                 const int b = m / E.T;
                 const int t = m - b * E.T;
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                store_bf16x4(base + ((size_t)(b * E.H + h) * tp + t) * E.DP + dd, v);
+                const size_t off = tiled ? ktile_off((size_t)(b * E.H + h), tp, t, dd, E.DP) : ((size_t)(b * E.H + h) * tp + t) * E.DP + dd;
+                store_bf16x4(base + off, v);
             }
             __builtin_amdgcn_sched_barrier(0);   // addresses just in time: hoisting all TM x TN of them costs registers (spills at 4 x 5)
         }

@@ -261,6 +261,7 @@ int main(int argc, char** argv) {
             P.ldo = H * d; P.o_rows_per_b = Nq;
             P.scale_log2e = 1.4426950408889634f / sqrtf((float)d);
             GC(attn_vt_ones_launch(a2, B * H, d, P.Tk_pad, s));
+            GC(attn_k_init_launch(a1, B * H, d, P.Tk_pad, s));
             relaunch = [=] { GC(attn_launch(P, B, cur_s)); };
             us = time_us(relaunch, reps, s);
         } else if (!strcmp(kind, "gn")) {

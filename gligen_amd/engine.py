@@ -17,8 +17,9 @@ from ._lib import Grounding, PlmsArgs, UNetConfig, VaeConfig, check
 GROUNDING_KINDS = {"text": 0, "text_image": 1, "keypoint": 2, "tokens": 3}
 
 
-def _stream() -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None) -> C.c_void_p:
+    # the current stream OF THE ENGINE'S DEVICE: torch's current device may be another GPU of the same process
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
@@ -135,7 +136,7 @@ class Engine:
         if b.shape[0] != ctx.shape[0]:
             raise ValueError("grounding batch does not match context batch")
         g.n = int(b.shape[1])
-        check(self.lib.gl_unet_set_cond(self._ctx, int(ctx.shape[0]), _ptr(ctx), int(ctx.shape[1]), C.byref(g), _stream()))
+        check(self.lib.gl_unet_set_cond(self._ctx, int(ctx.shape[0]), _ptr(ctx), int(ctx.shape[1]), C.byref(g), _stream(self.device)))
         self._keep = keep
         self._cond_shape = (int(ctx.shape[0]), g.n * (2 if kind == "text_image" else 1))
 
@@ -143,7 +144,7 @@ class Engine:
         """objs = position_net(**grounding_input) of the current conditioning, fp32 [Beff, Ng, out_dim]."""
         Beff, Ng = int(self._cond_shape[0]), int(self._cond_shape[1])
         out = torch.empty((Beff, Ng, self.unet_cfg["gr_out_dim"]), device=self.device, dtype=torch.float32)
-        check(self.lib.gl_unet_grounding_tokens(self._ctx, _ptr(out), _stream()))
+        check(self.lib.gl_unet_grounding_tokens(self._ctx, _ptr(out), _stream(self.device)))
         return out
 
     def spatial_tokens(self, image: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
@@ -155,7 +156,7 @@ class Engine:
         if mask.shape[0] != B:
             raise ValueError("spatial_tokens: one mask value per image")
         out = torch.empty((B, self.unet_cfg["tok_tokens"], self.unet_cfg["gr_out_dim"]), device=self.device, dtype=torch.float32)
-        check(self.lib.gl_op_spatial_tokens(self._ctx, _ptr(image), int(B), int(Cc), int(H), int(W), _ptr(mask), _ptr(out), _stream()))
+        check(self.lib.gl_op_spatial_tokens(self._ctx, _ptr(image), int(B), int(Cc), int(H), int(W), _ptr(mask), _ptr(out), _stream(self.device)))
         return out
 
     def grounding_downsample(self, img: torch.Tensor, n_in: int, resize: int, mode: str, convs) -> torch.Tensor:
@@ -167,25 +168,25 @@ class Engine:
         if convs is None:
             out = torch.empty((B, n_in, resize, resize), device=self.device, dtype=torch.float32)
             check(self.lib.gl_op_grounding_downsample(self._ctx, _ptr(img), B, Cimg, H, W, n_in, resize, m, None, None, 0, None, None, 0,
-                                                      _ptr(out), _stream()))
+                                                      _ptr(out), _stream(self.device)))
             return out
         w1, b1, w2, b2 = (_f32(t.detach(), self.device) for t in convs)
         out = torch.empty((B, w2.shape[0], resize // 4, resize // 4), device=self.device, dtype=torch.float32)
         check(self.lib.gl_op_grounding_downsample(self._ctx, _ptr(img), B, Cimg, H, W, n_in, resize, m, _ptr(w1), _ptr(b1), int(w1.shape[0]),
-                                                  _ptr(w2), _ptr(b2), int(w2.shape[0]), _ptr(out), _stream()))
+                                                  _ptr(w2), _ptr(b2), int(w2.shape[0]), _ptr(out), _stream(self.device)))
         return out
 
     def set_fuser_scale(self, scale: float) -> None:
-        check(self.lib.gl_unet_set_fuser_scale(self._ctx, C.c_float(float(scale)), _stream()))
+        check(self.lib.gl_unet_set_fuser_scale(self._ctx, C.c_float(float(scale)), _stream(self.device)))
 
     def set_fuser_scales(self, scales) -> None:
         """One gate multiplier per fuser module, in module order (for models whose fusers carry different `scale` values)."""
         arr = (C.c_float * len(scales))(*[float(v) for v in scales])
-        check(self.lib.gl_unet_set_fuser_scales(self._ctx, arr, len(scales), _stream()))
+        check(self.lib.gl_unet_set_fuser_scales(self._ctx, arr, len(scales), _stream(self.device)))
 
     def restore_first_conv(self, weight: torch.Tensor, bias: torch.Tensor) -> None:
         w, b = _f32(weight, self.device), _f32(bias, self.device)
-        check(self.lib.gl_unet_restore_first_conv(self._ctx, _ptr(w), _ptr(b), _stream()))
+        check(self.lib.gl_unet_restore_first_conv(self._ctx, _ptr(w), _ptr(b), _stream(self.device)))
         self._keep_conv = (w, b)
 
     def unet_forward(self, x: torch.Tensor, timesteps: torch.Tensor, inpaint_extra: Optional[torch.Tensor] = None,
@@ -197,7 +198,7 @@ class Engine:
         extra = None if inpaint_extra is None else _f32(inpaint_extra, dev)
         out = torch.empty((Beff, self.unet_cfg["out_channels"], x.shape[2], x.shape[3]), device=dev, dtype=torch.float32)
         check(self.lib.gl_unet_forward(self._ctx, Beff, int(x.shape[2]), int(x.shape[3]), _ptr(x), int(x.shape[0]), _ptr(t),
-                                       _ptr(extra), 0 if extra is None else int(extra.shape[0]), _ptr(out), _stream()))
+                                       _ptr(extra), 0 if extra is None else int(extra.shape[0]), _ptr(out), _stream(self.device)))
         return out
 
     def unet_profile(self, x: torch.Tensor, timesteps: torch.Tensor, inpaint_extra: Optional[torch.Tensor] = None,
@@ -214,7 +215,7 @@ class Engine:
         n = C.c_int(0)
         check(self.lib.gl_unet_profile(self._ctx, Beff, int(x.shape[2]), int(x.shape[3]), _ptr(x), int(x.shape[0]), _ptr(t),
                                        _ptr(extra), 0 if extra is None else int(extra.shape[0]), _ptr(out), recs, 512, C.byref(n),
-                                       _stream()))
+                                       _stream(self.device)))
         return [dict(name=recs[i].name.decode(), calls=recs[i].calls, ms=recs[i].ms, flops=recs[i].flops, bytes=recs[i].bytes)
                 for i in range(n.value)]
 
@@ -224,7 +225,7 @@ class Engine:
         B, _, h, w = z.shape
         f = 2 ** self.vae_cfg["n_up"]
         out = torch.empty((B, self.vae_cfg["out_ch"], h * f, w * f), device=dev, dtype=torch.float32)
-        check(self.lib.gl_vae_decode(self._ctx, int(B), int(h), int(w), _ptr(z), _ptr(out), _stream()))
+        check(self.lib.gl_vae_decode(self._ctx, int(B), int(h), int(w), _ptr(z), _ptr(out), _stream(self.device)))
         return out
 
     def vae_encode(self, img: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
@@ -233,7 +234,7 @@ class Engine:
         img, noise = _f32(img, dev), _f32(noise, dev)
         B, _, H, W = img.shape
         out = torch.empty_like(noise)
-        check(self.lib.gl_vae_encode(self._ctx, int(B), int(H), int(W), _ptr(img), _ptr(noise), _ptr(out), _stream()))
+        check(self.lib.gl_vae_encode(self._ctx, int(B), int(H), int(W), _ptr(img), _ptr(noise), _ptr(out), _stream(self.device)))
         return out
 
     def sample_plms(self, x: torch.Tensor, timesteps: np.ndarray, a_t: np.ndarray, a_prev: np.ndarray,
@@ -250,6 +251,7 @@ class Engine:
         at = np.ascontiguousarray(a_t, dtype=np.float32)
         ap = np.ascontiguousarray(a_prev, dtype=np.float32)
         a = PlmsArgs()
+        a.struct_size = C.sizeof(PlmsArgs)
         a.B, a.h, a.w, a.n_steps = int(x.shape[0]), int(x.shape[2]), int(x.shape[3]), n
         a.timesteps = ts.ctypes.data_as(C.POINTER(C.c_int64))
         a.a_t = at.ctypes.data_as(C.POINTER(C.c_float))
@@ -285,7 +287,7 @@ class Engine:
             if not 0 <= restore_at < n:
                 raise ValueError("sample_plms: sd_first_conv needs restore_at = the step index it is swapped in at")
             a.sd_conv_step = int(restore_at)
-        check(self.lib.gl_sample_plms(self._ctx, C.byref(a), _stream()))
+        check(self.lib.gl_sample_plms(self._ctx, C.byref(a), _stream(self.device)))
         self._keep_plms = keep
         return x
 
@@ -299,7 +301,7 @@ class Engine:
         img = _f32(img, self.device)
         B, Cc, H, W = img.shape
         out = torch.empty((B, H, W, Cc), device=self.device, dtype=torch.uint8)
-        check(self.lib.gl_to_uint8(_ptr(img), _ptr(out), int(B), int(Cc), int(H * W), _stream()))
+        check(self.lib.gl_to_uint8(_ptr(img), _ptr(out), int(B), int(Cc), int(H * W), _stream(self.device)))
         return out
 
     def arena_high_water(self) -> int:
@@ -317,14 +319,14 @@ class Engine:
         M, K = x.shape
         N = w.shape[0]
         y = torch.empty((M, N), device=x.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
-        check(self.lib.gl_op_linear(self._ctx, _ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(y), M, N, K, act, int(out_f32), _stream()))
+        check(self.lib.gl_op_linear(self._ctx, _ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(y), M, N, K, act, int(out_f32), _stream(self.device)))
         return y
 
     def op_geglu(self, x, w_f32, b_f32):
         M, K = x.shape
         inner = w_f32.shape[0] // 2
         y = torch.empty((M, inner), device=x.device, dtype=torch.bfloat16)
-        check(self.lib.gl_op_geglu(self._ctx, _ptr(x), _ptr(w_f32), _ptr(b_f32), _ptr(y), M, inner, K, _stream()))
+        check(self.lib.gl_op_geglu(self._ctx, _ptr(x), _ptr(w_f32), _ptr(b_f32), _ptr(y), M, inner, K, _stream(self.device)))
         return y
 
     def op_conv3x3(self, x0, w_oihw, bias, x1=None, stride=1, ups=0, pad_lo=1, res=None):
@@ -339,7 +341,7 @@ class Engine:
             Wo = (Wup + (2 if pad_lo else 1) - 3) // 2 + 1
         y = torch.empty((B, Ho, Wo, Cout), device=x0.device, dtype=torch.bfloat16)
         check(self.lib.gl_op_conv3x3(self._ctx, _ptr(x0), C0, _ptr(x1), C1, B, H, W, _ptr(w_oihw), _ptr(bias), Cout,
-                                     stride, ups, pad_lo, _ptr(res), _ptr(y), _stream()))
+                                     stride, ups, pad_lo, _ptr(res), _ptr(y), _stream(self.device)))
         return y
 
     def op_groupnorm(self, x0, gamma, beta, eps, silu, x1=None):
@@ -347,7 +349,7 @@ class Engine:
         C1 = 0 if x1 is None else x1.shape[2]
         y = torch.empty((B, HW, C0 + C1), device=x0.device, dtype=torch.bfloat16)
         check(self.lib.gl_op_groupnorm(self._ctx, _ptr(x0), C0, _ptr(x1), C1, B, HW, _ptr(gamma), _ptr(beta),
-                                       C.c_float(eps), int(silu), _ptr(y), _stream()))
+                                       C.c_float(eps), int(silu), _ptr(y), _stream(self.device)))
         return y
 
     def op_layernorm(self, x, gamma, beta, eps=1e-5, x2=None, Tpad=None):
@@ -356,7 +358,7 @@ class Engine:
         Tpad = Tpad or (N1 + N2)
         y = torch.empty((B, Tpad, Cc), device=x.device, dtype=torch.bfloat16)
         check(self.lib.gl_op_layernorm(self._ctx, _ptr(x), _ptr(x2), B, N1, N2, Tpad, Cc, _ptr(gamma), _ptr(beta),
-                                       C.c_float(eps), _ptr(y), _stream()))
+                                       C.c_float(eps), _ptr(y), _stream(self.device)))
         return y
 
     def op_attention(self, xq, xkv, wq, wk, wv, heads):
@@ -364,5 +366,5 @@ class Engine:
         _, Nk, Ck = xkv.shape
         o = torch.empty((B, Nq, Cc), device=xq.device, dtype=torch.bfloat16)
         check(self.lib.gl_op_attention(self._ctx, _ptr(xq), _ptr(xkv), B, Nq, Nk, Cc, Ck, heads, _ptr(wq), _ptr(wk), _ptr(wv),
-                                       _ptr(o), _stream()))
+                                       _ptr(o), _stream(self.device)))
         return o

@@ -367,7 +367,6 @@ def save_images(samples, output_folder, first_id=None):
         Image.fromarray(arr.astype(np.uint8)).save(os.path.join(output_folder, str(int(image_id)) + ".png"))
 
 
-@torch.no_grad()
 def _shard(t, lo, hi):
     return t[lo:hi] if torch.is_tensor(t) else t
 
@@ -390,6 +389,14 @@ def run(meta, config, starting_noise=None, models=None):
     B = args["batch_size"]
     rank, _, world = gdist.env_world()
     lo, hi = gdist.shard_range(B, rank, world)
+    folder = os.path.join(args["folder"], meta["save_folder_name"])
+    if hi == lo:
+        # more ranks than samples (e.g. the CLI's default batch_size 5 on 8 GPUs): this rank has nothing to sample, but it
+        # still joins the two barriers the other ranks wait in before they number their images
+        os.makedirs(folder, exist_ok=True)
+        gdist.barrier()
+        gdist.barrier()
+        return torch.empty((0, 3, 8 * model.image_size, 8 * model.image_size))
     prepare = next((fn for key, fn in _PREPARE_BY_NAME if key in meta["ckpt"]), prepare_batch)
     batch = {k: _shard(v, lo, hi) for k, v in prepare(meta, B).items()}
     if "grounding_tokens" in meta:   # spatial-map modalities: ConvNeXt tokens computed elsewhere (like precomputed CLIP features)
@@ -400,7 +407,12 @@ def run(meta, config, starting_noise=None, models=None):
         context = text_encoder.encode([meta["prompt"]] * (hi - lo))
         uc = text_encoder.encode((hi - lo) * [args.get("negative_prompt") or ""])
     if world > 1 or args.get("seed") is not None:
-        # one seeded draw for the whole batch, sliced: an N-GPU run reproduces the 1-GPU images
+        # one seeded draw for the whole batch, sliced: an N-GPU run reproduces the 1-GPU images. The device generator is
+        # seeded too, identically on every rank: the inpainting loop's per-step q_sample noise (randn_like(z0), batch 1 for
+        # the single encoded input image) comes from it, so that noise is the same on all ranks and run to run. (With a
+        # per-sample z0 batch that draw is batch-shaped and a sharded run is reproducible but not equal to the 1-GPU run.)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed(int(args.get("seed") or 0))
         if starting_noise is None:
             gen = torch.Generator().manual_seed(int(args.get("seed") or 0))
             starting_noise = torch.randn((B, model.in_channels, model.image_size, model.image_size), generator=gen)
@@ -427,7 +439,6 @@ def run(meta, config, starting_noise=None, models=None):
     samples = generate(model, autoencoder, diffusion, batch, context, uc, steps=steps, guidance_scale=args["guidance_scale"],
                        alpha_type=meta.get("alpha_type"), starting_noise=starting_noise, inpainting_mask=mask, z0=z0, no_plms=no_plms,
                        grounding_extra_input=grounding_extra_input, grounding_input=grounding_input)
-    folder = os.path.join(args["folder"], meta["save_folder_name"])
     if world > 1:
         os.makedirs(folder, exist_ok=True)
         gdist.barrier()

@@ -76,6 +76,8 @@ typedef struct gl_grounding {
 /* One PLMS run (reference ldm/models/diffusion/plms.py:65-162): schedule arrays are host
  * pointers of length n_steps, in sampling order (time descending). */
 typedef struct gl_plms_args {
+    unsigned struct_size;        /* = sizeof(gl_plms_args) of the header the caller was compiled against; anything else is
+                                    rejected (GL_ERR_ARG), so a caller built against another layout fails loudly */
     int B, h, w;                 /* latent batch / size; cond must have been set with Beff = 2B
                                     ([cond ; uncond]) when guidance != 1, else Beff = B */
     int n_steps;
@@ -95,9 +97,11 @@ typedef struct gl_plms_args {
     const float* sqrt_ac;        /* host [n_steps]: sqrt_alphas_cumprod[t] (ldm.py:19-22) */
     const float* sqrt_1mac;      /* host [n_steps] */
     int use_graph;               /* capture one UNet evaluation in a hipGraph and replay it */
-    const float* sd_conv_w;      /* device fp32 [mc][C][3][3] + [mc]: SD first-conv weights swapped in before step */
-    const float* sd_conv_b;      /*   sd_conv_step, the first step whose alpha is 0 (plms.py:88-89), or NULL */
-    int sd_conv_step;
+    const float* sd_conv_w;      /* device fp32 [mc][C][3][3] + [mc]: the SD first-conv weights, or NULL. With a fuser_scale */
+    const float* sd_conv_b;      /*   schedule they are swapped in before the first step whose scale is 0 (plms.py:88-89),  */
+    int sd_conv_step;            /*   whatever sd_conv_step says (a zero-initialised struct does the right thing; a value
+                                      that names another step is rejected); never if no scale is 0. Without a schedule
+                                      (per-fuser scales set by hand, gatedSA2) before step sd_conv_step, -1 = never. */
     int ddim;                    /* 0: PLMS (Adams-Bashforth multistep, plms.py:111-162). 1: DDIMSampler with eta = 0
                                     (reference ldm/models/diffusion/ddim.py:65-134): one evaluation per step,
                                     x_prev = sqrt(a_prev) pred_x0 + sqrt(1 - a_prev) e_t */

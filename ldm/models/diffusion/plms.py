@@ -132,8 +132,18 @@ class PLMSSampler(object):
         if gate_off and model.first_conv_restorable and not model.__dict__.get("_first_conv_restored"):
             sd_conv = model.load_sd_first_conv()  # swapped in on the device at the first gated-off step
         restore_at = int(np.argmax(alphas == 0)) if sd_conv is not None else -1
+        # channels concatenated to x in front of the first conv (reference openaimodel.py:442-447): the masked latent + mask
+        # of an inpainting model, or the GroundingDownsampler output of a spatial-map model. The reference's uncond call
+        # passes the same tensors (plms.py:118), so one [B] tensor serves both halves of the [cond ; uncond] evaluation; it
+        # stays bound after the SD first conv is swapped in (the packed conv keeps its 4 + k layout, those weights are zero).
+        if model.inpaint_mode:
+            first_conv_extra = input.get("inpainting_extra_input")
+            if first_conv_extra is None:
+                raise ValueError("inpaint_mode model needs input['inpainting_extra_input']")
+        else:
+            first_conv_extra = model.first_conv_extra(input)
         model.engine.sample_plms(img, time_range, a_t, a_prev, scales, guidance_scale if cfg else 1.0,
-                                 inpaint_extra=input.get("inpainting_extra_input"), use_graph=self.use_graph,
+                                 inpaint_extra=first_conv_extra, use_graph=self.use_graph,
                                  sd_first_conv=sd_conv, restore_at=restore_at, ddim=not self.multistep, **extra)
         if sd_conv is not None:
             model.restore_first_conv_from_SD()  # bring the module parameters in line with the engine

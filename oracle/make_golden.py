@@ -226,22 +226,28 @@ def plms_unet_case(name, S, hw, alpha_type, inpaint=False, sampler_cls=None, cfg
     print(f"{name}: x_out std {out.std():.4f} [{time.time() - t0:.1f}s]")
 
 
-def unet_pair_case(name, kind, B, hw, n_valid=8):
+def unet_pair_case(name, kind, B, hw, n_valid=8, inpaint=False):
     """The shipped topology at the benchmark's latent size: eps of the grounded batch and of the null-grounding / uc batch
-    (the two halves of the engine's [cond ; uncond] evaluation, reference plms.py:116-122)."""
+    (the two halves of the engine's [cond ; uncond] evaluation, reference plms.py:116-122). inpaint: the 9-channel first
+    conv of BASELINE C4 with the masked latent + mask of gligen_inference.py:396-407 (the same tensor in both halves)."""
     t0 = time.time()
-    model = build_unet(syn.UNET_CFG, kind)
+    model = build_unet(syn.UNET_CFG, kind, inpaint)
     batch = syn.make_batch(kind, B, n_valid=n_valid, seed=3)
     g = model.grounding_tokenizer_input.prepare(batch)
     x = syn.make_latent(B, 4, hw, hw, seed=3)
     ctx, uc = syn.make_context(B, seed=3), syn.make_context(B, seed=9)
     t = torch.full((B,), 501, dtype=torch.long)
+    extra = None
+    if inpaint:
+        mask = ref_draw_masks(batch["boxes"], hw)
+        z0 = syn.make_latent(B, 4, hw, hw, seed=2)
+        extra = torch.cat([z0 * mask, mask], dim=1)
     with torch.no_grad():
-        eps = model(dict(x=x, timesteps=t, context=ctx, grounding_input=g, inpainting_extra_input=None, grounding_extra_input=None)).numpy()
-        eps_u = model(dict(x=x, timesteps=t, context=uc, inpainting_extra_input=None, grounding_extra_input=None)).numpy()
+        eps = model(dict(x=x, timesteps=t, context=ctx, grounding_input=g, inpainting_extra_input=extra, grounding_extra_input=None)).numpy()
+        eps_u = model(dict(x=x, timesteps=t, context=uc, inpainting_extra_input=extra, grounding_extra_input=None)).numpy()
         objs = model.position_net(**g).numpy()
     np.savez_compressed(os.path.join(OUT, name + ".npz"), eps=eps.astype(np.float16), eps_uncond=eps_u.astype(np.float16), objs=objs.astype(np.float16),
-                        meta=json.dumps(dict(kind=kind, B=B, hw=hw, n_valid=n_valid, t=501, stored="float16")))
+                        meta=json.dumps(dict(kind=kind, B=B, hw=hw, n_valid=n_valid, t=501, stored="float16", inpaint=inpaint)))
     print(f"{name}: eps std {eps.std():.4f} cond-vs-uncond mse {((eps - eps_u) ** 2).mean():.3e} [{time.time() - t0:.1f}s]")
 
 
@@ -306,6 +312,92 @@ def spatial_case(name, modality, B=2, hw=16, res=128):
     print(f"{name}: eps std {out['eps'].std():.4f}; cond-vs-null mse {((out['eps'] - out['eps_null']) ** 2).mean():.3e}; ds std {out['ds'].std():.4f} "
           f"[{time.time() - t0:.1f}s]")
     return {k: list(v.shape) for k, v in model.state_dict().items()}
+
+
+def plms_spatial_case(name, modality, S=5, hw=16, res=128, alpha_type=(0.6, 0.0, 0.4), sampler_cls=None):
+    """The reference's sampler on a spatial-map model (GroundingDownsampler feeding a 4 + k channel first conv): CFG pairs with
+    the same grounding_extra_input in both halves (plms.py:118), an alpha schedule with gated-off steps, i.e. the SD first
+    conv swapped in mid-run, after which the downsampled map is no longer concatenated (openaimodel.py:442-444)."""
+    t0 = time.time()
+    from functools import partial
+    import tempfile
+    _timm_shim()
+    key = SPATIAL_KEYS[modality]
+    ds_params = dict(out_dim=1) if modality == "hed" else dict(resize_input=4 * hw, out_dim=8)
+    tk_params = dict(resize_input=128, out_dim=768)
+    cfg = dict(syn.UNET_CFG_SMALL,
+               grounding_downsampler=dict(target=f"ldm.modules.diffusionmodules.{modality}_grounding_downsampler.GroundingDownsampler", params=ds_params),
+               grounding_tokenizer=dict(target=f"ldm.modules.diffusionmodules.{modality}_grounding_net.PositionNet", params=tk_params))
+    real_hub = torch.hub.load_state_dict_from_url
+    torch.hub.load_state_dict_from_url = lambda *a, **k: {"model": {}}
+    try:
+        model = UNetModel(**cfg).eval()
+    finally:
+        torch.hub.load_state_dict_from_url = real_hub
+    syn.fill_module_(model, 1234)
+    gin = instantiate_from_config(dict(target=f"grounding_input.{modality}_grounding_tokinzer_input.GroundingNetInput"))
+    dsin = instantiate_from_config(dict(target=f"grounding_input.{modality}_grounding_downsampler_input.GroundingDSInput"))
+    model.grounding_tokenizer_input = gin
+    tmp = tempfile.mkdtemp()
+    torch.save(syn.sd_first_conv_state(), os.path.join(tmp, "SD_input_conv_weight_bias.pth"))
+    os.chdir(tmp)
+    B = 2
+    img = syn.make_spatial_map(modality, B, res, seed=1)
+    batch = {key: img, "mask": torch.ones(B, 1)}
+    g = gin.prepare(batch)
+    extra = dsin.prepare(batch)
+    x = syn.make_latent(B, 4, hw, hw, seed=6)
+    ctx, uc = syn.make_context(B, seed=1), syn.make_context(B, seed=9)
+    diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000)
+    sampler = (sampler_cls or PLMSSampler)(diffusion, model, alpha_generator_func=partial(ref_alpha_generator, type=list(alpha_type)),
+                                           set_alpha_scale=set_alpha_scale)
+    inp = dict(x=x.clone(), timesteps=None, context=ctx, grounding_input=g, inpainting_extra_input=None, grounding_extra_input=extra)
+    with torch.no_grad():
+        out = sampler.sample(S=S, shape=tuple(x.shape), input=inp, uc=uc, guidance_scale=7.5)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), x_out=out.numpy(),
+                        meta=json.dumps(dict(S=S, hw=hw, res=res, modality=modality, alpha_type=list(alpha_type), guidance_scale=7.5, B=B, cfg=cfg,
+                                             first_conv_type=model.first_conv_type)))
+    print(f"{name}: x_out std {out.std():.4f} first conv now {model.first_conv_type} [{time.time() - t0:.1f}s]")
+
+
+def c2_case(name="c2_end_to_end", S=50, hw=64):
+    """BASELINE config C2 for ONE image at its real size: box+text, 8 boxes, 512x512, 50 PLMS steps (102 UNet forwards), CFG
+    7.5, gate on at every step (alpha_type None = [1, 0, 0], the schedule the metric is quoted on), B = 1, fp32 on the CPU
+    through the reference's PLMSSampler + UNetModel + AutoencoderKL.decode (gligen_inference.py:389-446). The latent after
+    10 and 25 steps is recorded too (p_sample_plms hooked), so a divergence can be located."""
+    t0 = time.time()
+    from functools import partial
+    diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000)
+    model = build_unet(syn.UNET_CFG, "text")
+    ae = AutoencoderKL(ddconfig=syn.VAE_DDCONFIG, embed_dim=4, scale_factor=0.18215).eval()
+    syn.fill_module_(ae, 4321)
+    batch = syn.make_batch("text", 1, n_valid=8, seed=1)
+    g = model.grounding_tokenizer_input.prepare(batch)
+    x = syn.make_latent(1, 4, hw, hw, seed=6)
+    ctx, uc = syn.make_context(1, seed=1), syn.make_context(1, seed=9)
+    sampler = PLMSSampler(diffusion, model, alpha_generator_func=partial(ref_alpha_generator, type=None), set_alpha_scale=set_alpha_scale)
+    trace = {}
+    real_step = sampler.p_sample_plms
+    count = [0]
+
+    def rec_step(*a, **k):
+        r = real_step(*a, **k)
+        count[0] += 1
+        if count[0] in (10, 25):
+            trace[f"z_step{count[0]}"] = r[0].numpy().copy()
+        return r
+
+    sampler.p_sample_plms = rec_step
+    inp = dict(x=x.clone(), timesteps=None, context=ctx, grounding_input=g, inpainting_extra_input=None, grounding_extra_input=None)
+    with torch.no_grad():
+        z = sampler.sample(S=S, shape=tuple(x.shape), input=inp, uc=uc, guidance_scale=7.5)
+        t_s = time.time() - t0
+        img = ae.decode(z)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), z=z.numpy(), img=img.numpy().astype(np.float16), **trace,
+                        meta=json.dumps(dict(S=S, hw=hw, alpha_type=None, guidance_scale=7.5, B=1, n_valid=8, img_stored="float16",
+                                             ref_cpu_seconds=round(time.time() - t0, 1), ref_sampler_seconds=round(t_s, 1),
+                                             cpu_threads=torch.get_num_threads())))
+    print(f"{name}: z std {z.std():.4f} img std {img.std():.4f} [{time.time() - t0:.1f}s]")
 
 
 def c1_case(name="c1_end_to_end", S=20, hw=32):
@@ -408,6 +500,14 @@ CASES = {
     "unet_small_hed": lambda: spatial_case("unet_small_hed", "hed", B=1, hw=64),  # the hed downsampler always resizes to 64 x 64
     "unet_small_normal": lambda: spatial_case("unet_small_normal", "normal"),
     "unet_small_sem": lambda: spatial_case("unet_small_sem", "sem"),
+    # ---- round 3: the remaining parity holes
+    "unet_small_depth": lambda: spatial_case("unet_small_depth", "depth"),
+    "plms_unet_small_canny": lambda: plms_spatial_case("plms_unet_small_canny", "canny"),
+    "ddim_unet_small_hed": lambda: plms_spatial_case("ddim_unet_small_hed", "hed", S=6, hw=64, alpha_type=(0.5, 0.0, 0.5), sampler_cls=DDIMSampler),
+    "unet_full_64_inpaint": lambda: unet_pair_case("unet_full_64_inpaint", "text", 1, 64, inpaint=True),
+    "unet_full_64_text_image_b4": lambda: unet_pair_case("unet_full_64_text_image_b4", "text_image", 4, 64),
+    "unet_full_64_keypoint_b4": lambda: unet_pair_case("unet_full_64_keypoint_b4", "keypoint", 4, 64),
+    "c2_end_to_end": c2_case,
 }
 
 if __name__ == "__main__":
