@@ -46,16 +46,17 @@ def full_models():
     """The shipped topology, one engine per tokenizer kind, built once for this module (1.07 B parameters each)."""
     cache = {}
 
-    def get(kind):
-        if kind not in cache:
-            cache[kind] = build_product_unet(syn.UNET_CFG, kind, device=_dev())
-        return cache[kind]
+    def get(kind, inpaint=False):
+        if (kind, inpaint) not in cache:
+            cache[(kind, inpaint)] = build_product_unet(syn.UNET_CFG, kind, inpaint, device=_dev())
+        return cache[(kind, inpaint)]
     yield get
     for m in cache.values():
         m._drop_engine()
 
 
-@pytest.mark.parametrize("name", ["unet_full_64_text", "unet_full_64_text_image", "unet_full_64_keypoint"])
+@pytest.mark.parametrize("name", ["unet_full_64_text", "unet_full_64_text_image", "unet_full_64_keypoint",
+                                  "unet_full_64_text_image_b4", "unet_full_64_keypoint_b4", "unet_full_64_inpaint"])
 def test_unet_full_size_pair_vs_reference(name, full_models):
     """One [cond ; uncond] evaluation of the shipped UNet at the benchmark's latent size, exactly as the sampler issues it
     (batch 2B = 8 for box+text: BASELINE C2; Ng = 60 for text+image: C3; Ng = 136 for keypoints: C5), both halves against
@@ -64,7 +65,8 @@ def test_unet_full_size_pair_vs_reference(name, full_models):
     g = load_golden(name)
     meta = g["meta"]
     kind, B, hw = meta["kind"], meta["B"], meta["hw"]
-    model = full_models(kind)
+    inpaint = bool(meta.get("inpaint"))
+    model = full_models(kind, inpaint)
     batch = syn.make_batch(kind, B, n_valid=meta["n_valid"], seed=3)
     gin = model.grounding_tokenizer_input.prepare(_to(batch, dev))
     g_null = model.grounding_tokenizer_input.get_null_input()
@@ -75,7 +77,12 @@ def test_unet_full_size_pair_vs_reference(name, full_models):
     g2 = {k: torch.cat([gin[k], g_null[k].to(gin[k])]) for k in gin}
     model.set_conditioning(ctx2, g2)
     model.engine.set_fuser_scale(1.0)
-    eps = model.engine.unet_forward(x, t, None, batch=2 * B)     # sample b reads x[b % B]
+    extra = None
+    if inpaint:   # BASELINE C4: masked latent + mask in front of the 9-channel first conv, the same tensor for both halves
+        from oracle.gligen_oracle import draw_masks_from_boxes
+        mask = draw_masks_from_boxes(batch["boxes"], hw)
+        extra = torch.cat([syn.make_latent(B, 4, hw, hw, seed=2) * mask, mask], dim=1).to(dev)
+    eps = model.engine.unet_forward(x, t, extra, batch=2 * B)     # sample b reads x[b % B] (and extra[b % B])
     ref_c, ref_u = g["eps"].astype(np.float32), g["eps_uncond"].astype(np.float32)
     r = dict(eps_cond=mse(eps[:B], ref_c), eps_uncond=mse(eps[B:], ref_u), eps_var=float(ref_c.var()))
     d_ref = torch.from_numpy(ref_c - ref_u)
@@ -128,6 +135,87 @@ def test_c1_end_to_end_vs_reference(full_models, tmp_path, monkeypatch):
     assert r["z_rel_mse"] < 2e-3 and r["img_rel_mse"] < 5e-3, r
     model._drop_engine()
     ae._drop_engine()
+
+
+def test_c2_end_to_end_vs_reference(full_models, monkeypatch):
+    """BASELINE config C2 for one image at its real size: box+text, 8 boxes, 512x512, 50 PLMS steps (51 CFG evaluations of the
+    shipped UNet at the 64x64 latent), gate on at every step, decode -- gligen_inference.generate against the reference's own
+    PLMSSampler + UNetModel + AutoencoderKL.decode run on the CPU (oracle/make_golden.py:c2_case; the golden also holds the
+    reference's latent after 10 and 25 steps for locating a divergence by hand)."""
+    dev = _dev()
+    import gligen_inference as gi
+    from ldm.models.diffusion.ldm import LatentDiffusion
+    g = load_golden("c2_end_to_end")
+    meta = g["meta"]
+    hw, S = meta["hw"], meta["S"]
+    monkeypatch.setattr(gi, "device", dev)
+    model = full_models("text")
+    ae = build_product_vae(syn.VAE_DDCONFIG, device=dev)
+    diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000).to(dev)
+    batch = _to(syn.make_batch("text", 1, n_valid=meta["n_valid"], seed=1), dev)
+    ctx, uc = syn.make_context(1, seed=1).to(dev), syn.make_context(1, seed=9).to(dev)
+    captured = {}
+    real_decode = type(ae).decode
+
+    def decode(self, z):
+        captured["z"] = z.clone()
+        return real_decode(self, z)
+    monkeypatch.setattr(type(ae), "decode", decode)
+    img = gi.generate(model, ae, diffusion, batch, ctx, uc, steps=S, guidance_scale=meta["guidance_scale"], alpha_type=meta["alpha_type"],
+                      starting_noise=syn.make_latent(1, 4, hw, hw, seed=6).to(dev))
+    z_ref, img_ref = g["z"], g["img"].astype(np.float32)
+    r = dict(z_rel_mse=mse(captured["z"], z_ref) / float(z_ref.var()), z_std=float(z_ref.std()),
+             img_mse=mse(img, img_ref), img_var=float(img_ref.var()), ref_cpu_seconds=meta["ref_cpu_seconds"])
+    r["img_rel_mse"] = r["img_mse"] / r["img_var"]
+    REPORT["c2_end_to_end"] = r
+    assert img.shape == tuple(img_ref.shape) == (1, 3, 8 * hw, 8 * hw)
+    # 102 chained evaluations of a random-weight UNet under CFG 7.5 + the decoder, bf16 against fp32
+    assert r["z_rel_mse"] < 5e-3 and r["img_rel_mse"] < 1e-2, r
+    ae._drop_engine()
+
+
+@pytest.mark.parametrize("name", ["plms_unet_small_canny", "ddim_unet_small_hed"])
+def test_spatial_sampler_vs_reference(name, tmp_path, monkeypatch):
+    """The samplers on a spatial-map model (GroundingDownsampler -> 4 + k channel first conv, ConvNeXt tokens): CFG pairs share
+    the downsampled map, the alpha schedule gates the fusers off mid-run, where the SD first conv is swapped in and the map's
+    channels stop contributing (reference plms.py:85-89,118, openaimodel.py:400-413,442-444). Against the reference's own
+    sampler run; eager and hipGraph runs bit-identical."""
+    dev = _dev()
+    from gligen_inference import alpha_generator, set_alpha_scale
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.models.diffusion.ldm import LatentDiffusion
+    from ldm.models.diffusion.plms import PLMSSampler
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from ldm.util import instantiate_from_config
+    g = load_golden(name)
+    meta = g["meta"]
+    modality, B, hw, S = meta["modality"], meta["B"], meta["hw"], meta["S"]
+    assert meta["first_conv_type"] == "SD"     # the reference did swap the conv during this run
+    torch.save(syn.sd_first_conv_state(), tmp_path / "SD_input_conv_weight_bias.pth")
+    monkeypatch.chdir(tmp_path)
+    key = {"canny": "canny_edge", "hed": "hed_edge"}[modality]
+    diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000).to(dev)
+    ctx, uc = syn.make_context(B, seed=1).to(dev), syn.make_context(B, seed=9).to(dev)
+    results = []
+    for use_graph in (False, True):
+        model = syn.fill_module_(UNetModel(**meta["cfg"]).eval(), 1234).to(dev)
+        gin = instantiate_from_config(dict(target=f"grounding_input.{modality}_grounding_tokinzer_input.GroundingNetInput"))
+        dsin = instantiate_from_config(dict(target=f"grounding_input.{modality}_grounding_downsampler_input.GroundingDSInput"))
+        model.grounding_tokenizer_input = gin
+        batch = {key: syn.make_spatial_map(modality, B, meta["res"], seed=1).to(dev), "mask": torch.ones(B, 1, device=dev)}
+        sampler = (DDIMSampler if name.startswith("ddim") else PLMSSampler)(
+            diffusion, model, alpha_generator_func=partial(alpha_generator, type=meta["alpha_type"]), set_alpha_scale=set_alpha_scale)
+        sampler.use_graph = use_graph
+        inp = dict(x=syn.make_latent(B, 4, hw, hw, seed=6).to(dev), timesteps=None, context=ctx, grounding_input=gin.prepare(batch),
+                   inpainting_extra_input=None, grounding_extra_input=dsin.prepare(batch))
+        out = sampler.sample(S=S, shape=(B, 4, hw, hw), input=inp, uc=uc, guidance_scale=meta["guidance_scale"])
+        assert model.first_conv_type == "SD"
+        results.append(out.clone())
+        model._drop_engine()
+    rel = mse(results[0], g["x_out"]) / float(g["x_out"].var())
+    REPORT[name] = dict(x_rel_mse=rel, x_std=float(g["x_out"].std()))
+    assert rel < 2e-3, REPORT[name]
+    assert torch.equal(results[0], results[1]), "hipGraph replay must reproduce the eager launch sequence bit for bit"
 
 
 def test_vae_encode_512_vs_reference(monkeypatch):
@@ -246,7 +334,7 @@ def test_run_entry_inpaint_batch(tmp_path, monkeypatch):
     ae._drop_engine()
 
 
-@pytest.mark.parametrize("modality", ["canny", "hed", "normal", "sem"])
+@pytest.mark.parametrize("modality", ["canny", "hed", "normal", "sem", "depth"])
 def test_spatial_modality_vs_reference(modality):
     """Spatial-map modalities: GroundingDownsampler on the device against the reference's output, then the
     UNet with the 4 + k channel first conv and the reference tokenizer's tokens, cond and null, against the reference eps."""
@@ -259,7 +347,7 @@ def test_spatial_modality_vs_reference(modality):
     model = syn.fill_module_(UNetModel(**meta["cfg"]).eval(), 1234).to(dev)
     assert {k: list(v.shape) for k, v in model.state_dict().items()} == golden_shapes(name)
     B, hw = meta["B"], meta["hw"]
-    key = {"canny": "canny_edge", "hed": "hed_edge", "normal": "normal", "sem": "sem"}[modality]
+    key = {"canny": "canny_edge", "hed": "hed_edge", "normal": "normal", "sem": "sem", "depth": "depth"}[modality]
     img = syn.make_spatial_map(modality, B, meta["res"], seed=1).to(dev)
     batch = {key: img, "mask": torch.ones(B, 1, device=dev)}
     gin = instantiate_from_config(dict(target=f"grounding_input.{modality}_grounding_tokinzer_input.GroundingNetInput"))

@@ -80,3 +80,26 @@ def test_two_rank_gloo_shards_reproduce_global_batch(tmp_path):
         assert abs(res[r]["x"] - float(x[sl].sum())) < 1e-9
         assert abs(res[r]["ctx"] - float(ctx[sl].sum())) < 1e-9
         assert abs(res[r]["boxes"] - float(boxes[sl].sum())) < 1e-9
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher around it (the driver's scaling command) must start its N ranks itself:
+    re-executed under torch.distributed.run on 127.0.0.1, one JSON line from rank 0 with n_gpus = N and the size of the
+    process group the barrier / max-over-ranks clock ran in. --stub swaps the engine for a sleep (no GPU here) and the
+    collectives' backend for gloo; the launch path, argument hand-over, barrier and clock are the real ones."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub", "--config", "C3"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout          # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["collective_world_size"] == 2 and d["collective_backend"] == "gloo"
+    assert d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert "C3" in d["config"]["workload"]     # the arguments reached the ranks
+    assert 0 < d["ms_per_step"] < 2000 and d["value"] > 0
+    # a launcher / --gpus mismatch is an error, not a silent 1-GPU run
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                         capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert bad.returncode != 0 and "must agree" in (bad.stderr + bad.stdout)

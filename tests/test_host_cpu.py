@@ -484,3 +484,91 @@ def test_halo_kernel_geometry(H, W, B):
     """Every image geometry `halo_eligible` admits (power-of-two H, 8 <= W <= 64, at most 400 halo rows): the halo rows the DMA side
     fills are the rows the fragment side reads, image borders and tile borders inside an image included."""
     assert _halo_geometry_ok(H, W, B)
+
+
+# ---- CLIP front-end (SURVEY §8 f1): executed offline with random-init HF models and a fabricated byte-level BPE vocabulary
+def _fabricated_clip(tmp_path, hidden=768, proj=768):
+    import json as _json
+    from transformers import CLIPConfig, CLIPImageProcessor, CLIPModel, CLIPProcessor, CLIPTextConfig, CLIPTokenizer, CLIPVisionConfig
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("¡"), ord("¬") + 1)) + list(range(ord("®"), ord("ÿ") + 1))
+    cs, n = bs[:], 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b); cs.append(256 + n); n += 1
+    chars = [chr(c) for c in cs]
+    vocab = {c: i for i, c in enumerate(chars)}
+    vocab.update({c + "</w>": len(chars) + i for i, c in enumerate(chars)})
+    vocab["<|startoftext|>"], vocab["<|endoftext|>"] = len(vocab), len(vocab) + 1
+    (tmp_path / "vocab.json").write_text(_json.dumps(vocab))
+    (tmp_path / "merges.txt").write_text("#version: 0.2\n")
+    tok = CLIPTokenizer(str(tmp_path / "vocab.json"), str(tmp_path / "merges.txt"))
+    tcfg = CLIPTextConfig(vocab_size=49408, hidden_size=hidden, intermediate_size=256, num_hidden_layers=2, num_attention_heads=8,
+                          max_position_embeddings=77, hidden_act="quick_gelu", projection_dim=proj, eos_token_id=vocab["<|endoftext|>"],
+                          bos_token_id=vocab["<|startoftext|>"], pad_token_id=vocab["<|endoftext|>"])
+    vcfg = CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4, image_size=224, patch_size=32,
+                            projection_dim=proj)
+    torch.manual_seed(0)
+    model = CLIPModel(CLIPConfig(text_config=tcfg.to_dict(), vision_config=vcfg.to_dict(), projection_dim=proj)).eval()
+    return model, CLIPProcessor(image_processor=CLIPImageProcessor(), tokenizer=tok), tok
+
+
+def test_clip_front_end_executes(tmp_path, monkeypatch):
+    """FrozenCLIPEmbedder.encode, get_clip_feature (text: pooler output before the projection; image: image_embeds re-projected
+    with `projection_matrix` and scaled to norm 28.7) and prepare_batch WITHOUT precomputed features, executed end to end and
+    held to a restatement of the reference (gligen_inference.py:104-128,146-187, ldm/modules/encoders/modules.py:144-173).
+    The HF weights are not available offline: the models are random-init (same classes, small depth), the tokenizer a
+    fabricated byte-level BPE vocabulary, the projection matrix the reference's real file when it is mounted."""
+    import gligen_inference as gi
+    from PIL import Image
+    model, processor, tok = _fabricated_clip(tmp_path)
+    monkeypatch.setattr(gi, "device", "cpu")
+    monkeypatch.setattr(gi, "_CLIP", {"model": model, "processor": processor})
+    monkeypatch.chdir(tmp_path)
+    real = "/root/reference/projection_matrix"
+    P = torch.load(real).float() if os.path.exists(real) else torch.randn(768, 768, generator=torch.Generator().manual_seed(5)) * 0.03
+    assert tuple(P.shape) == (768, 768)
+    torch.save(P, tmp_path / "projection_matrix")        # cwd-relative, as in the reference
+    Image.fromarray((np.random.RandomState(0).rand(300, 200, 3) * 255).astype(np.uint8)).save(tmp_path / "ref.png")
+
+    # text phrase -> pooler_output of the text tower (which_layer_text = 'before')
+    f_txt = gi.get_clip_feature(model, processor, "a teddy bear", is_image=False)
+    ins = processor(text="a teddy bear", return_tensors="pt", padding=True)
+    with torch.no_grad():
+        want = model(input_ids=ins["input_ids"], attention_mask=ins["attention_mask"], pixel_values=torch.ones(1, 3, 224, 224)).text_model_output.pooler_output
+    assert f_txt.shape == want.shape and f_txt.shape[0] == 1 and torch.equal(f_txt, want)
+    # image -> image_embeds @ P (project(x, P.T) = x @ P), unit norm x 28.7
+    f_img = gi.get_clip_feature(model, processor, str(tmp_path / "ref.png"), is_image=True)
+    pix = processor(images=[Image.open(tmp_path / "ref.png").convert("RGB")], return_tensors="pt", padding=True)["pixel_values"]
+    with torch.no_grad():
+        emb = model(pixel_values=pix, input_ids=torch.tensor([[0, 1, 2, 3]])).image_embeds
+    want_img = emb @ P
+    want_img = (want_img.squeeze(0) / want_img.squeeze(0).norm() * 28.7).unsqueeze(0)
+    assert f_img.shape == (1, 768) and torch.allclose(f_img, want_img, atol=1e-5)
+    assert abs(float(f_img.norm()) - 28.7) < 1e-3
+    assert gi.get_clip_feature(model, processor, None, is_image=True) is None
+    assert torch.equal(gi.project(emb, P.T), emb @ P)
+
+    # prepare_batch without precomputed features: phrases / images go through CLIP (reference :146-187)
+    meta = dict(phrases=["a teddy bear", None], images=[None, str(tmp_path / "ref.png")], locations=[[0.0, 0.1, 0.3, 0.7], [0.5, 0.1, 1.0, 0.8]])
+    batch = gi.prepare_batch(meta, batch=2)
+    assert batch["text_embeddings"].shape == (2, 30, 768) and batch["image_embeddings"].shape == (2, 30, 768)
+    assert torch.equal(batch["text_embeddings"][1, 0], f_txt[0]) and torch.allclose(batch["image_embeddings"][0, 1], f_img[0])
+    assert batch["text_masks"][0].tolist()[:3] == [1, 0, 0] and batch["image_masks"][0].tolist()[:3] == [0, 1, 0]
+    assert batch["masks"][0].tolist()[:3] == [1, 1, 0] and float(batch["text_embeddings"][0, 1].abs().max()) == 0.0
+
+    # FrozenCLIPEmbedder: offline constructor (architecture from constants), then the fabricated tokenizer
+    from ldm.modules.encoders.modules import FrozenCLIPEmbedder
+    enc = FrozenCLIPEmbedder(device="cpu")
+    if enc.tokenizer is None:
+        with pytest.raises(RuntimeError):
+            enc.encode(["x"])
+        enc.tokenizer = tok
+    assert all(not p.requires_grad for p in enc.parameters()) and not enc.transformer.training
+    prompts = ["a teddy bear sitting next to a bird", ""]
+    z, pooled = enc.encode(prompts, return_pooler_output=True)
+    ids = tok(prompts, truncation=True, max_length=77, return_length=True, return_overflowing_tokens=False, padding="max_length", return_tensors="pt")["input_ids"]
+    assert ids.shape == (2, 77)
+    with torch.no_grad():
+        out = enc.transformer(input_ids=ids)
+    assert z.shape == (2, 77, 768) and torch.equal(z, out.last_hidden_state) and torch.equal(pooled, out.pooler_output)
+    assert torch.equal(enc.encode(prompts), z)

@@ -238,10 +238,10 @@ def test_bicubic_taps_of_the_resize_kernel():
 
 
 DOWNSAMPLER = {"canny": dict(n_in=1, mode="bicubic"), "hed": dict(n_in=1, mode="bicubic"), "normal": dict(n_in=3, mode="bicubic"),
-               "sem": dict(n_in=152, mode="nearest")}
+               "sem": dict(n_in=152, mode="nearest"), "depth": dict(n_in=1, mode="bicubic")}
 
 
-@pytest.mark.parametrize("modality", ["canny", "hed", "normal", "sem"])
+@pytest.mark.parametrize("modality", ["canny", "hed", "normal", "sem", "depth"])
 def test_spatial_modalities(modality):
     """ConvNeXt tokenizer, GroundingDownsampler and the 4 + k channel first conv of the spatial-map modalities against the
     reference's outputs (oracle/make_golden.py:spatial_case)."""
