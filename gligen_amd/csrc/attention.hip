@@ -304,28 +304,28 @@ __global__ void __launch_bounds__(256, DP == 48 ? 3 : 1) attn_kernel(AttnParams 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// v2 (round 3), d = 40 and d = 80: the same products and layouts, software-pipelined across key tiles.
+// v2 (round 3), d = 40: the same products and layouts, software-pipelined across key tiles.
 //
-// The kernel above runs, per 64-key tile and wave, QK^T (MFMA) -> softmax (VALU: 32 v_exp, 16 v_max3, 16 v_cvt_pk per lane) -> PV
-// (MFMA) one after the other; at d = 40 the two halves cost about the same issue time (14 MFMAs = 448 clocks against ~80 VALU
-// instructions) and a wave's own VALU and MFMA segments never overlap -- only other waves of the SIMD fill the gaps, partly
-// (tools/overlapbench.hip: a fine MFMA / VALU interleave inside ONE wave reaches 0.7x the time of the block form). Here every
-// iteration j holds three independent pieces of work in one straight-line region,
+// What bounds this kernel is INSTRUCTION ISSUE, not a pipe (profiles/r3: replacing the 32 v_exp per tile by v_mul changes nothing,
+// removing the MFMAs removes 57 % of the time, the MFMA pipe is 46 % busy; a wave issues about one instruction per 4 clocks and a
+// v_mfma_f32_32x32x16 covers 8 such slots, of which about 5 can hold other instructions of the same wave): per 64-key tile a wave
+// has 14 MFMAs = 448 clocks that hide ~70 other instructions, everything beyond that is exposed at ~4 clocks apiece. So the loop
+// is built to (a) interleave -- every iteration j holds three independent pieces of work in one straight-line region,
 //     S(j) = K(j) Q^T            (MFMA)   into the "next" score registers
 //     P(j-1) = exp2(S(j-1) - m)  (VALU)   from the "current" score registers
 //     O^T += V^T(j-1) P^T(j-1)   (MFMA)   in two halves, each behind the exps that feed it
-// so the matrix pipe runs S(j) under the first half of the exps, the first half of PV under the second half of the exps and the
-// second half of PV under the row maximum of S(j). The rare stabiliser move (a tile's scores exceed the running one by > 2^6)
-// sits at the end of the iteration, after PV(j-1): O^T -- then consistently at the old stabiliser -- and S(j) are rescaled there.
-// K and V^T tiles come by LDS-DMA (buffer_load ... lds) straight from their global layouts: no staging registers, no ds_write
-// pass; stage j of the two-slot ring holds {K(j), V^T(j-1)} and is fetched during iteration j-1. Fragment reads are inline asm
-// (hipcc would drain the DMA in front of a visible LDS load, see gemm.hip) with counted lgkmcnt waits.
+// so that the VALU work sits between the MFMAs instead of behind them -- and (b) to carry nothing else: K and V^T tiles come by
+// LDS-DMA (buffer_load ... lds, no staging registers, no ds_write pass; 3-4 instructions per wave and tile, addressed from a few
+// loop-invariant scalars), the ring slot is a compile-time constant of each of the two unrolled loop bodies, both score register
+// sets alternate roles from one iteration to the next (nothing is copied).
+// The rare stabiliser move (a tile's scores exceed the running one by > 2^6) sits at the end of the iteration, after PV(j-1):
+// O^T -- then consistently at the old stabiliser -- and S(j) are rescaled there.
+// Stage j of the two-slot ring holds {K(j), V^T(j-1)} and is fetched during iteration j-1. Fragment reads are inline asm (hipcc
+// would drain the DMA in front of a visible LDS load, see gemm.hip) with counted lgkmcnt waits.
 //   K tile   [DP/8 chunks][64 keys][16 B]: ds_read_b128 of chunk c for keys lrow is conflict free as it stands
 //   V^T tile [DPV rows][128 B], 16-byte chunk c of row r at slot c ^ ((r >> 1) & 7) (source-side swizzle of the DMA)
-// Both score register sets alternate roles from one iteration to the next (the loop is unrolled by two), so nothing is copied.
-#define GL_BLDS16(rsrc, ldst, voff, soff)                                                                   \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(ldst), 16, \
-                                             (int)(voff), (int)(soff), 0, 0)
+typedef __attribute__((address_space(3))) unsigned char* lds_ptr;
+#define GL_BLDS16(rsrc, ldst, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(ldst), 16, (int)(voff), (int)(soff), 0, 0)
 
 template <int OFF>
 __device__ __forceinline__ void lds_rd16(bf16x8& d, unsigned addr) {
@@ -336,7 +336,6 @@ __device__ __forceinline__ void pin_regs(bf16x8 (&d)[N]) {
 #pragma unroll
     for (int i = 0; i < N; ++i) asm volatile("" : "+v"(d[i]));
 }
-
 // kf[2 s + u] <- 16-byte chunk 2 s + half of keys 32 u + lrow: K tile offset s * 2048 + u * 512 from the lane's base
 template <int N, int I = 0, int BASE = 0>
 __device__ __forceinline__ void lds_rd_k(bf16x8 (&d)[N], unsigned a) {
@@ -353,7 +352,6 @@ __device__ __forceinline__ void lds_rd_v(bf16x8 (&d)[N], unsigned a0, unsigned a
         lds_rd_v<N, I + 1>(d, a0, a1);
     }
 }
-
 template <int DP, int DPV, bool BIAS, int NW>
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn2_kernel(AttnParams P) {
     constexpr int KS = DP / 16;            // k-steps of S^T = K Q^T
@@ -363,10 +361,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn2_kernel(AttnPar
     constexpr int KBYTES = KP * 1024;
     constexpr int VBYTES = VP * 1024;
     constexpr int STAGE = KBYTES + VBYTES;
-    constexpr int KPW = (KP + NW - 1) / NW, VPW = (VP + NW - 1) / NW;   // pieces per wave
-    static_assert(DPV % 32 == 0 && DP % 16 == 0 && DPV > DP - 8, "tile geometry");
+    constexpr int KR = (KP + NW - 1) / NW, VR = VP / NW;   // piece rounds: wave w takes pieces w, w + NW, ...
+    static_assert(DPV % 32 == 0 && DP % 16 == 0 && DPV > DP - 8 && VP % NW == 0, "tile geometry");
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // (the only LDS of this kernel: offset 0, 128-byte aligned)
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -394,33 +392,34 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn2_kernel(AttnPar
     const int myq = qblk * (NW * 32) + wave * 32 + lrow;
     const int myq_ld = myq < P.Tq_pad ? myq : P.Tq_pad - 1;     // (NW = 8: a 256-row block may reach past the 128-row padding)
 
-    // ---- DMA of stage jj = {K(jj), V^T(jj-1)} into ring slot jj & 1
-    unsigned vvoff[VPW];
+    // ---- DMA of stage jj = {K(jj), V^T(jj-1)} into ring slot `slot`. Wave w moves K pieces w, w + NW, .. and V^T pieces w, w + NW, ..;
+    // everything but jj is loop invariant: lane offsets in two / VR VGPRs, the wave's piece in one scalar.
+    const lds_ptr lbase = (lds_ptr)smem;
+    const int w1k = wave * 1024;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    unsigned vvoff[VR];
 #pragma unroll
-    for (int i = 0; i < VPW; ++i) {
+    for (int i = 0; i < VR; ++i) {
         const int r = 8 * (wave + NW * i) + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         vvoff[i] = (unsigned)(r * P.Tk_pad) * 2u + (unsigned)c * 16u;
     }
-    auto issue = [&](int jj_) {
-        const int jj = __builtin_amdgcn_readfirstlane(jj_);
-        unsigned char* st = smem + (jj & 1) * STAGE;
-        if (jj < nt) {
+    auto issue_k = [&](int jj, int slot) {
+        const lds_ptr st = lbase + slot * STAGE + w1k;
+        const int so = jj * KBYTES + w1k;
 #pragma unroll
-            for (int i = 0; i < KPW; ++i) {
-                const int pi = wave + NW * i;
-                if (pi < KP) GL_BLDS16(rk, st + pi * 1024, lane * 16, jj * KBYTES + pi * 1024);
-            }
-        }
-        if (jj >= 1) {
-#pragma unroll
-            for (int i = 0; i < VPW; ++i) {
-                const int pi = wave + NW * i;
-                if (pi < VP) GL_BLDS16(rv, st + KBYTES + pi * 1024, vvoff[i], (jj - 1) * 128);
-            }
+        for (int i = 0; i < KR; ++i) {
+            if ((i + 1) * NW <= KP) GL_BLDS16(rk, st + i * NW * 1024, lane16, so + i * NW * 1024);
+            else if (wave < KP - i * NW) GL_BLDS16(rk, st + i * NW * 1024, lane16, so + i * NW * 1024);   // short last round (wave-uniform)
         }
     };
-    issue(0);
+    auto issue_v = [&](int jj, int slot) {
+        const lds_ptr st = lbase + slot * STAGE + KBYTES + w1k;
+        const int so = (jj - 1) * 128;
+#pragma unroll
+        for (int i = 0; i < VR; ++i) GL_BLDS16(rv, st + i * NW * 1024, vvoff[i], so);
+    };
+    issue_k(0, 0);
 
     // ---- Q fragments, pre-multiplied by scale * log2(e) (scores come out of the matrix core in exp2 units)
     bf16x8 qf[KS];
@@ -441,52 +440,45 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn2_kernel(AttnPar
         for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
     float m_run = BIAS ? 0.f : -1e30f;   // BIAS: the stabiliser baked into Q column 40; else subtracted in front of the exps
 
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    const unsigned k_lane = lds0 + (unsigned)(lrow * 16 + half * 1024);
-    const unsigned v_lane = lds0 + KBYTES + (unsigned)(lrow * 128) + (unsigned)((half ^ ((lrow >> 1) & 7)) << 4);
+    const unsigned k_lane = (unsigned)(lrow * 16 + half * 1024);
+    const unsigned v_lane = KBYTES + (unsigned)(lrow * 128) + (unsigned)((half ^ ((lrow >> 1) & 7)) << 4);
 
-    // One iteration. SM: softmax + PV of tile j-1 (scores in sc). QK: scores of tile j into sn. TAILCK: tile j may be the partial
-    // last tile (run-time check). FIRSTMOVE: tile j is tile 0 (the stabiliser always moves there).
-    auto iter = [&](int j, f32x16 (&sc)[2], f32x16 (&sn)[2], auto sm_c, auto qk_c, auto tail_c, auto first_c) {
+    // One iteration. SLOT: ring slot of stage j (0 / 1; -1: j & 1 at run time, the once-only iterations). ISSUE: which parts of stage
+    // j+1 exist (0 none, 1 K and V^T, 2 V^T only, 3 V^T and, if j+1 < nt, K). SM: softmax + PV of tile j-1 (scores in sc). QK: scores
+    // of tile j into sn. TAILCK: tile j may be the partial last tile (run-time check). FIRSTMOVE: tile j is tile 0.
+    auto iter = [&](int j, f32x16 (&sc)[2], f32x16 (&sn)[2], auto slot_c, auto issue_c, auto sm_c, auto qk_c, auto tail_c, auto first_c) {
+        constexpr int SLOT = decltype(slot_c)::value, ISSUE = decltype(issue_c)::value;
         constexpr bool SM = decltype(sm_c)::value, QK = decltype(qk_c)::value, TAILCK = decltype(tail_c)::value, FIRSTMOVE = decltype(first_c)::value;
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): stage j has landed (this wave's pieces; the barrier covers the others')
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (j + 1 <= nt) issue(j + 1);        // into the slot every wave finished reading in iteration j-1
-        const unsigned sb = (unsigned)((j & 1) * STAGE);
+        const int slot = SLOT >= 0 ? SLOT : (j & 1);
+        if constexpr (ISSUE != 0) {           // stage j+1 into the slot every wave finished reading in iteration j-1
+            if constexpr (ISSUE == 1) issue_k(j + 1, slot ^ 1);
+            if constexpr (ISSUE == 3) { if (j + 1 < nt) issue_k(j + 1, slot ^ 1); }
+            issue_v(j + 1, slot ^ 1);
+        }
+        const unsigned sb = (unsigned)(slot * STAGE);
         const unsigned ak = k_lane + sb;
         unsigned av[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) av[jj] = (v_lane + sb) ^ (unsigned)(jj << 5);
 
-        bf16x8 vfa[2 * DT], vfb[2 * DT];
-        constexpr int KA = KS > 3 ? 3 : KS;                // k-steps whose K fragments are read up front (the rest reuse their registers)
-        bf16x8 kfa[2 * KA], kfb[KS > 3 ? 2 * (KS - KA) : 1];
-        if constexpr (QK) lds_rd_k(kfa, ak);
+        bf16x8 kf[2 * KS], vfa[2 * DT], vfb[2 * DT];
+        if constexpr (QK) lds_rd_k(kf, ak);
         if constexpr (SM) lds_rd_v(vfa, av[0], av[1]);     // key sub-tile 0 (keys 0..31 of tile j-1)
         // ---- region 1: S(j) on the matrix core  ||  exp2 of the first 32 keys of tile j-1
         if constexpr (QK) {
             if constexpr (SM) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * DT));
             else asm volatile("s_waitcnt lgkmcnt(0)");
-            pin_regs(kfa);
+            pin_regs(kf);
             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            sn[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[0], qf[0], zero, 0, 0, 0);
-            sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[1], qf[0], zero, 0, 0, 0);
+            sn[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], zero, 0, 0, 0);
+            sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[0], zero, 0, 0, 0);
 #pragma unroll
-            for (int s = 1; s < KA; ++s) {
-                sn[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[2 * s], qf[s], sn[0], 0, 0, 0);
-                sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[2 * s + 1], qf[s], sn[1], 0, 0, 0);
-            }
-            if constexpr (KS > KA) {
-                __builtin_amdgcn_sched_barrier(0);
-                lds_rd_k<2 * (KS - KA), 0, 2 * KA>(kfb, ak);
-                asm volatile("s_waitcnt lgkmcnt(0)");
-                pin_regs(kfb);
-#pragma unroll
-                for (int s = KA; s < KS; ++s) {
-                    sn[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfb[2 * (s - KA)], qf[s], sn[0], 0, 0, 0);
-                    sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfb[2 * (s - KA) + 1], qf[s], sn[1], 0, 0, 0);
-                }
+            for (int s = 1; s < KS; ++s) {
+                sn[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2 * s], qf[s], sn[0], 0, 0, 0);
+                sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2 * s + 1], qf[s], sn[1], 0, 0, 0);
             }
         }
         bf16x8 pb0, pb1, pb2, pb3;
@@ -535,7 +527,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn2_kernel(AttnPar
                         }
                 }
             }
-            float mx = sn[0][0];
+            float mx = sn[0][0];     // (hipcc fuses the chain into v_max3_f32; an asm v_max3 costs an s_nop behind each)
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -586,24 +578,31 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn2_kernel(AttnPar
 
     using T_ = std::true_type;
     using F_ = std::false_type;
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using SR = std::integral_constant<int, -1>;     // slot = j & 1 at run time
+    using I0 = std::integral_constant<int, 0>;      // nothing to fetch
+    using I1 = std::integral_constant<int, 1>;      // stage j+1 = {K, V^T}
+    using I2 = std::integral_constant<int, 2>;      // stage j+1 = {V^T} (j + 1 = nt)
+    using I3 = std::integral_constant<int, 3>;      // stage j+1 = {V^T} and K if it exists
     f32x16 sa[2], sb2[2];
-    iter(0, sb2, sa, F_{}, T_{}, T_{}, T_{});                      // S(0) -> sa
+    iter(0, sb2, sa, S0{}, I3{}, F_{}, T_{}, T_{}, T_{});                      // S(0) -> sa
     if (nt == 1) {
-        iter(1, sa, sb2, T_{}, F_{}, F_{}, F_{});                  // drain
+        iter(1, sa, sb2, S1{}, I0{}, T_{}, F_{}, F_{}, F_{});                  // drain
     } else {
         int j = 1;
-        for (; j + 1 <= nt - 2; j += 2) {
-            iter(j, sa, sb2, T_{}, T_{}, F_{}, F_{});
-            iter(j + 1, sb2, sa, T_{}, T_{}, F_{}, F_{});
+        for (; j + 1 <= nt - 2; j += 2) {                                      // j odd: stage j sits in slot 1
+            iter(j, sa, sb2, S1{}, I1{}, T_{}, T_{}, F_{}, F_{});
+            iter(j + 1, sb2, sa, S0{}, I1{}, T_{}, T_{}, F_{}, F_{});
         }
         if (j <= nt - 2) {
-            iter(j, sa, sb2, T_{}, T_{}, F_{}, F_{});
+            iter(j, sa, sb2, S1{}, I1{}, T_{}, T_{}, F_{}, F_{});
             ++j;
-            iter(j, sb2, sa, T_{}, T_{}, T_{}, F_{});              // j = nt-1: S(nt-1) -> sa
-            iter(j + 1, sa, sb2, T_{}, F_{}, F_{}, F_{});          // drain
+            iter(j, sb2, sa, S0{}, I2{}, T_{}, T_{}, T_{}, F_{});              // j = nt-1 (even): S(nt-1) -> sa
+            iter(j + 1, sa, sb2, S1{}, I0{}, T_{}, F_{}, F_{}, F_{});          // drain
         } else {
-            iter(j, sa, sb2, T_{}, T_{}, T_{}, F_{});              // j = nt-1: S(nt-1) -> sb2
-            iter(j + 1, sb2, sa, T_{}, F_{}, F_{}, F_{});          // drain
+            iter(j, sa, sb2, S1{}, I2{}, T_{}, T_{}, T_{}, F_{});              // j = nt-1 (odd): S(nt-1) -> sb2
+            iter(j + 1, sb2, sa, S0{}, I0{}, T_{}, F_{}, F_{}, F_{});          // drain
         }
     }
 
