@@ -59,14 +59,22 @@ struct ResW {
     bool has_skip = false;
     LinW skip;
 };
+// `folded`: the LayerNorm in front of the projection lives in its weights (W * gamma, bias = b + W beta, csum = row sums of the
+// packed bf16 rows; gemm.h Epilogue::ln_stats): the GEMM takes the raw residual-stream rows + row statistics, or rows normalised
+// WITHOUT affine by ln_kernel where no statistics exist
 struct SelfAttnW {
     const bf16* wqk = nullptr;   // [to_q ; to_k] rows (wqkv when the fused projection is active: [to_q ; to_k ; to_v])
     const bf16* wv = nullptr;
     bool fused = false;          // wqk holds all three: one EPI_QKV_HEADS GEMM instead of q,k + v^T launches
+    bool folded = false;
+    const float* b = nullptr;    // folded: [3C] bias, [3C] csum
+    const float* csum = nullptr;
     LinW out;
 };
-struct CrossAttnW { LinW q; const bf16* wk = nullptr; const bf16* wv = nullptr; LinW out; int ctx_dim = 0; };
-struct FFW { const bf16* w1 = nullptr; const float* b1 = nullptr; LinW w2; int C = 0; int geglu16 = 0; };
+struct CrossAttnW { LinW q; const bf16* wk = nullptr; const bf16* wv = nullptr; LinW out; int ctx_dim = 0; bool folded = false; const float* q_csum = nullptr; };
+struct FFW { const bf16* w1 = nullptr; const float* b1 = nullptr; LinW w2; int C = 0; int geglu16 = 0; bool folded = false; const float* csum1 = nullptr; };
+// partial row statistics written by the GEMM that produced a residual-stream tensor (nb = 0: none)
+struct RowStats { float2* p = nullptr; int nb = 0, ld = 0; };
 struct STW {
     int C = 0, d = 0, idx = 0;
     NormW gn;
@@ -181,22 +189,31 @@ class Engine {
     ConvW conv3(const std::string& prefix, int Npad = 0);
     LinW conv1(const std::string& prefix);
     const bf16* cast_rows(const std::vector<std::string>& weight_keys);
-    FFW ffw(const std::string& prefix, int C);
+    FFW ffw(const std::string& prefix, int C, const NormW* fold = nullptr);
+    // fp32 temporaries W * gamma, b + W beta of one linear layer (freed at the end of build_unet)
+    struct FoldTmp { float* w = nullptr; float* b = nullptr; int N = 0, K = 0; };
+    FoldTmp fold_ln(const std::string& weight_key, const float* bias, const NormW& n);
+    std::vector<void*> fold_tmps_;
+    bool ln_fold_ = false;       // LayerNorms folded into their consumers (GL_LN_FOLD=0: off)
     ResW resw(const std::string& prefix, int Cin, int Cout, bool unet);
     void build_unet();
     void build_vae();
 
     // execution helpers
     void gemm(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, hipStream_t s);
-    bf16* linear_rows(const bf16* x, int M, const LinW& L, int act, const bf16* res, const float* gate, hipStream_t s);
+    bf16* linear_rows(const bf16* x, int M, const LinW& L, int act, const bf16* res, const float* gate, hipStream_t s, RowStats* stats = nullptr);
+    bf16* layernorm_plain(const bf16* x, int B, int N, int C, bool pad64, hipStream_t s);   // (x - mean) * rstd, no affine
     bf16* groupnorm(const TRef& x, int B, int HW, const NormW& n, float eps, bool silu, hipStream_t s);
     bf16* layernorm(const bf16* x, int B, int N, int C, const NormW& n, bool pad64, hipStream_t s);
     bf16* conv3x3(const TRef& x, int B, int Hin, int Win, const ConvW& c, int stride, int ups, int pad_lo,
                   const float* bias2, int bias2_ld, const bf16* res, hipStream_t s);
     bf16* resblock(const ResW& r, const TRef& x, int B, int H, int W, const float* embout, int emb_ld, float eps, hipStream_t s);
     bf16* transformer(const STW& t, const bf16* x, int B, int H, int W, hipStream_t s);
-    bf16* feedforward(const FFW& f, const bf16* ln, int M, const bf16* res, const float* gate, hipStream_t s);
-    void self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, int Nq, int Nk, int C, int d, bf16* o, hipStream_t s);
+    // in_stats: `ln` holds RAW rows whose statistics are in_stats (folded LayerNorm applied by the GEMM); out_stats: statistics of the result
+    bf16* feedforward(const FFW& f, const bf16* ln, int M, const bf16* res, const float* gate, hipStream_t s, const RowStats* in_stats = nullptr,
+                      RowStats* out_stats = nullptr);
+    void self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, int Nq, int Nk, int C, int d, bf16* o, hipStream_t s,
+                        const RowStats* in_stats = nullptr);
     bf16* vae_attn(const VaeAttnW& a, const bf16* x, int B, int HW, hipStream_t s);
 
     int device_;

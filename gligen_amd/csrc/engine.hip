@@ -229,7 +229,21 @@ ConvW Engine::conv3(const std::string& p, int Npad) {
     return c;
 }
 
-FFW Engine::ffw(const std::string& p, int C) {
+Engine::FoldTmp Engine::fold_ln(const std::string& wkey, const float* bias, const NormW& n) {
+    const RawTensor& w = raw(wkey);
+    FoldTmp t;
+    t.N = (int)w.shape[0];
+    t.K = (int)(w.numel / w.shape[0]);
+    if (n.C != t.K) throw GlError(GL_ERR_ARG, "'" + wkey + "': LayerNorm width does not match the projection's input width");
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&t.w), (size_t)t.N * t.K * sizeof(float)));
+    HIPCK(hipMalloc(reinterpret_cast<void**>(&t.b), (size_t)t.N * sizeof(float)));
+    fold_tmps_.push_back(t.w);
+    fold_tmps_.push_back(t.b);
+    CK(ln_fold_launch(w.p, bias, n.g, n.b, t.w, t.b, t.N, t.K, 0));
+    return t;
+}
+
+FFW Engine::ffw(const std::string& p, int C, const NormW* fold) {
     FFW f;
     f.C = C;
     const RawTensor& w = raw(p + ".net.0.proj.weight");
@@ -238,7 +252,20 @@ FFW Engine::ffw(const std::string& p, int C) {
     bf16* wp = reinterpret_cast<bf16*>(persist((size_t)C8 * K * sizeof(bf16), false));
     float* bp = reinterpret_cast<float*>(persist(C8 * sizeof(float), false));
     f.geglu16 = gemm_geglu_layout();
-    CK(pack_geglu_launch(w.p, F(p + ".net.0.proj.bias"), wp, bp, 4 * C, K, f.geglu16, 0));
+    const float* wsrc = w.p;
+    const float* bsrc = F(p + ".net.0.proj.bias");
+    if (fold) {   // the LayerNorm in front of this feed-forward, folded into its GEGLU projection
+        const FoldTmp t = fold_ln(p + ".net.0.proj.weight", bsrc, *fold);
+        wsrc = t.w;
+        bsrc = t.b;
+    }
+    CK(pack_geglu_launch(wsrc, bsrc, wp, bp, 4 * C, K, f.geglu16, 0));
+    if (fold) {
+        float* cs = reinterpret_cast<float*>(persist(C8 * sizeof(float), false));
+        CK(rowsum_bf16_launch(wp, cs, C8, K, 0));
+        f.csum1 = cs;
+        f.folded = true;
+    }
     f.w1 = wp;
     f.b1 = bp;
     f.w2 = linear(p + ".net.2");
@@ -331,10 +358,27 @@ void Engine::build_unet() {
         // count / width allow it; GL_QKV_FUSED=0 keeps the two-launch form (q,k GEMM + operand-swapped v^T GEMM) for A/B runs
         const bool want_fused = !(getenv("GL_QKV_FUSED") && atoi(getenv("GL_QKV_FUSED")) == 0);
         const bool fuse_qkv = want_fused && gemm_supports_qkv() && (2 * C) % 128 == 0;
-        auto self_attn_w = [&](const std::string& a) {
+        // LayerNorms folded into the projections behind them (gemm.h Epilogue::ln_stats; GL_LN_FOLD=0: the LayerNorm kernels of
+        // rounds 1-2): norm1 -> attn1 q,k,v; fuser.norm1 -> fuser q,k,v; fuser.norm2 -> fuser.ff; norm2 -> attn2.to_q; norm3 -> ff
+        const bool fold = fuse_qkv && !(getenv("GL_LN_FOLD") && atoi(getenv("GL_LN_FOLD")) == 0);
+        ln_fold_ = fold;
+        auto self_attn_w = [&](const std::string& a, const NormW* ln) {
             SelfAttnW w;
             w.fused = fuse_qkv;
-            if (fuse_qkv) {
+            if (fuse_qkv && ln) {
+                const char* names[3] = {".to_q.weight", ".to_k.weight", ".to_v.weight"};
+                bf16* dst = reinterpret_cast<bf16*>(persist((size_t)3 * C * C * sizeof(bf16), false));
+                float* bias = reinterpret_cast<float*>(persist((size_t)3 * C * sizeof(float), false));
+                float* cs = reinterpret_cast<float*>(persist((size_t)3 * C * sizeof(float), false));
+                for (int i = 0; i < 3; ++i) {
+                    const FoldTmp t = fold_ln(a + names[i], nullptr, *ln);
+                    if (t.N != C || t.K != C) throw GlError(GL_ERR_ARG, "'" + a + "': q / k / v projections must be C x C");
+                    CK(cast_f32_bf16_launch(t.w, dst + (size_t)i * C * C, (int64_t)C * C, 0));
+                    HIPCK(hipMemcpy(bias + (size_t)i * C, t.b, C * sizeof(float), hipMemcpyDeviceToDevice));
+                }
+                CK(rowsum_bf16_launch(dst, cs, 3 * C, C, 0));
+                w.wqk = dst; w.b = bias; w.csum = cs; w.folded = true;
+            } else if (fuse_qkv) {
                 w.wqk = cast_rows({a + ".to_q.weight", a + ".to_k.weight", a + ".to_v.weight"});
             } else {
                 w.wqk = cast_rows({a + ".to_q.weight", a + ".to_k.weight"});
@@ -342,21 +386,33 @@ void Engine::build_unet() {
             }
             return w;
         };
-        t.a1 = self_attn_w(tb + ".attn1");
+        t.a1 = self_attn_w(tb + ".attn1", fold ? &t.ln1 : nullptr);
         t.a1.out = linear(tb + ".attn1.to_out.0");
-        t.a2.q = linear(tb + ".attn2.to_q", false);
+        if (fold) {
+            const FoldTmp q = fold_ln(tb + ".attn2.to_q.weight", nullptr, t.ln2);
+            bf16* dst = reinterpret_cast<bf16*>(persist((size_t)q.N * q.K * sizeof(bf16), false));
+            float* bias = reinterpret_cast<float*>(persist((size_t)q.N * sizeof(float), false));
+            float* cs = reinterpret_cast<float*>(persist((size_t)q.N * sizeof(float), false));
+            CK(cast_f32_bf16_launch(q.w, dst, (int64_t)q.N * q.K, 0));
+            HIPCK(hipMemcpy(bias, q.b, q.N * sizeof(float), hipMemcpyDeviceToDevice));
+            CK(rowsum_bf16_launch(dst, cs, q.N, q.K, 0));
+            t.a2.q.w = dst; t.a2.q.b = bias; t.a2.q.N = q.N; t.a2.q.K = q.K;
+            t.a2.q_csum = cs; t.a2.folded = true;
+        } else {
+            t.a2.q = linear(tb + ".attn2.to_q", false);
+        }
         t.a2.wk = cast_rows({tb + ".attn2.to_k.weight"});
         t.a2.wv = cast_rows({tb + ".attn2.to_v.weight"});
         t.a2.ctx_dim = (int)raw(tb + ".attn2.to_k.weight").shape[1];
         t.a2.out = linear(tb + ".attn2.to_out.0");
-        t.ff = ffw(tb + ".ff", C);
+        t.ff = ffw(tb + ".ff", C, fold ? &t.ln3 : nullptr);
         if (has(tb + ".fuser.linear.weight") != (c.fuser_kind != 2))
             throw GlError(GL_ERR_ARG, "fuser weights do not match fuser_kind (gatedSA has fuser.linear, gatedCA does not)");
         t.fn1 = norm(tb + ".fuser.norm1");
         t.fn2 = norm(tb + ".fuser.norm2");
         if (c.fuser_kind != 2) {  // gatedSA and gatedSA2 hold the same parameters
             t.flin = linear(tb + ".fuser.linear");
-            t.fa = self_attn_w(tb + ".fuser.attn");
+            t.fa = self_attn_w(tb + ".fuser.attn", fold ? &t.fn1 : nullptr);
             t.fa.out = linear(tb + ".fuser.attn.to_out.0");
         } else {  // gatedCA: CrossAttention(query_dim, key_dim = value_dim = grounding-token dim) -- attention.py:194
             t.fca.q = linear(tb + ".fuser.attn.to_q", false);
@@ -367,7 +423,7 @@ void Engine::build_unet() {
                 throw GlError(GL_ERR_ARG, "gatedCA: fuser.attn key / value dim must equal the grounding-token dim");
             t.fca.out = linear(tb + ".fuser.attn.to_out.0");
         }
-        t.fff = ffw(tb + ".fuser.ff", C);
+        t.fff = ffw(tb + ".fuser.ff", C, fold ? &t.fn2 : nullptr);
         raw(tb + ".fuser.alpha_attn");
         raw(tb + ".fuser.alpha_dense");
         st_.push_back(t);
@@ -743,6 +799,8 @@ void Engine::finalize() {
     if (has_vae_) build_vae();
     if (has_vae_ && has("vae/encoder.conv_in.weight")) build_vae_encoder();
     HIPCK(hipDeviceSynchronize());
+    for (void* p : fold_tmps_) (void)hipFree(p);   // fp32 W * gamma / b + W beta temporaries of the folded LayerNorms
+    fold_tmps_.clear();
     // matrices now live packed in bf16: drop their fp32 staging copies (vectors stay, they are used as is)
     for (auto it = raw_.begin(); it != raw_.end();) {
         if (it->second.shape.size() >= 2 && it->first.find("quant_conv") == std::string::npos && !keep_raw_.count(it->first)) {
@@ -775,10 +833,14 @@ void Engine::gemm(const AOperand& A, const bf16* W, int M, int N, int K, const E
         fprintf(launch_log, "%s|%d|%d|%d|%d|%.0f\n", gemm_last_kernel_name(), M, N, K, A.mode, bytes);
         fflush(launch_log);
     }
-    ++n_launches;
+    {
+        int tm, tn, sp;
+        gemm_last_cfg(&tm, &tn, &sp);
+        n_launches += sp > 1 ? 2 : 1;   // a split-K problem is followed by splitk_reduce_kernel
+    }
 }
 
-bf16* Engine::linear_rows(const bf16* x, int M, const LinW& L, int act, const bf16* res, const float* gate, hipStream_t s) {
+bf16* Engine::linear_rows(const bf16* x, int M, const LinW& L, int act, const bf16* res, const float* gate, hipStream_t s, RowStats* stats) {
     bf16* out = arena_.get<bf16>((size_t)M * L.N);
     AOperand A;
     aoperand_rows(A, x, L.K, L.K);
@@ -791,7 +853,17 @@ bf16* Engine::linear_rows(const bf16* x, int M, const LinW& L, int act, const bf
     E.res = res;
     E.ldres = L.N;
     E.gate = gate;
+    if (stats) {   // row statistics of the result, for the folded LayerNorm of the GEMM that reads it next
+        *stats = RowStats{};
+        if (ln_fold_ && L.N % 64 == 0) {
+            stats->ld = L.N / 64;
+            stats->p = arena_.get<float2>((size_t)M * stats->ld);
+            E.stats_out = stats->p;
+            E.stats_ld = stats->ld;
+        }
+    }
     gemm(A, L.w, M, L.N, L.K, E, s);
+    if (stats && stats->p) stats->nb = gemm_last_stats_nb();
     return out;
 }
 
@@ -805,7 +877,7 @@ bf16* Engine::groupnorm(const TRef& x, int B, int HW, const NormW& n, float eps,
     P.partial = reinterpret_cast<float*>(arena_.alloc(gn_partial_bytes(B, HW)));
     ProfScope ps(this, s, HW <= 256 ? "gn_small_kernel" : "gn_stats_kernel + gn_apply_kernel", 0.0, 2.0 * B * HW * (double)C * 2);
     CK(groupnorm_launch(P, s));
-    n_launches += 2;
+    n_launches += HW <= 256 ? 1 : 2;   // gn_small_kernel, or gn_stats_kernel + gn_apply_kernel
     return y;
 }
 
@@ -819,6 +891,12 @@ bf16* Engine::layernorm(const bf16* x, int B, int N, int C, const NormW& n, bool
     CK(layernorm_launch(P, s));
     ++n_launches;
     return y;
+}
+
+bf16* Engine::layernorm_plain(const bf16* x, int B, int N, int C, bool pad64, hipStream_t s) {
+    NormW none;
+    none.C = C;
+    return layernorm(x, B, N, C, none, pad64, s);
 }
 
 bf16* Engine::conv3x3(const TRef& x, int B, int Hin, int Win, const ConvW& c, int stride, int ups, int pad_lo,
@@ -901,11 +979,13 @@ AttnBufs& Engine::attn_bufs(int B, int H, int d, int Tq, int Tk) {
 
 // SelfAttention.forward (attention.py:167-186) on LayerNorm'ed rows ln [B][T][C] (T % 64 == 0,
 // rows >= Nk are zero), queries = first Nq rows, keys/values = first Nk rows.
-void Engine::self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, int Nq, int Nk, int C, int d, bf16* o, hipStream_t s) {
+void Engine::self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, int Nq, int Nk, int C, int d, bf16* o, hipStream_t s,
+                            const RowStats* in_stats) {
     const int H = C / d;
     int dp, dpv;
     CK(attn_dims(d, &dp, &dpv));
     AttnBufs& bufs = attn_bufs(B, H, d, T, T);
+    if (in_stats && !(a.fused && a.folded)) throw GlError(GL_ERR_STATE, "self_attention: row statistics given to an unfolded projection");
     if (a.fused) {
         AOperand A;
         aoperand_rows(A, ln, C, C);
@@ -914,6 +994,11 @@ void Engine::self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, in
         E.mode = EPI_QKV_HEADS;
         E.q = bufs.q; E.k = bufs.k; E.vt = bufs.vt; E.C = C; E.H = H; E.d = d; E.DP = dp; E.DPV = dpv; E.T = T;
         E.Tpad_q = bufs.Tq_pad; E.Tpad_k = bufs.Tk_pad;
+        if (a.folded) E.bias = a.b;      // W beta of the folded LayerNorm (to_q / to_k / to_v have no bias of their own)
+        if (in_stats) {                  // `ln` holds the raw rows: (x - mean) * rstd happens in the epilogue
+            E.ln_stats = in_stats->p; E.ln_nb = in_stats->nb; E.ln_ld = in_stats->ld; E.ln_csum = a.csum;
+            E.ln_inv_c = 1.f / (float)C; E.ln_eps = 1e-5f;
+        }
         gemm(A, a.wqk, B * T, 3 * C, C, E, s);
     } else {
         AOperand A;
@@ -947,7 +1032,8 @@ void Engine::self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, in
     ++n_launches;
 }
 
-bf16* Engine::feedforward(const FFW& f, const bf16* ln, int M, const bf16* res, const float* gate, hipStream_t s) {
+bf16* Engine::feedforward(const FFW& f, const bf16* ln, int M, const bf16* res, const float* gate, hipStream_t s, const RowStats* in_stats,
+                          RowStats* out_stats) {
     const int C = f.C;
     bf16* hbuf = arena_.get<bf16>((size_t)M * 4 * C);
     AOperand A;
@@ -955,8 +1041,13 @@ bf16* Engine::feedforward(const FFW& f, const bf16* ln, int M, const bf16* res, 
     Epilogue E;
     epilogue_defaults(E);
     E.act = ACT_GEGLU; E.geglu16 = f.geglu16; E.out = hbuf; E.ldo = 4 * C; E.bias = f.b1;
+    if (in_stats) {
+        if (!f.folded) throw GlError(GL_ERR_STATE, "feedforward: row statistics given to an unfolded projection");
+        E.ln_stats = in_stats->p; E.ln_nb = in_stats->nb; E.ln_ld = in_stats->ld; E.ln_csum = f.csum1;
+        E.ln_inv_c = 1.f / (float)C; E.ln_eps = 1e-5f;
+    }
     gemm(A, f.w1, M, 8 * C, C, E, s);
-    return linear_rows(hbuf, M, f.w2, ACT_NONE, res, gate, s);
+    return linear_rows(hbuf, M, f.w2, ACT_NONE, res, gate, s, out_stats);
 }
 
 // SpatialTransformer.forward + BasicTransformerBlock._forward + GatedSelfAttentionDense.forward
@@ -968,20 +1059,40 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
     if (cond_.Beff != B) throw GlError(GL_ERR_STATE, fmt("unet_forward batch %d != batch %d of the conditioning set by gl_unet_set_cond", B, cond_.Beff));
 
     bf16* n = groupnorm(TRef{x, C, nullptr, 0}, B, HW, t.gn, 1e-6f, false, s);
-    bf16* t0 = linear_rows(n, M, t.proj_in, ACT_NONE, nullptr, nullptr, s);
+    // Folded LayerNorms (gemm.h Epilogue::ln_stats): every GEMM that writes the residual stream also writes its rows' partial
+    // (sum, sum of squares); the projection behind the next LayerNorm then reads the RAW rows and normalises in its epilogue.
+    // Where no statistics exist (split-K producer, the [x ; objs] concatenation, an epilogue without the fold) the rows go
+    // through ln_kernel without affine -- gamma / beta live in the folded weights either way.
+    const int Tp = round_up(HW, 64);
+    auto can_fold = [&](const RowStats& st, int Nc, int mode, int act) {
+        if (!st.nb || Tp != HW) return false;
+        AOperand A;
+        aoperand_rows(A, x, C, C);
+        Epilogue E;
+        epilogue_defaults(E);
+        E.mode = mode; E.act = act; E.geglu16 = gemm_geglu_layout();
+        return gemm_ln_fold_supported(A, M, Nc, C, E);
+    };
+    auto normed = [&](const bf16* rows, const NormW& nw, bool folded, bool fuse, bool pad64) -> const bf16* {
+        if (fuse) return rows;
+        return folded ? layernorm_plain(rows, B, HW, C, pad64, s) : layernorm(rows, B, HW, C, nw, pad64, s);
+    };
+    RowStats st0, st1, st2, st3, st4;
+    bf16* t0 = linear_rows(n, M, t.proj_in, ACT_NONE, nullptr, nullptr, s, &st0);
 
     // x = attn1(norm1(x)) + x
-    const int Tp = round_up(HW, 64);
-    bf16* ln = layernorm(t0, B, HW, C, t.ln1, true, s);
+    const bool f1 = t.a1.folded && can_fold(st0, 3 * C, EPI_QKV_HEADS, ACT_NONE);
+    const bf16* ln = normed(t0, t.ln1, t.a1.folded, f1, true);
     bf16* o = arena_.get<bf16>((size_t)M * C);
-    self_attention(t.a1, ln, B, Tp, HW, HW, C, d, o, s);
-    bf16* t1 = linear_rows(o, M, t.a1.out, ACT_NONE, t0, nullptr, s);
+    self_attention(t.a1, ln, B, Tp, HW, HW, C, d, o, s, f1 ? &st0 : nullptr);
+    bf16* t1 = linear_rows(o, M, t.a1.out, ACT_NONE, t0, nullptr, s, &st1);
 
     const int Ng = cond_.Ng;
     bf16* t2;
     bf16* t3;
     if (fuser_off_) {
         t3 = t1;
+        st3 = st1;
     } else {
     if (ucfg_.fuser_kind == 1) {
         // fuser (gatedSA2, attention.py:271-297): the attention outputs AT the grounding tokens (an sg x sg grid) are
@@ -995,7 +1106,7 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
         {
             LNParams P{};
             P.x = t1; P.x2 = cond_.objs[t.idx]; P.B = B; P.N1 = HW; P.N2 = Ng; P.Tpad = Tf; P.C = C; P.eps = 1e-5f;
-            P.gamma = t.fn1.g; P.beta = t.fn1.b; P.y = lnc;
+            P.gamma = t.fa.folded ? nullptr : t.fn1.g; P.beta = t.fa.folded ? nullptr : t.fn1.b; P.y = lnc;
             ProfScope ps(this, s, "ln_kernel", 0.0, 2.0 * B * Ta * (double)C * 2);
             CK(layernorm_launch(P, s));
             ++n_launches;
@@ -1013,13 +1124,13 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
         {
             LNParams P{};
             P.x = t1; P.x2 = cond_.objs[t.idx]; P.B = B; P.N1 = HW; P.N2 = Ng; P.Tpad = Tf; P.C = C; P.eps = 1e-5f;
-            P.gamma = t.fn1.g; P.beta = t.fn1.b; P.y = lnc;
+            P.gamma = t.fa.folded ? nullptr : t.fn1.g; P.beta = t.fa.folded ? nullptr : t.fn1.b; P.y = lnc;
             ProfScope ps(this, s, "ln_kernel", 0.0, 2.0 * B * (HW + Ng) * (double)C * 2);
             CK(layernorm_launch(P, s));
             ++n_launches;
         }
         self_attention(t.fa, lnc, B, Tf, HW, HW + Ng, C, d, o, s);
-        t2 = linear_rows(o, M, t.fa.out, ACT_NONE, t1, gates_ + 2 * t.idx, s);
+        t2 = linear_rows(o, M, t.fa.out, ACT_NONE, t1, gates_ + 2 * t.idx, s, &st2);
     } else {
         // fuser (gatedCA, attention.py:207-212): x = x + scale*tanh(alpha_attn) * attn(norm1(x), objs, objs)
         ln = layernorm(t1, B, HW, C, t.fn1, true, s);
@@ -1043,15 +1154,17 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
             CK(attn_launch(P, B, s));
         }
         ++n_launches;
-        t2 = linear_rows(o, M, t.fca.out, ACT_NONE, t1, gates_ + 2 * t.idx, s);
+        t2 = linear_rows(o, M, t.fca.out, ACT_NONE, t1, gates_ + 2 * t.idx, s, &st2);
     }
     //        x = x + scale*tanh(alpha_dense) * ff(norm2(x))
-    ln = layernorm(t2, B, HW, C, t.fn2, false, s);
-    t3 = feedforward(t.fff, ln, M, t2, gates_ + 2 * t.idx + 1, s);
+    const bool f2 = t.fff.folded && can_fold(st2, 8 * C, EPI_ROWMAJOR, ACT_GEGLU);
+    ln = normed(t2, t.fn2, t.fff.folded, f2, false);
+    t3 = feedforward(t.fff, ln, M, t2, gates_ + 2 * t.idx + 1, s, f2 ? &st2 : nullptr, &st3);
     }
 
     // x = attn2(norm2(x), context) + x
-    ln = layernorm(t3, B, HW, C, t.ln2, true, s);
+    const bool f3 = t.a2.folded && can_fold(st3, C, EPI_QK_HEADS, ACT_NONE);
+    ln = normed(t3, t.ln2, t.a2.folded, f3, true);
     {
         int dp, dpv;
         CK(attn_dims(d, &dp, &dpv));
@@ -1062,6 +1175,11 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
         epilogue_defaults(E);
         E.mode = EPI_QK_HEADS;
         E.q = bufs.q; E.k = nullptr; E.C = C; E.H = heads; E.d = d; E.DP = dp; E.T = Tp; E.Tpad_q = bufs.Tq_pad; E.Tpad_k = 0;
+        E.bias = t.a2.q.b;               // null unless the LayerNorm is folded (to_q has no bias of its own)
+        if (f3) {
+            E.ln_stats = st3.p; E.ln_nb = st3.nb; E.ln_ld = st3.ld; E.ln_csum = t.a2.q_csum;
+            E.ln_inv_c = 1.f / (float)C; E.ln_eps = 1e-5f;
+        }
         gemm(A, t.a2.q.w, B * Tp, C, C, E, s);
         AttnParams P{};
         P.q = bufs.q; P.k = cond_.ctx_k[t.idx]; P.vt = cond_.ctx_vt[t.idx]; P.o = o;
@@ -1074,11 +1192,12 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
         }
         ++n_launches;
     }
-    bf16* t4 = linear_rows(o, M, t.a2.out, ACT_NONE, t3, nullptr, s);
+    bf16* t4 = linear_rows(o, M, t.a2.out, ACT_NONE, t3, nullptr, s, &st4);
 
     // x = ff(norm3(x)) + x
-    ln = layernorm(t4, B, HW, C, t.ln3, false, s);
-    bf16* t5 = feedforward(t.ff, ln, M, t4, nullptr, s);
+    const bool f4 = t.ff.folded && can_fold(st4, 8 * C, EPI_ROWMAJOR, ACT_GEGLU);
+    ln = normed(t4, t.ln3, t.ff.folded, f4, false);
+    bf16* t5 = feedforward(t.ff, ln, M, t4, nullptr, s, f4 ? &st4 : nullptr, nullptr);
 
     // proj_out + x_in
     {

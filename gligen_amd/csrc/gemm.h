@@ -51,6 +51,21 @@ struct Epilogue {
     // EPI_ROWMAJOR optional row remap: out row = (m / remap_in) * remap_out + m % remap_in + remap_off
     int remap_in, remap_out, remap_off;
     int geglu16;        // ACT_GEGLU: weight rows packed for the 16x16-tile kernel (pack_geglu layout 1)
+    // ---- LayerNorm folded into the GEMM that consumes it (reference attention.py:333-338: x + attn(norm(x)), ff(norm(x))):
+    //   LN(x) W^T + b = rstd_m (x W'^T - mean_m csum) + b',  W' = W * gamma (bf16), csum[n] = sum_k W'[n][k], b' = b + W beta
+    // so the consumer multiplies the RAW residual-stream rows and corrects in its epilogue, and the LayerNorm kernel (one
+    // read + one write of the activation, one launch) disappears. The row statistics come from the epilogue of the GEMM that
+    // PRODUCED x: it has every output value in registers anyway.
+    // Producer (EPI_ROWMAJOR bf16, unsplit): stats_out[row * stats_ld + colblock] = (sum, sum of squares) of the FINAL bf16
+    // outputs of that row over one wave's column block; gemm_last_stats_nb() tells how many column blocks a row has (0: this
+    // launch took a path that does not produce them -- the caller then runs the plain LayerNorm kernel without affine).
+    float2* stats_out;
+    int stats_ld;
+    // Consumer: W is the folded W', bias the folded b'; acc is corrected with the row's (mean, rstd) from ln_nb partials.
+    const float2* ln_stats;
+    int ln_nb, ln_ld;
+    const float* ln_csum;   // [N], in the packed row order of W
+    float ln_inv_c, ln_eps; // 1 / C of the normalised rows, LayerNorm eps
 };
 
 // Key-tile layout of every attention K buffer: [b*H + h][t / 64][DP / 8][64 keys][8]. A 64-key tile is one contiguous block of
@@ -83,6 +98,8 @@ void gemm_force_grid(int blocks);                  // 0 = automatic (512)
 void gemm_set_autotune(int on);                    // 1 (default): time candidates at the first eager launch of a problem
 void gemm_last_cfg(int* tm, int* tn, int* splits);
 const char* gemm_last_kernel_name();  // kernel symbol (template arguments included) of the most recent gemm_launch
+bool gemm_ln_fold_supported(const AOperand& A, int M, int N, int K, const Epilogue& E);   // may this launch take Epilogue::ln_stats?
+int gemm_last_stats_nb();             // column blocks per row written to Epilogue::stats_out by the most recent gemm_launch (0: none)
 void aoperand_rows(AOperand& A, const bf16* p, int K, int ld);
 
 }  // namespace gl

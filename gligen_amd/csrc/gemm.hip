@@ -982,14 +982,63 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
         }
     };
 
-    // q / k scatter of a QKV item outside the V third (the EPI_QK_HEADS store, no bias / residual forms)
-    auto epilogue_qk = [&](int tm, int tn) {
+    // Folded LayerNorm (gemm.h, Epilogue::ln_stats): (mean, rstd) of the item's BM rows from the producer's partial sums, into the
+    // ring slot whose K tile was multiplied last. TPR threads per row add the partials in a fixed order.
+    // ln_fetch (when the compute cursor enters an item: the loads fly under its K loop) + ln_prepare (in front of its epilogue)
+    // (the loaded pairs stay in registers untouched until ln_prepare: an add right behind the load would make hipcc wait for it there)
+    constexpr int LNV = 5;
+    float2 ln_v[LNV];
+    float ln_s = 0.f, ln_q = 0.f;
+    auto ln_fetch = [&](int tm) {
+        constexpr int TPR = NT / BM;
+        const int row = t / TPR, part = t % TPR;
+        const int m = tm * BM + row;
+        ln_s = ln_q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LNV; ++i) {
+            const int nb = part + i * TPR;
+            ln_v[i] = make_float2(0.f, 0.f);
+            if (m < M && nb < E.ln_nb) ln_v[i] = E.ln_stats[(size_t)m * E.ln_ld + nb];
+        }
+        if (m < M)
+            for (int nb = part + LNV * TPR; nb < E.ln_nb; nb += TPR) {   // (more than LNV * TPR column blocks: the 16x16 / 8x8 levels)
+                const float2 v = E.ln_stats[(size_t)m * E.ln_ld + nb];
+                ln_s += v.x; ln_q += v.y;
+            }
+    };
+    auto ln_prepare = [&](int tm, int slot_done) -> const float2* {
+        float2* lst = reinterpret_cast<float2*>(smem + slot_done * STAGE);
+        constexpr int TPR = NT / BM;
+        __builtin_amdgcn_s_barrier();          // every wave is done with the fragments of that slot
+        const int row = t / TPR, part = t % TPR;
+        float s = ln_s, q = ln_q;
+#pragma unroll
+        for (int i = 0; i < LNV; ++i) { s += ln_v[i].x; q += ln_v[i].y; }
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+        if (part == 0) {
+            const float mean = s * E.ln_inv_c;
+            const float var = fmaxf(q * E.ln_inv_c - mean * mean, 0.f);
+            lst[row] = make_float2(mean, rsqrtf(var + E.ln_eps));
+        }
+        __syncthreads();
+        return lst;
+    };
+
+    // q / k scatter of a QKV item outside the V third (the EPI_QK_HEADS store, no residual forms; a bias only with the folded LayerNorm)
+    auto epilogue_qk = [&](int tm, int tn, const float2* lst) {
         const int mrow = tm * BM + wm * TM * 16 + l15;
         const int ncol = tn * BN + wn * TN * 16 + (lane >> 4) * 4;
+        float2 st[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) st[i] = lst ? lst[wm * TM * 16 + i * 16 + l15] : make_float2(0.f, 1.f);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n0 = ncol + j * 16;
             if (n0 >= N) continue;
+            float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), bj = cs;
+            if (lst) cs = *reinterpret_cast<const float4*>(E.ln_csum + n0);
+            if (E.bias) bj = *reinterpret_cast<const float4*>(E.bias + n0);   // (W beta of a folded LayerNorm, with or without statistics)
             const int which = n0 >= E.C;
             const int cc = n0 - which * E.C;
             const int h = cc / E.d;
@@ -1003,7 +1052,8 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
                 if (m >= M) continue;
                 const int b = m / E.T;
                 const int t = m - b * E.T;
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                float v[4] = {st[i].y * (acc[i][j][0] - st[i].x * cs.x) + bj.x, st[i].y * (acc[i][j][1] - st[i].x * cs.y) + bj.y,
+                              st[i].y * (acc[i][j][2] - st[i].x * cs.z) + bj.z, st[i].y * (acc[i][j][3] - st[i].x * cs.w) + bj.w};
                 const size_t off = tiled ? ktile_off((size_t)(b * E.H + h), tp, t, dd, E.DP) : ((size_t)(b * E.H + h) * tp + t) * E.DP + dd;
                 store_bf16x4(base + off, v);
             }
@@ -1012,7 +1062,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
     };
 
     // v^T store of an operand-swapped item (EPI_QKV_HEADS): feature n = column, 4 consecutive tokens per lane
-    auto epilogue_vt = [&](int tm, int tn) {
+    auto epilogue_vt = [&](int tm, int tn, const float2* lst) {
         const int nfeat = tn * BN + wn * TN * 16 + l15;
         const int mtok = tm * BM + wm * TM * 16 + (lane >> 4) * 4;
 #pragma unroll
@@ -1022,6 +1072,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
             const int cfeat = n - 2 * E.C;
             const int h = cfeat / E.d;
             const int dd = cfeat - h * E.d;
+            const float cs = lst ? E.ln_csum[n] : 0.f, bn = E.bias ? E.bias[n] : 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int m0 = mtok + i * 16;
@@ -1029,6 +1080,13 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
                 const int b = m0 / E.T;
                 const int t0 = m0 - b * E.T;
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (lst) {   // the lane's four tokens: rows (wm TM + i) 16 + 4 q .. + 3 of the item
+                    const float4 s01 = *reinterpret_cast<const float4*>(lst + wm * TM * 16 + i * 16 + (lane >> 4) * 4);
+                    const float4 s23 = *reinterpret_cast<const float4*>(lst + wm * TM * 16 + i * 16 + (lane >> 4) * 4 + 2);
+                    v[0] = s01.y * (v[0] - s01.x * cs); v[1] = s01.w * (v[1] - s01.z * cs);
+                    v[2] = s23.y * (v[2] - s23.x * cs); v[3] = s23.w * (v[3] - s23.z * cs);
+                }
+                v[0] += bn; v[1] += bn; v[2] += bn; v[3] += bn;
                 store_bf16x4(E.vt + ((size_t)(b * E.H + h) * E.DPV + dd) * E.Tpad_k + perm_tok4(t0), v);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1194,7 +1252,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
     constexpr int NRI = (16 + RPI - 1) / RPI;      // read instructions per 16-row fragment row
     constexpr int RS = WCOLS * 4 + 16;             // staged row stride (bytes): +16 keeps the b128 writes conflict-free
     constexpr int EPW = 16 * RS;                   // bytes per wave
-    static_assert(WMW * 2 * EPW <= STAGE, "epilogue staging does not fit one ring slot");
+    static_assert(WMW * 2 * (EPW + 16 * LPR * 8) <= STAGE, "epilogue staging (+ row-statistics scratch) does not fit one ring slot");
     auto epilogue_staged = [&](int tm, int tn, int slot_done) -> bool {
         if (wd.splits > 1 || E.mode != EPI_ROWMAJOR || E.out_f32 || (N & 7) || (E.act == ACT_GEGLU && (TN & 1)) || E.act == ACT_GELU) return false;
         unsigned char* ep = smem + slot_done * STAGE + wave * EPW;
@@ -1247,6 +1305,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
         const int mrow = tm * BM + wm * TM * 16;               // first row of the wave's sub-tile
         const int ncb = tn * BN + wn * WCOLS;                  // first column
         const int rr = lane / LPR, cc = lane - rr * LPR;       // read side: row inside a read instruction, 8-column group
+        float2* scr = reinterpret_cast<float2*>(smem + slot_done * STAGE + WMW * 2 * EPW) + wave * 16 * LPR;   // row-statistics scratch (Epilogue::stats_out)
         const int ncol = ncb + cc * 8;
         const bool col_ok = rr < RPI && ncol < N;
         // every wave is done with the fragments of the last K tile before any wave overwrites the slot
@@ -1321,6 +1380,29 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
                     for (int e = 0; e < 8; ++e) o.e[e] = f2bf(v[e]);
                 }
                 *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(E.out) + (size_t)mo * E.ldo + ncol) = o.u;
+                if constexpr (AMODE == A_ROWS) {
+                    if (E.stats_out) {   // this lane's 8 FINAL outputs of row r -> (sum, sum of squares), through the wave's scratch
+                        float s8 = 0.f, q8 = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float f = bf2f(o.e[e]); s8 += f; q8 += f * f; }
+                        scr[r * LPR + cc] = make_float2(s8, q8);
+                    }
+                }
+            }
+            if constexpr (AMODE == A_ROWS) {
+                if (E.stats_out) {
+                    // lanes 0..15 add the LPR pieces of "their" row in a fixed order: the row's partial over this wave's column block
+                    __builtin_amdgcn_wave_barrier();
+                    const int m = mrow + i * 16 + lane;
+                    if (lane < 16 && m < M && ncb < N) {     // (a wave whose column block lies beyond N has nothing to report)
+                        float s = 0.f, q = 0.f;
+#pragma unroll
+                        for (int c = 0; c < LPR; ++c) { const float2 v2 = scr[lane * LPR + c]; s += v2.x; q += v2.y; }
+                        const int mo2 = E.remap_in ? (m / E.remap_in) * E.remap_out + (m % E.remap_in) + E.remap_off : m;
+                        E.stats_out[(size_t)mo2 * E.stats_ld + (tn * 2 + wn)] = make_float2(s, q);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
         }
         return true;
@@ -1333,6 +1415,9 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
     int c_item = l_item, c_tm, c_tn, c_z;
     decode(c_item, c_tm, c_tn, c_z);
     bool c_swap = QKV && c_tn * BN >= 2 * E.C;   // BN divides 2C (checked on the host): an item is all V or no V
+    if constexpr (QKV) {
+        if (E.ln_stats) ln_fetch(c_tm);
+    }
     int c_left = l_kt_end - l_kt;
     int ahead = 0;       // tiles issued and not yet multiplied (including the one about to be)
     int slot_i = 0;      // ring slot of the next issue
@@ -1384,8 +1469,10 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
             }
             if (!(wd.dbg & 4)) {
                 if constexpr (QKV) {
-                    if (c_swap) epilogue_vt(c_tm, c_tn);
-                    else epilogue_qk(c_tm, c_tn);
+                    // folded LayerNorm (the head-layout epilogues, unsplit by construction): row statistics first
+                    const float2* lst = E.ln_stats ? ln_prepare(c_tm, slot_done) : nullptr;
+                    if (c_swap) epilogue_vt(c_tm, c_tn, lst);
+                    else epilogue_qk(c_tm, c_tn, lst);
                 } else {
                     if ((wd.dbg & 8) || !epilogue_staged(c_tm, c_tn, slot_done)) epilogue(c_tm, c_tn, c_z);  // dbg 8: fragment-layout stores
                 }
@@ -1396,10 +1483,25 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
             zero_acc();
             decode(c_item, c_tm, c_tn, c_z);
             c_swap = QKV && c_tn * BN >= 2 * E.C;
+            if constexpr (QKV) {
+                if (E.ln_stats) ln_fetch(c_tm);
+            }
             c_left = min(nk, (c_z + 1) * wd.kt_per_split) - c_z * wd.kt_per_split;
         }
     }
 #undef GL_VMCNT
+}
+
+// (mean, rstd) of row m from the producer's partial sums (Epilogue::ln_stats), fixed summation order
+__device__ __forceinline__ float2 ln_row_stats(const Epilogue& E, int m) {
+    float s = 0.f, q = 0.f;
+    for (int nb = 0; nb < E.ln_nb; ++nb) {
+        const float2 v = E.ln_stats[(size_t)m * E.ln_ld + nb];
+        s += v.x; q += v.y;
+    }
+    const float mean = s * E.ln_inv_c;
+    const float var = fmaxf(q * E.ln_inv_c - mean * mean, 0.f);
+    return make_float2(mean, rsqrtf(var + E.ln_eps));
 }
 
 // Deterministic split-K reduction + epilogue: one thread per (row, group of 4 columns).
@@ -1438,6 +1540,12 @@ splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, Epi
             for (int z = 0; z < splits; ++z) {
                 float4 a = *reinterpret_cast<const float4*>(ws + ((size_t)z * M + m) * N + n0);
                 v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+            }
+            if (E.ln_stats) {   // folded LayerNorm (gemm.h): rstd (acc - mean csum); epi_finish4 adds the folded bias
+                const float2 st = ln_row_stats(E, m);
+                const float4 cs = *reinterpret_cast<const float4*>(E.ln_csum + n0);
+                v[0] = st.y * (v[0] - st.x * cs.x); v[1] = st.y * (v[1] - st.x * cs.y);
+                v[2] = st.y * (v[2] - st.x * cs.z); v[3] = st.y * (v[3] - st.x * cs.w);
             }
             epi_finish4(E, m, n0, v);
         }
@@ -1903,7 +2011,8 @@ gemm_wide_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
         step1();
     };
 
-    auto epilogue = [&]() {
+    // lst: (mean, rstd) of the item's 256 rows in LDS when the LayerNorm in front of this GEMM is folded into it (gemm.h)
+    auto epilogue = [&](const float2* lst) {
         const int mrow = m0 + wm * TM * 16 + l15;
         const int ncol = c_tn * BN + wn * TN * 16 + q * 4;
         if (wd.splits > 1) {
@@ -1926,6 +2035,21 @@ gemm_wide_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
                     if (E.bias) {
                         bv[jj] = *reinterpret_cast<const float4*>(E.bias + ncol + jj * 32);
                         bg[jj] = *reinterpret_cast<const float4*>(E.bias + ncol + jj * 32 + 16);
+                    }
+                }
+                if (lst) {   // folded LayerNorm: acc <- rstd (acc - mean csum), in place, before bias and GEGLU
+#pragma unroll
+                    for (int jj = 0; jj < TN / 2; ++jj) {
+                        const float4 cv = *reinterpret_cast<const float4*>(E.ln_csum + ncol + jj * 32);
+                        const float4 cg = *reinterpret_cast<const float4*>(E.ln_csum + ncol + jj * 32 + 16);
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            const float2 st = lst[wm * TM * 16 + i * 16 + l15];
+                            acc[i][2 * jj][0] = st.y * (acc[i][2 * jj][0] - st.x * cv.x); acc[i][2 * jj][1] = st.y * (acc[i][2 * jj][1] - st.x * cv.y);
+                            acc[i][2 * jj][2] = st.y * (acc[i][2 * jj][2] - st.x * cv.z); acc[i][2 * jj][3] = st.y * (acc[i][2 * jj][3] - st.x * cv.w);
+                            acc[i][2 * jj + 1][0] = st.y * (acc[i][2 * jj + 1][0] - st.x * cg.x); acc[i][2 * jj + 1][1] = st.y * (acc[i][2 * jj + 1][1] - st.x * cg.y);
+                            acc[i][2 * jj + 1][2] = st.y * (acc[i][2 * jj + 1][2] - st.x * cg.z); acc[i][2 * jj + 1][3] = st.y * (acc[i][2 * jj + 1][3] - st.x * cg.w);
+                        }
                     }
                 }
 #pragma unroll
@@ -1987,11 +2111,31 @@ gemm_wide_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
     if (item >= wd.n_items) return;
     int stg = 0;
     int kt = 0, kt_end = 0;
+    // folded LayerNorm: this thread's share of the partial sums of row t >> 1 of the item whose K loop starts (the loads fly under
+    // it); the finished item's pair is handed to its epilogue before the next item's fetch overwrites it
+    // (the loaded pairs stay in registers untouched until the epilogue: an add right behind the load would make hipcc wait for it there)
+    constexpr int LNV = 5;
+    float2 ln_v[LNV];
+    float ln_s = 0.f, ln_q = 0.f;
     auto begin_item = [&](int it) {
         setup(it);
         kt = c_z * wd.kt_per_split;
         kt_end = min(nk, kt + wd.kt_per_split);
         issue(kt, stg);
+        if (E.ln_stats) {
+            const float2* src = E.ln_stats + (size_t)(m0 + (t >> 1)) * E.ln_ld;
+            ln_s = ln_q = 0.f;
+#pragma unroll
+            for (int i = 0; i < LNV; ++i) {
+                const int nb = (t & 1) + 2 * i;
+                ln_v[i] = make_float2(0.f, 0.f);
+                if (nb < E.ln_nb) ln_v[i] = src[nb];
+            }
+            for (int nb = (t & 1) + 2 * LNV; nb < E.ln_nb; nb += 2) {   // (more than 10 column blocks: C = 1280)
+                const float2 v = src[nb];
+                ln_s += v.x; ln_q += v.y;
+            }
+        }
     };
     begin_item(item);
     zero_acc();
@@ -2012,13 +2156,33 @@ gemm_wide_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
         pending = false;
         // item done: start the next item's first tile (into the stage the last tile was not read from), then store
         const int done_m0 = m0, done_tn = c_tn, done_z = c_z;
+        float done_s = ln_s, done_q = ln_q;
+#pragma unroll
+        for (int i = 0; i < LNV; ++i) { done_s += ln_v[i].x; done_q += ln_v[i].y; }
         item += gridDim.x;
         const bool more = item < wd.n_items;
         if (more) begin_item(item);
         {
             const int nm0 = m0, ntn = c_tn, nz = c_z;
             m0 = done_m0; c_tn = done_tn; c_z = done_z;
-            epilogue();
+            const float2* lst = nullptr;
+            if (E.ln_stats && wd.splits == 1) {
+                // folded LayerNorm: (mean, rstd) of the finished item's 256 rows from the producer's partial sums, into the stage the
+                // last K tile was read from (free until the DMA behind the next barrier); two threads per row, fixed summation order
+                float2* l = reinterpret_cast<float2*>(smem + (stg ^ 1) * STAGE);
+                __builtin_amdgcn_s_barrier();          // every wave is done with that stage's fragments
+                const int row = t >> 1, part = t & 1;
+                float s = done_s, qq = done_q;
+                s += __shfl_xor(s, 1, 64); qq += __shfl_xor(qq, 1, 64);
+                if (part == 0) {
+                    const float mean = s * E.ln_inv_c;
+                    const float var = fmaxf(qq * E.ln_inv_c - mean * mean, 0.f);
+                    l[row] = make_float2(mean, rsqrtf(var + E.ln_eps));
+                }
+                __syncthreads();
+                lst = l;
+            }
+            epilogue(lst);
             m0 = nm0; c_tn = ntn; c_z = nz;
         }
         if (!more) break;
@@ -2046,6 +2210,8 @@ void gemm_force_cfg(int tm, int tn, int splits) { g_force_tm = tm; g_force_tn = 
 void gemm_force_grid(int g) { g_force_grid = g; }
 void gemm_set_autotune(int on);
 static thread_local int g_last_cfg[3] = {0, 0, 0};      // per calling thread: one engine context per thread
+static thread_local int g_last_stats_nb = 0;
+int gemm_last_stats_nb() { return g_last_stats_nb; }
 static thread_local char g_last_name[96] = "gemm";
 const char* gemm_last_kernel_name() { return g_last_name; }
 void gemm_last_cfg(int* tm, int* tn, int* splits) { *tm = g_last_cfg[0]; *tn = g_last_cfg[1]; *splits = g_last_cfg[2]; }
@@ -2131,8 +2297,9 @@ int launch_u(const AOperand& A, const bf16* W, int M, int N, int K, const Epilog
         }                                                                                                        \
         hipLaunchKernelGGL(kfn, grid, block, lds, stream, A, W, M, N, K, E, ws, wd);                             \
     } while (0)
-    if (E.mode == EPI_QKV_HEADS) {
+    if (E.mode == EPI_QKV_HEADS || (E.mode == EPI_QK_HEADS && E.ln_stats)) {
         // (the 128 x 160 tile is not built for QKV: with the second MFMA form it needs more than 256 registers)
+        // q-only / q,k projections behind a folded LayerNorm run here too: these instantiations hold the statistics code
         if constexpr ((TM == 4 && TN == 5) || NST != 2) return set_error(GL_ERR_UNSUPPORTED, "gemm: no 128x160 / deep-ring tile for EPI_QKV_HEADS");
         else GL_LAUNCH_U((gemm_u_kernel<WMW, TM, TN, A_ROWS, NST, true>));
     } else if (A.mode == A_ROWS) GL_LAUNCH_U((gemm_u_kernel<WMW, TM, TN, A_ROWS, NST>));
@@ -2313,6 +2480,7 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
         const int tm = kTm[c], tn = kTn[c];
         if (E.act == ACT_GEGLU && (tn & 1)) return false;
         if (E.mode == EPI_QKV_HEADS && (sp > 1 || (2 * E.C) % (tn * 32) || (tm == 4 && tn == 5))) return false;   // an item must not straddle the k | v boundary
+        if (E.mode == EPI_QK_HEADS && E.ln_stats && (sp > 1 || (tm == 4 && tn == 5))) return false;                   // (same kernel family, no V third)
         if (sp > 1 && (!ws || nk / sp < 2 || (size_t)sp * M * N * sizeof(float) > ws_bytes)) return false;
         const int kps = cdiv(nk, sp);
         sp = cdiv(nk, kps);
@@ -2345,6 +2513,13 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
                 }
         }
         g_last_cfg[0] = tm; g_last_cfg[1] = tn; g_last_cfg[2] = wd.splits;
+        // row statistics for a folded LayerNorm downstream: only the staged row-major epilogue of gemm_u_kernel produces them
+        // (one partial per row and wave column block of tn * 16 columns)
+        g_last_stats_nb = (E.stats_out && use_u && wd.splits == 1 && A.mode == A_ROWS && E.mode == EPI_ROWMAJOR && !E.out_f32 && E.act != ACT_GEGLU &&
+                           E.act != ACT_GELU && N % (tn * 16) == 0 && N / (tn * 16) <= E.stats_ld && !(dbg & 8))
+                              ? N / (tn * 16) : 0;
+        if (E.ln_stats && (!use_u || A.mode != A_ROWS || wd.splits > 1 || (tm == 4 && tn == 5) || (E.mode != EPI_QKV_HEADS && E.mode != EPI_QK_HEADS)))
+            return set_error(GL_ERR_UNSUPPORTED, "gemm: the folded-LayerNorm epilogue exists for the head layouts of gemm_u_kernel and the GEGLU form of gemm_wide_kernel");
         if (use_u && E.mode == EPI_QKV_HEADS) snprintf(g_last_name, sizeof g_last_name, "gemm_u_kernel<2, %d, %d, 0, 2, true>", tm, tn);
         else if (use_u) snprintf(g_last_name, sizeof g_last_name, "gemm_u_kernel<2, %d, %d, %d, 2, false>", tm, tn, A.mode);
         else snprintf(g_last_name, sizeof g_last_name, "gemm_p_kernel<%d, %d, %d>", tm, tn, A.mode);
@@ -2400,8 +2575,9 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
         g_autotune = e ? atoi(e) : 1;
     }
     char key[160];
-    snprintf(key, sizeof key, "%d,%d,%d|%d,%d,%d,%d,%d,%d,%d|%d,%d,%d,%d,%d,%d|%d", M, N, K, A.mode, A.C0, A.C1, A.stride, A.ups, A.Win,
-             A.Hin, E.mode, E.act, E.res != nullptr, E.bias2 != nullptr, E.out_f32, E.gate != nullptr, (int)use_u);
+    snprintf(key, sizeof key, "%d,%d,%d|%d,%d,%d,%d,%d,%d,%d|%d,%d,%d,%d,%d,%d|%d%s", M, N, K, A.mode, A.C0, A.C1, A.stride, A.ups, A.Win,
+             A.Hin, E.mode, E.act, E.res != nullptr, E.bias2 != nullptr, E.out_f32, E.gate != nullptr, (int)use_u,
+             (E.mode == EPI_QK_HEADS && E.ln_stats) ? "|ln" : "");   // (q-only projection behind a folded LayerNorm: another kernel family)
     std::unique_lock<std::mutex> tune_lock(g_tune_mu);
     if (g_tuned.empty() && use_u && !getenv("GL_GEMM_NO_TABLE")) {
         // shipped choices for the problems of the benchmark configurations (generated by tools/make_tuned_table.py from an
@@ -2494,9 +2670,22 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
 
 void gemm_set_autotune(int on) { gemm_set_autotune_impl(on); }
 
+// Can a GEMM with this epilogue consume raw rows + row statistics instead of LayerNorm'ed rows (Epilogue::ln_stats)?
+// Mirrors the routing of gemm_launch: the head-layout epilogues of gemm_u_kernel, the GEGLU epilogue of gemm_wide_kernel.
+bool gemm_ln_fold_supported(const AOperand& A, int M, int N, int K, const Epilogue& E) {
+    if (gemm_variant() != 4 || A.mode != A_ROWS || A.C1 || N < 128 || K % 64) return false;
+    if ((size_t)M * (size_t)A.ld0 * 2 >= 0x7fff0000ull || (size_t)N * K * 2 >= 0x7fff0000ull) return false;
+    static const int wide = getenv("GL_GEMM_WIDE") ? atoi(getenv("GL_GEMM_WIDE")) : 1;
+    if (E.act == ACT_GEGLU) return wide && E.mode == EPI_ROWMAJOR && wide_eligible(A, M, N, K, E);
+    return E.mode == EPI_QKV_HEADS || E.mode == EPI_QK_HEADS;
+}
+
 int gemm_launch(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, float* ws,
                 size_t ws_bytes, hipStream_t stream) {
+    g_last_stats_nb = 0;
     if (M <= 0 || N <= 0 || K <= 0) return set_error(GL_ERR_ARG, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
+    if (E.ln_stats && (!E.ln_csum || !E.bias || E.ln_nb < 1 || E.ln_ld < E.ln_nb || !gemm_ln_fold_supported(A, M, N, K, E)))
+        return set_error(GL_ERR_UNSUPPORTED, "gemm: folded LayerNorm needs csum + folded bias + statistics, and an epilogue that applies them");
     if (K % 64 != 0) return set_error(GL_ERR_ARG, "gemm: K=%d must be a multiple of 64", K);
     if (N % 4 != 0) return set_error(GL_ERR_ARG, "gemm: N=%d must be a multiple of 4", N);
     if (A.mode == A_CONV3) {
@@ -2545,6 +2734,7 @@ int gemm_launch(const AOperand& A, const bf16* W, int M, int N, int K, const Epi
     }
     int kt_per_split = cdiv(nk, splits);
     splits = cdiv(nk, kt_per_split);
+    g_last_cfg[0] = cf.bm / 32; g_last_cfg[1] = cf.bn / 32; g_last_cfg[2] = splits;
 
     int rc;
     switch (best) {

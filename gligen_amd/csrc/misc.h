@@ -62,6 +62,10 @@ int conv4x4s2_f32_launch(const float* x, const float* w, const float* bias, floa
 // layout: gemm_geglu_layout() of the GEMM variant that will consume the packed rows
 int pack_geglu_launch(const float* w, const float* b, bf16* wp, float* bp, int C4, int K, int layout, hipStream_t stream);
 
+// LayerNorm folded into the linear layer behind it (gemm.h Epilogue::ln_stats): wf = w * gamma (columns), bf = b + w beta (b may be null)
+int ln_fold_launch(const float* w, const float* b, const float* gamma, const float* beta, float* wf, float* bf, int N, int K, hipStream_t stream);
+// csum[n] = sum_k w[n][k] of packed bf16 rows
+int rowsum_bf16_launch(const bf16* w, float* csum, int N, int K, hipStream_t stream);
 int fill_f32_launch(float* dst, float v, int n, hipStream_t stream);
 // gates[i] = scale[i / 2] * tanh(alpha[i])   (reference attention.py:241-242; one scale per fuser module)
 int gates_launch(const float* const* alpha_ptrs, const float* scale, float* gates, int n, hipStream_t stream);

@@ -251,6 +251,45 @@ int pack_geglu_launch(const float* w, const float* b, bf16* wp, float* bp, int C
     return GL_OK;
 }
 
+// ---- LayerNorm folded into the linear layer that consumes it (gemm.h, Epilogue::ln_stats; reference attention.py:333-338):
+//   wf[n][k] = w[n][k] gamma[k]          bf[n] = b[n] + sum_k w[n][k] beta[k]          (fp32; one block per output row)
+__global__ void __launch_bounds__(256) ln_fold_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ wf, float* __restrict__ bf, int K) {
+    __shared__ float red[4];
+    const int n = blockIdx.x;
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float v = w[(size_t)n * K + k];
+        wf[(size_t)n * K + k] = v * gamma[k];
+        acc += v * beta[k];
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) bf[n] = (b ? b[n] : 0.f) + ((red[0] + red[1]) + (red[2] + red[3]));
+}
+int ln_fold_launch(const float* w, const float* b, const float* gamma, const float* beta, float* wf, float* bf, int N, int K, hipStream_t stream) {
+    hipLaunchKernelGGL(ln_fold_kernel, dim3(N), dim3(256), 0, stream, w, b, gamma, beta, wf, bf, K);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+// csum[n] = sum_k w[n][k] over the PACKED bf16 rows (what the matrix core multiplies), fp32, fixed order
+__global__ void __launch_bounds__(256) rowsum_bf16_kernel(const bf16* __restrict__ w, float* __restrict__ csum, int K) {
+    __shared__ float red[4];
+    const int n = blockIdx.x;
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) acc += bf2f(w[(size_t)n * K + k]);
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) csum[n] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+int rowsum_bf16_launch(const bf16* w, float* csum, int N, int K, hipStream_t stream) {
+    hipLaunchKernelGGL(rowsum_bf16_kernel, dim3(N), dim3(256), 0, stream, w, csum, K);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
 // scale: one value per fuser (gates 2i and 2i+1 belong to fuser i)
 __global__ void gates_kernel(const float* const* alpha_ptrs, const float* scale, float* gates, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

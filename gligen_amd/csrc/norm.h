@@ -29,7 +29,7 @@ struct LNParams {
     const bf16* x2;
     int B, N1, N2, Tpad, C;
     float eps;
-    const float* gamma;
+    const float* gamma;    // both null: plain (x - mean) * rstd (the affine part is folded into the consumer's weights)
     const float* beta;
     bf16* y;
     int ldx, ldy;  // row strides in elements of x / y; 0 = C. ldy > C: columns [C, ldy) of y are written as zeros (K padding

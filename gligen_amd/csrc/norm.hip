@@ -306,15 +306,20 @@ __global__ void __launch_bounds__(256) ln_kernel(LNParams P) {
     for (int i = 0; i < 3; ++i) {
         const int ch = lane + 64 * i;
         if (ch < C8) {
-            const float4 g0 = *reinterpret_cast<const float4*>(P.gamma + ch * 8);
-            const float4 g1 = *reinterpret_cast<const float4*>(P.gamma + ch * 8 + 4);
-            const float4 b0 = *reinterpret_cast<const float4*>(P.beta + ch * 8);
-            const float4 b1 = *reinterpret_cast<const float4*>(P.beta + ch * 8 + 4);
-            const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-            const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
             U4BF8 o;
+            if (P.gamma) {
+                const float4 g0 = *reinterpret_cast<const float4*>(P.gamma + ch * 8);
+                const float4 g1 = *reinterpret_cast<const float4*>(P.gamma + ch * 8 + 4);
+                const float4 b0 = *reinterpret_cast<const float4*>(P.beta + ch * 8);
+                const float4 b1 = *reinterpret_cast<const float4*>(P.beta + ch * 8 + 4);
+                const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o.e[e] = f2bf((v[i][e] - mean) * rstd * gm[e] + bt[e]);
+                for (int e = 0; e < 8; ++e) o.e[e] = f2bf((v[i][e] - mean) * rstd * gm[e] + bt[e]);
+            } else {   // no affine: gamma and beta live in the consumer's folded weights (gemm.h Epilogue::ln_stats)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o.e[e] = f2bf((v[i][e] - mean) * rstd);
+            }
             *reinterpret_cast<uint4*>(dst + ch * 8) = o.u;
         }
     }

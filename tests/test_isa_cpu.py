@@ -41,15 +41,24 @@ def test_gemm_main_loop_has_no_dma_drain(gemm_asm):
         seen += 1
         barrier = [i for i, l in enumerate(body) if "s_barrier" in l]
         mfma = [i for i, l in enumerate(body) if "v_mfma" in l]
+        dma_i = [i for i, l in enumerate(body) if "buffer_load_dwordx4" in l and " lds" in l]
+        reads = [i for i, l in enumerate(body) if "ds_read_b128" in l]
         assert barrier and mfma, name
-        loop = body[barrier[0] + 1:mfma[-1]]
-        waits = [l.strip() for l in loop if "s_waitcnt" in l and "vmcnt" in l]
-        assert not waits, f"{name}: vmcnt wait(s) between the loop barrier and the MFMAs: {waits[:4]}"
-        dma = [l for l in loop if "buffer_load_dwordx4" in l and " lds" in l]
-        assert len(dma) >= 6, f"{name}: expected the K-tile DMA issue inside the loop, found {len(dma)}"
-        assert "ds_read_b128" in "\n".join(loop), name
+        # the loop-top barrier is the one that is followed by the K-tile DMA issue before any other barrier (the epilogues
+        # of the head-layout instantiations have barriers of their own, around the folded LayerNorm's row statistics, and
+        # hipcc lays that code out between the loop top and the MFMAs)
+        top = next(b for k, b in enumerate(barrier) if any(b < d < (barrier[k + 1] if k + 1 < len(barrier) else len(body)) for d in dma_i))
+        issue = [d for d in dma_i if d > top and all(not (top < b < d) for b in barrier)]
+        assert len(issue) >= 6, f"{name}: expected the K-tile DMA issue right behind the loop barrier, found {len(issue)}"
+        head = body[top + 1:issue[-1]]
+        # the multiply: the fragment reads in front of the first MFMA up to the last MFMA
+        first_read = min(r for r in reads if 0 < mfma[0] - r < 300)
+        mult = body[first_read:mfma[-1]]
+        for what, seg in (("the loop barrier and the DMA issue", head), ("the fragment reads and the last MFMA", mult)):
+            waits = [l.strip() for l in seg if "s_waitcnt" in l and "vmcnt" in l]
+            assert not waits, f"{name}: vmcnt wait(s) between {what}: {waits[:4]}"
         # DMA must not be wrapped in waterfall loops (descriptor / soffset / m0 proven wave-uniform)
-        text = "\n".join(loop)
+        text = "\n".join(head)
         assert len(re.findall(r"v_readfirstlane_b32", text)) <= 12, f"{name}: waterfall loops around the LDS-DMA?"
     assert seen >= 8
 
