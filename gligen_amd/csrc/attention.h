@@ -20,7 +20,7 @@ struct AttnParams {
 // padded head dims used by the q/k (DP) and v^T (DPV) buffers for a real head dim d
 int attn_dims(int d, int* DP, int* DPV);
 int attn_launch(const AttnParams& P, int B, hipStream_t stream);
-const char* attn_kernel_name(int d);  // kernel symbol attn_launch uses for head dim d
+const char* attn_kernel_name(int d, int Nk);  // kernel symbol attn_launch uses for head dim d and Nk keys
 // one-time init of a V^T buffer [BH][DPV][Tk_pad]: padding row d := 1.0 (the softmax denominator row)
 int attn_vt_ones_launch(bf16* vt, int BH, int d, int Tk_pad, hipStream_t stream);
 // one-time init of a K buffer [BH][Tk_pad/64][DP/8][64][8] (key-tile layout, gemm.h ktile_off): d = 40: column 40 := 1.0

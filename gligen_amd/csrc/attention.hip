@@ -701,8 +701,12 @@ static int attn_v2_mode() {
     return m;
 }
 
-const char* attn_kernel_name(int d) {
-    const int v2 = attn_v2_mode();
+// (short key sequences -- the 77 text tokens of the cross-attention: two tiles -- stay on the unpipelined kernel: nothing to
+// pipeline, and its four workgroups per CU start and drain faster; 19.5 against 22.8 us at 4096 x 77, profiles/r3)
+static bool attn_use_v2(int d, int Nk) { return d == 40 && attn_v2_mode() != 0 && Nk > 128; }
+
+const char* attn_kernel_name(int d, int Nk) {
+    const int v2 = attn_use_v2(d, Nk) ? attn_v2_mode() : 0;
     if (d == 40) return v2 == 0 ? "attn_kernel<48, 64, true>" : v2 == 1 ? "attn2_kernel<48, 64, true, 4>" : "attn2_kernel<48, 64, true, 8>";
     if (d == 80) return "attn_kernel<80, 96, true>";
     return "attn_kernel<160, 160, false>";
@@ -725,7 +729,7 @@ int attn_launch(const AttnParams& P, int B, hipStream_t stream) {
     if (P.Nq <= 0 || P.Nk <= 0) return set_error(GL_ERR_ARG, "attention: empty Nq=%d Nk=%d", P.Nq, P.Nk);
     if (P.Tq_pad % 128 != 0 || P.Tk_pad % 64 != 0 || P.Tq_pad < P.Nq || P.Tk_pad < P.Nk)
         return set_error(GL_ERR_ARG, "attention: bad padding Tq_pad=%d Tk_pad=%d (Nq=%d Nk=%d)", P.Tq_pad, P.Tk_pad, P.Nq, P.Nk);
-    const int v2 = attn_v2_mode();
+    const int v2 = attn_use_v2(P.d, P.Nk) ? attn_v2_mode() : 0;
     switch (P.d) {
         case 40:
             if (v2 == 1) return launch_attn2<48, 64, true, 4>(P, B, stream);

@@ -42,6 +42,11 @@ struct DeviceGuard {
     if (!device_guard_.ok) return gl::set_error(GL_ERR_HIP, "hipSetDevice(%d) failed", (ctx)->eng->device());
 
 static inline hipStream_t S(gl_stream s) { return reinterpret_cast<hipStream_t>(s); }
+#define HIPCK_API(expr)                                                                           \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) throw GlError(GL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
 
 extern "C" {
 
@@ -302,6 +307,74 @@ int gl_op_geglu(gl_ctx* ctx, const void* x, const float* w_f32, const float* b_f
     E.act = ACT_GEGLU; E.geglu16 = layout; E.out = y; E.ldo = inner; E.bias = bp;
     r = gemm_launch(A, wp, M, 2 * inner, K, E, ctx->eng->splitk_ws(), ctx->eng->splitk_ws_bytes(), S(s));
     if (r != GL_OK) throw GlError(r, gl::last_error());
+    GL_API_END
+}
+
+int gl_op_ln_linear(gl_ctx* ctx, const void* a, int M, int K0, const float* w0, const float* b0, const void* res, int C,
+                    const float* gamma, const float* beta, const float* w1, const float* b1, int mode, int inner_or_heads, int T,
+                    void* x_out, void* y_out, int* used_fold, gl_stream s) {
+    NEED(ctx);
+    if (!a || !w0 || !gamma || !beta || !w1 || !x_out || !y_out || !used_fold) return gl::set_error(GL_ERR_ARG, "gl_op_ln_linear: null pointer");
+    GL_API_BEGIN
+    Engine& eng = *ctx->eng;
+    Arena& ar = eng.arena();
+    ar.reset();
+    auto ck = [&](int rc) { if (rc != GL_OK) throw GlError(rc, gl::last_error()); };
+    if (C % 64 || K0 % 64 || M <= 0) throw GlError(GL_ERR_ARG, "gl_op_ln_linear: C and K0 must be multiples of 64");
+    const int N1 = mode == 0 ? 2 * inner_or_heads : C;
+    // ---- producer: x = a W0^T + b0 (+ res), with the row statistics of x
+    bf16* w0b = ar.get<bf16>((size_t)C * K0);
+    ck(cast_f32_bf16_launch(w0, w0b, (int64_t)C * K0, S(s)));
+    const int ld = C / 32;
+    float2* stats = ar.get<float2>((size_t)M * ld);
+    {
+        AOperand A;
+        aoperand_rows(A, (const bf16*)a, K0, K0);
+        Epilogue E;
+        epilogue_defaults(E);
+        E.out = x_out; E.ldo = C; E.bias = b0; E.res = (const bf16*)res; E.ldres = C;
+        E.stats_out = stats; E.stats_ld = ld;
+        ck(gemm_launch(A, w0b, M, C, K0, E, eng.splitk_ws(), eng.splitk_ws_bytes(), S(s)));
+    }
+    const int nb = gemm_last_stats_nb();
+    // ---- the consumer's folded weights: W1 * gamma, b1 + W1 beta, csum of the packed rows
+    float* wf = ar.get<float>((size_t)N1 * C);
+    float* bf = ar.get<float>((size_t)N1);
+    ck(ln_fold_launch(w1, b1, gamma, beta, wf, bf, N1, C, S(s)));
+    bf16* wp = ar.get<bf16>((size_t)N1 * C);
+    float* bp = ar.get<float>((size_t)N1);
+    float* cs = ar.get<float>((size_t)N1);
+    AOperand A;
+    Epilogue E;
+    epilogue_defaults(E);
+    if (mode == 0) {
+        const int layout = gl::gemm_geglu_layout();
+        ck(pack_geglu_launch(wf, bf, wp, bp, inner_or_heads, C, layout, S(s)));
+        E.act = ACT_GEGLU; E.geglu16 = layout; E.out = y_out; E.ldo = inner_or_heads; E.bias = bp;
+    } else {
+        const int H = inner_or_heads, d = C / H;
+        int dp, dpv;
+        ck(attn_dims(d, &dp, &dpv));
+        if (T <= 0 || M % T || T % 64) throw GlError(GL_ERR_ARG, "gl_op_ln_linear: mode 1 needs T (tokens per sample, a multiple of 64) dividing M");
+        ck(cast_f32_bf16_launch(wf, wp, (int64_t)N1 * C, S(s)));
+        HIPCK_API(hipMemcpyAsync(bp, bf, (size_t)N1 * sizeof(float), hipMemcpyDeviceToDevice, S(s)));
+        E.mode = EPI_QK_HEADS; E.q = (bf16*)y_out; E.k = nullptr; E.C = C; E.H = H; E.d = d; E.DP = dp; E.T = T;
+        E.Tpad_q = round_up(T, 128); E.bias = bp;
+    }
+    ck(rowsum_bf16_launch(wp, cs, N1, C, S(s)));
+    aoperand_rows(A, (const bf16*)x_out, C, C);
+    const bool fold = nb > 0 && gemm_ln_fold_supported(A, M, N1, C, E);
+    *used_fold = fold ? 1 : 0;
+    if (fold) {
+        E.ln_stats = stats; E.ln_nb = nb; E.ln_ld = ld; E.ln_csum = cs; E.ln_inv_c = 1.f / (float)C; E.ln_eps = 1e-5f;
+    } else {   // the fallback the engine takes where no statistics exist: ln_kernel without affine, same folded weights
+        bf16* xn = ar.get<bf16>((size_t)M * C);
+        LNParams P{};
+        P.x = (const bf16*)x_out; P.B = 1; P.N1 = M; P.N2 = 0; P.Tpad = M; P.C = C; P.eps = 1e-5f; P.y = xn;
+        ck(layernorm_launch(P, S(s)));
+        aoperand_rows(A, xn, C, C);
+    }
+    ck(gemm_launch(A, wp, M, N1, C, E, eng.splitk_ws(), eng.splitk_ws_bytes(), S(s)));
     GL_API_END
 }
 

@@ -856,7 +856,7 @@ bf16* Engine::linear_rows(const bf16* x, int M, const LinW& L, int act, const bf
     if (stats) {   // row statistics of the result, for the folded LayerNorm of the GEMM that reads it next
         *stats = RowStats{};
         if (ln_fold_ && L.N % 64 == 0) {
-            stats->ld = L.N / 64;
+            stats->ld = L.N / 32;     // one slot per wave column block of the narrowest tile (64 x 64: 32 columns per wave)
             stats->p = arena_.get<float2>((size_t)M * stats->ld);
             E.stats_out = stats->p;
             E.stats_ld = stats->ld;
@@ -1026,7 +1026,7 @@ void Engine::self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, in
     P.ldo = C; P.o_rows_per_b = Nq;
     P.scale_log2e = (float)(1.4426950408889634 / std::sqrt((double)d));
     {
-        ProfScope ps(this, s, attn_kernel_name(d), 4.0 * B * H * (double)Nq * Nk * d, 0.0);
+        ProfScope ps(this, s, attn_kernel_name(d, Nk), 4.0 * B * H * (double)Nq * Nk * d, 0.0);
         CK(attn_launch(P, B, s));
     }
     ++n_launches;
@@ -1150,7 +1150,7 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
         P.ldo = C; P.o_rows_per_b = HW;
         P.scale_log2e = (float)(1.4426950408889634 / std::sqrt((double)d));
         {
-            ProfScope ps(this, s, attn_kernel_name(d), 4.0 * B * heads * (double)HW * Ng * d, 0.0);
+            ProfScope ps(this, s, attn_kernel_name(d, Ng), 4.0 * B * heads * (double)HW * Ng * d, 0.0);
             CK(attn_launch(P, B, s));
         }
         ++n_launches;
@@ -1187,7 +1187,7 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
         P.ldo = C; P.o_rows_per_b = HW;
         P.scale_log2e = (float)(1.4426950408889634 / std::sqrt((double)d));
         {
-            ProfScope ps(this, s, attn_kernel_name(d), 4.0 * B * heads * (double)HW * cond_.ctx_T * d, 0.0);
+            ProfScope ps(this, s, attn_kernel_name(d, cond_.ctx_T), 4.0 * B * heads * (double)HW * cond_.ctx_T * d, 0.0);
             CK(attn_launch(P, B, s));
         }
         ++n_launches;

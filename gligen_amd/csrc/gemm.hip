@@ -2453,7 +2453,10 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
     // Measured and dropped (twice: round 1 sweeps, round 2 on-device autotune over all 107 problems of the benchmark, 0 wins):
     // the same tiles on a 4-stage ring (three K tiles in flight) with ONE workgroup per CU for the <= 256-item problems of the
     // 16x16 / 8x8 UNet levels; and (round 1) an 8-wave 256-row tile on a 3-stage ring.
-    static const int kTm[4] = {4, 4, 2, 2}, kTn[4] = {5, 4, 5, 4};
+    // candidate 4 (round 3): 64 x 64 tiles, 32 KB of LDS, up to four workgroups per CU -- for the M = 2048 / 512 problems of the
+    // 16x16 / 8x8 levels, whose 128 / 64-row tiles leave each CU one or two K-tile-deep latency chains (v5 kernel only)
+    constexpr int NC = 5;
+    static const int kTm[NC] = {4, 4, 2, 2, 2}, kTn[NC] = {5, 4, 5, 4, 2};
     static const int kSp[10] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
     const int nk = K / 64;
     // v5 addresses both operands through 32-bit buffer offsets: every operand must be < 2 GiB
@@ -2478,6 +2481,7 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
 
     auto feasible = [&](int c, int& sp) {
         const int tm = kTm[c], tn = kTn[c];
+        if (c == 4 && !use_u) return false;
         if (E.act == ACT_GEGLU && (tn & 1)) return false;
         if (E.mode == EPI_QKV_HEADS && (sp > 1 || (2 * E.C) % (tn * 32) || (tm == 4 && tn == 5))) return false;   // an item must not straddle the k | v boundary
         if (E.mode == EPI_QK_HEADS && E.ln_stats && (sp > 1 || (tm == 4 && tn == 5))) return false;                   // (same kernel family, no V third)
@@ -2520,6 +2524,9 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
                               ? N / (tn * 16) : 0;
         if (E.ln_stats && (!use_u || A.mode != A_ROWS || wd.splits > 1 || (tm == 4 && tn == 5) || (E.mode != EPI_QKV_HEADS && E.mode != EPI_QK_HEADS)))
             return set_error(GL_ERR_UNSUPPORTED, "gemm: the folded-LayerNorm epilogue exists for the head layouts of gemm_u_kernel and the GEGLU form of gemm_wide_kernel");
+        Epilogue Ek = E;                                   // what the kernels see: no statistics pointer unless this launch produces them
+        if (!g_last_stats_nb) Ek.stats_out = nullptr;     // (the staged epilogue writes whenever the pointer is set)
+        const Epilogue& E = Ek;
         if (use_u && E.mode == EPI_QKV_HEADS) snprintf(g_last_name, sizeof g_last_name, "gemm_u_kernel<2, %d, %d, 0, 2, true>", tm, tn);
         else if (use_u) snprintf(g_last_name, sizeof g_last_name, "gemm_u_kernel<2, %d, %d, %d, 2, false>", tm, tn, A.mode);
         else snprintf(g_last_name, sizeof g_last_name, "gemm_p_kernel<%d, %d, %d>", tm, tn, A.mode);
@@ -2533,6 +2540,7 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
                 case 1: rc = launch_u<2, 4, 4, 2>(A, W, M, N, K, E, ws, wd, stream); break;
                 case 2: rc = launch_u<2, 2, 5, 2>(A, W, M, N, K, E, ws, wd, stream); break;
                 case 3: rc = launch_u<2, 2, 4, 2>(A, W, M, N, K, E, ws, wd, stream); break;
+                case 4: rc = launch_u<2, 2, 2, 2>(A, W, M, N, K, E, ws, wd, stream); break;
                 default: g_force_grid = saved_grid; return set_error(GL_ERR_UNSUPPORTED, "gemm: unknown tile candidate");
             }
         } else {
@@ -2556,7 +2564,7 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
 
     // ---- developer override (kbench sweeps): exactly this tile / split if it fits the problem
     if (g_force_tm) {
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < NC; ++c) {
             if (kTm[c] != g_force_tm || kTn[c] != g_force_tn) continue;
             for (int si = 0; si < 10; ++si) {
                 int sp = kSp[si];
@@ -2597,7 +2605,7 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
     // ---- analytic model (also the capture-time / tuning-off fallback)
     double best_t = 1e30;
     int best_c = -1, best_sp = 1;
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < 4; ++c) {   // (the analytic model was fitted without the 64 x 64 candidate: the autotuner alone may pick it)
         const int tm = kTm[c], tn = kTn[c];
         const int bm = tm * 32, bn = tn * 32;
         const int tiles = cdiv(M, bm) * cdiv(N, bn);
@@ -2634,17 +2642,19 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
     TunedCfg win{best_c, best_sp, 0};
     float win_ms = 1e30f;
     static const int tune_reps = getenv("GL_GEMM_TUNE_REPS") ? std::max(1, atoi(getenv("GL_GEMM_TUNE_REPS"))) : 3;
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const int tiles = cdiv(M, kTm[c] * 32) * cdiv(N, kTn[c] * 32);
+        if (c == 4 && ((size_t)M * N > ((size_t)1 << 23) || N % 64)) continue;   // small problems only (M N <= 8 M outputs: 2048 x 3840, 8192 x 640 ..)
         int last_sp = -1;
         for (int si = 0; si < 10; ++si) {
             int sp = kSp[si];
             if (!feasible(c, sp) || sp == last_sp) continue;
             last_sp = sp;
             if (sp > 1 && tiles * sp > 4096) continue;      // splitting an already over-subscribed grid never paid
-            for (int gi = 0; gi < 2; ++gi) {
-                const int grid = gi ? 768 : 0;
-                if (gi && (kTm[c] * 32 + kTn[c] * 32 > 192 || tiles * sp <= 512)) continue;  // 3 workgroups/CU need <= 48 KB LDS each
+            for (int gi = 0; gi < 3; ++gi) {
+                const int grid = gi == 0 ? 0 : gi == 1 ? 768 : 1024;
+                if (gi == 1 && (kTm[c] * 32 + kTn[c] * 32 > 192 || tiles * sp <= 512)) continue;  // 3 workgroups/CU need <= 48 KB LDS each
+                if (gi == 2 && (kTm[c] * 32 + kTn[c] * 32 > 128 || tiles * sp <= 768)) continue;  // 4 workgroups/CU: the 64 x 64 tile (32 KB)
                 GL_TRY(run_cfg(c, sp, grid));  // warm-up (also sets the kernel's LDS attribute outside the timed region)
                 GL_HIP(hipEventRecord(g_tune_ev[0], stream));
                 for (int r = 0; r < tune_reps; ++r) GL_TRY(run_cfg(c, sp, grid));

@@ -329,6 +329,22 @@ class Engine:
         check(self.lib.gl_op_geglu(self._ctx, _ptr(x), _ptr(w_f32), _ptr(b_f32), _ptr(y), M, inner, K, _stream(self.device)))
         return y
 
+    def op_ln_linear(self, a, w0, b0, res, gamma, beta, w1, b1, mode, inner_or_heads, T=0):
+        """Producer GEMM + folded-LayerNorm consumer GEMM (gl_op_ln_linear). Returns (x, y, used_fold)."""
+        M, K0 = a.shape
+        Cc = w0.shape[0]
+        x = torch.empty((M, Cc), device=a.device, dtype=torch.bfloat16)
+        if mode == 0:
+            y = torch.empty((M, inner_or_heads), device=a.device, dtype=torch.bfloat16)
+        else:
+            d = Cc // inner_or_heads
+            dp = {40: 48, 80: 80, 160: 160}[d]
+            y = torch.zeros((M // T * inner_or_heads, ((T + 127) // 128) * 128, dp), device=a.device, dtype=torch.bfloat16)
+        used = C.c_int(-1)
+        check(self.lib.gl_op_ln_linear(self._ctx, _ptr(a), M, K0, _ptr(w0), _ptr(b0), _ptr(res), Cc, _ptr(gamma), _ptr(beta), _ptr(w1),
+                                       _ptr(b1), int(mode), int(inner_or_heads), int(T), _ptr(x), _ptr(y), C.byref(used), _stream(self.device)))
+        return x, y, int(used.value)
+
     def op_conv3x3(self, x0, w_oihw, bias, x1=None, stride=1, ups=0, pad_lo=1, res=None):
         B, H, W, C0 = x0.shape
         C1 = 0 if x1 is None else x1.shape[3]

@@ -192,6 +192,17 @@ int gl_op_linear(gl_ctx* ctx, const void* x, const void* w, const float* bias, c
 /* GEGLU (reference attention.py:37-44): x [M][K] bf16, proj weight [2*inner][K] fp32 + bias ->
  * y [M][inner] bf16 = (x Wv^T + bv) * gelu(x Wg^T + bg) */
 int gl_op_geglu(gl_ctx* ctx, const void* x, const float* w_f32, const float* b_f32, void* y, int M, int inner, int K, gl_stream s);
+/* A LayerNorm folded into the projection behind it, as the engine runs the transformer blocks (reference attention.py:333-338,
+ * x = x + f(norm(x))): first the PRODUCER x = a W0^T + b0 (+ res) [M][C] bf16, whose epilogue also emits the rows' partial
+ * (sum, sum of squares); then the CONSUMER on the raw rows of x with weights W1 * gamma, bias b1 + W1 beta and the correction
+ * rstd (acc - mean csum) in its epilogue:
+ *   mode 0: y [M][inner] = GEGLU(LN(x) W1^T + b1), W1 [2*inner][C]   (feed-forward, attention.py:37-64)
+ *   mode 1: y [M][C] = LN(x) W1^T (+ b1), W1 [C][C], written in the q head layout [M / T * heads][T][DP] (attn2.to_q)
+ * a [M][K0] bf16, W0 [C][K0] / W1 fp32, b0 / b1 / res may be NULL. *used_fold = 1 if the statistics path ran, 0 if the launch
+ * fell back to ln_kernel without affine + the same folded weights (both are product paths). eps 1e-5. */
+int gl_op_ln_linear(gl_ctx* ctx, const void* a, int M, int K0, const float* w0, const float* b0, const void* res, int C,
+                    const float* gamma, const float* beta, const float* w1, const float* b1, int mode, int inner_or_heads, int T,
+                    void* x_out, void* y_out, int* used_fold, gl_stream s);
 /* 3x3 conv over NHWC bf16 (channel-concat of x0,x1), weight OIHW fp32, stride 1|2, optional
  * nearest 2x upsample of the input, pad_lo 1 (symmetric) or 0 (VAE-encoder style). y NHWC bf16. */
 int gl_op_conv3x3(gl_ctx* ctx, const void* x0, int C0, const void* x1, int C1, int B, int H, int W,

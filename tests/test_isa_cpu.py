@@ -145,3 +145,40 @@ def test_attention_d40_loop_is_lean(attn_asm):
     assert count("v_mfma_f32_32x32x16_bf16") == 28
     assert 64 <= count("v_exp_f32") <= 70
     assert count("v_fma_f32") <= 8
+
+
+def test_attn2_loop_is_pipelined_and_lean(attn_asm):
+    """attn2_kernel (d = 40): the steady-state loop is two iterations (the score register sets swap roles), each with its 14
+    MFMAs interleaved with the 32 exps / 16 packs of the previous tile -- the interleave is hipcc's, nothing in the source pins
+    it but three sched_barriers, so it is pinned here -- one vmcnt wait + one barrier per iteration at the top, the K / V^T tiles
+    by LDS-DMA (4 pieces per wave and iteration), no scratch, and a DMA issue that costs a handful of scalar instructions
+    (the first version spent ~80 per iteration on wave-uniform branches around each piece)."""
+    name = re.search(r"^(_ZN2gl12attn2_kernelILi48ELi64ELb1ELi4EE[^:\s]*):", attn_asm, re.M).group(1)
+    a = attn_asm.index(name + ":")
+    body = attn_asm[a:attn_asm.index(".Lfunc_end", a)].split("\n")
+    meta = attn_asm[attn_asm.index(".name:           " + name):]
+    assert int(re.search(r"\.vgpr_spill_count:\s*(\d+)", meta).group(1)) == 0
+    assert int(re.search(r"\.private_segment_fixed_size:\s*(\d+)", meta).group(1)) == 0
+    head = next(i for i, l in enumerate(body) if "Inner Loop Header" in l)
+    label = body[head].split(":")[0].strip()
+    back = max(i for i, l in enumerate(body) if re.search(r"s_(c?branch\w*)\s+" + re.escape(label) + r"\s*$", l))
+    loop = [l.strip() for l in body[head:back + 1] if l.strip() and not l.strip().startswith((";", "."))]
+    ops = [l.split()[0] for l in loop]
+    count = lambda op: sum(1 for o in ops if o.startswith(op))
+    assert count("v_mfma_f32_32x32x16_bf16") == 28 and count("s_barrier") == 2
+    assert count("buffer_load_dwordx4") == 8 and count("ds_read_b128") == 28
+    assert count("global_load") == 0 and count("ds_write") == 0 and count("scratch_") == 0
+    assert [l for l in loop if l.startswith("s_waitcnt") and "vmcnt" in l] == ["s_waitcnt vmcnt(0)"] * 2
+    assert count("s_") - count("s_waitcnt") - count("s_nop") - count("s_barrier") <= 48, "the DMA issue / loop control grew scalar code again"
+    # the interleave: in each iteration's hot path, between the first and the last MFMA, VALU work is spread between the MFMAs --
+    # no run of more than 10 VALU instructions without an MFMA, no run of more than 3 MFMAs back to back
+    first = next(i for i, o in enumerate(ops) if o.startswith("v_mfma"))
+    last_first_iter = [i for i, o in enumerate(ops) if o.startswith("v_mfma")][13]
+    run_v = run_m = worst_v = worst_m = 0
+    for o in ops[first:last_first_iter + 1]:
+        if o.startswith("v_mfma"):
+            run_m += 1; run_v = 0
+        elif o.startswith("v_"):
+            run_v += 1; run_m = 0
+        worst_v, worst_m = max(worst_v, run_v), max(worst_m, run_m)
+    assert worst_v <= 10 and worst_m <= 3, (worst_v, worst_m)

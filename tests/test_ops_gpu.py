@@ -244,3 +244,51 @@ def test_attention_spike(engine):
     ref = attn_ref(xq, xkv, wq, wk, wv, H)
     y = engine.op_attention(xq, xkv, wq, wk, wv, H)
     assert rel_err(y, ref) < 2.5e-2
+
+
+# ---- LayerNorm folded into the GEMM behind it (gemm.h Epilogue::ln_stats): producer GEMM (+ residual) writing the residual
+# stream AND its rows' partial statistics, consumer GEMM on the raw rows with W * gamma and the rstd (acc - mean csum) epilogue.
+# (M, K0, C): (4096, 320, 320) the 64x64-level shapes with several items per workgroup; (2048, 1280, 1280): 20 column blocks per
+# row; (512, 1280, 640): M of the 8x8 level; (300, 320, 320): M % 256 != 0 -> the GEGLU consumer falls back to ln_kernel
+# without affine + the same folded weights (used_fold = 0), the q-only consumer still folds; a large row mean (|mean| = 8 sigma)
+@pytest.mark.parametrize("M,K0,C,shift", [(4096, 320, 320, 0.0), (2048, 1280, 1280, 0.0), (512, 1280, 640, 0.0), (300, 320, 320, 0.0),
+                                          (1024, 640, 640, 8.0)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_ln_folded_into_gemm(engine, M, K0, C, shift, mode):
+    heads = 8
+    T = 64 if mode == 1 else 0
+    if mode == 1 and M % 64:
+        M = (M // 64) * 64
+    a = bf(rnd(M, K0, seed=1))
+    w0, b0 = rnd(C, K0, scale=K0 ** -0.5, seed=2), rnd(C, seed=3) + shift
+    res = bf(rnd(M, C, seed=4))
+    gamma, beta = 1.0 + 0.3 * rnd(C, seed=5), 0.2 * rnd(C, seed=6)
+    N1 = 8 * C if mode == 0 else C
+    w1 = rnd(N1, C, scale=C ** -0.5, seed=7)
+    b1 = rnd(N1, seed=8) if mode == 0 else None
+    x, y, used = engine.op_ln_linear(a, w0, b0, res, gamma, beta, w1, b1, mode, 4 * C if mode == 0 else heads, T)
+    # producer: the residual stream
+    x_ref = a.float() @ bf(w0).float().t() + b0 + res.float()
+    assert rel_err(x, x_ref) < TOL
+    # consumer, from the rows the kernel actually normalises (x as stored, bf16)
+    xs = x.float()
+    h = F.layer_norm(xs, (C,), gamma, beta, 1e-5) @ w1.t()
+    if mode == 0:
+        h = h + b1
+        val, gate = h.chunk(2, dim=-1)
+        ref = val * F.gelu(gate)
+        got = y.float()
+        assert used in (0, 1) and (used == 0 if M % 256 else True) and (used == 1 if M == 4096 else True)   # (a split-K producer has no statistics)
+    else:
+        d = C // heads
+        Bq = M // T
+        got = y.float().view(Bq, heads, y.shape[1], y.shape[2])[:, :, :T, :d].permute(0, 2, 1, 3).reshape(M, C)
+        if y.shape[2] > d:   # d = 40: the head dim is padded to 48
+            assert float(y.float().view(Bq, heads, y.shape[1], y.shape[2])[:, :, :, d:].abs().max()) == 0.0     # padding untouched
+        ref = h
+        assert used in (0, 1) and (used == 1 if M == 4096 else True)
+    # bf16 weights (W * gamma rounded once) and a bf16 output: same bar as the unfolded kernels
+    assert rel_err(got, ref) < TOL, (used, rel_err(got, ref))
+    # and determinism: the statistics are summed in a fixed order
+    x2, y2, _ = engine.op_ln_linear(a, w0, b0, res, gamma, beta, w1, b1, mode, 4 * C if mode == 0 else heads, T)
+    assert torch.equal(x, x2) and torch.equal(y, y2)
