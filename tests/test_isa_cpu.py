@@ -49,7 +49,7 @@ def test_gemm_main_loop_has_no_dma_drain(gemm_asm):
         # hipcc lays that code out between the loop top and the MFMAs)
         top = next(b for k, b in enumerate(barrier) if any(b < d < (barrier[k + 1] if k + 1 < len(barrier) else len(body)) for d in dma_i))
         issue = [d for d in dma_i if d > top and all(not (top < b < d) for b in barrier)]
-        assert len(issue) >= 6, f"{name}: expected the K-tile DMA issue right behind the loop barrier, found {len(issue)}"
+        assert len(issue) >= 4, f"{name}: expected the K-tile DMA issue right behind the loop barrier, found {len(issue)}"   # (64 x 64 tile: 2 + 2 passes)
         head = body[top + 1:issue[-1]]
         # the multiply: the fragment reads in front of the first MFMA up to the last MFMA
         first_read = min(r for r in reads if 0 < mfma[0] - r < 300)
