@@ -388,6 +388,7 @@ def main():
                                                        f"measured in an untimed pass with one batch in flight)",
             "vae_decode_ms": dec_ms,
             "launches_per_unet_eval": launches_per_eval,
+            "arena_high_water_gb": round(lanes[0][0].engine.arena_high_water() / 2 ** 30, 3),   # activation arena of one execution context (gl_arena_high_water)
             "collective_world_size": dist_world, "collective_backend": dist_backend,   # the RCCL world the barrier / max-over-ranks ran in
             "gpu_clocks": clk,
             "roofline": roofline,

@@ -697,7 +697,7 @@ int attn_vt_ones_launch(bf16* vt, int BH, int d, int Tk_pad, hipStream_t stream)
 // GL_ATTN_V2 (developer A/B): 0 = the unpipelined kernel for every head dim, 1 (default) = attn2_kernel with 4 waves (two
 // workgroups per CU) for d = 40, 2 = attn2_kernel with 8 waves (one workgroup per CU: half the K / V^T DMA per query row)
 static int attn_v2_mode() {
-    static const int m = getenv("GL_ATTN_V2") ? atoi(getenv("GL_ATTN_V2")) : 1;
+    static const int m = dev_env("GL_ATTN_V2") ? atoi(dev_env("GL_ATTN_V2")) : 1;
     return m;
 }
 

@@ -457,7 +457,7 @@ int gl_op_attention(gl_ctx* ctx, const void* xq, const void* xkv, int B, int Nq,
     ck(pad_rows_bf16_launch((const bf16*)xkv, xkp, B, Nk, Tk, Ck, S(s)));
     // self-attention (same rows for q, k, v): the engine's fused projection, one EPI_QKV_HEADS GEMM (GL_QKV_FUSED=0: off)
     const bool fused = xq == xkv && C == Ck && Nq == Nk && gemm_supports_qkv() && (2 * C) % 128 == 0 &&
-                       !(getenv("GL_QKV_FUSED") && atoi(getenv("GL_QKV_FUSED")) == 0);
+                       !(dev_env("GL_QKV_FUSED") && atoi(dev_env("GL_QKV_FUSED")) == 0);
     if (fused) {
         bf16* wqkv = ar.get<bf16>((size_t)3 * C * C);
         ck(cast_f32_bf16_launch(wq, wqkv, (int64_t)C * C, S(s)));

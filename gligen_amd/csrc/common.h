@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 typedef __bf16 bf16;
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -37,6 +38,17 @@ const char* last_error();
     } while (0)
 
 #define GL_LAUNCH_CHECK() GL_HIP(hipGetLastError())
+
+// Developer A/B switches (GL_GEMM_*, GL_CONV_HALO, GL_ATTN_V2, GL_LN_FOLD, ...; tools/README.md). The product library does not
+// let the environment pick kernels behind the caller's back: the switches are read only when GL_DEV_SWITCHES=1 is set (the
+// tools/gpu_*.sh scripts export it), i.e. the library itself consults exactly one environment variable, once.
+inline const char* dev_env(const char* name) {
+    static const bool on = [] {
+        const char* e = getenv("GL_DEV_SWITCHES");
+        return e && atoi(e) != 0;
+    }();
+    return on ? getenv(name) : nullptr;
+}
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -356,11 +356,11 @@ void Engine::build_unet() {
         t.ln3 = norm(tb + ".norm3");
         // q, k and v^T of a self-attention come out of ONE GEMM over the LayerNorm'ed rows (EPI_QKV_HEADS) when the head
         // count / width allow it; GL_QKV_FUSED=0 keeps the two-launch form (q,k GEMM + operand-swapped v^T GEMM) for A/B runs
-        const bool want_fused = !(getenv("GL_QKV_FUSED") && atoi(getenv("GL_QKV_FUSED")) == 0);
+        const bool want_fused = !(dev_env("GL_QKV_FUSED") && atoi(dev_env("GL_QKV_FUSED")) == 0);
         const bool fuse_qkv = want_fused && gemm_supports_qkv() && (2 * C) % 128 == 0;
         // LayerNorms folded into the projections behind them (gemm.h Epilogue::ln_stats; GL_LN_FOLD=0: the LayerNorm kernels of
         // rounds 1-2): norm1 -> attn1 q,k,v; fuser.norm1 -> fuser q,k,v; fuser.norm2 -> fuser.ff; norm2 -> attn2.to_q; norm3 -> ff
-        const bool fold = fuse_qkv && !(getenv("GL_LN_FOLD") && atoi(getenv("GL_LN_FOLD")) == 0);
+        const bool fold = fuse_qkv && !(dev_env("GL_LN_FOLD") && atoi(dev_env("GL_LN_FOLD")) == 0);
         ln_fold_ = fold;
         auto self_attn_w = [&](const std::string& a, const NormW* ln) {
             SelfAttnW w;
@@ -814,18 +814,31 @@ void Engine::finalize() {
 }
 
 // ---------------------------------------------------------------- execution helpers
+// developer aid (GL_LAUNCH_LOG=file, tools/gpu_traffic.sh): one line per GEMM / conv / attention launch, in launch order
+static FILE* launch_log_file() {
+    static FILE* f = dev_env("GL_LAUNCH_LOG") ? fopen(dev_env("GL_LAUNCH_LOG"), "w") : nullptr;
+    return f;
+}
+// attention launches in the same log: symbol | Nq | Nk | d | mode 2 | algorithmic bytes (q, k, v read once, o written once, unpadded)
+static void log_attention(const char* sym, int B, int H, int Nq, int Nk, int d) {
+    if (FILE* f = launch_log_file()) {
+        fprintf(f, "%s|%d|%d|%d|2|%.0f\n", sym, Nq, Nk, d, 2.0 * B * H * d * (2.0 * Nq + 2.0 * Nk));
+        fflush(f);
+    }
+}
+
 void Engine::gemm(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, hipStream_t s) {
     ProfScope ps(this, s, "gemm", 2.0 * M * N * K, 0.0);
     CK(gemm_launch(A, W, M, N, K, E, ws_, ws_bytes_, s));
     if (profiling_) {
-        static const bool by_shape = getenv("GL_PROF_SHAPES") != nullptr;  // developer aid: one record per problem, not per symbol
+        static const bool by_shape = dev_env("GL_PROF_SHAPES") != nullptr;  // developer aid: one record per problem, not per symbol
         std::string nm = gemm_last_kernel_name();  // the symbol the tile selection actually launched
         if (by_shape) nm += fmt(" M%d N%d K%d", M, N, K);
         ps.rename(nm);
     }
     // developer aid (tools/gpu_traffic.sh): one line per GEMM / conv launch, in launch order, to join rocprofv3's per-dispatch
     // counter rows (which carry the kernel symbol but not the problem) with their shapes
-    static FILE* launch_log = getenv("GL_LAUNCH_LOG") ? fopen(getenv("GL_LAUNCH_LOG"), "w") : nullptr;
+    FILE* launch_log = launch_log_file();
     if (launch_log) {
         const double a_rows = A.mode == A_CONV3 ? (double)(M / (A.Ho * A.Wo)) * A.Hin * A.Win : (double)M;
         const double out_b = E.mode == EPI_NCHW_F32 ? 4.0 * M * E.n_real : (E.act == ACT_GEGLU ? 1.0 : 2.0) * M * (double)N * (E.out_f32 ? 2 : 1);
@@ -1028,6 +1041,7 @@ void Engine::self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, in
     {
         ProfScope ps(this, s, attn_kernel_name(d, Nk), 4.0 * B * H * (double)Nq * Nk * d, 0.0);
         CK(attn_launch(P, B, s));
+        log_attention(attn_kernel_name(d, Nk), B, H, Nq, Nk, d);
     }
     ++n_launches;
 }
@@ -1152,6 +1166,7 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
         {
             ProfScope ps(this, s, attn_kernel_name(d, Ng), 4.0 * B * heads * (double)HW * Ng * d, 0.0);
             CK(attn_launch(P, B, s));
+            log_attention(attn_kernel_name(d, Ng), B, heads, HW, Ng, d);
         }
         ++n_launches;
         t2 = linear_rows(o, M, t.fca.out, ACT_NONE, t1, gates_ + 2 * t.idx, s, &st2);
@@ -1189,6 +1204,7 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
         {
             ProfScope ps(this, s, attn_kernel_name(d, cond_.ctx_T), 4.0 * B * heads * (double)HW * cond_.ctx_T * d, 0.0);
             CK(attn_launch(P, B, s));
+            log_attention(attn_kernel_name(d, cond_.ctx_T), B, heads, HW, cond_.ctx_T, d);
         }
         ++n_launches;
     }

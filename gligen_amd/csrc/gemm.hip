@@ -2195,7 +2195,7 @@ static int g_gemm_variant = -1;  // 1: LDS-DMA v2 (one tile per workgroup), 2: p
 void gemm_set_variant(int v) { g_gemm_variant = v; }
 static int gemm_variant() {
     if (g_gemm_variant < 0) {
-        const char* e = getenv("GL_GEMM_VARIANT");
+        const char* e = dev_env("GL_GEMM_VARIANT");
         g_gemm_variant = e ? atoi(e) : 4;
     }
     return g_gemm_variant;
@@ -2463,21 +2463,21 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
     const size_t a_rows = A.mode == A_CONV3 ? (size_t)(M / (A.Ho * A.Wo)) * A.Hin * A.Win : (size_t)M;
     const bool fits32 = a_rows * (size_t)std::max(A.ld0, A.ld1) * 2 < 0x7fff0000ull && (size_t)N * K * 2 < 0x7fff0000ull;
     const bool use_u = gemm_variant() == 4 && fits32 && !(E.bias2 && E.res);  // v5's epilogue has no bias2 + residual form
-    static const int dbg = getenv("GL_GEMM_DBG") ? atoi(getenv("GL_GEMM_DBG")) : 0;
+    static const int dbg = dev_env("GL_GEMM_DBG") ? atoi(dev_env("GL_GEMM_DBG")) : 0;
     // eligible 3x3 convs with M >= 256 * GL_CONV_HALO (default 8; 0 = never) go to the halo kernel (GL_CONV_HALO_SPLITS=n forces its
     // K split): at M = 512 (the 8 x 8 level) its 16 tiles x deep split lose to the 64 x 160 tiles of the kernel above
-    static const int halo = getenv("GL_CONV_HALO") ? atoi(getenv("GL_CONV_HALO")) : 8;
-    static const int halo_splits = getenv("GL_CONV_HALO_SPLITS") ? atoi(getenv("GL_CONV_HALO_SPLITS")) : 0;
+    static const int halo = dev_env("GL_CONV_HALO") ? atoi(dev_env("GL_CONV_HALO")) : 8;
+    static const int halo_splits = dev_env("GL_CONV_HALO_SPLITS") ? atoi(dev_env("GL_CONV_HALO_SPLITS")) : 0;
     if (halo && use_u && !g_force_tm && halo_eligible(A, M, N, K, E) && M >= halo * 256)
         return launch_halo(A, W, M, N, K, E, ws, ws_bytes, halo_splits, stream);
     // The wide kernel takes the GEGLU projections (GL_GEMM_WIDE=1, default): 0.78-0.82x the time of gemm_u_kernel's 128x128 tiles at the
     // 64x64 / 32x32 levels, even below. Everything else it is eligible for is slower there (narrow N: 256-row tiles leave CUs idle or
     // need a K split) or within 4 % (FF-out): GL_GEMM_WIDE=2 sends all of it for A/B runs, 0 none. (profiles/r2_final/wide_kbench.txt)
-    static const int wide = getenv("GL_GEMM_WIDE") ? atoi(getenv("GL_GEMM_WIDE")) : 1;
-    static const int wide_splits = getenv("GL_GEMM_WIDE_SPLITS") ? atoi(getenv("GL_GEMM_WIDE_SPLITS")) : 0;
+    static const int wide = dev_env("GL_GEMM_WIDE") ? atoi(dev_env("GL_GEMM_WIDE")) : 1;
+    static const int wide_splits = dev_env("GL_GEMM_WIDE_SPLITS") ? atoi(dev_env("GL_GEMM_WIDE_SPLITS")) : 0;
     if (wide && use_u && !g_force_tm && (wide >= 2 || E.act == ACT_GEGLU) && wide_eligible(A, M, N, K, E))
         return launch_wide(A, W, M, N, K, E, ws, ws_bytes, wide_splits, stream);
-    static const int xcd_boxes = getenv("GL_GEMM_XCD_BOXES") ? atoi(getenv("GL_GEMM_XCD_BOXES")) : 1;
+    static const int xcd_boxes = dev_env("GL_GEMM_XCD_BOXES") ? atoi(dev_env("GL_GEMM_XCD_BOXES")) : 1;
 
     auto feasible = [&](int c, int& sp) {
         const int tm = kTm[c], tn = kTn[c];
@@ -2579,7 +2579,7 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
 
     // ---- autotuned choice
     if (g_autotune < 0) {
-        const char* e = getenv("GL_GEMM_AUTOTUNE");
+        const char* e = dev_env("GL_GEMM_AUTOTUNE");
         g_autotune = e ? atoi(e) : 1;
     }
     char key[160];
@@ -2587,7 +2587,7 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
              A.Hin, E.mode, E.act, E.res != nullptr, E.bias2 != nullptr, E.out_f32, E.gate != nullptr, (int)use_u,
              (E.mode == EPI_QK_HEADS && E.ln_stats) ? "|ln" : "");   // (q-only projection behind a folded LayerNorm: another kernel family)
     std::unique_lock<std::mutex> tune_lock(g_tune_mu);
-    if (g_tuned.empty() && use_u && !getenv("GL_GEMM_NO_TABLE")) {
+    if (g_tuned.empty() && use_u && !dev_env("GL_GEMM_NO_TABLE")) {
         // shipped choices for the problems of the benchmark configurations (generated by tools/make_tuned_table.py from an
         // autotune log taken on MI355X with 10 timed launches per candidate): deterministic kernel selection run to run
         static const struct { const char* key; int c, sp, grid; } kTable[] = {
@@ -2641,7 +2641,7 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
     struct EvGuard { hipEvent_t* e; ~EvGuard() { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); } } ev_guard{g_tune_ev};
     TunedCfg win{best_c, best_sp, 0};
     float win_ms = 1e30f;
-    static const int tune_reps = getenv("GL_GEMM_TUNE_REPS") ? std::max(1, atoi(getenv("GL_GEMM_TUNE_REPS"))) : 3;
+    static const int tune_reps = dev_env("GL_GEMM_TUNE_REPS") ? std::max(1, atoi(dev_env("GL_GEMM_TUNE_REPS"))) : 3;
     for (int c = 0; c < NC; ++c) {
         const int tiles = cdiv(M, kTm[c] * 32) * cdiv(N, kTn[c] * 32);
         if (c == 4 && ((size_t)M * N > ((size_t)1 << 23) || N % 64)) continue;   // small problems only (M N <= 8 M outputs: 2048 x 3840, 8192 x 640 ..)
@@ -2668,7 +2668,7 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
     }
     g_tuned[key] = win;
     tune_lock.unlock();
-    static const bool tune_log = getenv("GL_GEMM_TUNE_LOG") != nullptr;
+    static const bool tune_log = dev_env("GL_GEMM_TUNE_LOG") != nullptr;
     if (tune_log)
         fprintf(stderr, "[gemm autotune] %s -> %dx%d / %d splits @%d (%.1f us; model said %dx%d / %d) cfg %d %d %d\n", key, kTm[win.c] * 32,
                 kTn[win.c] * 32, win.sp, win.grid ? win.grid : 512, win_ms * 1e3f / tune_reps, kTm[best_c] * 32, kTn[best_c] * 32, best_sp,
@@ -2685,7 +2685,7 @@ void gemm_set_autotune(int on) { gemm_set_autotune_impl(on); }
 bool gemm_ln_fold_supported(const AOperand& A, int M, int N, int K, const Epilogue& E) {
     if (gemm_variant() != 4 || A.mode != A_ROWS || A.C1 || N < 128 || K % 64) return false;
     if ((size_t)M * (size_t)A.ld0 * 2 >= 0x7fff0000ull || (size_t)N * K * 2 >= 0x7fff0000ull) return false;
-    static const int wide = getenv("GL_GEMM_WIDE") ? atoi(getenv("GL_GEMM_WIDE")) : 1;
+    static const int wide = dev_env("GL_GEMM_WIDE") ? atoi(dev_env("GL_GEMM_WIDE")) : 1;
     if (E.act == ACT_GEGLU) return wide && E.mode == EPI_ROWMAJOR && wide_eligible(A, M, N, K, E);
     return E.mode == EPI_QKV_HEADS || E.mode == EPI_QK_HEADS;
 }

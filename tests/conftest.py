@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# A few GPU tests flip the library's developer switches (GL_QKV_FUSED, GL_GEMM_WIDE) to reach kernels the default selection does
+# not pick; the library reads them only with GL_DEV_SWITCHES=1 (csrc/common.h dev_env), decided at its first use in the process.
+os.environ.setdefault("GL_DEV_SWITCHES", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

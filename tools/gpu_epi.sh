@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 mkdir -p gpurun_out
 K=gligen_amd/build/kbench
 timeout 300 $K tools/unet_b8.shapes 10 - check > gpurun_out/kb_epi.txt 2>&1

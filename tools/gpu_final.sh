@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 # Round-end evidence: GPU tests, bench line, rocprofv3 kernel stats of the bench command, per-shape kbench tables
 export TMPDIR=/tmp
 R=$PWD

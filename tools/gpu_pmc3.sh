@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 # PMC passes (each in its own rocprofv3 run, --kernel-trace only) on single GEMM/conv shapes: v3 vs v5-wide
 export TMPDIR=/tmp
 mkdir -p gpurun_out/pmc4

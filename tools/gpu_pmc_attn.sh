@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 export TMPDIR=/tmp
 mkdir -p gpurun_out/pmc_attn
 K=$PWD/gligen_amd/build/kbench

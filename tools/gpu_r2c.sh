@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 # round 2, call C: kbench (bit/tolerance check against the v2 kernel) + GPU tests + in-situ profile + bench, after the in-kernel split-K reduce
 export TMPDIR=/tmp
 mkdir -p gpurun_out

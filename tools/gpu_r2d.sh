@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 # round 2, call D: spatial-modality tests first (new ConvNeXt path), then the whole GPU suite, a fresh GEMM autotune log (for the
 # shipped tile table) and the in-situ profile
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 # round 2, call F: fresh on-device autotune with the deep-ring candidates (kbench on the UNet shapes, tolerance-checked against the
 # v2 kernel) + the op-level GPU tests; the log feeds tools/make_tuned_table.py
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 # round 2, call G2: profile evidence -- per-shape kbench tables, in-situ per-problem table, rocprofv3 kernel stats of the bench
 # command, FETCH / WRITE PMC passes folded per symbol and per problem
 export TMPDIR=/tmp

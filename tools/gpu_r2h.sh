@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 # round 2, call H: chunk-major conv K order -- op tests, same-box A/B of the gather order (kbench, timing only), suite, in-situ,
 # bench, PMC traffic
 export TMPDIR=/tmp

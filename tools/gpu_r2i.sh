@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 # round 2, call I: conv gather with per-pixel tap masks (no per-tile coordinate rebuild) + in-kernel split-K fold (agent-scope
 # stores, ticket per tile): op tests, kbench conv / gemm A/B of the fold on one box, in-situ A/B, suite, bench
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 # round 2, call J: same-box A/B of (a) the conv K order (old tree = tap-major as of 181fed6; var_tapmajor = the new gather walked
 # tap-major, timing only) and (b) the depth up to which split-K partials are folded inside the GEMM
 export TMPDIR=/tmp

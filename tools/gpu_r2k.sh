@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 # round 2, call K: conv gather with 24-bit multiplies vs the tap-major tree (181fed6) on one box, op tests
 export TMPDIR=/tmp
 mkdir -p gpurun_out

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 # round 2, call L: whole-path A/B of the conv K order on one box -- bench.py + in-situ with the library built from the same tree
 # minus the K-order commit (var_tap: tap-major gather, weights packed to match) against the current one, alternating
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 # round 2, call O: halo kernel ablation (what bounds a tile: DMA, fragment reads, MFMAs)
 export TMPDIR=/tmp
 mkdir -p gpurun_out

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 # round 2, call Q: halo kernel v3 (activation fragments of the next tile read ahead, reads interleaved with the MFMA rows): 4 vs 8 waves
 export TMPDIR=/tmp
 mkdir -p gpurun_out

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 # round 2, call T: halo kernel K-split sweep (GL_CONV_HALO_SPLITS) per shape
 export TMPDIR=/tmp
 mkdir -p gpurun_out

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 # round 2, call V: K step 1 deferred by one tile in the persistent GEMM / conv kernel (all tiles but 128x160) against the same tree
 # built with -DGL_GEMM_DEFER_S1=0: kbench per class + check, op tests, then bench.py with the libraries swapped
 export TMPDIR=/tmp

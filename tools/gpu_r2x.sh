@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 # round 2, call X: wide GEMM kernel for the GEGLU projections -- op tests, whole-path A/B (GL_GEMM_WIDE=0 vs default), full suite
 export TMPDIR=/tmp
 mkdir -p gpurun_out

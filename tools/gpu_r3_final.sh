@@ -1,0 +1,39 @@
+#!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
+# round 3 evidence run: full GPU suite, bench lines of every BASELINE configuration (+ gate schedule, + one batch in flight),
+# per-shape kbench tables, in-situ per-problem table, rocprofv3 kernel stats of the bench command, FETCH / WRITE PMC passes folded
+# per symbol and per problem (attention launches included) -> gpurun_out/r3_final/ (copied to profiles/r3_final/)
+export TMPDIR=/tmp
+R=$PWD
+O=$R/gpurun_out/r3_final
+mkdir -p $O
+K=gligen_amd/build/kbench
+( timeout 1500 python -m pytest tests -m gpu -q ) > $O/pytest_gpu.log 2>&1
+echo "pytest rc=$?" >> $O/pytest_gpu.log
+grep -E "^FAILED|^ERROR|passed|failed|pytest rc" $O/pytest_gpu.log | cut -c1-250 | tee $O/pytest_gpu_summary.txt
+cp gpurun_out/parity_report.json gpurun_out/parity_report_configs.json $O/ 2>/dev/null
+( unset GL_DEV_SWITCHES; timeout 700 python bench.py > $O/bench.json 2> $O/bench.err )     # exactly the driver's command
+cut -c1-400 $O/bench.json; tail -2 $O/bench.err | cut -c1-200
+for c in C3 C4 C5; do
+  timeout 400 python bench.py --config $c --steps 2 --no-cpu-baseline > $O/bench_$c.json 2> $O/bench_$c.err
+  cut -c1-140 $O/bench_$c.json; tail -1 $O/bench_$c.err | cut -c1-200
+done
+timeout 400 python bench.py --alpha-type 0.3,0,0.7 --steps 2 --no-cpu-baseline > $O/bench_alpha.json 2> $O/bench_alpha.err
+cut -c1-140 $O/bench_alpha.json
+timeout 400 python bench.py --lanes 1 --steps 2 --no-cpu-baseline > $O/bench_l1.json 2> $O/bench_l1.err
+cut -c1-140 $O/bench_l1.json
+timeout 300 $K tools/unet_b8.shapes 10 - check > $O/kbench_unet.txt 2>&1
+grep "^TOTAL\|CHECK\|MISMATCH" $O/kbench_unet.txt | cut -c1-160
+timeout 300 $K tools/vae_b4.shapes 5 - check > $O/kbench_vae.txt 2>&1
+tail -3 $O/kbench_vae.txt
+timeout 300 python tools/insitu.py > $O/insitu_per_problem.txt 2> $O/insitu.err
+head -1 $O/insitu_per_problem.txt
+rm -rf gpurun_out/prof
+( cd /tmp && unset GL_DEV_SWITCHES && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -- python $R/bench.py --no-cpu-baseline ) > $O/prof.log 2>&1
+tail -2 $O/prof.log | cut -c1-300
+find gpurun_out/prof -name "*kernel_trace*" -delete
+cp $(find gpurun_out/prof -name "*kernel_stats*" | head -1) $O/bench_kernel_stats.csv
+head -12 $O/bench_kernel_stats.csv | cut -c1-200
+bash tools/gpu_traffic.sh > $O/traffic.log 2>&1
+tail -26 $O/traffic.log | cut -c1-220
+cp gpurun_out/pmc_traffic.csv gpurun_out/pmc_traffic_per_problem.csv $O/

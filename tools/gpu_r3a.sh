@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 # round 3, call A: pipelined d = 40 attention (attn2_kernel) -- op tests, per-shape A/B against the unpipelined kernel
 # (GL_ATTN_V2 = 0 / 1 / 2), VALU issue-cost microbenchmark, short path tests, whole-path bench A/B
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 # round 3, call B: where does attn2_kernel's time go? Ablations (GL_ATTN_DBG: 1 no DMA in the loop, 2 no barrier, 3 both, 4 exp2 -> mul,
 # 8 no MFMAs), ring depth / block size variants (GL_ATTN_V2 = 1: 4 waves x 2 slots, 2: 8 x 2, 3: 4 x 3, 4: 8 x 3), PMC passes
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 # round 3, call D: LayerNorms folded into their consumer GEMMs (row statistics from the producer's epilogue): parity suite + A/B
 export TMPDIR=/tmp
 O=$PWD/gpurun_out/r3d

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 # round 3, call E: fresh on-device autotune of every BASELINE configuration with the 64 x 64 tile candidate (4 workgroups per CU)
 # and the folded-LayerNorm problem keys -> logs for tools/make_tuned_table.py; A/B shipped table vs fresh tuning
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 # round 3, call F: op test of the folded LayerNorm, full GPU suite with the re-tuned tile table, bench
 export TMPDIR=/tmp
 O=$PWD/gpurun_out/r3f

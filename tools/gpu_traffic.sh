@@ -1,4 +1,5 @@
 #!/bin/bash
+export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
 # HBM-side traffic of the bench command: FETCH_SIZE and WRITE_SIZE in separate --pmc passes (--kernel-trace only; eager
 # launches: counter collection over hipGraph replays crashes rocprofv3 here), folded to per-launch means per kernel symbol
 # -> gpurun_out/pmc_traffic.csv, and per PROBLEM (symbol + M,N,K via the engine's launch log) -> gpurun_out/pmc_traffic_per_problem.csv

@@ -2,6 +2,7 @@
 """In-situ per-problem GEMM/conv times of one eager UNet evaluation (GL_PROF_SHAPES=1), to set against kbench's
 isolated per-shape table: which problems pay for cold weights / cold L2 inside the real forward."""
 import os, sys
+os.environ["GL_DEV_SWITCHES"] = "1"   # the library reads developer switches only with this set
 os.environ["GL_PROF_SHAPES"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

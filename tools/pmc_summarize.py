@@ -70,7 +70,7 @@ if log and per_problem:
     ctrs = sorted({c for v in prob.values() for c in v})
     with open(per_problem, "w", newline="") as fh:
         w = csv.writer(fh)
-        w.writerow(["kernel", "M", "N", "K", "mode(0 rows,1 conv3x3)", "dispatches", "algorithmic_bytes"] + [f"{c}_mean" for c in ctrs])
+        w.writerow(["kernel", "M", "N", "K", "mode(0 rows,1 conv3x3,2 attention: M=Nq N=Nk K=d)", "dispatches", "algorithmic_bytes"] + [f"{c}_mean" for c in ctrs])
         for key, v in sorted(prob.items(), key=lambda kv: -alg[kv[0]] * max(x[0] for x in kv[1].values())):
             n = max(x[0] for x in v.values())
             w.writerow(list(key) + [n, f"{alg[key]:.0f}"] + [f"{v[c][1] / v[c][0]:.3f}" if c in v else "" for c in ctrs])
