@@ -28,6 +28,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <unordered_map>
 
 namespace gl {
@@ -1886,8 +1887,16 @@ conv_halo_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
 // (hipcc runs the second K step's MFMAs behind the next barrier, as in the halo kernel). Against gemm_u_kernel's 128-row tiles
 // the weight tile is fetched once per 256 rows: 52 KB of LDS-DMA per 256x160x64 multiply instead of 72 KB. For the long-K,
 // wide-N problems (FF-out, the GEGLU projections of the 32x32 / 16x16 levels); whole tiles only (M % 256 == 0, N % BN == 0).
+// LDS ring depth of the wide kernel. 3 (two K tiles in flight, counted vmcnt wait) was built and measured: 3-5 % SLOWER than 2 on
+// every GEGLU projection (profiles/r3/wide_ring_kbench.txt) -- the K loop is not waiting for the fabric, it is sharing the LDS
+// port between 128 KB of fragment reads and 48 KB of DMA writes per tile next to 0.43 us of MFMAs. tools/build_variant.sh NAME
+// -DGL_WIDE_NST=3 rebuilds that arm.
+#ifndef GL_WIDE_NST
+#define GL_WIDE_NST 2
+#endif
 struct WideDesc {
     int tiles_n, splits, kt_per_split, n_items;
+    int xcd;   // 1: every XCD walks a contiguous range of the (tile_m, tile_n) order (see launch_wide)
 };
 
 template <int TN>
@@ -1900,6 +1909,7 @@ gemm_wide_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
     constexpr int WP = (BN + 63) / 64;          // weight DMA passes; the last one is partial when BN % 64 != 0
     constexpr int WREM = BN % 64;
     constexpr int STAGE = (BM + BN) * 128;
+    constexpr int NST = GL_WIDE_NST;            // LDS ring depth: NST - 1 K tiles in flight behind the one being multiplied
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -1927,7 +1937,15 @@ gemm_wide_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
     // ---- work item state
     int m0 = 0, c_tn = 0, c_z = 0;
     unsigned vx0 = 0, vx1 = 0, vw0 = 0;   // byte offsets of this lane's chunk of row (tile's first row + r0) in p0 / p1 / W; pass i adds 64 rows
-    auto setup = [&](int item) {
+    auto setup = [&](int item_) {
+        int item = item_;
+        if (wd.xcd) {
+            // block b sits on XCD b % 8 and the grid is a multiple of 8, so item & 7 is this workgroup's XCD: give every XCD a
+            // contiguous range of the (tile_m, tile_n) order -- the 32 workgroups of an XCD then walk the column tiles of the same
+            // one or two 256-row stripes together and the stripe crosses the fabric once, not once per XCD
+            const int q = wd.n_items >> 3, r = wd.n_items & 7, xcd = item & 7, idx = item >> 3;
+            item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
         const int tile = item / wd.splits;
         c_z = item - tile * wd.splits;
         const int tm = tile / wd.tiles_n;
@@ -2117,11 +2135,15 @@ gemm_wide_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
     constexpr int LNV = 5;
     float2 ln_v[LNV];
     float ln_s = 0.f, ln_q = 0.f;
+    auto ring_next = [](int s_) { return NST == 2 ? s_ ^ 1 : (s_ == NST - 1 ? 0 : s_ + 1); };
+    // DMA instructions one K tile costs this wave (the wait below leaves exactly one tile in flight)
+    const bool w_short = WREM && wave >= WREM / 8;
     auto begin_item = [&](int it) {
         setup(it);
         kt = c_z * wd.kt_per_split;
         kt_end = min(nk, kt + wd.kt_per_split);
         issue(kt, stg);
+        if (NST == 3 && kt + 1 < kt_end) issue(kt + 1, ring_next(stg));
         if (E.ln_stats) {
             const float2* src = E.ln_stats + (size_t)(m0 + (t >> 1)) * E.ln_ld;
             ln_s = ln_q = 0.f;
@@ -2139,21 +2161,36 @@ gemm_wide_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
     };
     begin_item(item);
     zero_acc();
-    bool pending = false;             // K step 1 of the previous tile of this item waits in xb / wb
-    for (;;) {
+    // one K tile: wait for it, barrier, send the tile NST - 1 ahead, multiply. An item's first tile is its own copy of the body
+    // (first = true): it drains the counter through the builtin -- the previous item's epilogue stores sit in the same counter as
+    // the DMA (loads and stores do not retire in order with each other), and hipcc then KNOWS that nothing is pending, the
+    // statistics prefetch of begin_item included; behind an asm wait its scoreboard would carry those loads around the K loop and
+    // drain in front of every register copy it places on the back edge. The other tiles leave the tile behind them in flight.
+    int stg_done = 0;
+    auto tile = [&](auto first_c) {
+        constexpr bool first = decltype(first_c)::value;
         stg = __builtin_amdgcn_readfirstlane(stg);
         kt = __builtin_amdgcn_readfirstlane(kt);
         kt_end = __builtin_amdgcn_readfirstlane(kt_end);
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this K tile has landed
+        if (NST == 3 && !first && kt + 1 < kt_end) {
+            if (w_short) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XP + WP - 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XP + WP) : "memory");
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + 1 < kt_end) issue(kt + 1, stg ^ 1);
-        compute(stg, pending);
-        pending = true;
-        stg ^= 1;
-        if (++kt < kt_end) continue;
+        if (NST == 3) { if (kt + 2 < kt_end) issue(kt + 2, ring_next(ring_next(stg))); }
+        else if (kt + 1 < kt_end) issue(kt + 1, stg ^ 1);
+        compute(stg, !first);
+        stg_done = stg;
+        stg = ring_next(stg);
+        ++kt;
+    };
+    for (;;) {
+        tile(std::true_type{});
+        while (kt < kt_end) tile(std::false_type{});
         finish();
-        pending = false;
         // item done: start the next item's first tile (into the stage the last tile was not read from), then store
         const int done_m0 = m0, done_tn = c_tn, done_z = c_z;
         float done_s = ln_s, done_q = ln_q;
@@ -2169,7 +2206,7 @@ gemm_wide_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
             if (E.ln_stats && wd.splits == 1) {
                 // folded LayerNorm: (mean, rstd) of the finished item's 256 rows from the producer's partial sums, into the stage the
                 // last K tile was read from (free until the DMA behind the next barrier); two threads per row, fixed summation order
-                float2* l = reinterpret_cast<float2*>(smem + (stg ^ 1) * STAGE);
+                float2* l = reinterpret_cast<float2*>(smem + stg_done * STAGE);
                 __builtin_amdgcn_s_barrier();          // every wave is done with that stage's fragments
                 const int row = t >> 1, part = t & 1;
                 float s = done_s, qq = done_q;
@@ -2414,10 +2451,19 @@ int launch_wide(const AOperand& A, const bf16* W, int M, int N, int K, const Epi
     wd.kt_per_split = cdiv(nk, sp);
     wd.splits = cdiv(nk, wd.kt_per_split);
     wd.n_items = tiles * wd.splits;
+    // Item order against the 8 XCD L2s (profiles/r3/wide_ring_kbench.txt, per-problem fabric traffic in profiles/r3_final/).
+    // Linear order with tiles_n a multiple of 8 is weight-stationary by accident: XCD x only ever sees the column tiles = x mod 8,
+    // an eighth of the weight matrix stays in its L2 and the activations cross the fabric 8 times -- the cheaper side when the
+    // weights are the larger operand (32x32 / 16x16 levels: 6.5 / 26 MB of weights against 10 / 5 MB of activations; contiguous
+    // ranges measured 7-8 % slower there). At 64x64 (tiles_n = 20, 1.6 MB of weights, 21 MB of activations) linear order sends
+    // every stripe to every XCD for nothing: contiguous ranges are 4-5 % faster.
+    static const char* xcd_env = dev_env("GL_WIDE_XCD");
+    wd.xcd = xcd_env ? atoi(xcd_env) : (wd.tiles_n % 8 != 0 && wd.n_items >= 512);
+    if (wd.n_items < 256 || std::min(wd.n_items, 256) % 8) wd.xcd = 0;
     g_last_cfg[0] = 8; g_last_cfg[1] = tn; g_last_cfg[2] = wd.splits;
     snprintf(g_last_name, sizeof g_last_name, "gemm_wide_kernel<%d>%s", tn, wd.splits > 1 ? " + splitk_reduce_kernel" : "");
     dim3 grid(std::min(wd.n_items, 256)), block(512);
-    const size_t lds = 2 * (256 + bn) * 128;
+    const size_t lds = GL_WIDE_NST * (256 + bn) * 128;
 #define GL_LAUNCH_WIDE(KFN)                                                                                      \
     do {                                                                                                         \
         auto kfn = KFN;                                                                                          \
