@@ -36,6 +36,8 @@ struct Epilogue {
     const float* bias2; // [M / rows_per_b][bias2_ld] broadcast over the rows of one sample
     int bias2_ld;
     int rows_per_b;
+    unsigned rpb_magic; // m / rows_per_b without a divide: (umulhi(m, rpb_magic) + m) >> rpb_shift for 0 <= m < 2^31 (gemm_launch fills both)
+    int rpb_shift;
     const bf16* res;    // residual [M][ldres]
     int ldres;
     const float* gate;  // optional device scalar: out = res + gate * v

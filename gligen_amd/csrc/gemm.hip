@@ -38,6 +38,7 @@ void epilogue_defaults(Epilogue& E) {
     E.mode = EPI_ROWMAJOR;
     E.act = ACT_NONE;
     E.rows_per_b = 1;
+    E.rpb_magic = 1; E.rpb_shift = 0;
 }
 
 void aoperand_rows(AOperand& A, const bf16* p, int K, int ld) {
@@ -65,13 +66,19 @@ __device__ __forceinline__ void store_bf16x4(bf16* dst, const float v[4]) {
     *reinterpret_cast<uint2*>(dst) = o.u;
 }
 
+// m / E.rows_per_b through the multiplier gemm_launch prepared (round-up method: shift = ceil(log2 d), magic = floor(2^32 (2^shift - d) / d) + 1).
+// A per-lane "/" by a kernel argument makes hipcc build the reciprocal in VGPRs in front of the K loop and keep it there.
+__device__ __forceinline__ int div_rpb(const Epilogue& E, int m) {
+    return (int)((__umulhi((unsigned)m, E.rpb_magic) + (unsigned)m) >> E.rpb_shift);
+}
+
 __device__ __forceinline__ void epi_finish4(const Epilogue& E, int m, int n0, float v[4]) {
     if (E.bias) {
         float4 b = *reinterpret_cast<const float4*>(E.bias + n0);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
     }
     if (E.bias2) {
-        int bb = m / E.rows_per_b;
+        int bb = div_rpb(E, m);
         float4 b = *reinterpret_cast<const float4*>(E.bias2 + (size_t)bb * E.bias2_ld + n0);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
     }
@@ -124,7 +131,7 @@ __device__ __forceinline__ void epi_finish4(const Epilogue& E, int m, int n0, fl
             break;
         }
         case EPI_NCHW_F32: {
-            int b = m / E.rows_per_b;
+            int b = div_rpb(E, m);
             int pix = m - b * E.rows_per_b;
             float* o = reinterpret_cast<float*>(E.out);
 #pragma unroll
@@ -184,7 +191,7 @@ __device__ __forceinline__ void epi_store4(const Epilogue& E, int m, int n0, flo
             break;
         }
         case EPI_NCHW_F32: {
-            int b = m / E.rows_per_b;
+            int b = div_rpb(E, m);
             int pix = m - b * E.rows_per_b;
             float* o = reinterpret_cast<float*>(E.out);
 #pragma unroll
@@ -482,7 +489,6 @@ struct WorkDesc {
     // rm x tiles_n x rz box (tiles_n = N tiles PER BOX then), so that an activation panel is fetched by 2^lgn L2s and a
     // weight panel by 2^lgm (the K axis duplicates nothing). rz = splits when box < 0.
     int box, rm, rz;
-    int dbg;  // developer ablation (GL_GEMM_DBG): bit 0 = skip the DMA, bit 1 = skip the MFMAs, bit 2 = skip the epilogue (results are garbage), bit 3 = fragment-layout epilogue stores
 };
 
 template <int TM, int TN, int AMODE>
@@ -700,26 +706,17 @@ gemm_p_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
 }
 
 // ---------------------------------------------------------------------------------------------
-// v5 (unified persistent kernel, variant 4). Two geometries of the same code:
-//   WMW = 4: 8 waves (4 M x 2 N), 256 x (TN*32) tile, THREE LDS stages, one workgroup per CU
-//   WMW = 2: 4 waves (2 M x 2 N), (TM*32) x (TN*32) tile, two LDS stages, two workgroups per CU
+// v5 (unified persistent kernel, variant 4): 4 waves (2 M x 2 N), (TM*32) x (TN*32) tile, two LDS stages, two to four workgroups
+// per CU. (Rounds 1-2 carried an 8-wave / three-stage geometry and a four-stage ring at one workgroup per CU in the same code;
+// both lost every A/B and every autotune, DESIGN.md section 4, and were taken out in round 3.)
 // What changed against v3/v4 is the loader. PMC showed v3 spending ~300 VALU/SALU instructions per
 // K tile per wave on 64-bit DMA source addresses against 20-40 MFMAs (SQ_ACTIVE_INST_ANY ~ the
-// whole budget of a wave, MFMA pipe 28 % busy), so:
-//   * both operands are fetched with buffer_load_dwordx4 ... lds through wave-uniform buffer
-//     descriptors: the per-lane byte offset (row, swizzled 16-byte chunk) is computed once per
-//     work item (conv: once per filter tap), the K-tile offset rides in the SGPR soffset, and a
-//     DMA costs one s_mov m0 + one buffer_load. Rows outside M / N and conv padding taps use an
-//     offset beyond num_records, for which the hardware returns zeros.
-//   * (WMW = 4) two K tiles are in flight behind the one being multiplied and the main loop only
-//     waits with COUNTED vmcnt (raw s_barrier, one per K tile):
-//       top(c): vmcnt(NI) -> s_barrier -> DMA of tile c+2 into slot (c+2)%3 -> MFMAs on slot c%3
-//     Every wave issues exactly NI DMAs per tile (a partial last weight pass is padded with an
-//     out-of-range DMA into a dump area), so one immediate count is right for all waves. vmcnt also
-//     counts the epilogue's stores; outstanding stores can only make a counted wait stricter (DMA
-//     loads retire in order among themselves). At an item's last K tile the next DMA is issued
-//     AFTER the epilogue (whose bias/residual loads would otherwise drain the in-order counter
-//     through a freshly issued tile); tile c+1, drained there, is not waited for again.
+// whole budget of a wave, MFMA pipe 28 % busy), so both operands are fetched with
+// buffer_load_dwordx4 ... lds through wave-uniform buffer descriptors: the per-lane byte offset
+// (row, swizzled 16-byte chunk) is computed once per work item (conv: once per filter tap), the
+// K-tile offset rides in the SGPR soffset, and a DMA costs one s_mov m0 + one buffer_load. Rows
+// outside M / N and conv padding taps use an offset beyond num_records, for which the hardware
+// returns zeros.
 // LDS fragment reads in inline asm. hipcc cannot tell that a ds_read of one ring slot does not alias the LDS-DMA
 // just issued into another, so with compiler-visible LDS loads it puts s_waitcnt vmcnt(0) in front of the first
 // ds_read after every DMA issue: the "prefetch" is drained before the multiply it should run under (seen in the
@@ -751,24 +748,18 @@ __device__ __forceinline__ void pin_regs(bf16x8 (&d)[N]) {
 
 // QKV (EPI_QKV_HEADS, A_ROWS only): its own instantiations, so that the other kernels' register allocation is untouched
 template <int WMW, int TM, int TN, int AMODE, int NST, bool QKV = false>
-__global__ void __launch_bounds__(WMW * 128, (WMW == 2 && NST > 2) ? 1 : 2)
+__global__ void __launch_bounds__(WMW * 128, 2)
 gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilogue E, float* __restrict__ ws, WorkDesc wd) {
     constexpr int NT = WMW * 128;               // threads
     constexpr int RPP = NT / 8;                 // tile rows per DMA pass (one 128-byte row per 8 lanes)
     constexpr int BM = WMW * TM * 16;
     constexpr int BN = TN * 32;
     constexpr int XP = BM / RPP;                // activation passes
-    constexpr int WPF = BN / RPP;               // full weight passes
-    constexpr int WREM = BN % RPP;              // rows of the partial last weight pass (issued by the first WREM/8 waves)
-    constexpr int WP = WPF + (WREM ? 1 : 0);
-    constexpr int NI = XP + WP;                 // DMA wave-instructions per wave per K tile
-    // NST = LDS stages: 2 (two 4-wave workgroups per CU hide each other's DMA latency), 3 (8 waves), or 4 with 4 waves
-    // and ONE workgroup per CU: three K tiles in flight, for the small-M problems whose K loop is a latency chain
-    constexpr int AHEAD = NST - 1;              // K tiles in flight ahead of the one being multiplied
-    constexpr int STAGE = (BM + BN) * 128;
-    constexpr int DUMP = NST * STAGE;
+    constexpr int WP = BN / RPP;                // weight passes
+    constexpr int STAGE = (BM + BN) * 128;      // two stages: the two (to four) 4-wave workgroups of a CU hide each other's DMA latency
     constexpr unsigned SENT = 0x80000000u;      // >= num_records of every descriptor: reads as zeros
-    static_assert(BM % RPP == 0 && WREM % 8 == 0, "tile/loader mismatch");
+    static_assert(WMW == 2 && NST == 2, "one geometry: 4 waves, two LDS stages (deeper rings and the 8-wave form lost every A/B, DESIGN.md section 4)");
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/loader mismatch");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -858,8 +849,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
 #pragma unroll
         for (int i = 0; i < WP; ++i) {
             const int n = tn * BN + r0 + i * RPP;
-            const bool in_tile = !(WREM && i == WP - 1) || wave < WREM / 8;
-            vw[i] = (in_tile && n < N) ? (unsigned)(n * K) * 2u + chb : SENT;
+            vw[i] = (n < N) ? (unsigned)(n * K) * 2u + chb : SENT;
         }
         const int k0 = l_kt << 6;
         if constexpr (AMODE == A_ROWS) {
@@ -884,7 +874,6 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
         unsigned char* wsm = xs + BM * 128;
         const bool first = l_cc < A.C0;
         const int soff = (first ? l_cc : l_cc - A.C0) * 2;
-        if (!(wd.dbg & 1)) {
         if (first) {
 #pragma unroll
             for (int i = 0; i < XP; ++i) GL_BLDS16(ra0, xs + i * RPP * 128, va[i], soff);
@@ -894,11 +883,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
         }
         const int woff = l_kt << 7;
 #pragma unroll
-        for (int i = 0; i < WP; ++i) {
-            unsigned char* dst = (WREM && i == WP - 1 && wave >= WREM / 8) ? smem + DUMP : wsm + i * RPP * 128;
-            GL_BLDS16(rw, dst, vw[i], woff);
-        }
-        }
+        for (int i = 0; i < WP; ++i) GL_BLDS16(rw, wsm + i * RPP * 128, vw[i], woff);
         // advance
         l_cc += 64;
         if (++l_kt >= l_kt_end) {
@@ -1162,14 +1147,14 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = mrow + i * 16;
-            mo[i] = (E.mode == EPI_ROWMAJOR && E.remap_in) ? (m / E.remap_in) * E.remap_out + (m % E.remap_in) + E.remap_off : m;
+            mo[i] = (AMODE == A_ROWS && E.mode == EPI_ROWMAJOR && E.remap_in) ? (m / E.remap_in) * E.remap_out + (m % E.remap_in) + E.remap_off : m;
         }
         if (E.bias2) {  // + broadcast per-sample bias (ResBlock time embedding); never combined with a residual
             float4 b2[TM][TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int m = mrow + i * 16;
-                const int bb = m / E.rows_per_b;
+                const int bb = div_rpb(E, m);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int n0 = ncol + j * 16;
@@ -1192,7 +1177,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
             }
         } else if (E.mode == EPI_ROWMAJOR && E.res) {
             uint2 rs[TM][TN];
-            const float g = E.gate ? *E.gate : 1.f;
+            const float g = (AMODE == A_ROWS && E.gate) ? *E.gate : 1.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int m = mrow + i * 16;
@@ -1319,12 +1304,12 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
             bj[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (E.bias && n0 < N) bj[j] = *reinterpret_cast<const float4*>(E.bias + n0);
         }
-        const float g = E.gate ? *E.gate : 1.f;
+        const float g = (AMODE == A_ROWS && E.gate) ? *E.gate : 1.f   /* (gate and row remap exist for row GEMMs only: gemm_launch rejects them on a conv) */;
         auto out_row = [&](int i, int k) {  // output row of read instruction k of fragment row i, or -1
             const int r = k * RPI + rr;
             const int m = mrow + i * 16 + r;
             if (!(col_ok && r < 16 && m < M)) return -1;
-            return E.remap_in ? (m / E.remap_in) * E.remap_out + (m % E.remap_in) + E.remap_off : m;
+            return (AMODE == A_ROWS && E.remap_in) ? (m / E.remap_in) * E.remap_out + (m % E.remap_in) + E.remap_off : m;
         };
         // the residual is prefetched for two fragment rows at a time (register budget); the second pair's loads queue behind
         // the first pair's stores, one extra store round trip per work item instead of one per fragment
@@ -1351,7 +1336,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
                 if (E.bias2) {
                     const int n0 = ncb + j * 16 + (lane >> 4) * 4;
                     if (mf < M && n0 < N) {
-                        const float4 b2 = *reinterpret_cast<const float4*>(E.bias2 + (size_t)(mf / E.rows_per_b) * E.bias2_ld + n0);
+                        const float4 b2 = *reinterpret_cast<const float4*>(E.bias2 + (size_t)div_rpb(E, mf) * E.bias2_ld + n0);
                         v.x += b2.x; v.y += b2.y; v.z += b2.z; v.w += b2.w;
                     }
                 }
@@ -1409,8 +1394,6 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
         return true;
     };
 
-#define GL_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-
     if (l_item >= wd.n_items) return;
     setup_load(l_item);
     int c_item = l_item, c_tm, c_tn, c_z;
@@ -1420,67 +1403,34 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
         if (E.ln_stats) ln_fetch(c_tm);
     }
     int c_left = l_kt_end - l_kt;
-    int ahead = 0;       // tiles issued and not yet multiplied (including the one about to be)
-    int slot_i = 0;      // ring slot of the next issue
-    int slot_c = 0;      // ring slot of the tile being multiplied
-    auto issue_one = [&]() {
-        issue_next(slot_i);
-        slot_i = slot_i == NST - 1 ? 0 : slot_i + 1;
-        ++ahead;
-    };
-#pragma unroll
-    for (int i = 0; i < AHEAD; ++i)
-        if (more) issue_one();
-    int landed = 0;  // upcoming tiles known to have landed already (drained before the previous epilogue)
+    int slot_c = 0;      // ring slot of the tile being multiplied; the next tile's DMA goes into the other one
+    if (more) issue_next(slot_c);
     for (;;) {
-        ahead = __builtin_amdgcn_readfirstlane(ahead);
         c_left = __builtin_amdgcn_readfirstlane(c_left);
         slot_c = __builtin_amdgcn_readfirstlane(slot_c);
         more = __builtin_amdgcn_readfirstlane((int)more) != 0;
-        landed = __builtin_amdgcn_readfirstlane(landed);
-        if constexpr (AHEAD == 1) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): unconditional, so that hipcc knows it (see below)
-        } else if (landed > 0) {
-            --landed;
-        } else {
-            // tile c must have landed; the ahead - 1 tiles issued after it may stay in flight (DMA loads retire in order)
-            const int keep = ahead - 1;
-            if (AHEAD >= 4 && keep >= 3) GL_VMCNT(3 * NI);
-            else if (AHEAD >= 3 && keep == 2) GL_VMCNT(2 * NI);
-            else if (AHEAD >= 2 && keep == 1) GL_VMCNT(NI);
-            // full drain through the builtin: hipcc then KNOWS nothing is pending. With an asm wait its scoreboard still
-            // carries the epilogue's bias/residual loads (whose destination VGPRs the fragments reuse) around the loop and
-            // it re-waits vmcnt(0) in front of the first fragment register write, i.e. right after the next DMA issue.
-            else __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), gfx9 encoding
-        }
+        // vmcnt(0), unconditional and through the builtin so that hipcc KNOWS nothing is pending: behind an asm wait its scoreboard
+        // carries the epilogue's bias / residual loads (whose destination VGPRs the fragments reuse) around the loop and it re-waits
+        // vmcnt(0) in front of the first fragment register write, i.e. right after the next DMA issue
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         // tile c is in LDS for every wave after this barrier, and every wave has finished reading tile c-1
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const bool last = c_left == 1;
-        const bool defer = AHEAD >= 2 && last;
-        if (!defer && more) issue_one();
-        if (!(wd.dbg & 2)) compute(slot_c, c_swap);
+        if (more) issue_next(slot_c ^ 1);
+        compute(slot_c, c_swap);
         const int slot_done = slot_c;
-        slot_c = slot_c == NST - 1 ? 0 : slot_c + 1;
-        --ahead;
+        slot_c ^= 1;
         if (--c_left == 0) {
-            if constexpr (AHEAD >= 2) {
-                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): tiles c+1 .. c+AHEAD-1 (issued 1+ K tiles ago) have landed now
-                landed = min(ahead, AHEAD - 1);
-            }
-            if (!(wd.dbg & 4)) {
-                if constexpr (QKV) {
-                    // folded LayerNorm (the head-layout epilogues, unsplit by construction): row statistics first
-                    const float2* lst = E.ln_stats ? ln_prepare(c_tm, slot_done) : nullptr;
-                    if (c_swap) epilogue_vt(c_tm, c_tn, lst);
-                    else epilogue_qk(c_tm, c_tn, lst);
-                } else {
-                    if ((wd.dbg & 8) || !epilogue_staged(c_tm, c_tn, slot_done)) epilogue(c_tm, c_tn, c_z);  // dbg 8: fragment-layout stores
-                }
+            if constexpr (QKV) {
+                // folded LayerNorm (the head-layout epilogues, unsplit by construction): row statistics first
+                const float2* lst = E.ln_stats ? ln_prepare(c_tm, slot_done) : nullptr;
+                if (c_swap) epilogue_vt(c_tm, c_tn, lst);
+                else epilogue_qk(c_tm, c_tn, lst);
+            } else {
+                if (!epilogue_staged(c_tm, c_tn, slot_done)) epilogue(c_tm, c_tn, c_z);
             }
             c_item += gridDim.x;
             if (c_item >= wd.n_items) break;
-            if (defer && more) issue_one();
             zero_acc();
             decode(c_item, c_tm, c_tn, c_z);
             c_swap = QKV && c_tn * BN >= 2 * E.C;
@@ -1490,7 +1440,6 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
             c_left = min(nk, (c_z + 1) * wd.kt_per_split) - c_z * wd.kt_per_split;
         }
     }
-#undef GL_VMCNT
 }
 
 // (mean, rstd) of row m from the producer's partial sums (Epilogue::ln_stats), fixed summation order
@@ -1773,7 +1722,7 @@ conv_halo_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int m = mrow + i * 16;
-                const float* b2p = E.bias2 + (size_t)(m / E.rows_per_b) * E.bias2_ld + ncol;
+                const float* b2p = E.bias2 + (size_t)div_rpb(E, m) * E.bias2_ld + ncol;
                 float4 b2[TN];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b2[j] = *reinterpret_cast<const float4*>(b2p + j * 16);
@@ -2319,11 +2268,10 @@ template <int WMW, int TM, int TN, int NST>
 int launch_u(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, float* ws, const WorkDesc& wd,
              hipStream_t stream) {
     constexpr int NT = WMW * 128, RPP = NT / 8, BM = WMW * TM * 16, BN = TN * 32;
-    const int cap_def = (WMW == 4 || NST > 2) ? 256 : 512;  // workgroups resident per launch: 1 or 2 per CU
-    const int cap = (g_force_grid && ((WMW == 2 && NST == 2) || g_force_grid < 256)) ? g_force_grid : cap_def;
+    const int cap = g_force_grid ? g_force_grid : 512;   // workgroups resident per launch: two per CU unless the tuner says otherwise
     dim3 grid(wd.n_items < cap ? wd.n_items : cap);
     dim3 block(NT);
-    const size_t lds = NST * (BM + BN) * 128 + (BN % RPP ? 1024 : 0);
+    const size_t lds = NST * (BM + BN) * 128;
 #define GL_LAUNCH_U(KFN)                                                                                         \
     do {                                                                                                         \
         auto kfn = KFN;                                                                                          \
@@ -2337,7 +2285,7 @@ int launch_u(const AOperand& A, const bf16* W, int M, int N, int K, const Epilog
     if (E.mode == EPI_QKV_HEADS || (E.mode == EPI_QK_HEADS && E.ln_stats)) {
         // (the 128 x 160 tile is not built for QKV: with the second MFMA form it needs more than 256 registers)
         // q-only / q,k projections behind a folded LayerNorm run here too: these instantiations hold the statistics code
-        if constexpr ((TM == 4 && TN == 5) || NST != 2) return set_error(GL_ERR_UNSUPPORTED, "gemm: no 128x160 / deep-ring tile for EPI_QKV_HEADS");
+        if constexpr (TM == 4 && TN == 5) return set_error(GL_ERR_UNSUPPORTED, "gemm: no 128x160 tile for EPI_QKV_HEADS");
         else GL_LAUNCH_U((gemm_u_kernel<WMW, TM, TN, A_ROWS, NST, true>));
     } else if (A.mode == A_ROWS) GL_LAUNCH_U((gemm_u_kernel<WMW, TM, TN, A_ROWS, NST>));
     else GL_LAUNCH_U((gemm_u_kernel<WMW, TM, TN, A_CONV3, NST>));
@@ -2509,7 +2457,6 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
     const size_t a_rows = A.mode == A_CONV3 ? (size_t)(M / (A.Ho * A.Wo)) * A.Hin * A.Win : (size_t)M;
     const bool fits32 = a_rows * (size_t)std::max(A.ld0, A.ld1) * 2 < 0x7fff0000ull && (size_t)N * K * 2 < 0x7fff0000ull;
     const bool use_u = gemm_variant() == 4 && fits32 && !(E.bias2 && E.res);  // v5's epilogue has no bias2 + residual form
-    static const int dbg = dev_env("GL_GEMM_DBG") ? atoi(dev_env("GL_GEMM_DBG")) : 0;
     // eligible 3x3 convs with M >= 256 * GL_CONV_HALO (default 8; 0 = never) go to the halo kernel (GL_CONV_HALO_SPLITS=n forces its
     // K split): at M = 512 (the 8 x 8 level) its 16 tiles x deep split lose to the 64 x 160 tiles of the kernel above
     static const int halo = dev_env("GL_CONV_HALO") ? atoi(dev_env("GL_CONV_HALO")) : 8;
@@ -2538,7 +2485,6 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
     };
     auto run_cfg = [&](int c, int sp, int grid_cap) -> int {
         WorkDesc wd;
-        wd.dbg = dbg;
         const int tm = kTm[c], tn = kTn[c];
         wd.tiles_n = cdiv(N, tn * 32);
         wd.kt_per_split = cdiv(nk, sp);
@@ -2566,7 +2512,7 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
         // row statistics for a folded LayerNorm downstream: only the staged row-major epilogue of gemm_u_kernel produces them
         // (one partial per row and wave column block of tn * 16 columns)
         g_last_stats_nb = (E.stats_out && use_u && wd.splits == 1 && A.mode == A_ROWS && E.mode == EPI_ROWMAJOR && !E.out_f32 && E.act != ACT_GEGLU &&
-                           E.act != ACT_GELU && N % (tn * 16) == 0 && N / (tn * 16) <= E.stats_ld && !(dbg & 8))
+                           E.act != ACT_GELU && N % (tn * 16) == 0 && N / (tn * 16) <= E.stats_ld)
                               ? N / (tn * 16) : 0;
         if (E.ln_stats && (!use_u || A.mode != A_ROWS || wd.splits > 1 || (tm == 4 && tn == 5) || (E.mode != EPI_QKV_HEADS && E.mode != EPI_QK_HEADS)))
             return set_error(GL_ERR_UNSUPPORTED, "gemm: the folded-LayerNorm epilogue exists for the head layouts of gemm_u_kernel and the GEGLU form of gemm_wide_kernel");
@@ -2736,9 +2682,18 @@ bool gemm_ln_fold_supported(const AOperand& A, int M, int N, int K, const Epilog
     return E.mode == EPI_QKV_HEADS || E.mode == EPI_QK_HEADS;
 }
 
-int gemm_launch(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, float* ws,
+int gemm_launch(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E_in, float* ws,
                 size_t ws_bytes, hipStream_t stream) {
     g_last_stats_nb = 0;
+    Epilogue E = E_in;
+    if (E.rows_per_b < 1) return set_error(GL_ERR_ARG, "gemm: rows_per_b=%d", E.rows_per_b);
+    {   // divide-free m / rows_per_b for the epilogues (div_rpb)
+        const unsigned d = (unsigned)E.rows_per_b;
+        int sh = 0;
+        while ((1ull << sh) < d) ++sh;
+        E.rpb_shift = sh;
+        E.rpb_magic = (unsigned)((((1ull << sh) - d) << 32) / d + 1);
+    }
     if (M <= 0 || N <= 0 || K <= 0) return set_error(GL_ERR_ARG, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
     if (E.ln_stats && (!E.ln_csum || !E.bias || E.ln_nb < 1 || E.ln_ld < E.ln_nb || !gemm_ln_fold_supported(A, M, N, K, E)))
         return set_error(GL_ERR_UNSUPPORTED, "gemm: folded LayerNorm needs csum + folded bias + statistics, and an epilogue that applies them");
@@ -2751,6 +2706,8 @@ int gemm_launch(const AOperand& A, const bf16* W, int M, int N, int K, const Epi
         if (K != A.C0 + A.C1 || (A.C1 && A.C0 % 64 != 0))
             return set_error(GL_ERR_ARG, "gemm: K=%d does not match operand channels (%d,%d)", K, A.C0, A.C1);
     }
+    if (A.mode == A_CONV3 && (E.gate || E.remap_in))
+        return set_error(GL_ERR_UNSUPPORTED, "conv3x3: the gated residual and the row remap are row-GEMM epilogues");
     if (E.act == ACT_GELU && (E.res || E.bias2 || A.mode != A_ROWS))
         return set_error(GL_ERR_UNSUPPORTED, "gemm: the GELU epilogue has no residual / broadcast-bias form");
     if (E.act == ACT_GEGLU && (N % 32 != 0 || E.mode != EPI_ROWMAJOR))
