@@ -140,6 +140,9 @@ def test_conv3x3(engine, cfg):
 @pytest.mark.parametrize("B,HW,C0,C1,silu,eps", [
     (2, 256, 320, 0, True, 1e-5), (2, 1024, 128, 0, True, 1e-6), (1, 4096, 640, 320, True, 1e-5),
     (3, 64, 1280, 1280, False, 1e-6), (2, 4, 1280, 0, True, 1e-5), (1, 16384, 256, 0, True, 1e-6),
+    # the benchmark's own shapes (batch 8 = 4 prompts x [cond ; uncond]) at the 64x64 / 32x32 levels, and the VAE mid block
+    (8, 4096, 320, 0, True, 1e-5), (8, 1024, 640, 0, True, 1e-5), (8, 1024, 320, 0, False, 1e-5), (8, 1024, 640, 320, True, 1e-5),
+    (4, 4096, 512, 0, True, 1e-6),
 ])
 def test_groupnorm(engine, B, HW, C0, C1, silu, eps):
     x0 = bf(rnd(B, HW, C0, seed=1) * 2 + 0.5)
