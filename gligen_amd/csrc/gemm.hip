@@ -736,6 +736,9 @@ __device__ __forceinline__ void lds_rd16_n(bf16x8 (&d)[N], unsigned addr) {
         lds_rd16_n<N, STRIDE, I + 1>(d, addr);
     }
 }
+// "this value has arrived": an empty asm that reads (and re-defines) a loaded value makes hipcc place the wait for it HERE, once,
+// instead of in every guarded block that uses it later
+__device__ __forceinline__ void epi_ready(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 template <int N>
 __device__ __forceinline__ void pin_regs(bf16x8 (&d)[N]) {
 #pragma unroll
@@ -1012,19 +1015,40 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
     };
 
     // q / k scatter of a QKV item outside the V third (the EPI_QK_HEADS store, no residual forms; a bias only with the folded LayerNorm)
+    // Both head-layout epilogues fetch every coefficient (bias, csum, row statistics) BEFORE their first store and make hipcc wait
+    // for them right there (epi_ready): vmcnt counts stores too, so a coefficient load between stores -- or a wait the compiler
+    // re-inserts in every guarded block because the guard's other path has not waited -- makes each store wait for the
+    // acknowledgement of the one before it (28 of the 32 stores of an item did, round 3).
     auto epilogue_qk = [&](int tm, int tn, const float2* lst) {
         const int mrow = tm * BM + wm * TM * 16 + l15;
         const int ncol = tn * BN + wn * TN * 16 + (lane >> 4) * 4;
         float2 st[TM];
+        int rb[TM], rt[TM];   // sample and token of this lane's row in each row block
 #pragma unroll
-        for (int i = 0; i < TM; ++i) st[i] = lst ? lst[wm * TM * 16 + i * 16 + l15] : make_float2(0.f, 1.f);
+        for (int i = 0; i < TM; ++i) {
+            st[i] = lst ? lst[wm * TM * 16 + i * 16 + l15] : make_float2(0.f, 1.f);
+            const int m = mrow + i * 16;
+            rb[i] = m / E.T;
+            rt[i] = m - rb[i] * E.T;
+        }
+        float4 cs[TN], bj[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n0 = ncol + j * 16;
+            cs[j] = bj[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n0 < N) {
+                if (lst) cs[j] = *reinterpret_cast<const float4*>(E.ln_csum + n0);
+                if (E.bias) bj[j] = *reinterpret_cast<const float4*>(E.bias + n0);   // (W beta of a folded LayerNorm, with or without statistics)
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { epi_ready(cs[j]); epi_ready(bj[j]); }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(st[i].x), "+v"(st[i].y));
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n0 = ncol + j * 16;
             if (n0 >= N) continue;
-            float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), bj = cs;
-            if (lst) cs = *reinterpret_cast<const float4*>(E.ln_csum + n0);
-            if (E.bias) bj = *reinterpret_cast<const float4*>(E.bias + n0);   // (W beta of a folded LayerNorm, with or without statistics)
             const int which = n0 >= E.C;
             const int cc = n0 - which * E.C;
             const int h = cc / E.d;
@@ -1034,12 +1058,10 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
             const bool tiled = which || E.q_tiled;   // keys: key-tile layout (gemm.h ktile_off)
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int m = mrow + i * 16;
-                if (m >= M) continue;
-                const int b = m / E.T;
-                const int t = m - b * E.T;
-                float v[4] = {st[i].y * (acc[i][j][0] - st[i].x * cs.x) + bj.x, st[i].y * (acc[i][j][1] - st[i].x * cs.y) + bj.y,
-                              st[i].y * (acc[i][j][2] - st[i].x * cs.z) + bj.z, st[i].y * (acc[i][j][3] - st[i].x * cs.w) + bj.w};
+                if (mrow + i * 16 >= M) continue;
+                const int b = rb[i], t = rt[i];
+                float v[4] = {st[i].y * (acc[i][j][0] - st[i].x * cs[j].x) + bj[j].x, st[i].y * (acc[i][j][1] - st[i].x * cs[j].y) + bj[j].y,
+                              st[i].y * (acc[i][j][2] - st[i].x * cs[j].z) + bj[j].z, st[i].y * (acc[i][j][3] - st[i].x * cs[j].w) + bj[j].w};
                 const size_t off = tiled ? ktile_off((size_t)(b * E.H + h), tp, t, dd, E.DP) : ((size_t)(b * E.H + h) * tp + t) * E.DP + dd;
                 store_bf16x4(base + off, v);
             }
@@ -1051,6 +1073,27 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
     auto epilogue_vt = [&](int tm, int tn, const float2* lst) {
         const int nfeat = tn * BN + wn * TN * 16 + l15;
         const int mtok = tm * BM + wm * TM * 16 + (lane >> 4) * 4;
+        float csv[TN], bnv[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = nfeat + j * 16;
+            csv[j] = (lst && n < N) ? E.ln_csum[n] : 0.f;
+            bnv[j] = (E.bias && n < N) ? E.bias[n] : 0.f;
+        }
+        float4 s01[TM], s23[TM];   // (mean, rstd) of the lane's four tokens of each row block: rows (wm TM + i) 16 + 4 q .. + 3 of the item
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            s01[i] = make_float4(0.f, 1.f, 0.f, 1.f);
+            s23[i] = s01[i];
+            if (lst) {
+                s01[i] = *reinterpret_cast<const float4*>(lst + wm * TM * 16 + i * 16 + (lane >> 4) * 4);
+                s23[i] = *reinterpret_cast<const float4*>(lst + wm * TM * 16 + i * 16 + (lane >> 4) * 4 + 2);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(csv[j]), "+v"(bnv[j]));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { epi_ready(s01[i]); epi_ready(s23[i]); }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = nfeat + j * 16;
@@ -1058,21 +1101,15 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
             const int cfeat = n - 2 * E.C;
             const int h = cfeat / E.d;
             const int dd = cfeat - h * E.d;
-            const float cs = lst ? E.ln_csum[n] : 0.f, bn = E.bias ? E.bias[n] : 0.f;
+            const float cs = csv[j], bn = bnv[j];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int m0 = mtok + i * 16;
                 if (m0 >= M) continue;
                 const int b = m0 / E.T;
                 const int t0 = m0 - b * E.T;
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (lst) {   // the lane's four tokens: rows (wm TM + i) 16 + 4 q .. + 3 of the item
-                    const float4 s01 = *reinterpret_cast<const float4*>(lst + wm * TM * 16 + i * 16 + (lane >> 4) * 4);
-                    const float4 s23 = *reinterpret_cast<const float4*>(lst + wm * TM * 16 + i * 16 + (lane >> 4) * 4 + 2);
-                    v[0] = s01.y * (v[0] - s01.x * cs); v[1] = s01.w * (v[1] - s01.z * cs);
-                    v[2] = s23.y * (v[2] - s23.x * cs); v[3] = s23.w * (v[3] - s23.z * cs);
-                }
-                v[0] += bn; v[1] += bn; v[2] += bn; v[3] += bn;
+                float v[4] = {s01[i].y * (acc[i][j][0] - s01[i].x * cs) + bn, s01[i].w * (acc[i][j][1] - s01[i].z * cs) + bn,
+                              s23[i].y * (acc[i][j][2] - s23[i].x * cs) + bn, s23[i].w * (acc[i][j][3] - s23[i].z * cs) + bn};
                 store_bf16x4(E.vt + ((size_t)(b * E.H + h) * E.DPV + dd) * E.Tpad_k + perm_tok4(t0), v);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1149,7 +1186,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
             const int m = mrow + i * 16;
             mo[i] = (AMODE == A_ROWS && E.mode == EPI_ROWMAJOR && E.remap_in) ? (m / E.remap_in) * E.remap_out + (m % E.remap_in) + E.remap_off : m;
         }
-        if (E.bias2) {  // + broadcast per-sample bias (ResBlock time embedding); never combined with a residual
+        if (AMODE == A_CONV3 && E.bias2) {  // + broadcast per-sample bias (ResBlock time embedding); never combined with a residual; convs only (gemm_p_launch)
             float4 b2[TM][TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -1176,28 +1213,35 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
                 }
             }
         } else if (E.mode == EPI_ROWMAJOR && E.res) {
+            // (the fallback of epilogue_staged: fp32 / NCHW outputs, GELU, ragged N. The 128 x 160 tile fetches the residual one row
+            // block at a time -- all 20 pieces at once do not fit its registers)
+            constexpr bool ROWWISE = TM == 4 && TN == 5;
             uint2 rs[TM][TN];
             const float g = (AMODE == A_ROWS && E.gate) ? *E.gate : 1.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
+            auto fetch_row = [&](int i) {
                 const int m = mrow + i * 16;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int n0 = ncol + j * 16;
-                    rs[i][j] = make_uint2(0, 0);
-                    if (m < M && n0 < N) rs[i][j] = *reinterpret_cast<const uint2*>(E.res + (size_t)mo[i] * E.ldres + n0);
+                    rs[ROWWISE ? 0 : i][j] = make_uint2(0, 0);
+                    if (m < M && n0 < N) rs[ROWWISE ? 0 : i][j] = *reinterpret_cast<const uint2*>(E.res + (size_t)mo[i] * E.ldres + n0);
                 }
+            };
+            if constexpr (!ROWWISE) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fetch_row(i);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int m = mrow + i * 16;
+                if constexpr (ROWWISE) fetch_row(i);
                 if (m >= M) continue;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int n0 = ncol + j * 16;
                     if (n0 >= N) continue;
                     U2BF4 r;
-                    r.u = rs[i][j];
+                    r.u = rs[ROWWISE ? 0 : i][j];
                     float v[4] = {acc[i][j][0] + bj[j].x, acc[i][j][1] + bj[j].y, acc[i][j][2] + bj[j].z, acc[i][j][3] + bj[j].w};
                     if (E.act == ACT_SILU) {
 #pragma unroll
@@ -1241,6 +1285,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
     static_assert(WMW * 2 * (EPW + 16 * LPR * 8) <= STAGE, "epilogue staging (+ row-statistics scratch) does not fit one ring slot");
     auto epilogue_staged = [&](int tm, int tn, int slot_done) -> bool {
         if (wd.splits > 1 || E.mode != EPI_ROWMAJOR || E.out_f32 || (N & 7) || (E.act == ACT_GEGLU && (TN & 1)) || E.act == ACT_GELU) return false;
+        if (E.res && E.act == ACT_SILU) return false;   // (no caller combines them; the fragment-layout epilogue handles it)
         unsigned char* ep = smem + slot_done * STAGE + wave * EPW;
         if constexpr ((TN & 1) == 0) {
             // value / gate fragments alternate (16 columns each), so a wave's TN*16 accumulator columns become TN*8 output
@@ -1313,17 +1358,32 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
         };
         // the residual is prefetched for two fragment rows at a time (register budget); the second pair's loads queue behind
         // the first pair's stores, one extra store round trip per work item instead of one per fragment
-        constexpr int PF = TM >= 2 ? 2 : 1;
+        // Two copies of the row loop, chosen by a uniform branch: with the residual its loads have no "or zeros" alternative, so
+        // hipcc cannot fold the bf16 unpacking into the block that loads (which made it wait for every load right behind its issue:
+        // 32 of the epilogue's loads in the round-2 form, one memory round trip each)
+        constexpr int PF = (TM >= 2 && !(TM == 4 && TN == 5)) ? 2 : 1;   // (128 x 160: one row block at a time, the tile sits at the 256-register limit)
+        auto rows = [&](auto res_c) {
+        constexpr bool HAS_RES = decltype(res_c)::value;
         uint4 rs[PF][NRI];
         auto prefetch_res = [&](int i0) {
+            if constexpr (!HAS_RES) return;
 #pragma unroll
             for (int ii = 0; ii < PF; ++ii)
 #pragma unroll
                 for (int k = 0; k < NRI; ++k) {
+                    // UNCONDITIONAL per lane (a lane without an output row reads the tensor's first 16 bytes and never uses them):
+                    // behind a per-lane guard hipcc unpacks the bf16 pairs inside the guarded block, i.e. waits for every load
+                    // right behind its issue -- the residual reads of an item then cost one memory round trip EACH
                     const int mo = out_row(i0 + ii, k);
-                    rs[ii][k] = make_uint4(0, 0, 0, 0);
-                    if (E.res && mo >= 0) rs[ii][k] = *reinterpret_cast<const uint4*>(E.res + (size_t)mo * E.ldres + ncol);
+                    rs[ii][k] = *reinterpret_cast<const uint4*>(E.res + (mo >= 0 ? (size_t)mo * E.ldres + ncol : (size_t)0));
                 }
+        };
+        auto res_ready = [&]() {   // one wait for the pair in front of its first store block (see epi_ready)
+            if constexpr (!HAS_RES) return;
+#pragma unroll
+            for (int ii = 0; ii < PF; ++ii)
+#pragma unroll
+                for (int k = 0; k < NRI; ++k) asm volatile("" : "+v"(rs[ii][k].x), "+v"(rs[ii][k].y), "+v"(rs[ii][k].z), "+v"(rs[ii][k].w));
         };
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -1333,7 +1393,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 float4 v = make_float4(acc[i][j][0] + bj[j].x, acc[i][j][1] + bj[j].y, acc[i][j][2] + bj[j].z, acc[i][j][3] + bj[j].w);
-                if (E.bias2) {
+                if (AMODE == A_CONV3 && E.bias2) {
                     const int n0 = ncb + j * 16 + (lane >> 4) * 4;
                     if (mf < M && n0 < N) {
                         const float4 b2 = *reinterpret_cast<const float4*>(E.bias2 + (size_t)div_rpb(E, mf) * E.bias2_ld + n0);
@@ -1342,6 +1402,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
                 }
                 *reinterpret_cast<float4*>(ep + l15 * RS + (j * 16 + (lane >> 4) * 4) * 4) = v;
             }
+            if (i % PF == 0) res_ready();
             // LDS -> whole-row pieces: 8 consecutive columns per lane
 #pragma unroll
             for (int k = 0; k < NRI; ++k) {
@@ -1351,12 +1412,14 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
                 const float4 a = *reinterpret_cast<const float4*>(ep + r * RS + cc * 32);
                 const float4 b = *reinterpret_cast<const float4*>(ep + r * RS + cc * 32 + 16);
                 float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-                if (E.act == ACT_SILU) {
+                if constexpr (!HAS_RES) {
+                    if (E.act == ACT_SILU) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+                        for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+                    }
                 }
                 U4BF8 o;
-                if (E.res) {
+                if constexpr (HAS_RES) {
                     U4BF8 rv;
                     rv.u = rs[i % PF][k];
 #pragma unroll
@@ -1391,6 +1454,9 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
                 }
             }
         }
+        };
+        if (E.res) rows(std::true_type{});
+        else rows(std::false_type{});
         return true;
     };
 
@@ -2177,6 +2243,7 @@ gemm_wide_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
 }
 
 
+
 static int g_gemm_variant = -1;  // 1: LDS-DMA v2 (one tile per workgroup), 2: persistent v3, 4: v5 buffer-DMA persistent (default)
 void gemm_set_variant(int v) { g_gemm_variant = v; }
 static int gemm_variant() {
@@ -2456,7 +2523,8 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
     // v5 addresses both operands through 32-bit buffer offsets: every operand must be < 2 GiB
     const size_t a_rows = A.mode == A_CONV3 ? (size_t)(M / (A.Ho * A.Wo)) * A.Hin * A.Win : (size_t)M;
     const bool fits32 = a_rows * (size_t)std::max(A.ld0, A.ld1) * 2 < 0x7fff0000ull && (size_t)N * K * 2 < 0x7fff0000ull;
-    const bool use_u = gemm_variant() == 4 && fits32 && !(E.bias2 && E.res);  // v5's epilogue has no bias2 + residual form
+    // v5's epilogue has no bias2 + residual form, and the per-sample bias only in its conv instantiations
+    const bool use_u = gemm_variant() == 4 && fits32 && !(E.bias2 && (E.res || A.mode == A_ROWS));
     // eligible 3x3 convs with M >= 256 * GL_CONV_HALO (default 8; 0 = never) go to the halo kernel (GL_CONV_HALO_SPLITS=n forces its
     // K split): at M = 512 (the 8 x 8 level) its 16 tiles x deep split lose to the 64 x 160 tiles of the kernel above
     static const int halo = dev_env("GL_CONV_HALO") ? atoi(dev_env("GL_CONV_HALO")) : 8;

@@ -183,3 +183,49 @@ def test_attn2_loop_is_pipelined_and_lean(attn_asm):
             run_v += 1; run_m = 0
         worst_v, worst_m = max(worst_v, run_v), max(worst_m, run_m)
     assert worst_v <= 10 and worst_m <= 3, (worst_v, worst_m)
+
+
+@pytest.fixture(scope="module")
+def norm_asm(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = tmp_path_factory.mktemp("isa") / "norm.s"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", str(ROOT / "include"), "--offload-device-only", "-S",
+           str(ROOT / "gligen_amd" / "csrc" / "norm.hip"), "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return out.read_text()
+
+
+def _wait_scan(asm, *filters):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_waits", ROOT / "tools" / "isa_waits.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return {name: (loads, imm, stores, after) for name, loads, imm, stores, after in mod.scan(None, filters, text=asm)}
+
+
+def test_norm_kernels_keep_their_loads_in_flight(norm_asm):
+    """GroupNorm / LayerNorm are latency-bound unless every thread has several 16-byte loads in flight. Written as
+    `x = 0; if (pixel in range) x = load`, hipcc folds the bf16 unpacking into the guarded block and waits for each load right
+    behind its issue (seen in round 3: 7 of 8 loads in gn_stats_kernel, 22 in gn_apply_kernel incl. its 16 partial sums). The
+    kernels now load unconditionally from a clamped address; this pins that no load is followed by vmcnt(0) within two
+    instructions (tools/isa_waits.py)."""
+    res = _wait_scan(norm_asm, "gn_stats_kernel", "gn_apply_kernel", "ln_kernel")
+    assert len(res) == 3
+    for name, (loads, imm, stores, after) in res.items():
+        assert loads >= 8 and imm <= 1, (name, loads, imm)
+
+
+def test_gemm_epilogues_wait_once_before_their_stores(gemm_asm):
+    """vmcnt counts stores: a coefficient load between stores, or a wait hipcc re-inserts in every guarded block, makes each store
+    wait for the acknowledgement of the one before it. The head-layout epilogues of the q,k,v^T projection (QKV instantiations)
+    fetch everything first and force one wait (epi_ready): at most one vmcnt(0) behind a store; the row-GEMM instantiations keep
+    no load that is waited for right behind its issue (the residual of the staged epilogue used to be: 32 of them)."""
+    res = _wait_scan(gemm_asm, "gemm_u_kernel")
+    qkv = {n: v for n, v in res.items() if "Lb1E" in n}
+    rows = {n: v for n, v in res.items() if "ELi0ELi2ELb0E" in n}
+    assert len(qkv) == 4 and len(rows) == 5
+    for name, (loads, imm, stores, after) in qkv.items():
+        assert stores >= 8 and after <= 1, (name, stores, after)
+    for name, (loads, imm, stores, after) in rows.items():
+        assert imm == 0, (name, loads, imm)
