@@ -1552,10 +1552,31 @@ splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, Epi
             }
             epi_geglu4(E, m, n0, val, gate);
         } else {
+            // Row-major bf16 outputs (every split-K conv and projection of the UNet): bias, per-sample bias, residual and gate are
+            // requested BEFORE the slabs, unconditionally (an absent operand reads the slab area and is never used -- behind
+            // `if (E.res)` hipcc would unpack inside the branch and wait there); they arrive while the slabs are summed
+            const bool fast = E.mode == EPI_ROWMAJOR && !E.out_f32 && !E.remap_in && E.act != ACT_GELU && !E.ln_stats;
+            // (no `if (fast)` around the loads either: a value that is "loaded or zero" is the pattern that gets waited for in place)
+            const float4 pb = *reinterpret_cast<const float4*>((fast && E.bias) ? E.bias + n0 : ws);
+            const float4 pb2 = *reinterpret_cast<const float4*>((fast && E.bias2) ? E.bias2 + (size_t)div_rpb(E, m) * E.bias2_ld + n0 : ws);
+            const uint2 pr = *reinterpret_cast<const uint2*>((fast && E.res) ? reinterpret_cast<const void*>(E.res + (size_t)m * E.ldres + n0)
+                                                                              : reinterpret_cast<const void*>(ws));
+            const float pg = *((fast && E.res && E.gate) ? E.gate : ws);
+            // slabs four at a time, all four loads in flight before the first add (a slab beyond `splits` re-reads the last one and
+            // counts as zero): one load per loop trip is one L2 round trip per slab and thread, 8-16 of them in a row at the 8 x 8
+            // level. Summation order stays z = 0 .. splits - 1.
             float v[4] = {0, 0, 0, 0};
-            for (int z = 0; z < splits; ++z) {
-                float4 a = *reinterpret_cast<const float4*>(ws + ((size_t)z * M + m) * N + n0);
-                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+            const float* p0 = ws + (size_t)m * N + n0;
+            const size_t zs = (size_t)M * N;
+            for (int z = 0; z < splits; z += 4) {
+                float4 a[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(p0 + (size_t)min(z + u, splits - 1) * zs);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool ok = z + u < splits;
+                    v[0] += ok ? a[u].x : 0.f; v[1] += ok ? a[u].y : 0.f; v[2] += ok ? a[u].z : 0.f; v[3] += ok ? a[u].w : 0.f;
+                }
             }
             if (E.ln_stats) {   // folded LayerNorm (gemm.h): rstd (acc - mean csum); epi_finish4 adds the folded bias
                 const float2 st = ln_row_stats(E, m);
@@ -1563,7 +1584,24 @@ splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, Epi
                 v[0] = st.y * (v[0] - st.x * cs.x); v[1] = st.y * (v[1] - st.x * cs.y);
                 v[2] = st.y * (v[2] - st.x * cs.z); v[3] = st.y * (v[3] - st.x * cs.w);
             }
-            epi_finish4(E, m, n0, v);
+            if (fast) {
+                if (E.bias) { v[0] += pb.x; v[1] += pb.y; v[2] += pb.z; v[3] += pb.w; }
+                if (E.bias2) { v[0] += pb2.x; v[1] += pb2.y; v[2] += pb2.z; v[3] += pb2.w; }
+                if (E.act == ACT_SILU) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = silu_f(v[i]);
+                }
+                if (E.res) {
+                    U2BF4 r;
+                    r.u = pr;
+                    const float g = E.gate ? pg : 1.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = bf2f(r.e[i]) + g * v[i];
+                }
+                store_bf16x4(reinterpret_cast<bf16*>(E.out) + (size_t)m * E.ldo + n0, v);
+            } else {
+                epi_finish4(E, m, n0, v);
+            }
         }
     }
 }

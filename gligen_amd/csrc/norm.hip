@@ -10,8 +10,6 @@
 // reduction order, so results are bit-reproducible run to run.
 #include "norm.h"
 
-#include <type_traits>
-
 namespace gl {
 
 // Both kernels use the same thread shape: block = C8 * R threads, thread (cx, ry) owns the 8 channels [8cx, 8cx+8)
@@ -276,56 +274,53 @@ __global__ void __launch_bounds__(256) ln_kernel(LNParams P) {
         for (int ch = lane; ch < C8; ch += 64) *reinterpret_cast<uint4*>(dst + ch * 8) = make_uint4(0, 0, 0, 0);
         return;
     }
-    // NCH = 64-lane chunks of the row (C <= 512 / 1024 / 1536), chosen by a uniform branch; inside a copy the loads are unconditional
-    // from a clamped address (see gn_stats_kernel: behind a guard each load would be waited for right behind its issue)
-    auto row = [&](auto nch_c) {
-        constexpr int NCH = decltype(nch_c)::value;
-        float v[NCH][8];
-        float s = 0.f;
-        U4BF8 u[NCH];
+    float v[3][8];
+    float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) u[i].u = *reinterpret_cast<const uint4*>(src + min(lane + 64 * i, C8 - 1) * 8);
+    for (int i = 0; i < 3; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < C8) {
+            U4BF8 u;
+            u.u = *reinterpret_cast<const uint4*>(src + ch * 8);
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const bool ok = lane + 64 * i < C8;
+            for (int e = 0; e < 8; ++e) { v[i][e] = bf2f(u.e[e]); s += v[i][e]; }
+        } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { v[i][e] = ok ? bf2f(u[i].e[e]) : 0.f; s += v[i][e]; }
+            for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
         }
-        const float mean = wave_sum(s) / P.C;
-        float q = 0.f;
+    }
+    const float mean = wave_sum(s) / P.C;
+    float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            if (lane + 64 * i < C8) {
+    for (int i = 0; i < 3; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < C8) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { float d = v[i][e] - mean; q += d * d; }
+            for (int e = 0; e < 8; ++e) { float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / P.C + P.eps);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < C8) {
+            U4BF8 o;
+            if (P.gamma) {
+                const float4 g0 = *reinterpret_cast<const float4*>(P.gamma + ch * 8);
+                const float4 g1 = *reinterpret_cast<const float4*>(P.gamma + ch * 8 + 4);
+                const float4 b0 = *reinterpret_cast<const float4*>(P.beta + ch * 8);
+                const float4 b1 = *reinterpret_cast<const float4*>(P.beta + ch * 8 + 4);
+                const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o.e[e] = f2bf((v[i][e] - mean) * rstd * gm[e] + bt[e]);
+            } else {   // no affine: gamma and beta live in the consumer's folded weights (gemm.h Epilogue::ln_stats)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o.e[e] = f2bf((v[i][e] - mean) * rstd);
             }
+            *reinterpret_cast<uint4*>(dst + ch * 8) = o.u;
         }
-        const float rstd = rsqrtf(wave_sum(q) / P.C + P.eps);
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int ch = lane + 64 * i;
-            if (ch < C8) {
-                U4BF8 o;
-                if (P.gamma) {
-                    const float4 g0 = *reinterpret_cast<const float4*>(P.gamma + ch * 8);
-                    const float4 g1 = *reinterpret_cast<const float4*>(P.gamma + ch * 8 + 4);
-                    const float4 b0 = *reinterpret_cast<const float4*>(P.beta + ch * 8);
-                    const float4 b1 = *reinterpret_cast<const float4*>(P.beta + ch * 8 + 4);
-                    const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-                    const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o.e[e] = f2bf((v[i][e] - mean) * rstd * gm[e] + bt[e]);
-                } else {   // no affine: gamma and beta live in the consumer's folded weights (gemm.h Epilogue::ln_stats)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o.e[e] = f2bf((v[i][e] - mean) * rstd);
-                }
-                *reinterpret_cast<uint4*>(dst + ch * 8) = o.u;
-            }
-        }
-    };
-    if (C8 <= 64) row(std::integral_constant<int, 1>{});
-    else if (C8 <= 128) row(std::integral_constant<int, 2>{});
-    else row(std::integral_constant<int, 3>{});
+    }
 }
 
 int layernorm_launch(const LNParams& P, hipStream_t stream) {

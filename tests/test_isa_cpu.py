@@ -205,13 +205,13 @@ def _wait_scan(asm, *filters):
 
 
 def test_norm_kernels_keep_their_loads_in_flight(norm_asm):
-    """GroupNorm / LayerNorm are latency-bound unless every thread has several 16-byte loads in flight. Written as
+    """GroupNorm is latency-bound unless every thread has several 16-byte loads in flight. Written as
     `x = 0; if (pixel in range) x = load`, hipcc folds the bf16 unpacking into the guarded block and waits for each load right
     behind its issue (seen in round 3: 7 of 8 loads in gn_stats_kernel, 22 in gn_apply_kernel incl. its 16 partial sums). The
     kernels now load unconditionally from a clamped address; this pins that no load is followed by vmcnt(0) within two
     instructions (tools/isa_waits.py)."""
-    res = _wait_scan(norm_asm, "gn_stats_kernel", "gn_apply_kernel", "ln_kernel")
-    assert len(res) == 3
+    res = _wait_scan(norm_asm, "gn_stats_kernel", "gn_apply_kernel")   # (ln_kernel keeps its guards: one load per lane at C = 320,
+    assert len(res) == 2                                                # where the guarded form measured 17 % faster)
     for name, (loads, imm, stores, after) in res.items():
         assert loads >= 8 and imm <= 1, (name, loads, imm)
 
