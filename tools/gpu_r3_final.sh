@@ -5,7 +5,7 @@ export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*
 # per symbol and per problem (attention launches included) -> gpurun_out/r3_final/ (copied to profiles/r3_final/)
 export TMPDIR=/tmp
 R=$PWD
-O=$R/gpurun_out/r3_final
+O=$R/gpurun_out/r3_final2
 mkdir -p $O
 K=gligen_amd/build/kbench
 ( timeout 1500 python -m pytest tests -m gpu -q ) > $O/pytest_gpu.log 2>&1
