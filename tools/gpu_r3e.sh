@@ -1,9 +1,9 @@
 #!/bin/bash
 export GL_DEV_SWITCHES=1   # the library reads its developer switches (GL_GEMM_*, GL_ATTN_V2, ...) only with this set
-# round 3, call E: fresh on-device autotune of every BASELINE configuration with the 64 x 64 tile candidate (4 workgroups per CU)
+# round 3, calls E and Q (Q: again at the end of the round, after the epilogue changes): fresh on-device autotune of every BASELINE configuration with the 64 x 64 tile candidate (4 workgroups per CU)
 # and the folded-LayerNorm problem keys -> logs for tools/make_tuned_table.py; A/B shipped table vs fresh tuning
 export TMPDIR=/tmp
-O=$PWD/gpurun_out/r3e
+O=$PWD/gpurun_out/r3q
 mkdir -p $O
 for c in C2 C3 C4 C5; do
   GL_GEMM_NO_TABLE=1 GL_GEMM_TUNE_LOG=1 GL_GEMM_TUNE_REPS=10 timeout 600 python bench.py --steps 1 --warmup 1 --lanes 1 --no-cpu-baseline --config $c > $O/tune_$c.json 2> $O/tune_$c.log
