@@ -1654,6 +1654,12 @@ conv_halo_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
     const int q = lane >> 4;
     const int r0 = t >> 3;                                          // row inside a DMA pass
     const unsigned chb = (((t & 7) ^ ((r0 >> 1) & 7)) * 16);        // byte offset of this lane's (swizzled) source chunk
+    // The halo buffer is read at nine different row shifts (the filter taps), so its swizzle has to stay conflict free under any
+    // shift: chunk ^= row & 6 does (a lane group of ds_read_b128 mixes rows {0-3, 12-15} of one 16-byte column with rows {4-11} of the
+    // next; the column's low bit then tells the two sets apart and row mod 8 separates the rows inside each, whatever the first row
+    // is). With the (row >> 1) & 7 swizzle of the aligned tiles only shifts that are multiples of 4 rows are conflict free: PMC
+    // showed 23-25 % of this kernel's LDS cycles as bank conflicts (profiles/r3_final/pmc_mfma_report.txt), on the port that bounds it.
+    const unsigned chb_h = (((t & 7) ^ (r0 & 6)) * 16);                  // (halo rows of a DMA pass: h = pass * 64 + r0)
     const int Cin = A.C0 + A.C1;
 
     const int Wd = 1 << hd.lgW, Hd = 1 << hd.lgH;
@@ -1723,7 +1729,7 @@ conv_halo_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
         const int hx = rem - hy * W2;
         const bool ok = h < NH && hx >= 1 && hx <= Wd && (hy != 0 || top_ok) && (hy != HB + 1 || bot_ok);
         const int hrel = ((blk << lgHB) + hy - 1) * Wd + hx - 1;
-        const unsigned va = ok ? __umul24((unsigned)(m0 + hrel), ld2) + chb : SENT;
+        const unsigned va = ok ? __umul24((unsigned)(m0 + hrel), ld2) + chb_h : SENT;
         unsigned char* dst = smem + hb * HBUF + (p * RPP + wave * 8) * 128;
         if (first) GL_BLDS16(ra0, dst, va, soff);
         else GL_BLDS16(ra1, dst, va, soff);
@@ -1761,7 +1767,7 @@ conv_halo_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const unsigned hr = (unsigned)(hr00 + hr_delta(i) + tapoff);
-            ax0[i] = hbase + hr * 128u + (((unsigned)q ^ ((hr >> 1) & 7u)) << 4);
+            ax0[i] = hbase + hr * 128u + (((unsigned)q ^ (hr & 6u)) << 4);
             ax1[i] = ax0[i] ^ 64u;    // k-step 1 = chunks 4..7: (q + 4) ^ s = (q ^ s) ^ 4
         }
         const unsigned aw0 = wbase + foff0, aw1 = wbase + foff1;
