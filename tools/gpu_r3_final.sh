@@ -37,3 +37,7 @@ head -12 $O/bench_kernel_stats.csv | cut -c1-200
 bash tools/gpu_traffic.sh > $O/traffic.log 2>&1
 tail -26 $O/traffic.log | cut -c1-220
 cp gpurun_out/pmc_traffic.csv gpurun_out/pmc_traffic_per_problem.csv $O/
+bash tools/gpu_mfma_util.sh > $O/mfma.log 2>&1
+cp gpurun_out/pmc_mfma.csv gpurun_out/pmc_mfma_report.txt $O/
+head -8 $O/pmc_mfma_report.txt | cut -c1-150
+( unset GL_DEV_SWITCHES; timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2>/dev/null ); cut -c1-200 $O/bench_driver_cmd.json
