@@ -16,7 +16,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 INCLUDE = HERE.parent / "include"
 LIB = HERE / "libgligen_amd.so"
-SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "misc.hip", "convnext.hip", "engine.hip", "capi.hip"]
+SOURCES = ["gemm.hip", "ffn.hip", "attention.hip", "norm.hip", "misc.hip", "convnext.hip", "engine.hip", "capi.hip"]
 # attention: keep MFMA accumulators in VGPRs (gfx950 has one unified register file); the default AGPR
 # form costs a v_accvgpr_read/write pair per accumulator per KV tile around the softmax rescale
 EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}

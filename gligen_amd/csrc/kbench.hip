@@ -13,11 +13,15 @@
 #include <vector>
 
 #include "attention.h"
+#include "ffn.h"
 #include "gemm.h"
 #include "misc.h"
 #include "norm.h"
 
 using namespace gl;
+#ifdef GL_FFN_ABLATE
+namespace gl { void ff_rows_set_ablation(int abl); }
+#endif
 
 static hipStream_t cur_s = nullptr;  // stream the recorded launch closures enqueue on (switched by the "seq" mode)
 
@@ -229,6 +233,81 @@ int main(int argc, char** argv) {
                 }
                 relaunch = [=] { GC(gemm_launch(A, w, M, N, K, E, cur_s == s ? ws : ws2, ws_bytes, cur_s)); };
                 us = time_us(relaunch, reps, s);
+            }
+        } else if (!strcmp(kind, "ffn")) {
+            // row-local feed-forward (ffn.hip) against the two-GEMM form it replaces: ffn M C normalize count
+            const int M = v[0], C = v[1], norm = v[2];
+            count = v[3]; c = 0;
+            flop = 24.0 * M * (double)C * C;
+            static float *fw1 = nullptr, *fb1, *fw2, *fb2, *fgate;
+            static bf16 *wp1, *w2b, *hid, *xn;
+            static float* bp1;
+            static void* strm;
+            if (!fw1) {
+                fw1 = dev_f32((size_t)8 * 320 * 320, 11, 0.05f);
+                fb1 = dev_f32(8 * 320, 12, 0.1f);
+                fw2 = dev_f32((size_t)320 * 4 * 320, 13, 0.03f);
+                fb2 = dev_f32(320, 14, 0.1f);
+                fgate = dev_f32(4, 15, 0.7f);
+                HC(hipMalloc(&wp1, (size_t)8 * 320 * 320 * 2));
+                HC(hipMalloc(&bp1, 8 * 320 * 4));
+                HC(hipMalloc(&w2b, (size_t)320 * 4 * 320 * 2));
+                HC(hipMalloc(&strm, ff_stream_bytes(320)));
+                HC(hipMalloc(&hid, (size_t)65536 * 4 * 320 * 2));
+                HC(hipMalloc(&xn, (size_t)65536 * 320 * 2));
+            }
+            if (!ff_rows_supported(M, C) || M > 65536) { printf("ffn: unsupported %d %d\n", M, C); continue; }
+            GC(pack_geglu_launch(fw1, fb1, wp1, bp1, 4 * C, C, gemm_geglu_layout(), s));
+            GC(cast_f32_bf16_launch(fw2, w2b, (int64_t)C * 4 * C, s));
+            GC(ff_pack_launch(fw1, fb1, fw2, strm, C, s));
+            FFRowsParams P{};
+            P.x = a0; P.ldx = C; P.normalize = norm; P.eps = 1e-5f; P.stream = strm; P.b2 = fb2; P.res = a1; P.ldres = C; P.gate = fgate;
+            P.out = a2; P.ldo = C; P.M = M;
+            float2* st = reinterpret_cast<float2*>(partial);
+            if (M * 8 <= (1 << 20)) { P.stats_out = st; P.stats_ld = 1; }
+            relaunch = [=] { GC(ff_rows_launch(P, C, cur_s)); };
+            auto two_gemm = [=] {
+                const bf16* in = a0;
+                if (norm) {
+                    LNParams L{};
+                    L.x = a0; L.B = 1; L.N1 = M; L.N2 = 0; L.Tpad = M; L.C = C; L.eps = 1e-5f; L.y = xn;
+                    GC(layernorm_launch(L, cur_s));
+                    in = xn;
+                }
+                AOperand A;
+                aoperand_rows(A, in, C, C);
+                Epilogue E;
+                epilogue_defaults(E);
+                E.act = ACT_GEGLU; E.geglu16 = gemm_geglu_layout(); E.out = hid; E.ldo = 4 * C; E.bias = bp1;
+                GC(gemm_launch(A, wp1, M, 8 * C, C, E, ws, ws_bytes, cur_s));
+                AOperand A2;
+                aoperand_rows(A2, hid, 4 * C, 4 * C);
+                Epilogue E2;
+                epilogue_defaults(E2);
+                E2.out = r2 ? r2 : a2 + ((size_t)100 << 20); E2.ldo = C; E2.bias = fb2; E2.res = a1; E2.ldres = C; E2.gate = fgate;
+                GC(gemm_launch(A2, w2b, M, C, 4 * C, E2, ws, ws_bytes, cur_s));
+            };
+            const float us_ref = time_us(two_gemm, reps, s);
+#ifdef GL_FFN_ABLATE
+            {
+                static const int abls[] = {1, 2, 4, 8, 16, 24, 32, 3, 6, 7, 25, 31};
+                for (int ab : abls) {
+                    ff_rows_set_ablation(ab);
+                    const float t_ab = time_us(relaunch, reps, s);
+                    printf("  ablation %2d: %.1f us\n", ab, t_ab);
+                }
+                ff_rows_set_ablation(0);
+            }
+#endif
+            us = time_us(relaunch, reps, s);
+            {
+                const bf16* ref = r2 ? r2 : a2 + ((size_t)100 << 20);
+                float d, m;
+                maxdiff(a2, ref, (size_t)M * C, s, &d, &m);
+                const bool ok = d <= 0.03f * m + 1e-6f;
+                if (!ok) ++n_bad;
+                printf("FFN M%d C%d norm%d: fused %.1f us (%.0f TF/s) vs two GEMMs%s %.1f us; maxdiff %g of %g %s\n", M, C, norm, us, flop / us * 1e-6,
+                       norm ? " + ln_kernel" : "", us_ref, d, m, ok ? "ok" : "MISMATCH");
             }
         } else if (!strcmp(kind, "conv")) {
             const int B = v[0], H = v[1], W = v[2], C0 = v[3], C1 = v[4], Cout = v[5], stride = v[6], ups = v[7];
