@@ -5,24 +5,27 @@
 //
 // Why: as two GEMMs the pair is bound by operand delivery, not by the matrix cores -- the 256 x 128 tiles of gemm_wide_kernel stage
 // one byte through the LDS-DMA per 85 FLOP, the hidden [M][4C] activation goes out to HBM and comes back (2 x 84 MB at the 64 x 64
-// level), and the erf-GEGLU epilogue of a K = 320 projection is as long as its K loop. Here a WAVE owns 32 complete rows from the
-// first instruction to the last:
-//   * its x rows live in registers as MFMA B-operand fragments (80 VGPRs at C = 320), normalised in place;
-//   * per chunk of 32 hidden features:  S^T[64 x 32 rows] = W1c X^T (80 MFMAs), bias preloaded into the accumulators, erf-GEGLU on
-//     the accumulators in registers, and the packed result IS the B operand of  Y^T[C x 32 rows] += W2c P^T  (40 MFMAs) --
-//     v_mfma_f32_16x16x32_bf16 with the weights as the A operand leaves a lane with 4 consecutive features of ONE row, two such
-//     accumulators are the 8 k-slots a lane supplies to the next product, and the pack kernel permutes W2's columns to match
+// level), and the erf-GEGLU epilogue of a K = 320 projection is as long as its K loop. Here a WAVE owns 32 complete rows (one per
+// lane pair) from the first instruction to the last:
+//   * its x rows live in the AGPR half as v_mfma_f32_32x32x16_bf16 B operands (80 registers at C = 320), normalised in registers;
+//   * per chunk of 32 hidden features:  S^T[64 x 32 rows] = W1c X^T (40 MFMAs + 2 for the bias, which rides as a 21st k-step against
+//     a constant one-hot operand), erf-GEGLU on the accumulators in registers, and the packed result IS the B operand of
+//     Y^T[C x 32 rows] += W2c P^T (20 MFMAs): with the weights as the A operand a lane's accumulator holds features 8 j + 4 h + e of
+//     ONE row, value rows and their gate rows of a block sit in the same lane, and the pack kernel orders W2's k-slots to match
 //     (the S^T -> P^T trick of attention.hip);
 //   * the FF-out accumulator Y^T (160 registers) stays in the AGPR half until the epilogue adds bias, gate and residual.
 // So nothing but weights goes through LDS: one byte per 128 FLOP (4 waves x 32 rows share every weight fragment), no activation
-// staging, no LDS hop for the hidden tile, no cross-wave data at all. The price is one wave per SIMD at up to 512 registers;
-// latency is hidden inside the wave by a 2-group-deep fragment prefetch and by the GEGLU of chunk c-1 riding under the
-// projection MFMAs of chunk c.
+// staging, no LDS hop for the hidden tile, no cross-wave data at all. The price is ONE wave per SIMD (up to 512 registers): nothing
+// hides a wave's own fragment reads, DMA issue and GEGLU arithmetic except its own MFMAs, and a first version that left the order to
+// hipcc ran the three back to back (profiles/r4/ffn_v2_ablation.txt: skeleton 34 us + MFMAs 47 us = 81 us per workgroup). The main
+// loop is therefore one fixed instruction order: every MFMA, fragment read, wait and DMA is an asm statement (volatile asm keeps its
+// order), and the GEGLU is cut into 64 micro-steps of 2-3 VALU instructions, each pinned between two empty asm statements into the
+// gap behind one particular MFMA -- ~5 issue slots per 32-cycle MFMA, the budget MI355X_MICROARCH.md gives a lone wave.
 //
 // The weights are a STREAM of 1 KiB fragment blocks in exactly the order the waves consume them (ff_pack_kernel): a block is one
 // MFMA A operand in lane order, so an LDS-DMA instruction copies it verbatim and a fragment read is ds_read_b128 at lane * 16 --
-// conflict free without any swizzle. Stage c = [W1 of chunk c : 4 KS blocks][W2 of chunk c-1 : C/16 blocks]; two stages in LDS,
-// one barrier per chunk: vmcnt(0) -> barrier -> DMA of stage c+1 (spread over the chunk's MFMA groups) -> compute stage c.
+// conflict free without any swizzle. Stage c = [W1 + bias of chunk c : 42 blocks][W2 of chunk c-1 : 20 blocks][2 blocks of padding];
+// two stages in LDS, one barrier per chunk: vmcnt(0) -> barrier -> compute stage c with the DMA of stage c+1 spread over it.
 #include "ffn.h"
 
 #include <type_traits>
@@ -32,28 +35,33 @@ namespace gl {
 
 namespace {
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 template <int C>
 struct FFGeom {
-    static_assert(C % 64 == 0, "C must be a multiple of 64");
-    static constexpr int KS = C / 32;            // k-steps of the GEGLU projection (K = C)
-    static constexpr int NCF = C / 16;           // output-feature fragments of FF-out
-    static_assert(NCF % 4 == 0, "FF-out fragments are read in groups of 4");
+    static_assert(C % 32 == 0, "C must be a multiple of 32");
+    static constexpr int KS = C / 16;            // k-steps (16 wide) of the GEGLU projection (K = C)
+    static constexpr int NKP = KS + 1;           // + the bias step
+    static constexpr int NCB = C / 32;           // output-feature blocks (32 rows) of FF-out
     static constexpr int NCH = 4 * C / 32;       // hidden chunks of 32 features
-    static constexpr int NB = 4 * KS + NCF;      // 1 KiB blocks per stage
-    static_assert(NB % 4 == 0, "every wave copies NB / 4 blocks of a stage");
-    static constexpr int STAGE = NB * 1024;
-    static_assert(STAGE < 65536, "fragment reads address a stage through the 16-bit offset field");
-    static constexpr int NSTAGE = NCH + 1;       // stage c = [W1(c)][W2(c-1)], c = 0 .. NCH
-    // b1 of every chunk as [chunk][nf][16] fp32, resident in LDS (+ one zero chunk: the last chunk prefetches "the next" bias)
-    static constexpr int BIAS_BYTES = ((NCH + 1) * 256 + 1023) / 1024 * 1024;
-    static constexpr size_t STREAM_BYTES = (size_t)NSTAGE * STAGE + BIAS_BYTES;
-    static constexpr int LDS_BYTES = 2 * STAGE + BIAS_BYTES;
-    static constexpr int NG = KS + NCF / 4;      // fragment groups of 4 per stage: KS projection k-steps, then NCF / 4 FF-out groups
+    static constexpr int NPB = 2 * NKP;          // projection blocks per chunk, order (k-step, block nb)
+    static constexpr int NOB = 2 * NCB;          // FF-out blocks per chunk, order (k-step nb, feature block cb)
+    static constexpr int NBLK = NPB + NOB;       // = MFMAs per chunk
+    static constexpr int NBS = (NBLK + 3) / 4 * 4;   // blocks per stage incl. padding: every wave copies NBS / 4
+    static constexpr int STAGE = NBS * 1024;
+    static_assert((NBLK - 1) * 1024 < 65536, "fragment reads address a stage through the 16-bit offset field");
+    static constexpr int NSTAGE = NCH + 1;       // stage c = [W1(c) + b1(c)][W2(c-1)], c = 0 .. NCH
+    static constexpr size_t STREAM_BYTES = (size_t)NSTAGE * STAGE;
+    static constexpr int LDS_BYTES = 2 * STAGE;
+    static_assert(NCH % 2 == 0, "chunk parity of the last chunk");
 };
 
-// original GEGLU.proj row of fragment row r (0..15) of fragment nf (0: value, 1: gate, 2: value + 16, 3: gate + 16) of chunk c
-__device__ __forceinline__ int w1_row(int C, int c, int nf, int r) { return (nf & 1) * 4 * C + c * 32 + (nf >> 1) * 16 + r; }
-
+// Fragment layouts (v_mfma_f32_32x32x16_bf16, weights as the A operand): A lane L holds row L & 31, k-slots 8 (L >> 5) .. + 7;
+// B lane L holds column (= activation row) L & 31, the same k-slots; D lane L holds column L & 31, register 4 j + e = row 8 j + 4 (L >> 5) + e.
+//  * projection block (chunk c, nb): rows 0..15 = VALUE features c 32 + nb 16 + r, rows 16..31 = their GATE features (reference GEGLU:
+//    x, gate = proj(x).chunk(2)), so a lane's registers 0..7 are 8 values and 8..15 the gates of the same 8 hidden features
+//    f = 8 jj + 4 h + e (jj = 0, 1);
+//  * P^T operand of FF-out k-step nb: k-slot 8 h + 4 jj + e  <->  hidden feature c 32 + nb 16 + 8 jj + 4 h + e.
 template <int C>
 __global__ void __launch_bounds__(256) ff_pack_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
                                                       unsigned char* __restrict__ stream) {
@@ -63,52 +71,32 @@ __global__ void __launch_bounds__(256) ff_pack_kernel(const float* __restrict__ 
         U4BF8 o;
         o.u = make_uint4(0, 0, 0, 0);
         const size_t byte = pc * 16;
-        if (byte >= (size_t)G::NSTAGE * G::STAGE) {   // bias table
-            const int f0 = (int)((byte - (size_t)G::NSTAGE * G::STAGE) / 4);   // first of 4 floats
-            const int c = f0 >> 6, nf = (f0 >> 4) & 3, r = f0 & 15;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < G::NCH) {
-            v.x = b1[w1_row(C, c, nf, r)]; v.y = b1[w1_row(C, c, nf, r + 1)]; v.z = b1[w1_row(C, c, nf, r + 2)]; v.w = b1[w1_row(C, c, nf, r + 3)];
-            }
-            *reinterpret_cast<float4*>(stream + byte) = v;
-            continue;
-        }
         const int st = (int)(byte / G::STAGE);
         const int in = (int)(byte % G::STAGE);
-        const int blk = in >> 10, L = (in >> 4) & 63, l15 = L & 15, q = L >> 4;
-        if (blk < 4 * G::KS) {
-            const int ks = blk >> 2, nf = blk & 3;
+        const int blk = in >> 10, L = (in >> 4) & 63, r = L & 31, h = L >> 5;
+        if (blk < G::NPB) {
+            const int ks = blk >> 1, nb = blk & 1;
             if (st < G::NCH) {
-                const float* src = w1 + (size_t)w1_row(C, st, nf, l15) * C + ks * 32 + q * 8;
+                const int row = (r >> 4) * 4 * C + st * 32 + nb * 16 + (r & 15);
+                if (ks < G::KS) {
+                    const float* src = w1 + (size_t)row * C + ks * 16 + h * 8;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o.e[e] = f2bf(src[e]);
+                    for (int e = 0; e < 8; ++e) o.e[e] = f2bf(src[e]);
+                } else if (h == 0) {
+                    o.e[0] = f2bf(b1[row]);      // the bias step multiplies k-slot 0 by one (bf16 bias: the accumulator is rounded to bf16 anyway)
+                }
             }
-        } else {
-            const int cf = blk - 4 * G::KS, c = st - 1;
+        } else if (blk < G::NBLK) {
+            const int ob = blk - G::NPB, nb = ob / G::NCB, cb = ob % G::NCB, c = st - 1;
             if (c >= 0) {
-                // k-slot 8 q + e of the P^T operand holds hidden feature 4 q + e (e < 4: from the first value / gate accumulator pair)
-                // or 16 + 4 q + (e - 4) (from the second pair)
-                const float* src = w2 + (size_t)(cf * 16 + l15) * 4 * C + c * 32;
+                const float* src = w2 + (size_t)(cb * 32 + r) * 4 * C + c * 32 + nb * 16 + 4 * h;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o.e[e] = f2bf(src[e < 4 ? 4 * q + e : 16 + 4 * q + (e - 4)]);
+                for (int e = 0; e < 8; ++e) o.e[e] = f2bf(src[8 * (e >> 2) + (e & 3)]);
             }
         }
         *reinterpret_cast<uint4*>(stream + byte) = o.u;
     }
 }
-
-template <int OFF>
-__device__ __forceinline__ void ffr_rd16(bf16x8& d, unsigned addr) {
-    // (no "memory" clobber: an asm that may touch memory makes hipcc's waitcnt pass drain the pending LDS-DMA, gemm.hip)
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
-}
-template <int N>
-__device__ __forceinline__ void ffr_pin(bf16x8 (&d)[N]) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(d[i]));
-}
-template <int N>
-__device__ __forceinline__ void ffr_wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
 
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -119,266 +107,332 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-#define FFR_BLDS16(rsrc, ldst, voff, soff)                                                                 \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(ldst), 16, \
-                                             (int)(voff), (int)(soff), 0, 0)
+// ---- the asm vocabulary of the main loop (all volatile: they keep their source order; none clobbers "memory")
+template <int OFF>
+__device__ __forceinline__ void ffr_rd16(bf16x8& d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void ffr_wait_lgkm() {
+#ifdef GL_FFN_LGKM0
+    asm volatile("s_waitcnt lgkmcnt(0)");
+#else
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
+#endif
+}
+// LDS-DMA of one 1 KiB block (gfx950: buffer_load_dwordx4 ... lds): M0 = LDS byte address of the block, lane * 16 rides in the VGPR
+// offset, the stream offset in the SGPR offset. Both cursors step to the wave's next block (4 KiB on) inside the statement; the first
+// s_add is also the wait state between the write of M0 and its use.
+// PAD: a VMEM instruction must not read an SGPR (descriptor, offset) within 5 wait states of the SALU write -- hipcc does not pad
+// an asm statement. In the main loop the statements are four MFMAs apart; the prologue's sit back to back and open with s_nop 4.
+template <bool PAD = false>
+__device__ __forceinline__ void ffr_dma(const u32x4& rsrc, unsigned lane16, unsigned& lds_dst, unsigned& soff) {
+#ifdef GL_FFN_BUILTIN_DMA
+    {
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)rsrc.y << 32) | rsrc.x), 0, (int)rsrc.z, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(uintptr_t)lds_dst, 16, (int)lane16, (int)soff, 0, 0);
+        lds_dst += 0x1000;
+        soff += 0x1000;
+        return;
+    }
+#endif
+    if constexpr (PAD)
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_add_u32 %0, %0, 0x1000\n\tbuffer_load_dwordx4 %2, %3, %1 offen lds\n\ts_add_u32 %1, %1, 0x1000"
+                     : "+s"(lds_dst), "+s"(soff)
+                     : "v"(lane16), "s"(rsrc)
+                     : "scc");
+    else
+        asm volatile("s_mov_b32 m0, %0\n\ts_add_u32 %0, %0, 0x1000\n\tbuffer_load_dwordx4 %2, %3, %1 offen lds\n\ts_add_u32 %1, %1, 0x1000"
+                     : "+s"(lds_dst), "+s"(soff)
+                     : "v"(lane16), "s"(rsrc)
+                     : "scc");
+}
+// The GEGLU state rides through every MFMA statement as in/out operands (no instruction reads them): the VALU micro-step that
+// follows an MFMA in the source consumes what that statement "defined" and feeds the next one, so hipcc can place it nowhere but
+// in the gap between the two.
+struct GegluState { float l0, l1, m0, m1; };
+#define FFR_GS(s) "+v"(s.l0), "+v"(s.l1), "+v"(s.m0), "+v"(s.m1)
+// D = A B (+ D): A = weight fragment (VGPR), B = activation operand
+#ifdef GL_FFN_MFMA_PAD
+#define FFR_PAD "\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+#else
+#define FFR_PAD
+#endif
+__device__ __forceinline__ void mfma_first_ba(f32x16& d, const bf16x8& a, const bf16x8& b, GegluState& s) {   // B in the AGPR half, C = 0
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %5, %6, 0" FFR_PAD : "=&v"(d), FFR_GS(s) : "v"(a), "a"(b));
+}
+__device__ __forceinline__ void mfma_acc_ba(f32x16& d, const bf16x8& a, const bf16x8& b, GegluState& s) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %5, %6, %0" FFR_PAD : "+v"(d), FFR_GS(s) : "v"(a), "a"(b));
+}
+__device__ __forceinline__ void mfma_acc_bv(f32x16& d, const bf16x8& a, const bf16x8& b, GegluState& s) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %5, %6, %0" FFR_PAD : "+v"(d), FFR_GS(s) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_acc_aa(f32x16& d, const bf16x8& a, const u32x4& b, GegluState& s) {      // accumulator in the AGPR half
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %5, %6, %0" FFR_PAD : "+a"(d), FFR_GS(s) : "v"(a), "v"(b));
+}
+
+// erf-GELU of the gate times the value for one pair of hidden features, in 7 micro-steps of 1-4 plain fp32 VALU instructions
+// (packed fp32 costs a wait state per dependent pair on gfx950 and is dearer than two plain ops beside MFMAs, MI355X_MICROARCH.md):
+//   gelu(x) = x Phi(x) = max(x, 0) - |x| h(|x|),   h(a) = erfc(a / sqrt2) / 2 = 2^L(a),
+// L a cubic fitted to log2(erfc(a / sqrt2) / 2) on [0, 9] (weighted towards the absolute error of a h(a)): |gelu error| <= 7.8e-5 for
+// every x (tools/fit_gelu.py; the output is rounded to bf16, 2^-9 relative), all coefficients negative, so h -> 0 for large |x|.
+// One transcendental per feature instead of the two (rcp + exp) of the Abramowitz-Stegun form in common.h, 7 VALU instead of 16.
+#define FFR_GELU_C3 -0.026971418f
+#define FFR_GELU_C2 -0.49073458f
+#define FFR_GELU_C1 -1.1382852f
+#define FFR_GELU_C0 -1.0007436f
+template <int J>
+__device__ __forceinline__ void geglu_step(GegluState& s, float v0, float v1, float x0, float x1, unsigned& out) {
+    const float a0 = __builtin_fabsf(x0), a1 = __builtin_fabsf(x1);
+    if constexpr (J == 0) {
+        s.l0 = fmaf(a0, FFR_GELU_C3, FFR_GELU_C2);
+        s.l1 = fmaf(a1, FFR_GELU_C3, FFR_GELU_C2);
+    } else if constexpr (J == 1) {
+        s.l0 = fmaf(a0, s.l0, FFR_GELU_C1);
+        s.l1 = fmaf(a1, s.l1, FFR_GELU_C1);
+    } else if constexpr (J == 2) {
+        s.l0 = fmaf(a0, s.l0, FFR_GELU_C0);
+        s.l1 = fmaf(a1, s.l1, FFR_GELU_C0);
+        s.m0 = fmaxf(x0, 0.f);
+        s.m1 = fmaxf(x1, 0.f);
+    } else if constexpr (J == 3) {
+        s.l0 = __builtin_amdgcn_exp2f(s.l0);
+        s.l1 = __builtin_amdgcn_exp2f(s.l1);
+    } else if constexpr (J == 4) {
+        s.l0 = fmaf(-a0, s.l0, s.m0);
+        s.l1 = fmaf(-a1, s.l1, s.m1);
+    } else if constexpr (J == 5) {
+        s.l0 *= v0;
+        s.l1 *= v1;
+    } else {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        const bf16x2 o = __builtin_convertvector(f32x2{s.l0, s.l1}, bf16x2);
+        out = __builtin_bit_cast(unsigned, o);
+    }
+}
 
 // ABL: developer ablation bits (tools/gpu_r4b.sh; only ABL = 0 is in the product library): 1 no GEGLU arithmetic, 2 no DMA behind the
-// first two stages, 4 no fragment reads behind each chunk's first two groups, 8 no projection MFMAs, 16 no FF-out MFMAs, 32 no barrier
+// prologue's, 8 no projection MFMAs, 16 no FF-out MFMAs, 32 no barrier
 template <int C, int ABL = 0>
 __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
     using G = FFGeom<C>;
-    constexpr int KS = G::KS, NCF = G::NCF, NCH = G::NCH, STAGE = G::STAGE, NG = G::NG;
+    constexpr int KS = G::KS, NKP = G::NKP, NCB = G::NCB, NCH = G::NCH, NPB = G::NPB, NBLK = G::NBLK, STAGE = G::STAGE;
+    constexpr int NR = 12;      // fragment ring (blocks): the read of block i + RD is issued behind MFMA i
+    constexpr int RD = 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int l15 = lane & 15;
-    const int q = lane >> 4;
-    const int m0 = blockIdx.x * 128 + wave * 32;      // this wave's 32 rows
+    const int h = lane >> 5;
+    const int row = blockIdx.x * 128 + wave * 32 + (lane & 31);      // this lane's row (shared with lane ^ 32)
     const unsigned lane16 = (unsigned)lane * 16u;
 
-    // ---- the wave's rows as B-operand fragments: lane (l15, q) holds x[m0 + 16 rb + l15][32 ks + 8 q .. + 7]
-    bf16x8 xf[2][KS];
+    // ---- weights: stage 0 on its way while the rows are loaded and normalised
+    u32x4 rs;
+    {
+        const unsigned long long a = (unsigned long long)(uintptr_t)p.stream;
+        rs.x = (unsigned)a;
+        rs.y = (unsigned)(a >> 32);           // base[47:32], stride 0
+        rs.z = (unsigned)G::STREAM_BYTES;     // num_records
+        rs.w = 0x00020000u;                   // raw buffer, dword format (as __builtin_amdgcn_make_buffer_rsrc builds it for gfx950)
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    // DMA cursors of this wave (it copies blocks wave, wave + 4, ... of every stage): LDS destination and stream offset of its next block
+    const unsigned lds_w = lds0 + (unsigned)wave * 1024u;
+    unsigned dma_lds = lds_w;
+    unsigned dma_off = (unsigned)wave * 1024u;
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        const bf16* src = p.x + (size_t)(m0 + rb * 16 + l15) * p.ldx + q * 8;
+    for (int i = 0; i < G::NBS / 4; ++i) ffr_dma<true>(rs, lane16, dma_lds, dma_off);
+
+    // ---- the wave's rows as B-operand fragments: lane holds x[row][16 ks + 8 h .. + 7]
+    bf16x8 xf[KS];
+    {
+        const bf16* src = p.x + (size_t)row * p.ldx + h * 8;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) xf[rb][ks] = *reinterpret_cast<const bf16x8*>(src + ks * 32);
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(src + ks * 16);
     }
     const float gate = (p.res && p.gate) ? *p.gate : 1.f;
-
-    // ---- weights: stage 0 and the bias table on their way while the rows are normalised
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.stream), 0, (int)G::STREAM_BYTES, 0x00020000);
-    auto dma_piece = [&](int st, int piece) {     // this wave's piece-th block of stage st (a wave copies blocks wave, wave + 4, ...)
-        const int blk = wave + 4 * piece;
-        if ((ABL & 2) && st > 1) return;
-        FFR_BLDS16(rs, smem + (st & 1) * STAGE + blk * 1024, lane16, st * STAGE + blk * 1024);
-    };
-#pragma unroll
-    for (int i = 0; i < G::NB / 4; ++i) dma_piece(0, i);
-#pragma unroll
-    for (int i = 0; i < (G::BIAS_BYTES / 1024 + 3) / 4; ++i) {
-        const int blk = wave + 4 * i;
-        if (blk < G::BIAS_BYTES / 1024) FFR_BLDS16(rs, smem + 2 * STAGE + blk * 1024, lane16, G::NSTAGE * STAGE + blk * 1024);
-    }
-
     if (p.normalize) {
+        float s = 0.f, ss = 0.f;
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            float s = 0.f, ss = 0.f;
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
+            for (int e = 0; e < 8; ++e) {
+                const float v = bf2f(xf[ks][e]);
+                s += v;
+                ss = fmaf(v, v, ss);
+            }
+        s += __shfl_xor(s, 32, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        const float mean = s * (1.f / C);
+        const float var = fmaxf(ss * (1.f / C) - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + p.eps);
+        const float nm = -mean * rstd;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float v = bf2f(xf[rb][ks][e]);
-                    s += v;
-                    ss = fmaf(v, v, ss);
-                }
-            s += __shfl_xor(s, 16, 64); ss += __shfl_xor(ss, 16, 64);
-            s += __shfl_xor(s, 32, 64); ss += __shfl_xor(ss, 32, 64);
-            const float mean = s * (1.f / C);
-            const float var = fmaxf(ss * (1.f / C) - mean * mean, 0.f);
-            const float rstd = rsqrtf(var + p.eps);
-            const float nm = -mean * rstd;
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xf[rb][ks][e] = f2bf(fmaf(bf2f(xf[rb][ks][e]), rstd, nm));
-        }
+            for (int e = 0; e < 8; ++e) xf[ks][e] = f2bf(fmaf(bf2f(xf[ks][e]), rstd, nm));
     }
-
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    unsigned rbias = lds0 + 2 * STAGE + (unsigned)q * 16u;   // this lane's float4 of fragment 0 of chunk 0; + 64 per fragment, + 256 per chunk
-
-    f32x4 acc2[NCF][2];
+    bf16x8 xb;                                   // B operand of the bias step: k-slot 0 = 1
 #pragma unroll
-    for (int cf = 0; cf < NCF; ++cf) acc2[cf][0] = acc2[cf][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // two projection accumulator sets: chunk c multiplies into a1[c & 1] while the GEGLU of chunk c - 1 reads a1[(c - 1) & 1]
-    f32x4 a1[2][4][2];
-    float hv[2][8];        // GEGLU outputs of the chunk being activated, per row block, in k-slot order of the P^T operand
-    bf16x8 P[2];
+    for (int e = 0; e < 8; ++e) xb[e] = f2bf(0.f);
+    xb[0] = f2bf(h == 0 ? 1.f : 0.f);
 
-    // GEGLU call k (0..7) of a chunk: row block k >> 2, half hf = (k >> 1) & 1 (value = fragment 2 hf, gate = fragment 2 hf + 1),
-    // element pair pr = k & 1
-    auto geglu_call = [&](auto kc, f32x4 (&src)[4][2]) {
-        constexpr int k = decltype(kc)::value, rb = k >> 2, hf = (k >> 1) & 1, pr = k & 1;
+    f32x16 acc2[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[cb][e] = 0.f;
+    // two projection accumulator sets: chunk c multiplies into a1[c & 1] while the GEGLU of chunk c - 1 reads a1[(c - 1) & 1]; likewise
+    // the GEGLU of chunk c writes the P^T operand P[c & 1] while the FF-out product of chunk c - 1 reads P[(c - 1) & 1]
+    f32x16 a1[2][2];
+    u32x4 P[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) P[i][0] = P[i][1] = u32x4{0u, 0u, 0u, 0u};
+    GegluState gs;
+    gs.l0 = gs.l1 = gs.m0 = gs.m1 = 0.f;
+    const unsigned ra_st[2] = {lds0 + lane16, lds0 + (unsigned)STAGE + lane16};
+
+    // micro-step u (0..55) of the GEGLU of one chunk: call k = u / 7 handles block nb = k >> 2, feature pair (jj, pr); source = that
+    // chunk's projection accumulators, destination dword 2 jj + pr of its P^T operand
+    auto gstep = [&](auto uc, f32x16 (&src)[2], u32x4 (&dst)[2]) {
+        constexpr int u = decltype(uc)::value, k = u / 7, j = u % 7, nb = k >> 2, jj = (k >> 1) & 1, pr = k & 1;
+        constexpr int v0 = 4 * jj + 2 * pr, g0 = 8 + 4 * jj + 2 * pr;
         if constexpr (ABL & 1) {
-            hv[rb][4 * hf + 2 * pr] = src[2 * hf][rb][2 * pr] + src[2 * hf + 1][rb][2 * pr];
-            hv[rb][4 * hf + 2 * pr + 1] = src[2 * hf][rb][2 * pr + 1] + src[2 * hf + 1][rb][2 * pr + 1];
+            if constexpr (j == 6) {
+                U2BF4 o;
+                o.e[0] = f2bf(src[nb][v0] + src[nb][g0]);
+                o.e[1] = f2bf(src[nb][v0 + 1] + src[nb][g0 + 1]);
+                dst[nb][2 * jj + pr] = o.u.x;
+            }
             return;
         }
-        const f32x2 r = geglu2(f32x2{src[2 * hf][rb][2 * pr], src[2 * hf][rb][2 * pr + 1]},
-                               f32x2{src[2 * hf + 1][rb][2 * pr], src[2 * hf + 1][rb][2 * pr + 1]});
-        hv[rb][4 * hf + 2 * pr] = r.x;
-        hv[rb][4 * hf + 2 * pr + 1] = r.y;
-    };
-    auto pack_p = [&](int rb) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) P[rb][e] = f2bf(hv[rb][e]);
+        unsigned out = 0;
+        geglu_step<j>(gs, src[nb][v0], src[nb][v0 + 1], src[nb][g0], src[nb][g0 + 1], out);
+        if constexpr (j == 6) dst[nb][2 * jj + pr] = out;
     };
 
-    // One chunk `it` (PAR = it & 1). Its 15 fragment groups (10 projection k-steps, 5 FF-out groups of 4 fragments) each carry 8
-    // MFMAs; the VALU work is spread over them so that no group is VALU-only:
-    //   g = 0,2,4,6,8 : GEGLU calls 3..7 of chunk it - 1 (source a1[PAR ^ 1])     g = 1 / 9 : pack P[0] / P[1]
-    //   g = 10,12,14  : GEGLU calls 0..2 of chunk it (source a1[PAR], complete after g = 9), carried to the next chunk in hv
-    //   g = 9         : bias fragments of chunk it + 1 requested        g = 11, 13 : a1[PAR ^ 1] <- bias of chunk it + 1
-    // MODE 0: the first chunk (no previous chunk: no FF-out product, calls 3..7 and packs skipped).
-    auto chunk = [&](auto mode_c, auto par_c, int it) {
-        constexpr int MODE = decltype(mode_c)::value;
+    // One chunk `it` (PAR = it & 1): 62 MFMAs in stream order. Slots 0..41 multiply the projection of chunk `it` into T = a1[PAR]
+    // (k-step major; the 21st k-step is the bias), slots 42..61 the FF-out product of chunk it - 1 from P[PAR ^ 1]. Behind MFMA i:
+    // the read of block i + 8, every fourth gap one DMA block of the next stage, and one GEGLU micro-step:
+    //   gaps 0..36 : u = 19..55 of chunk it - 1 (source S = a1[PAR ^ 1])                     -> P[PAR ^ 1], complete long before slot 42
+    //   gaps 43..61: u = 0..18 of chunk it (source T, whose last MFMAs are slots 40 / 41)   -> P[PAR]
+    // FIRST: chunk 0 (no previous chunk: its FF-out blocks are zeros and P[1] = 0).
+    auto chunk = [&](auto first_c, auto par_c) {
+        constexpr bool FIRST = decltype(first_c)::value;
         constexpr int PAR = decltype(par_c)::value;
-        constexpr bool OUT = MODE != 0;
-        f32x4 (&T)[4][2] = a1[PAR];
-        f32x4 (&S)[4][2] = a1[PAR ^ 1];
-        __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): this wave's pieces of the stage have landed (hipcc then knows nothing is pending)
+        f32x16 (&T)[2] = a1[PAR];
+        f32x16 (&S)[2] = a1[PAR ^ 1];
+        asm volatile("s_waitcnt vmcnt(0)");            // this wave's blocks of the stage have landed
         if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();   // ... and everybody's; every wave is done reading the other stage
-        asm volatile("" ::: "memory");
-        const unsigned ra = lds0 + (unsigned)(it & 1) * STAGE + lane16;
-
-        bf16x8 fr[3][4];                           // fragment ring: group g lives in fr[g % 3], two groups in flight ahead of the multiply
-        bf16x8 bfr[4];                             // the next chunk's projection bias (4 x float4 per lane)
-        auto issue = [&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            static_for<4>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                ffr_rd16<(g * 4 + i) * 1024>(fr[g % 3][i], ra);
-            });
-        };
-        auto issue_bias = [&]() {
-            static_for<4>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                ffr_rd16<i * 64>(bfr[i], rbias);
-            });
-            rbias += 256;
-        };
-        if constexpr (MODE == 0) {                 // the first chunk initialises its own accumulators
-            issue_bias();
-            ffr_wait_lgkm<0>();
-            ffr_pin(bfr);
-#pragma unroll
-            for (int nf = 0; nf < 4; ++nf) T[nf][0] = T[nf][1] = __builtin_bit_cast(f32x4, bfr[nf]);
-        }
-        constexpr int G1 = OUT ? NG : KS;          // fragment groups this chunk reads
-        issue(std::integral_constant<int, 0>{});
-        issue(std::integral_constant<int, 1>{});
-        __builtin_amdgcn_sched_barrier(0);
-
-        static_for<NG>([&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            dma_piece(it + 1, g);                  // next stage, one block per wave and group
-            if constexpr (g == KS - 1) issue_bias();
-            if constexpr (g + 2 < G1 && !(ABL & 4)) issue(std::integral_constant<int, g + 2>{});
-            constexpr bool heavy = (g % 2 == 0) && (g >= KS || OUT);   // a GEGLU call rides in this group
-            if constexpr (g < G1) {
-                // reads issued behind group g's: groups g + 1, g + 2 (where they exist) and, around g = KS - 1, the bias fragments
-                constexpr int younger = 4 * ((G1 - 1 - g) < 2 ? (G1 - 1 - g) : 2) + ((g == KS - 1 || g == KS) ? 4 : 0);
-                if constexpr (ABL & 4) ffr_wait_lgkm<0>();
-                else ffr_wait_lgkm<younger>();
-                ffr_pin(fr[g % 3]);
-                if constexpr (heavy) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA,
-                        __builtin_amdgcn_sched_group_barrier(0x402, 4, 0);   // then a piece of the GEGLU (VALU / transcendental)
-                    }
-                }
-                if constexpr (g < KS) {
-                    // projection k-step g: S^T[4 fragments][2 row blocks] += W1 fragment x X fragment
-#pragma unroll
-                    for (int nf = 0; nf < 4; ++nf)
-#pragma unroll
-                        for (int rb = 0; rb < 2; ++rb)
-                            if constexpr (!(ABL & 8)) T[nf][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][nf], xf[rb][g], T[nf][rb], 0, 0, 0);
-                } else {
-                    // FF-out group: Y^T[4 fragments][2 row blocks] += W2 fragment x P^T
-                    constexpr int j = g - KS;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int rb = 0; rb < 2; ++rb)
-                            if constexpr (!(ABL & 16)) acc2[4 * j + i][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g % 3][i], P[rb], acc2[4 * j + i][rb], 0, 0, 0);
-                }
-            } else if constexpr (g == KS) {
-                ffr_wait_lgkm<0>();                // (first chunk: only the bias fragments are outstanding)
+#ifdef GL_FFN_SLOW_SYNC
+        __builtin_amdgcn_s_sleep(20);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
+        __builtin_amdgcn_s_barrier();
+#endif
+        const unsigned ra = ra_st[PAR];
+        dma_lds = lds_w + (PAR ? 0u : (unsigned)STAGE);   // the next stage goes where the previous one was
+        bf16x8 fr[NR];
+        static_for<RD>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            ffr_rd16<i * 1024>(fr[i % NR], ra);
+        });
+        static_for<NBLK>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (i % 4 == 0) {
+                // blocks i .. i + 3 have arrived when at most the reads of blocks i + 4 .. i + RD - 1 are outstanding
+                constexpr int last = (i + RD - 1 < NBLK - 1) ? i + RD - 1 : NBLK - 1;
+                constexpr int need = (i + 3 < NBLK - 1) ? i + 3 : NBLK - 1;
+                ffr_wait_lgkm<last - need>();
             }
-            if constexpr (g < KS) {
-                if constexpr (OUT && g % 2 == 0) geglu_call(std::integral_constant<int, 3 + g / 2>{}, S);
-                if constexpr (OUT && g == 1) pack_p(0);
-                if constexpr (OUT && g == KS - 1) pack_p(1);
+            if constexpr (i < NPB) {
+                constexpr int ks = i >> 1, nb = i & 1;
+                if constexpr (!(ABL & 8)) {
+                    if constexpr (ks == 0) mfma_first_ba(T[nb], fr[i % NR], xf[0], gs);
+                    else if constexpr (ks < KS) mfma_acc_ba(T[nb], fr[i % NR], xf[ks], gs);
+                    else mfma_acc_bv(T[nb], fr[i % NR], xb, gs);
+                }
             } else {
-                if constexpr ((g - KS) % 2 == 0 && (g - KS) / 2 < 3) geglu_call(std::integral_constant<int, (g - KS) / 2>{}, T);
-                if constexpr (g == KS + 1 || g == KS + 3) {
-                    if constexpr (g == KS + 1) ffr_pin(bfr);
-                    constexpr int n0 = g == KS + 1 ? 0 : 2;
-#pragma unroll
-                    for (int nf = n0; nf < n0 + 2; ++nf) S[nf][0] = S[nf][1] = __builtin_bit_cast(f32x4, bfr[nf]);
-                }
+                constexpr int ob = i - NPB, nb = ob / NCB, cb = ob % NCB;
+                if constexpr (!(ABL & 16)) mfma_acc_aa(acc2[cb], fr[i % NR], P[PAR ^ 1][nb], gs);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (i + RD < NBLK) ffr_rd16<(i + RD) * 1024>(fr[(i + RD) % NR], ra);
+            if constexpr (i % 4 == 1 && !(ABL & 2)) ffr_dma(rs, lane16, dma_lds, dma_off);
+            if constexpr (i < 37) {
+                if constexpr (!FIRST) gstep(std::integral_constant<int, 19 + i>{}, S, P[PAR ^ 1]);
+            } else if constexpr (i > NPB) {
+                gstep(std::integral_constant<int, i - NPB - 1>{}, T, P[PAR]);
+            }
         });
     };
+    static_assert(NPB == 42 && NBLK == 62, "the GEGLU micro-step placement above is written for 42 projection + 20 FF-out MFMAs per chunk");
 
-    static_assert(KS == 10 && NG == 15, "the VALU placement above is written for 10 projection k-steps + 5 FF-out groups");
-    static_assert(NCH % 2 == 0, "chunk parity of the last chunk");
-    __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): scalar loads done (else hipcc drains lgkmcnt inside the loop, behind the fragment reads)
-    chunk(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0);
+    // Every load hipcc knows about (the x rows, the gate) has to be BACK before the first asm DMA of the main loop: its counted
+    // vmcnt waits do not see those. And the x fragments have to be IN the AGPR half here, not copied there in front of their first
+    // MFMA: a v_accvgpr_write needs wait states before an MFMA may read the register, and hipcc does not pad in front of an asm
+    // statement (seen as lane-local NaNs -- whatever the previous kernel had left in those AGPRs -- that came and went between runs).
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(xf[ks]));
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) asm volatile("" : "+a"(acc2[cb]));
+    asm volatile("s_nop 7" : "+v"(xb));
+    chunk(std::true_type{}, std::integral_constant<int, 0>{});
 #pragma unroll 1
     for (int it = 1; it + 1 < NCH; it += 2) {
-        chunk(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, it);
-        chunk(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, it + 1);
+        chunk(std::false_type{}, std::integral_constant<int, 1>{});
+        chunk(std::false_type{}, std::integral_constant<int, 0>{});
     }
-    chunk(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, NCH - 1);
+    chunk(std::false_type{}, std::integral_constant<int, 1>{});
     {
-        // last stage: the rest of the GEGLU of the last chunk (calls 0..2 ran behind its projection), then its FF-out product
-        f32x4 (&S)[4][2] = a1[(NCH - 1) & 1];
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const unsigned ra = lds0 + (unsigned)(NCH & 1) * STAGE + lane16;
-        static_for<5>([&](auto kc) { geglu_call(std::integral_constant<int, 3 + decltype(kc)::value>{}, S); });
-        pack_p(0);
-        pack_p(1);
-        static_for<NCF / 4>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            bf16x8 fr[4];
-            static_for<4>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                ffr_rd16<((KS + j) * 4 + i) * 1024>(fr[i], ra);
-            });
-            ffr_wait_lgkm<0>();
-            ffr_pin(fr);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
-                    acc2[4 * j + i][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[i], P[rb], acc2[4 * j + i][rb], 0, 0, 0);
+        // last stage (index NCH, even): the rest of the GEGLU of the last chunk, then its FF-out product; nothing left to fetch
+        constexpr int PAR = NCH & 1;
+        f32x16 (&S)[2] = a1[PAR ^ 1];
+        asm volatile("s_waitcnt vmcnt(0)");
+        if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
+        const unsigned ra = ra_st[PAR];
+        bf16x8 fr[NR];
+        static_for<RD>([&](auto ic) {
+            constexpr int i = NPB + decltype(ic)::value;
+            ffr_rd16<i * 1024>(fr[i % NR], ra);
         });
+        static_for<37>([&](auto uc) { gstep(std::integral_constant<int, 19 + decltype(uc)::value>{}, S, P[PAR ^ 1]); });
+        static_for<NBLK - NPB>([&](auto oc) {
+            constexpr int i = NPB + decltype(oc)::value;
+            constexpr int ob = i - NPB, nb = ob / NCB, cb = ob % NCB;
+            if constexpr (ob % 4 == 0) {
+                constexpr int last = (i + RD - 1 < NBLK - 1) ? i + RD - 1 : NBLK - 1;
+                constexpr int need = (i + 3 < NBLK - 1) ? i + 3 : NBLK - 1;
+                ffr_wait_lgkm<last - need>();
+            }
+            if constexpr (!(ABL & 16)) mfma_acc_aa(acc2[cb], fr[i % NR], P[PAR ^ 1][nb], gs);
+            if constexpr (i + RD < NBLK) ffr_rd16<(i + RD) * 1024>(fr[(i + RD) % NR], ra);
+        });
+        asm volatile("s_nop 15\n\ts_nop 15");      // the last MFMAs' results before hipcc's own reads of the accumulators
     }
 
-    // ---- epilogue: lane (l15, q) holds features 16 cf + 4 q .. + 3 of row m0 + 16 rb + l15. Two copies under one uniform branch
+    // ---- epilogue: lane holds features 32 cb + 8 j + 4 h + e of its row. Two copies under one uniform branch
     // (a residual load behind a per-use guard is waited for in place)
-    float4 b2v[NCF];
-#pragma unroll
-    for (int cf = 0; cf < NCF; ++cf) b2v[cf] = *reinterpret_cast<const float4*>(p.b2 + cf * 16 + q * 4);
     auto epilogue = [&](auto res_c) {
         constexpr bool RES = decltype(res_c)::value;
+        float s = 0.f, ss = 0.f;
+        bf16* dst = p.out + (size_t)row * p.ldo + h * 4;
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const int row = m0 + rb * 16 + l15;
-            uint2 rv[NCF];
-            if constexpr (RES) {
+        for (int cb = 0; cb < NCB; ++cb) {
+            float4 bv[4];
+            uint2 rv[4];
 #pragma unroll
-                for (int cf = 0; cf < NCF; ++cf) rv[cf] = *reinterpret_cast<const uint2*>(p.res + (size_t)row * p.ldres + cf * 16 + q * 4);
+            for (int j = 0; j < 4; ++j) {
+                bv[j] = *reinterpret_cast<const float4*>(p.b2 + cb * 32 + j * 8 + h * 4);
+                if constexpr (RES) rv[j] = *reinterpret_cast<const uint2*>(p.res + (size_t)row * p.ldres + cb * 32 + j * 8 + h * 4);
             }
-            float s = 0.f, ss = 0.f;
-            bf16* dst = p.out + (size_t)row * p.ldo + q * 4;
 #pragma unroll
-            for (int cf = 0; cf < NCF; ++cf) {
-                float v[4] = {acc2[cf][rb][0] + b2v[cf].x, acc2[cf][rb][1] + b2v[cf].y, acc2[cf][rb][2] + b2v[cf].z, acc2[cf][rb][3] + b2v[cf].w};
+            for (int j = 0; j < 4; ++j) {
+                float v[4] = {acc2[cb][4 * j] + bv[j].x, acc2[cb][4 * j + 1] + bv[j].y, acc2[cb][4 * j + 2] + bv[j].z, acc2[cb][4 * j + 3] + bv[j].w};
                 if constexpr (RES) {
                     U2BF4 r;
-                    r.u = rv[cf];
+                    r.u = rv[j];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = bf2f(r.e[e]) + gate * v[e];
                 }
@@ -390,13 +444,13 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
                     s += r;
                     ss = fmaf(r, r, ss);
                 }
-                *reinterpret_cast<uint2*>(dst + cf * 16) = o.u;
+                *reinterpret_cast<uint2*>(dst + cb * 32 + j * 8) = o.u;
             }
-            if (p.stats_out) {
-                s += __shfl_xor(s, 16, 64); ss += __shfl_xor(ss, 16, 64);
-                s += __shfl_xor(s, 32, 64); ss += __shfl_xor(ss, 32, 64);
-                if (q == 0) p.stats_out[(size_t)row * p.stats_ld] = make_float2(s, ss);
-            }
+        }
+        if (p.stats_out) {
+            s += __shfl_xor(s, 32, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            if (h == 0) p.stats_out[(size_t)row * p.stats_ld] = make_float2(s, ss);
         }
     };
     if (p.res) epilogue(std::true_type{});

@@ -304,6 +304,31 @@ int main(int argc, char** argv) {
                 const bf16* ref = r2 ? r2 : a2 + ((size_t)100 << 20);
                 float d, m;
                 maxdiff(a2, ref, (size_t)M * C, s, &d, &m);
+                {
+                    float d1, m1, d2, m2;
+                    maxdiff(a2, a2, (size_t)M * C, s, &d1, &m1);
+                    maxdiff(ref, ref, (size_t)M * C, s, &d2, &m2);
+                    if (d1 != 0.f || d2 != 0.f) printf("  NaN check: fused %s (max %g), reference %s (max %g)\n", d1 != 0.f ? "HAS NaN" : "clean", m1, d2 != 0.f ? "HAS NaN" : "clean", m2);
+                    // first bad row of the fused output
+                    if (d1 != 0.f) {
+                        std::vector<bf16> hb((size_t)M * C);
+                        HC(hipMemcpy(hb.data(), a2, hb.size() * 2, hipMemcpyDeviceToHost));
+                        int nbad = 0, first = -1, last = -1;
+                        for (int r = 0; r < M; ++r) {
+                            bool bad = false;
+                            for (int cc = 0; cc < C; ++cc) { float f = (float)hb[(size_t)r * C + cc]; if (f != f) bad = true; }
+                            if (bad) { ++nbad; if (first < 0) first = r; last = r; }
+                        }
+                        printf("  rows with NaN: %d of %d (first %d, last %d)\n", nbad, M, first, last);
+                        int hist[32] = {0};
+                        for (int r = 0; r < M; ++r) { bool bad = false; for (int cc = 0; cc < C; ++cc) { float f = (float)hb[(size_t)r * C + cc]; if (f != f) bad = true; } if (bad) ++hist[r & 31]; }
+                        printf("  NaN rows by row %% 32:"); for (int i = 0; i < 32; ++i) printf(" %d", hist[i]); printf("\n");
+                        printf("  NaN columns of row %d:", first); for (int cc = 0; cc < C; ++cc) { float f = (float)hb[(size_t)first * C + cc]; if (f != f) printf(" %d", cc); } printf("\n");
+                        int chist[320] = {0}; long tot = 0;
+                        for (int r = 0; r < M; ++r) for (int cc = 0; cc < C; ++cc) { float f = (float)hb[(size_t)r * C + cc]; if (f != f) { ++chist[cc]; ++tot; } }
+                        printf("  NaN elements total %ld; by column (nonzero):", tot); for (int cc = 0; cc < C; ++cc) if (chist[cc]) printf(" %d:%d", cc, chist[cc]); printf("\n");
+                    }
+                }
                 const bool ok = d <= 0.03f * m + 1e-6f;
                 if (!ok) ++n_bad;
                 printf("FFN M%d C%d norm%d: fused %.1f us (%.0f TF/s) vs two GEMMs%s %.1f us; maxdiff %g of %g %s\n", M, C, norm, us, flop / us * 1e-6,
