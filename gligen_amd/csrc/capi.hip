@@ -378,6 +378,69 @@ int gl_op_ln_linear(gl_ctx* ctx, const void* a, int M, int K0, const float* w0, 
     GL_API_END
 }
 
+int gl_op_feedforward(gl_ctx* ctx, const void* x, int M, int C, const float* gamma, const float* beta, const float* w1, const float* b1,
+                      const float* w2, const float* b2, const void* res, const float* gate, void* y, void* stats, int* used_rows,
+                      gl_stream s) {
+    NEED(ctx);
+    if (!x || !w1 || !b1 || !w2 || !b2 || !y || !used_rows) return gl::set_error(GL_ERR_ARG, "gl_op_feedforward: null pointer");
+    if ((gamma == nullptr) != (beta == nullptr)) return gl::set_error(GL_ERR_ARG, "gl_op_feedforward: gamma and beta come together");
+    GL_API_BEGIN
+    Engine& eng = *ctx->eng;
+    Arena& ar = eng.arena();
+    ar.reset();
+    auto ck = [&](int rc) { if (rc != GL_OK) throw GlError(rc, gl::last_error()); };
+    if (C % 64 || M <= 0) throw GlError(GL_ERR_ARG, "gl_op_feedforward: C must be a multiple of 64");
+    const float* w1e = w1;
+    const float* b1e = b1;
+    if (gamma) {   // LayerNorm folded into the projection: W1 * gamma, b1 + W1 beta
+        float* wf = ar.get<float>((size_t)8 * C * C);
+        float* bf = ar.get<float>((size_t)8 * C);
+        ck(ln_fold_launch(w1, b1, gamma, beta, wf, bf, 8 * C, C, S(s)));
+        w1e = wf; b1e = bf;
+    }
+    const bool rows = ff_rows_supported(M, C) && !(gl::dev_env("GL_FF_ROWS") && atoi(gl::dev_env("GL_FF_ROWS")) == 0);
+    *used_rows = rows ? 1 : 0;
+    if (rows) {
+        void* st = ar.alloc(ff_stream_bytes(C));
+        ck(ff_pack_launch(w1e, b1e, w2, st, C, S(s)));
+        FFRowsParams P{};
+        P.x = (const bf16*)x; P.ldx = C; P.normalize = gamma ? 1 : 0; P.eps = 1e-5f; P.stream = st; P.b2 = b2;
+        P.res = (const bf16*)res; P.ldres = C; P.gate = gate; P.out = (bf16*)y; P.ldo = C; P.M = M;
+        P.stats_out = (float2*)stats; P.stats_ld = 1;
+        ck(ff_rows_launch(P, C, S(s)));
+    } else {
+        const bf16* in = (const bf16*)x;
+        if (gamma) {
+            bf16* xn = ar.get<bf16>((size_t)M * C);
+            LNParams L{};
+            L.x = in; L.B = 1; L.N1 = M; L.N2 = 0; L.Tpad = M; L.C = C; L.eps = 1e-5f; L.y = xn;
+            ck(layernorm_launch(L, S(s)));
+            in = xn;
+        }
+        const int layout = gl::gemm_geglu_layout();
+        bf16* wp = ar.get<bf16>((size_t)8 * C * C);
+        float* bp = ar.get<float>((size_t)8 * C);
+        ck(pack_geglu_launch(w1e, b1e, wp, bp, 4 * C, C, layout, S(s)));
+        bf16* w2b = ar.get<bf16>((size_t)C * 4 * C);
+        ck(cast_f32_bf16_launch(w2, w2b, (int64_t)C * 4 * C, S(s)));
+        bf16* hid = ar.get<bf16>((size_t)M * 4 * C);
+        AOperand A;
+        aoperand_rows(A, in, C, C);
+        Epilogue E;
+        epilogue_defaults(E);
+        E.act = ACT_GEGLU; E.geglu16 = layout; E.out = hid; E.ldo = 4 * C; E.bias = bp;
+        ck(gemm_launch(A, wp, M, 8 * C, C, E, eng.splitk_ws(), eng.splitk_ws_bytes(), S(s)));
+        AOperand A2;
+        aoperand_rows(A2, hid, 4 * C, 4 * C);
+        Epilogue E2;
+        epilogue_defaults(E2);
+        E2.out = y; E2.ldo = C; E2.bias = b2; E2.res = (const bf16*)res; E2.ldres = C; E2.gate = gate;
+        ck(gemm_launch(A2, w2b, M, C, 4 * C, E2, eng.splitk_ws(), eng.splitk_ws_bytes(), S(s)));
+        if (stats) HIPCK_API(hipMemsetAsync(stats, 0, (size_t)M * sizeof(float2), S(s)));
+    }
+    GL_API_END
+}
+
 int gl_op_conv3x3(gl_ctx* ctx, const void* x0, int C0, const void* x1, int C1, int B, int H, int W,
                   const float* w_oihw, const float* bias, int Cout, int stride, int ups, int pad_lo,
                   const void* res, void* y, gl_stream s) {

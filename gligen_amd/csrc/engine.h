@@ -10,6 +10,7 @@
 #include "attention.h"
 #include "common.h"
 #include "convnext.h"
+#include "ffn.h"
 #include "gemm.h"
 #include "misc.h"
 #include "norm.h"
@@ -72,7 +73,10 @@ struct SelfAttnW {
     LinW out;
 };
 struct CrossAttnW { LinW q; const bf16* wk = nullptr; const bf16* wv = nullptr; LinW out; int ctx_dim = 0; bool folded = false; const float* q_csum = nullptr; };
-struct FFW { const bf16* w1 = nullptr; const float* b1 = nullptr; LinW w2; int C = 0; int geglu16 = 0; bool folded = false; const float* csum1 = nullptr; };
+struct FFW {
+    const bf16* w1 = nullptr; const float* b1 = nullptr; LinW w2; int C = 0; int geglu16 = 0; bool folded = false; const float* csum1 = nullptr;
+    const void* rows_stream = nullptr;   // the same weights as the fragment stream of the row-local kernel (ffn.hip), where one exists for C
+};
 // partial row statistics written by the GEMM that produced a residual-stream tensor (nb = 0: none)
 struct RowStats { float2* p = nullptr; int nb = 0, ld = 0; };
 struct STW {
@@ -195,6 +199,7 @@ class Engine {
     FoldTmp fold_ln(const std::string& weight_key, const float* bias, const NormW& n);
     std::vector<void*> fold_tmps_;
     bool ln_fold_ = false;       // LayerNorms folded into their consumers (GL_LN_FOLD=0: off)
+    bool ff_rows_ = true;        // row-local feed-forward kernel where it exists (GL_FF_ROWS=0: off)
     ResW resw(const std::string& prefix, int Cin, int Cout, bool unet);
     void build_unet();
     void build_vae();
@@ -210,8 +215,10 @@ class Engine {
     bf16* resblock(const ResW& r, const TRef& x, int B, int H, int W, const float* embout, int emb_ld, float eps, hipStream_t s);
     bf16* transformer(const STW& t, const bf16* x, int B, int H, int W, hipStream_t s);
     // in_stats: `ln` holds RAW rows whose statistics are in_stats (folded LayerNorm applied by the GEMM); out_stats: statistics of the result
+    // raw_rows: with a folded LayerNorm, `ln` may be the RAW rows (no in_stats needed) when ff_rows(f, M) says the row-local kernel runs
     bf16* feedforward(const FFW& f, const bf16* ln, int M, const bf16* res, const float* gate, hipStream_t s, const RowStats* in_stats = nullptr,
-                      RowStats* out_stats = nullptr);
+                      RowStats* out_stats = nullptr, bool raw_rows = false);
+    bool ff_rows(const FFW& f, int M) const;
     void self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, int Nq, int Nk, int C, int d, bf16* o, hipStream_t s,
                         const RowStats* in_stats = nullptr);
     bf16* vae_attn(const VaeAttnW& a, const bf16* x, int B, int HW, hipStream_t s);

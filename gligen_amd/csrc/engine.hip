@@ -269,6 +269,11 @@ FFW Engine::ffw(const std::string& p, int C, const NormW* fold) {
     f.w1 = wp;
     f.b1 = bp;
     f.w2 = linear(p + ".net.2");
+    if (ff_rows_ && ff_stream_bytes(C)) {   // the row-local kernel's fragment stream of the same (folded) weights
+        void* st = persist(ff_stream_bytes(C), false);
+        CK(ff_pack_launch(wsrc, bsrc, raw(p + ".net.2.weight").p, st, C, 0));
+        f.rows_stream = st;
+    }
     return f;
 }
 
@@ -362,6 +367,7 @@ void Engine::build_unet() {
         // rounds 1-2): norm1 -> attn1 q,k,v; fuser.norm1 -> fuser q,k,v; fuser.norm2 -> fuser.ff; norm2 -> attn2.to_q; norm3 -> ff
         const bool fold = fuse_qkv && !(dev_env("GL_LN_FOLD") && atoi(dev_env("GL_LN_FOLD")) == 0);
         ln_fold_ = fold;
+        ff_rows_ = !(dev_env("GL_FF_ROWS") && atoi(dev_env("GL_FF_ROWS")) == 0);   // row-local feed-forward kernel (ffn.hip) where it exists
         auto self_attn_w = [&](const std::string& a, const NormW* ln) {
             SelfAttnW w;
             w.fused = fuse_qkv;
@@ -1046,9 +1052,37 @@ void Engine::self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, in
     ++n_launches;
 }
 
+bool Engine::ff_rows(const FFW& f, int M) const { return f.rows_stream && ff_rows_supported(M, f.C); }
+
 bf16* Engine::feedforward(const FFW& f, const bf16* ln, int M, const bf16* res, const float* gate, hipStream_t s, const RowStats* in_stats,
-                          RowStats* out_stats) {
+                          RowStats* out_stats, bool raw_rows) {
     const int C = f.C;
+    if (ff_rows(f, M)) {
+        // one launch: LayerNorm (where folded and the rows are raw) + GEGLU projection + FF-out + (gated) residual + row statistics
+        bf16* out = arena_.get<bf16>((size_t)M * C);
+        FFRowsParams P{};
+        P.x = ln; P.ldx = C; P.normalize = (raw_rows || in_stats) ? 1 : 0; P.eps = 1e-5f;
+        if (P.normalize && !f.folded) throw GlError(GL_ERR_STATE, "feedforward: raw rows given to an unfolded projection");
+        P.stream = f.rows_stream; P.b2 = f.w2.b; P.res = res; P.ldres = C; P.gate = gate; P.out = out; P.ldo = C; P.M = M;
+        if (out_stats) {
+            *out_stats = RowStats{};
+            if (ln_fold_) {
+                out_stats->ld = 1; out_stats->nb = 1;
+                out_stats->p = arena_.get<float2>((size_t)M);
+                P.stats_out = out_stats->p; P.stats_ld = 1;
+            }
+        }
+        ProfScope ps(this, s, "ff_rows_kernel", 24.0 * M * (double)C * C, 0.0);
+        CK(ff_rows_launch(P, C, s));
+        FILE* launch_log = launch_log_file();
+        if (launch_log) {
+            fprintf(launch_log, "ff_rows_kernel|%d|%d|%d|0|%.0f\n", M, C, 4 * C, (double)ff_stream_bytes(C) + (res ? 6.0 : 4.0) * M * C);
+            fflush(launch_log);
+        }
+        ++n_launches;
+        return out;
+    }
+    if (raw_rows && !in_stats) throw GlError(GL_ERR_STATE, "feedforward: raw rows without statistics outside the row-local kernel");
     bf16* hbuf = arena_.get<bf16>((size_t)M * 4 * C);
     AOperand A;
     aoperand_rows(A, ln, C, C);
@@ -1092,6 +1126,8 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
         return folded ? layernorm_plain(rows, B, HW, C, pad64, s) : layernorm(rows, B, HW, C, nw, pad64, s);
     };
     RowStats st0, st1, st2, st3, st4;
+    // the row-local feed-forward kernel normalises its raw input rows itself: their producers need not write statistics
+    const bool r2 = t.fff.folded && ff_rows(t.fff, M), r4 = t.ff.folded && ff_rows(t.ff, M);
     bf16* t0 = linear_rows(n, M, t.proj_in, ACT_NONE, nullptr, nullptr, s, &st0);
 
     // x = attn1(norm1(x)) + x
@@ -1144,7 +1180,7 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
             ++n_launches;
         }
         self_attention(t.fa, lnc, B, Tf, HW, HW + Ng, C, d, o, s);
-        t2 = linear_rows(o, M, t.fa.out, ACT_NONE, t1, gates_ + 2 * t.idx, s, &st2);
+        t2 = linear_rows(o, M, t.fa.out, ACT_NONE, t1, gates_ + 2 * t.idx, s, r2 ? nullptr : &st2);
     } else {
         // fuser (gatedCA, attention.py:207-212): x = x + scale*tanh(alpha_attn) * attn(norm1(x), objs, objs)
         ln = layernorm(t1, B, HW, C, t.fn1, true, s);
@@ -1169,12 +1205,12 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
             log_attention(attn_kernel_name(d, Ng), B, heads, HW, Ng, d);
         }
         ++n_launches;
-        t2 = linear_rows(o, M, t.fca.out, ACT_NONE, t1, gates_ + 2 * t.idx, s, &st2);
+        t2 = linear_rows(o, M, t.fca.out, ACT_NONE, t1, gates_ + 2 * t.idx, s, r2 ? nullptr : &st2);
     }
     //        x = x + scale*tanh(alpha_dense) * ff(norm2(x))
-    const bool f2 = t.fff.folded && can_fold(st2, 8 * C, EPI_ROWMAJOR, ACT_GEGLU);
+    const bool f2 = r2 || (t.fff.folded && can_fold(st2, 8 * C, EPI_ROWMAJOR, ACT_GEGLU));
     ln = normed(t2, t.fn2, t.fff.folded, f2, false);
-    t3 = feedforward(t.fff, ln, M, t2, gates_ + 2 * t.idx + 1, s, f2 ? &st2 : nullptr, &st3);
+    t3 = feedforward(t.fff, ln, M, t2, gates_ + 2 * t.idx + 1, s, (f2 && !r2) ? &st2 : nullptr, &st3, r2);
     }
 
     // x = attn2(norm2(x), context) + x
@@ -1208,12 +1244,12 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
         }
         ++n_launches;
     }
-    bf16* t4 = linear_rows(o, M, t.a2.out, ACT_NONE, t3, nullptr, s, &st4);
+    bf16* t4 = linear_rows(o, M, t.a2.out, ACT_NONE, t3, nullptr, s, r4 ? nullptr : &st4);
 
     // x = ff(norm3(x)) + x
-    const bool f4 = t.ff.folded && can_fold(st4, 8 * C, EPI_ROWMAJOR, ACT_GEGLU);
+    const bool f4 = r4 || (t.ff.folded && can_fold(st4, 8 * C, EPI_ROWMAJOR, ACT_GEGLU));
     ln = normed(t4, t.ln3, t.ff.folded, f4, false);
-    bf16* t5 = feedforward(t.ff, ln, M, t4, nullptr, s, f4 ? &st4 : nullptr, nullptr);
+    bf16* t5 = feedforward(t.ff, ln, M, t4, nullptr, s, (f4 && !r4) ? &st4 : nullptr, nullptr, r4);
 
     // proj_out + x_in
     {

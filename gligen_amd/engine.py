@@ -345,6 +345,16 @@ class Engine:
                                        _ptr(b1), int(mode), int(inner_or_heads), int(T), _ptr(x), _ptr(y), C.byref(used), _stream(self.device)))
         return x, y, int(used.value)
 
+    def op_feedforward(self, x, w1, b1, w2, b2, gamma=None, beta=None, res=None, gate=None, want_stats=False):
+        """LayerNorm + GEGLU projection + FF-out + (gated) residual (gl_op_feedforward). Returns (y, stats | None, used_rows)."""
+        M, Cc = x.shape
+        y = torch.empty((M, Cc), device=x.device, dtype=torch.bfloat16)
+        stats = torch.zeros((M, 2), device=x.device, dtype=torch.float32) if want_stats else None
+        used = C.c_int(-1)
+        check(self.lib.gl_op_feedforward(self._ctx, _ptr(x), M, Cc, _ptr(gamma), _ptr(beta), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2),
+                                         _ptr(res), _ptr(gate), _ptr(y), _ptr(stats), C.byref(used), _stream(self.device)))
+        return y, stats, int(used.value)
+
     def op_conv3x3(self, x0, w_oihw, bias, x1=None, stride=1, ups=0, pad_lo=1, res=None):
         B, H, W, C0 = x0.shape
         C1 = 0 if x1 is None else x1.shape[3]

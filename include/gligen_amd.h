@@ -203,6 +203,16 @@ int gl_op_geglu(gl_ctx* ctx, const void* x, const float* w_f32, const float* b_f
 int gl_op_ln_linear(gl_ctx* ctx, const void* a, int M, int K0, const float* w0, const float* b0, const void* res, int C,
                     const float* gamma, const float* beta, const float* w1, const float* b1, int mode, int inner_or_heads, int T,
                     void* x_out, void* y_out, int* used_fold, gl_stream s);
+/* The whole feed-forward of a transformer block as the engine runs it (reference attention.py:37-64 FeedForward / GEGLU,
+ * :333-338 x = ff(norm3(x)) + x, :236-244 x = x + scale*tanh(alpha_dense) * ff(norm2(x))):
+ *   y = res + gate * ( GEGLU( LN(x) W1^T + b1 ) W2^T + b2 ),  LN over C with gamma / beta (NULL: x is multiplied as it is)
+ * x / res / y [M][C] bf16 (res may be NULL), W1 [8C][C] fp32 (value rows, then gate rows), b1 [8C], W2 [C][4C] fp32, b2 [C],
+ * gate: device scalar or NULL (1). stats: optional [M] float2 (sum, sum of squares) of each output row.
+ * *used_rows = 1: the row-local kernel ran (one launch, hidden activation on chip: C = 320, M % 128 == 0); 0: LayerNorm kernel +
+ * GEGLU GEMM + FF-out GEMM (both are product paths). */
+int gl_op_feedforward(gl_ctx* ctx, const void* x, int M, int C, const float* gamma, const float* beta, const float* w1, const float* b1,
+                      const float* w2, const float* b2, const void* res, const float* gate, void* y, void* stats, int* used_rows,
+                      gl_stream s);
 /* 3x3 conv over NHWC bf16 (channel-concat of x0,x1), weight OIHW fp32, stride 1|2, optional
  * nearest 2x upsample of the input, pad_lo 1 (symmetric) or 0 (VAE-encoder style). y NHWC bf16. */
 int gl_op_conv3x3(gl_ctx* ctx, const void* x0, int C0, const void* x1, int C1, int B, int H, int W,

@@ -295,3 +295,50 @@ def test_ln_folded_into_gemm(engine, M, K0, C, shift, mode):
     # and determinism: the statistics are summed in a fixed order
     x2, y2, _ = engine.op_ln_linear(a, w0, b0, res, gamma, beta, w1, b1, mode, 4 * C if mode == 0 else heads, T)
     assert torch.equal(x, x2) and torch.equal(y, y2)
+
+
+# ---- the row-local feed-forward kernel (ffn.hip): LayerNorm + GEGLU projection + erf-GEGLU + FF-out + gated residual + row
+# statistics in one launch, against fp32 torch (reference attention.py:37-64, 333-338, 236-244). (M, C): (4096, 320) and (128, 320)
+# run the row-local kernel, (300, 320) (M % 128 != 0) and (1024, 640) the LayerNorm kernel + two GEMMs behind the same entry.
+@pytest.mark.parametrize("M,C", [(4096, 320), (128, 320), (300, 320), (1024, 640)])
+@pytest.mark.parametrize("ln,gated", [(True, True), (True, False), (False, False)])
+def test_feedforward_rows(engine, M, C, ln, gated):
+    x = bf(rnd(M, C, seed=1) * 1.5 + 0.3)
+    w1, b1 = rnd(8 * C, C, scale=C ** -0.5, seed=2), 0.5 * rnd(8 * C, seed=3)
+    w2, b2 = rnd(C, 4 * C, scale=(4 * C) ** -0.5, seed=4), 0.1 * rnd(C, seed=5)
+    gamma, beta = (1.0 + 0.3 * rnd(C, seed=6), 0.2 * rnd(C, seed=7)) if ln else (None, None)
+    res = bf(rnd(M, C, seed=8))
+    gate = torch.tensor([0.37], device=x.device) if gated else None
+    y, stats, used = engine.op_feedforward(x, w1, b1, w2, b2, gamma, beta, res, gate, want_stats=True)
+    assert used == (1 if (C == 320 and M % 128 == 0) else 0)
+    xs = x.float()
+    h = (F.layer_norm(xs, (C,), gamma, beta, 1e-5) if ln else xs) @ w1.t() + b1
+    val, g = h.chunk(2, dim=-1)
+    ff = (val * F.gelu(g)) @ w2.t() + b2
+    ref = res.float() + (0.37 if gated else 1.0) * ff
+    assert rel_err(y, ref) < TOL, rel_err(y, ref)
+    # the feed-forward term itself (the residual dominates the sum)
+    assert rel_err(y.float() - res.float(), ref - res.float()) < 2.5e-2
+    if used:
+        ys = y.float()
+        assert torch.allclose(stats[:, 0], ys.sum(-1), rtol=1e-4, atol=1e-3)
+        assert torch.allclose(stats[:, 1], (ys * ys).sum(-1), rtol=1e-4, atol=1e-3)
+        y2, _, _ = engine.op_feedforward(x, w1, b1, w2, b2, gamma, beta, res, gate)
+        assert torch.equal(y, y2)
+
+
+def test_feedforward_rows_large_gate_inputs(engine):
+    """The GELU of the row-local kernel (cubic exp2 form of erfc) far outside its fitted range: huge positive / negative gate
+    pre-activations must give value * gate and 0, never a NaN."""
+    M, C = 128, 320
+    x = bf(torch.ones(M, C, device="cuda"))
+    w1 = torch.zeros(8 * C, C, device="cuda")
+    b1 = torch.zeros(8 * C, device="cuda")
+    b1[: 4 * C] = 1.0                                            # value = 1
+    b1[4 * C:] = torch.linspace(-300.0, 300.0, 4 * C, device="cuda")   # gate pre-activations
+    w2 = torch.eye(C, device="cuda").repeat(1, 4) / 4.0         # FF-out averages groups of hidden features
+    b2 = torch.zeros(C, device="cuda")
+    y, _, used = engine.op_feedforward(x, w1, b1, w2, b2)
+    assert used == 1 and bool(torch.isfinite(y.float()).all())
+    ref = (F.gelu(b1[4 * C:]).view(4, C).sum(0) / 4.0).expand(M, C)
+    assert rel_err(y, ref) < TOL
