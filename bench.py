@@ -242,9 +242,10 @@ def main():
     ap.add_argument("--plms-steps", type=int, default=50)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--lanes", type=int, default=2,
-                    help="batches in flight per GPU: consecutive steps are issued round-robin to this many independent engine "
-                         "contexts (own weights copy, arena, hipGraph, HIP stream), so one batch's kernel tails, launch gaps and "
-                         "memory-bound kernels overlap the other's MFMA work. 1 = strictly one batch at a time")
+                    help="batches in flight per GPU: consecutive steps are issued round-robin to this many execution contexts (engine "
+                         "forks: ONE set of packed weights, own arena, hipGraph, HIP stream each), so one batch's kernel tails, launch "
+                         "gaps and memory-bound kernels overlap the other's MFMA work. 1 = strictly one batch at a time; the line "
+                         "carries that number too (value_one_lane)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--alpha-type", default=None,
                     help="gate schedule 'on,decay,off' (fractions of the steps), e.g. 0.3,0,0.7 as in the reference's demo prompts; default: "
@@ -279,11 +280,14 @@ def main():
     kind = cfg["kind"]
     # random-init weights of the shipped architecture, generated on the device (fast), same statistics as the test fixture
     L = max(1, min(args.lanes, args.steps))
-    lanes = []
-    for _ in range(L):
-        model, autoencoder, diffusion, mcfg = gi.load_synthetic(kind, inpaint=cfg["inpaint"], seed=1234, fast=True)
-        model.grounding_tokenizer_input = gi.instantiate_from_config(mcfg["grounding_tokenizer_input"])
-        lanes.append((model, autoencoder, diffusion, torch.cuda.Stream(device=dev)))
+    model, autoencoder, diffusion, mcfg = gi.load_synthetic(kind, inpaint=cfg["inpaint"], seed=1234, fast=True)
+    model.grounding_tokenizer_input = gi.instantiate_from_config(mcfg["grounding_tokenizer_input"])
+    lanes = [(model, autoencoder, diffusion, torch.cuda.Stream(device=dev))]
+    for _ in range(1, L):    # further lanes: forks of the first lane's engines (shared packed weights, gl_ctx_fork), own tokenizer-input state
+        import copy
+        m, ae = gi._lane_clone(model), gi._lane_clone(autoencoder)
+        m.grounding_tokenizer_input = copy.copy(model.grounding_tokenizer_input)
+        lanes.append((m, ae, diffusion, torch.cuda.Stream(device=dev)))
     lo, hi = gdist.shard_range(B * world, rank, world)
     batch = {k: v[lo:hi].to(dev) for k, v in syn.make_batch(kind, B * world, n_valid=8, seed=0).items()}
     context = syn.make_context(B * world, seed=0)[lo:hi].to(dev)
@@ -325,6 +329,16 @@ def main():
     torch.cuda.synchronize(); gdist.barrier()
     elapsed = gdist.max_over_ranks(time.perf_counter() - t0, dev)
     clk = clocks.summary()
+    # the strict BASELINE C2 reading -- one batch at a time on one context -- over the same number of steps, outside the timed
+    # region above (what gligen_inference.run() delivers below 8 samples per GPU)
+    elapsed_one = None
+    if L > 1:
+        gdist.barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            one_pass(0)
+        torch.cuda.synchronize(); gdist.barrier()
+        elapsed_one = gdist.max_over_ranks(time.perf_counter() - t1, dev)
     out = outs[-1]
     assert out.shape == (B, 512, 512, 3) and out.dtype == torch.uint8
     if not cfg["inpaint"]:   # (inpainting draws fresh q_sample / posterior noise every pass, as the reference does)
@@ -389,11 +403,16 @@ def main():
             "vae_decode_ms": dec_ms,
             "launches_per_unet_eval": launches_per_eval,
             "arena_high_water_gb": round(lanes[0][0].engine.arena_high_water() / 2 ** 30, 3),   # activation arena of one execution context (gl_arena_high_water)
+            # footprint of this rank: packed weights + slabs of every context (forks share the weights: theirs are slabs only) and the
+            # device memory committed behind the arenas (UNet + VAE contexts of every lane)
+            "per_gpu_weight_bytes": sum(e.memory()["own_bytes"] for ln in lanes for e in (ln[0].engine, ln[1].engine)),
+            "arena_reserved_bytes": sum(e.memory()["arena_bytes"] for ln in lanes for e in (ln[0].engine, ln[1].engine)),
+            "value_one_lane": (B * world * args.steps / elapsed_one) if elapsed_one else value,
             "collective_world_size": dist_world, "collective_backend": dist_backend,   # the RCCL world the barrier / max-over-ranks ran in
             "gpu_clocks": clk,
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:   # rank 0's host cores, whatever the world size
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)
     gdist.shutdown()

@@ -65,6 +65,8 @@ _I = C.c_int
 SYMBOLS = {
     "gl_last_error": (C.c_char_p, []),
     "gl_ctx_create": (_I, [_I, C.c_size_t, C.POINTER(_P)]),
+    "gl_ctx_fork": (_I, [_P, C.c_size_t, C.POINTER(_P)]),
+    "gl_ctx_memory": (_I, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(_I)]),
     "gl_ctx_destroy": (_I, [_P]),
     "gl_unet_configure": (_I, [_P, C.POINTER(UNetConfig)]),
     "gl_vae_configure": (_I, [_P, C.POINTER(VaeConfig)]),

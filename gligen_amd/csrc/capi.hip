@@ -8,6 +8,7 @@
 using namespace gl;
 
 struct gl_ctx {
+    std::shared_ptr<Engine> holder;   // forks (gl_ctx_fork) keep the context whose weights they share alive
     Engine* eng;
 };
 
@@ -65,16 +66,28 @@ int gl_ctx_create(int device, size_t arena_bytes, gl_ctx** out) {
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) throw GlError(GL_ERR_HIP, "hipGetDeviceProperties failed");
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         throw GlError(GL_ERR_UNSUPPORTED, std::string("libgligen_amd is built for gfx950 (MI355X); device is ") + prop.gcnArchName);
-    gl_ctx* c = new gl_ctx{new Engine(device)};
-    try {
-        c->eng->arena().init(arena_bytes ? arena_bytes : (size_t(8) << 30));
-        c->eng->init_workspace();
-    } catch (...) {
-        delete c->eng;
-        delete c;
-        throw;
-    }
-    *out = c;
+    std::shared_ptr<Engine> eng(new Engine(device));
+    eng->arena().init(arena_bytes ? arena_bytes : (size_t(8) << 30));
+    eng->init_workspace();
+    *out = new gl_ctx{eng, eng.get()};
+    GL_API_END
+}
+
+int gl_ctx_fork(gl_ctx* parent, size_t arena_bytes, gl_ctx** out) {
+    NEED(parent);
+    if (!out) return gl::set_error(GL_ERR_ARG, "null out pointer");
+    GL_API_BEGIN
+    std::shared_ptr<Engine> e = Engine::fork(parent->holder, arena_bytes);
+    *out = new gl_ctx{e, e.get()};
+    GL_API_END
+}
+
+int gl_ctx_memory(gl_ctx* ctx, size_t* own_bytes, size_t* arena_bytes, int* is_fork) {
+    NEED(ctx);
+    GL_API_BEGIN
+    if (own_bytes) *own_bytes = ctx->eng->weight_bytes();
+    if (arena_bytes) *arena_bytes = ctx->eng->arena_bytes();
+    if (is_fork) *is_fork = ctx->eng->is_fork() ? 1 : 0;
     GL_API_END
 }
 
@@ -82,8 +95,7 @@ int gl_ctx_destroy(gl_ctx* ctx) {
     if (!ctx) return GL_OK;
     GL_API_BEGIN
     (void)hipDeviceSynchronize();
-    delete ctx->eng;
-    delete ctx;
+    delete ctx;      // the engine goes with its last holder: a parent outlives its forks
     GL_API_END
 }
 
@@ -260,6 +272,14 @@ int gl_unet_profile(gl_ctx* ctx, int Beff, int h, int w, const float* x, int xB,
 
 int gl_to_uint8(const float* img, uint8_t* out, int B, int C, int HW, gl_stream s) {
     if (!img || !out) return gl::set_error(GL_ERR_ARG, "null pointer");
+    // no context: the launch has to go to the device that holds the image, whatever the caller's current device is
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, img) != hipSuccess) {
+        (void)hipGetLastError();
+        return gl::set_error(GL_ERR_ARG, "gl_to_uint8: img is not a device pointer");
+    }
+    DeviceGuard guard(at.device);
+    if (!guard.ok) return gl::set_error(GL_ERR_HIP, "hipSetDevice(%d) failed", at.device);
     return to_uint8_launch(img, out, B, C, HW, S(s));
 }
 

@@ -1,6 +1,7 @@
 // gligen_amd engine: owns packed weights + workspace for one device and runs the GLIGEN
 // denoising path (UNet forward, CFG + PLMS loop, VAE decode) as sequences of HIP kernels.
 #pragma once
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -42,10 +43,19 @@ class Arena {
     void reset() { off_ = 0; }
     size_t capacity() const { return cap_; }
     size_t high_water() const { return hw_; }
+    size_t committed() const { return vmm_ ? mapped_ : cap_; }   // device memory actually behind the reservation
 
    private:
+    void grow(size_t need);
     char* base_ = nullptr;
     size_t cap_ = 0, off_ = 0, hw_ = 0;
+    // virtual-memory form: `cap_` bytes of ADDRESSES are reserved (the bump sequence, and with it every address a captured graph
+    // holds, is a pure function of the allocation sequence), physical memory is mapped behind them in chunks as the high-water
+    // mark rises -- a context costs what it uses, not what it was told it might
+    bool vmm_ = false;
+    size_t mapped_ = 0, gran_ = 0;
+    std::vector<void*> handles_;   // hipMemGenericAllocationHandle_t, one per mapped chunk
+    int dev_ = 0;
 };
 
 struct NormW { const float* g = nullptr; const float* b = nullptr; int C = 0; };
@@ -128,6 +138,13 @@ class Engine {
    public:
     explicit Engine(int device);
     ~Engine();
+    // A second EXECUTION CONTEXT over the same packed weights (gl_ctx_fork): everything finalize() packed is shared with -- and
+    // kept alive by -- `parent`; the fork owns what a forward pass writes: its arena, split-K slab, conditioning cache, attention
+    // buffers, gate / fuser-scale vectors, sampler state + captured graphs, and its own copy of the restorable first conv.
+    static std::shared_ptr<Engine> fork(const std::shared_ptr<Engine>& parent, size_t arena_bytes);
+    size_t weight_bytes() const { return persist_bytes_; }       // device bytes this context allocated outside the arena
+    size_t arena_bytes() const { return arena_.committed(); }       // device memory behind the arena (reservation: arena().capacity())
+    bool is_fork() const { return (bool)parent_; }
 
     void upload(const std::string& key, const void* src, int ndim, const int64_t* shape, bool is_device);
     void configure_unet(const gl_unet_config& c);
@@ -223,9 +240,13 @@ class Engine {
                         const RowStats* in_stats = nullptr);
     bf16* vae_attn(const VaeAttnW& a, const bf16* x, int B, int HW, hipStream_t s);
 
+    Engine(const Engine&) = default;       // (fork() copies the weight descriptors member by member, then resets the per-context state)
+    Engine& operator=(const Engine&) = delete;
+    std::shared_ptr<Engine> parent_;       // fork: the context that owns the shared weights
+    size_t persist_bytes_ = 0;
     int device_;
     bool finalized_ = false;
-    std::unordered_map<std::string, RawTensor> raw_;
+    std::unordered_map<std::string, RawTensor> raw_;   // (a fork sees the parent's tensors, it does not own them)
     std::vector<void*> owned_;  // persistent device allocations
     Arena arena_;
     float* ws_ = nullptr;

@@ -43,12 +43,79 @@ static std::string fmt(const char* f, ...) {
 
 // ---------------------------------------------------------------- Arena
 void Arena::init(size_t bytes) {
+    off_ = hw_ = 0;
+    HIPCK(hipGetDevice(&dev_));
+    int vmm = 0;
+    const char* sw = dev_env("GL_ARENA_VMM");
+    if (!(sw && atoi(sw) == 0) && hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, dev_) == hipSuccess && vmm) {
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = dev_;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran) {
+            const size_t want = (bytes + gran - 1) / gran * gran;
+            void* p = nullptr;
+            if (hipMemAddressReserve(&p, want, gran, nullptr, 0) == hipSuccess && p) {
+                base_ = reinterpret_cast<char*>(p);
+                cap_ = want;
+                gran_ = gran;
+                vmm_ = true;
+                mapped_ = 0;
+                return;
+            }
+        }
+        (void)hipGetLastError();
+    }
     HIPCK(hipMalloc(reinterpret_cast<void**>(&base_), bytes));
     cap_ = bytes;
-    off_ = hw_ = 0;
+}
+void Arena::grow(size_t need) {
+    // 64 MiB steps (a multiple of the granularity): a few dozen mappings for a 1 GB high-water mark, none once it is reached
+    const size_t step = std::max(gran_, ((size_t(64) << 20) + gran_ - 1) / gran_ * gran_);
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev_;
+    while (mapped_ < need) {
+        const size_t chunk = std::min(step, cap_ - mapped_);
+        hipMemGenericAllocationHandle_t h;
+        HIPCK(hipMemCreate(&h, chunk, &prop, 0));
+        hipError_t e = hipMemMap(base_ + mapped_, chunk, 0, h, 0);
+        if (e != hipSuccess) {
+            (void)hipMemRelease(h);
+            throw GlError(GL_ERR_HIP, fmt("workspace arena: hipMemMap of %zu bytes failed: %s", chunk, hipGetErrorString(e)));
+        }
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(base_ + mapped_, chunk, &acc, 1);
+        if (e != hipSuccess) {
+            (void)hipMemUnmap(base_ + mapped_, chunk);
+            (void)hipMemRelease(h);
+            throw GlError(GL_ERR_HIP, fmt("workspace arena: hipMemSetAccess failed: %s", hipGetErrorString(e)));
+        }
+        handles_.push_back(reinterpret_cast<void*>(h));
+        mapped_ += chunk;
+    }
 }
 void Arena::destroy() {
-    if (base_) (void)hipFree(base_);
+    if (vmm_) {
+        const size_t step = handles_.empty() ? 0 : std::max(gran_, ((size_t(64) << 20) + gran_ - 1) / gran_ * gran_);
+        size_t at = 0;
+        for (void* h : handles_) {
+            const size_t chunk = std::min(step, cap_ - at);
+            (void)hipMemUnmap(base_ + at, chunk);
+            (void)hipMemRelease(reinterpret_cast<hipMemGenericAllocationHandle_t>(h));
+            at += chunk;
+        }
+        handles_.clear();
+        if (base_) (void)hipMemAddressFree(base_, cap_);
+        vmm_ = false;
+        mapped_ = 0;
+    } else if (base_) {
+        (void)hipFree(base_);
+    }
     base_ = nullptr;
 }
 void* Arena::alloc(size_t bytes) {
@@ -56,6 +123,7 @@ void* Arena::alloc(size_t bytes) {
     if (a + bytes > cap_)
         throw GlError(GL_ERR_STATE, fmt("workspace arena exhausted: need %zu more bytes (capacity %zu); "
                                         "create the context with a larger arena", bytes, cap_));
+    if (vmm_ && a + bytes > mapped_) grow(a + bytes);
     off_ = a + bytes;
     hw_ = std::max(hw_, off_);
     return base_ + a;
@@ -70,8 +138,9 @@ Engine::~Engine() {
     if (smp_.ev_in) (void)hipEventDestroy(smp_.ev_in);
     if (smp_.ev_out) (void)hipEventDestroy(smp_.ev_out);
     if (smp_.stream) (void)hipStreamDestroy(smp_.stream);
-    for (auto& kv : raw_)
-        if (kv.second.p) (void)hipFree(kv.second.p);
+    if (!parent_)
+        for (auto& kv : raw_)
+            if (kv.second.p) (void)hipFree(kv.second.p);
     for (void* p : owned_) (void)hipFree(p);
     for (void* p : cond_.allocs) (void)hipFree(p);
     arena_.destroy();
@@ -127,7 +196,54 @@ void* Engine::persist(size_t bytes, bool zero) {
     HIPCK(hipMalloc(&p, std::max<size_t>(bytes, 256)));
     if (zero) HIPCK(hipMemset(p, 0, std::max<size_t>(bytes, 256)));
     owned_.push_back(p);
+    persist_bytes_ += std::max<size_t>(bytes, 256);
     return p;
+}
+
+std::shared_ptr<Engine> Engine::fork(const std::shared_ptr<Engine>& parent, size_t arena_bytes) {
+    if (!parent || !parent->finalized_) throw GlError(GL_ERR_STATE, "gl_ctx_fork: the parent context is not finalized");
+    HIPCK(hipDeviceSynchronize());                     // (the first-conv copy below reads what the parent's streams may still be writing)
+    std::shared_ptr<Engine> c(new Engine(*parent));    // every weight descriptor: plain pointers into the parent's allocations
+    Engine& e = *c;
+    e.parent_ = parent->parent_ ? parent->parent_ : parent;
+    // ---- what a context owns itself
+    e.owned_.clear();
+    e.persist_bytes_ = 0;
+    e.fold_tmps_.clear();
+    e.arena_ = Arena{};
+    e.ws_ = nullptr;
+    e.ws_bytes_ = 0;
+    e.cond_ = Cond{};
+    e.attn_bufs_.clear();
+    e.smp_ = Sampler{};
+    e.profiling_ = false;
+    e.prof_.clear();
+    e.prof_pool_.clear();
+    e.n_launches = 0;
+    try {
+        e.arena_.init(arena_bytes ? arena_bytes : parent->arena_.capacity());
+        e.init_workspace();
+        if (e.has_unet_) {
+            const size_t ng = 2 * e.st_.size();
+            e.gates_ = reinterpret_cast<float*>(e.persist(std::max<size_t>(ng, 1) * sizeof(float), true));
+            e.fuser_scale_ = reinterpret_cast<float*>(e.persist(std::max<size_t>(e.st_.size(), 1) * sizeof(float), true));
+            if (ng) HIPCK(hipMemcpy(e.gates_, parent->gates_, ng * sizeof(float), hipMemcpyDeviceToDevice));
+            if (!e.st_.empty()) HIPCK(hipMemcpy(e.fuser_scale_, parent->fuser_scale_, e.st_.size() * sizeof(float), hipMemcpyDeviceToDevice));
+            // the first conv is rewritten in place by gl_unet_restore_first_conv: a copy per context, in the parent's current state
+            const int mc = e.ucfg_.model_channels;
+            const size_t wb = (size_t)mc * e.conv_in_kpad_ * sizeof(bf16);
+            bf16* w = reinterpret_cast<bf16*>(e.persist(wb, false));
+            float* b = reinterpret_cast<float*>(e.persist(mc * sizeof(float), false));
+            HIPCK(hipMemcpy(w, parent->conv_in_small_.w, wb, hipMemcpyDeviceToDevice));
+            HIPCK(hipMemcpy(b, parent->conv_in_small_.b, mc * sizeof(float), hipMemcpyDeviceToDevice));
+            e.conv_in_small_.w = w;
+            e.conv_in_small_.b = b;
+        }
+    } catch (...) {
+        c.reset();
+        throw;
+    }
+    return c;
 }
 
 void Engine::upload(const std::string& key, const void* src, int ndim, const int64_t* shape, bool is_device) {

@@ -2624,7 +2624,8 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
         // row statistics for a folded LayerNorm downstream: only the staged row-major epilogue of gemm_u_kernel produces them
         // (one partial per row and wave column block of tn * 16 columns)
         g_last_stats_nb = (E.stats_out && use_u && wd.splits == 1 && A.mode == A_ROWS && E.mode == EPI_ROWMAJOR && !E.out_f32 && E.act != ACT_GEGLU &&
-                           E.act != ACT_GELU && N % (tn * 16) == 0 && N / (tn * 16) <= E.stats_ld)
+                           E.act != ACT_GELU && !(E.res && E.act == ACT_SILU) /* (epilogue_staged does not take that combination) */ &&
+                           N % (tn * 16) == 0 && N / (tn * 16) <= E.stats_ld)
                               ? N / (tn * 16) : 0;
         if (E.ln_stats && (!use_u || A.mode != A_ROWS || wd.splits > 1 || (tm == 4 && tn == 5) || (E.mode != EPI_QKV_HEADS && E.mode != EPI_QK_HEADS)))
             return set_error(GL_ERR_UNSUPPORTED, "gemm: the folded-LayerNorm epilogue exists for the head layouts of gemm_u_kernel and the GEGLU form of gemm_wide_kernel");

@@ -46,6 +46,26 @@ class Engine:
         self.vae_cfg: Optional[dict] = None
         self._keep: list = []
 
+    def fork(self, arena_gb: Optional[float] = None) -> "Engine":
+        """A second execution context on the same packed weights (gl_ctx_fork): its own arena, conditioning, gates, captured
+        graphs and first-conv copy; everything gl_finalize packed is shared with -- and kept alive by -- this engine."""
+        e = Engine.__new__(Engine)
+        e.device, e.lib = self.device, self.lib
+        e._ctx = C.c_void_p()
+        e.unet_cfg, e.vae_cfg = self.unet_cfg, self.vae_cfg
+        e._keep = []
+        nbytes = 0 if arena_gb is None else int(arena_gb * (1 << 30))
+        check(self.lib.gl_ctx_fork(self._ctx, C.c_size_t(nbytes), C.byref(e._ctx)))
+        return e
+
+    def memory(self) -> dict:
+        """Device bytes this context allocated itself outside the arena (packed weights + slabs; a fork: slabs only), its
+        arena reservation and the arena's high-water mark."""
+        own, arena, fk, hw = C.c_size_t(0), C.c_size_t(0), C.c_int(0), C.c_size_t(0)
+        check(self.lib.gl_ctx_memory(self._ctx, C.byref(own), C.byref(arena), C.byref(fk)))
+        check(self.lib.gl_arena_high_water(self._ctx, C.byref(hw)))
+        return dict(own_bytes=int(own.value), arena_bytes=int(arena.value), arena_high_water=int(hw.value), is_fork=bool(fk.value))
+
     def close(self) -> None:
         if self._ctx:
             check(self.lib.gl_ctx_destroy(self._ctx))

@@ -358,14 +358,39 @@ def generate(model, autoencoder, diffusion, batch, context, uc, *, steps=50, gui
 
 def _lane_clone(module):
     """A second execution context for the same weights: a shallow copy of the module (parameters and sub-modules shared)
-    whose native engine -- packed weights, arena, hipGraph, stream -- is its own and is built on first use."""
+    whose native engine is a FORK of the module's own (gl_ctx_fork): the packed weights are shared, the arena, conditioning,
+    gates, captured hipGraph, stream and the restorable first conv are the lane's. Forking needs the parent's engine, so it
+    is built here if it was not yet -- every lane exists before any lane samples."""
     import copy
+    parent_engine = module.engine
     m = copy.copy(module)
     m.__dict__ = dict(module.__dict__)
-    for key in ("_engine", "_cond_key", "_cond_held", "_ds_cache"):
+    for key in ("_cond_key", "_cond_held", "_ds_cache", "_lanes"):
         if key in m.__dict__:
             m.__dict__[key] = None
+    m.__dict__["_engine"] = parent_engine.fork()
+    m.__dict__["_fork_of"] = parent_engine
     return m
+
+
+def _lanes_of(model, autoencoder, lanes, device):
+    """The (UNet clone, VAE clone, stream) triples of lanes 1 .. lanes - 1, cached on the model and dropped with its engine
+    (UNetModel._drop_engine: .to() / load_state_dict / a first-conv that no longer matches). A clone made when the model's first
+    conv was in another state than now (GLIGEN vs restored SD conv) is stale: its fork carries the old conv."""
+    state = (model.first_conv_type, bool(model.__dict__.get("_first_conv_restored")))
+    ctxs = model.__dict__.get("_lanes")
+    stale = lambda c: (c[3] != state or c[0].__dict__.get("_engine") is None or c[1].__dict__.get("_engine") is None
+                       or c[0].__dict__.get("_fork_of") is not model.__dict__.get("_engine")           # the parent engine was rebuilt
+                       or c[1].__dict__.get("_fork_of") is not autoencoder.__dict__.get("_engine"))   # (weights reloaded / moved)
+    if ctxs is None or any(stale(c) for c in ctxs):
+        for c in ctxs or ():
+            for m in c[:2]:
+                if m.__dict__.get("_engine") is not None:
+                    m.__dict__["_engine"].close()
+        ctxs = model.__dict__["_lanes"] = []
+    while len(ctxs) < lanes - 1:
+        ctxs.append((_lane_clone(model), _lane_clone(autoencoder), torch.cuda.Stream(device=device), state))
+    return ctxs
 
 
 @torch.no_grad()
@@ -373,29 +398,51 @@ def generate_lanes(model, autoencoder, diffusion, batch, context, uc, *, lanes=2
                    grounding_input=None, **kw):
     """generate() with the batch split over `lanes` execution contexts that run concurrently on their own HIP streams, so that
     one half's kernel tails, launch gaps and memory-bound kernels overlap the other half's matrix work (what bench.py's
-    --lanes measures: +10 % images/s at 2). Every sample's trajectory is independent, so the images are generate()'s up to the
-    rounding of the tile / split-K configurations the GEMMs pick at the sub-batch size (another fp32 summation order)."""
+    --lanes measures: +15 % images/s at 2). Every sample's trajectory is independent, so the images are generate()'s up to the
+    rounding of the tile / split-K configurations the GEMMs pick at the sub-batch size (another fp32 summation order).
+    The lanes share ONE set of packed weights (engine forks); each has its own arena, conditioning, graph and first-conv copy,
+    and every lane's engine exists before the first lane samples -- a lane that swaps the SD first conv in at a gated-off step
+    (alpha_type [0.3, 0, 0.7]) changes its own engine and the shared nn.Module, never another lane's packed weights."""
+    import copy
     n = context.shape[0]
     if lanes < 2 or n < 2 * lanes:
         return generate(model, autoencoder, diffusion, batch, context, uc, starting_noise=starting_noise,
                         grounding_extra_input=grounding_extra_input, grounding_input=grounding_input, **kw)
-    ctxs = model.__dict__.setdefault("_lanes", [])
-    while len(ctxs) < lanes - 1:
-        ctxs.append((_lane_clone(model), _lane_clone(autoencoder), torch.cuda.Stream(device=context.device)))
+    model.engine, autoencoder.engine            # (built before the first fork)
+    ctxs = _lanes_of(model, autoencoder, lanes, context.device)
     cuts = [n * i // lanes for i in range(lanes + 1)]
     cut = lambda t, i: t[cuts[i]:cuts[i + 1]] if torch.is_tensor(t) and t.shape[0] == n else t
     outs, main = [], torch.cuda.current_stream(context.device)
-    for i in range(lanes):
-        m, ae, stream = (model, autoencoder, main) if i == 0 else ctxs[i - 1]
-        if i:
-            m.grounding_tokenizer_input = model.grounding_tokenizer_input
-            stream.wait_stream(main)          # the inputs were produced on the caller's stream
-        with torch.cuda.stream(stream):
-            outs.append(generate(m, ae, diffusion, {k: cut(v, i) for k, v in batch.items()}, cut(context, i), cut(uc, i),
-                                 starting_noise=cut(starting_noise, i), grounding_extra_input=cut(grounding_extra_input, i),
-                                 grounding_input=None if grounding_input is None else {k: cut(v, i) for k, v in grounding_input.items()}, **kw))
-    for _, _, stream in ctxs[:lanes - 1]:
-        main.wait_stream(stream)
+    tokenizer = model.grounding_tokenizer_input
+    try:
+        for i in range(lanes):
+            m, ae, stream = (model, autoencoder, main) if i == 0 else ctxs[i - 1][:3]
+            sub = {k: cut(v, i) for k, v in batch.items()}
+            # the tokenizer input object remembers the batch its null (unconditional) input has to have: one per lane
+            m.grounding_tokenizer_input = copy.copy(tokenizer)
+            gi = None
+            if grounding_input is not None:
+                m.grounding_tokenizer_input.prepare(sub)          # shapes of this lane's null input
+                gi = {k: cut(v, i) for k, v in grounding_input.items()}
+            if i:
+                m.first_conv_type = model.first_conv_type
+                stream.wait_stream(main)          # the inputs were produced on the caller's stream
+            with torch.cuda.stream(stream):
+                outs.append(generate(m, ae, diffusion, sub, cut(context, i), cut(uc, i), starting_noise=cut(starting_noise, i),
+                                     grounding_extra_input=cut(grounding_extra_input, i), grounding_input=gi, **kw))
+    finally:
+        model.grounding_tokenizer_input = tokenizer
+    for c in ctxs[:lanes - 1]:
+        main.wait_stream(c[2])
+    # a lane that restored the SD first conv did it for the shared module: every context is in that state now
+    if any(c[0].__dict__.get("_first_conv_restored") for c in ctxs[:lanes - 1]) or model.__dict__.get("_first_conv_restored"):
+        model.first_conv_type = "SD"
+        model.__dict__["_first_conv_restored"] = True
+        state = (model.first_conv_type, True)
+        model.__dict__["_lanes"] = [(c[0], c[1], c[2], state) for c in ctxs]
+        for c in ctxs:
+            c[0].first_conv_type = "SD"
+            c[0].__dict__["_first_conv_restored"] = True
     return torch.cat(outs, dim=0)
 
 
@@ -481,7 +528,10 @@ def run(meta, config, starting_noise=None, models=None):
     steps = int(args.get("steps") or (250 if no_plms else 50))
     # batches of 8 and more run as two half-batches in flight (generate_lanes). Not for inpainting: its per-step q_sample noise
     # comes from the device generator, whose draws would interleave differently
-    lanes = int(args.get("lanes") or 2) if (mask is None and (hi - lo) >= 8) else 1
+    lanes = args.get("lanes")
+    lanes = 2 if lanes is None else max(1, int(lanes))      # (--lanes 0 and 1 both mean one batch at a time)
+    if mask is not None or (hi - lo) < 8:
+        lanes = 1
     if lanes > 1 and starting_noise is None:   # x_T as the sampler would draw it (plms.py:71), before the batch is split
         starting_noise = torch.randn((hi - lo, model.in_channels, model.image_size, model.image_size), device=device)
     samples = generate_lanes(model, autoencoder, diffusion, batch, context, uc, lanes=lanes, steps=steps,

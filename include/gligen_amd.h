@@ -111,6 +111,15 @@ const char* gl_last_error(void);
 
 /* load_ckpt / instantiate_from_config(...).to(device) (reference gligen_inference.py:70-86) */
 int gl_ctx_create(int device, size_t arena_bytes, gl_ctx** out);
+/* A second execution context on the SAME packed weights (one more batch in flight on its own stream: bench.py --lanes,
+ * gligen_inference.generate_lanes): shares everything gl_finalize packed with `parent` (which stays alive until its last fork is
+ * destroyed) and owns its arena (arena_bytes; 0 = the parent's size), split-K slab, conditioning, gates, captured graphs and its
+ * own copy of the restorable first conv. The parent must be finalized. The reference has one model object per process
+ * (gligen_inference.py:343-446); this is the engine-side counterpart of running two of its batches at once. */
+int gl_ctx_fork(gl_ctx* parent, size_t arena_bytes, gl_ctx** out);
+/* device memory this context allocated itself outside the arena (packed weights + slabs; a fork: slabs only), its arena size, and
+ * whether it is a fork */
+int gl_ctx_memory(gl_ctx* ctx, size_t* own_bytes, size_t* arena_bytes, int* is_fork);
 int gl_ctx_destroy(gl_ctx* ctx);
 int gl_unet_configure(gl_ctx* ctx, const gl_unet_config* cfg);
 int gl_vae_configure(gl_ctx* ctx, const gl_vae_config* cfg);

@@ -150,6 +150,12 @@ class UNetModel(nn.Module):
         return super().load_state_dict(*a, **k)
 
     def _drop_engine(self):
+        # the execution lanes forked from this engine (gligen_inference.generate_lanes) go first: they share its packed weights
+        for lane in self.__dict__.pop("_lanes", None) or ():
+            for m in lane[:2]:
+                if m.__dict__.get("_engine") is not None:
+                    m.__dict__["_engine"].close()
+                    m.__dict__["_engine"] = None
         eng = self.__dict__.get("_engine")
         if eng is not None:
             eng.close()

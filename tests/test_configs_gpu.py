@@ -363,10 +363,12 @@ def test_run_two_lanes_equal_one(tmp_path, monkeypatch):
     REPORT["run_two_lanes"] = dict(rel_mse_vs_one_lane=rel)
     assert rel < 1e-3, rel
     assert sorted(os.listdir(tmp_path / "out2" / "lanes")) == [f"{i}.png" for i in range(B)]
-    for m, a, _ in model.__dict__["_lanes"]:
-        m._drop_engine()
-        a._drop_engine()
-    model._drop_engine()
+    lane_model, lane_ae = model.__dict__["_lanes"][0][:2]
+    mem, lane_mem = model.engine.memory(), lane_model.engine.memory()
+    assert lane_mem["is_fork"] and not mem["is_fork"]
+    assert lane_mem["own_bytes"] < 0.6 * mem["own_bytes"] + (300 << 20)   # a lane's own memory: its slabs and buffers, not a second weight set
+    model._drop_engine()                                          # takes the lanes forked from it along
+    assert lane_model.__dict__["_engine"] is None and lane_ae.__dict__["_engine"] is None and "_lanes" not in model.__dict__
     ae._drop_engine()
 
 
@@ -417,3 +419,100 @@ def test_spatial_modality_vs_reference(modality):
     assert r["tokens_rel_mse"] < 3e-4 and r["tokens_null_rel_mse"] < 3e-4, r      # 18 bf16 blocks + 3 MLP layers against fp32 (measured 1.2e-5 / 1.8e-5)
     assert r["eps_e2e"] < EPS_MSE_TOL and r["eps_null_e2e"] < EPS_MSE_TOL, r
     model._drop_engine()
+
+
+def test_engine_fork_shares_weights():
+    """gl_ctx_fork: a second execution context on the same packed weights gives bit-identical epsilons, keeps working after the
+    parent handle is closed (it holds the weights alive), and restoring the SD first conv in one context leaves the other alone."""
+    dev = _dev()
+    import gligen_inference as gi
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from ldm.util import instantiate_from_config
+    cfg = dict(syn.UNET_CFG_SMALL, image_size=16, grounding_tokenizer=syn.GROUNDING_TOKENIZERS["text"])
+    model = syn.fill_module_(UNetModel(**cfg).eval(), 1234).to(dev)
+    gin = instantiate_from_config(dict(target="grounding_input.text_grounding_tokinzer_input.GroundingNetInput"))
+    model.grounding_tokenizer_input = gin
+    B = 2
+    batch = {k: v.to(dev) for k, v in syn.make_batch("text", B, n_valid=3, seed=0).items()}
+    inp = dict(x=syn.make_latent(B, 4, 16, 16, seed=6).to(dev), timesteps=torch.full((B,), 500, device=dev, dtype=torch.long),
+               context=syn.make_context(B, seed=1).to(dev), grounding_input=gin.prepare(batch), inpainting_extra_input=None,
+               grounding_extra_input=None)
+    e0 = model(inp).clone()
+    lane = gi._lane_clone(model)
+    assert lane.engine is not model.engine and lane.engine.memory()["is_fork"]
+    e1 = lane(inp).clone()
+    assert torch.equal(e0, e1)
+    # the fork's first conv is its own: swapping the SD conv into the parent changes the parent only
+    sd = syn.sd_first_conv_state()
+    model.engine.restore_first_conv(sd["weight"].to(dev), sd["bias"].to(dev))
+    assert not torch.equal(model(inp), e0)
+    assert torch.equal(lane(inp), e0)
+    # the parent's handle may go first: the fork keeps the shared weights alive
+    model.__dict__["_engine"].close()
+    model.__dict__["_engine"] = None
+    assert torch.equal(lane(inp), e0)
+    lane.__dict__["_engine"].close()
+
+
+@pytest.mark.parametrize("modality", ["canny", "text"])
+def test_lanes_with_gate_off_schedule(modality, tmp_path, monkeypatch):
+    """Two lanes under an alpha schedule that gates the fusers off ([0.3, 0, 0.7]): the SD first conv is swapped in mid-run
+    (reference plms.py:85-89, openaimodel.py:400-413) -- by every lane in its own engine, once for the shared module -- on a
+    4 + k channel spatial-map model (the swap replaces the module) and on a 4-channel model (in-place copy). Also the lanes
+    form of precomputed grounding tokens. All against the one-lane run."""
+    dev = _dev()
+    import gligen_inference as gi
+    from ldm.util import instantiate_from_config
+    monkeypatch.setattr(gi, "device", dev)
+    torch.save(syn.sd_first_conv_state(), tmp_path / "SD_input_conv_weight_bias.pth")
+    monkeypatch.chdir(tmp_path)
+    B, hw, S = 8, 16, 6
+    if modality == "canny":
+        meta = load_golden("plms_unet_small_canny")["meta"]
+        ucfg, res = meta["cfg"], meta["res"]
+        gtarget, dstarget = "grounding_input.canny_grounding_tokinzer_input.GroundingNetInput", "grounding_input.canny_grounding_downsampler_input.GroundingDSInput"
+    else:
+        ucfg = dict(syn.UNET_CFG_SMALL, image_size=hw, grounding_tokenizer=syn.GROUNDING_TOKENIZERS["text"])
+        gtarget, dstarget = "grounding_input.text_grounding_tokinzer_input.GroundingNetInput", None
+    cfg = gi.synthetic_config("text", inpaint=False, image_size=hw)
+    cfg["autoencoder"]["params"]["ddconfig"] = syn.VAE_DDCONFIG_SMALL
+    ae = syn.fill_module_(gi.instantiate_from_config(cfg["autoencoder"]).eval(), 4321).to(dev)
+    diffusion = gi.instantiate_from_config(cfg["diffusion"]).to(dev)
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    ctx, uc = syn.make_context(B, seed=1).to(dev), syn.make_context(B, seed=9).to(dev)
+    x_T = syn.make_latent(B, 4, hw, hw, seed=6).to(dev)
+    out = {}
+    for lanes, tokens in ((1, False), (2, False), (2, True)):
+        if modality == "text" and tokens:
+            continue
+        model = syn.fill_module_(UNetModel(**ucfg).eval(), 1234).to(dev)
+        model.grounding_tokenizer_input = instantiate_from_config(dict(target=gtarget))
+        if modality == "canny":
+            batch = {"canny_edge": syn.make_spatial_map("canny", B, res, seed=1).to(dev), "mask": torch.ones(B, 1, device=dev)}
+            extra = instantiate_from_config(dict(target=dstarget)).prepare(batch)
+        else:
+            batch = {k: v.to(dev) for k, v in syn.make_batch("text", B, n_valid=3, seed=0).items()}
+            extra = None
+        gin = None
+        if tokens:   # ConvNeXt tokens computed up front (run()'s meta["grounding_tokens"]): the tokenizer input only supplies the null shapes
+            gin = {"tokens": model.position_net.tokens(engine=model.engine, **model.grounding_tokenizer_input.prepare(batch))}
+            batch = dict(batch, tokens=gin["tokens"])
+        assert model.first_conv_type == ("GLIGEN" if modality == "canny" else "SD")
+        out[(lanes, tokens)] = gi.generate_lanes(model, ae, diffusion, batch, ctx, uc, lanes=lanes, steps=S, guidance_scale=5.0,
+                                                 alpha_type=[0.3, 0.0, 0.7], starting_noise=x_T.clone(), grounding_extra_input=extra,
+                                                 grounding_input=gin).clone()
+        assert model.first_conv_type == "SD" and model.__dict__["_first_conv_restored"]
+        if lanes == 2:
+            assert len(model.__dict__["_lanes"]) == 1 and model.__dict__["_lanes"][0][0].first_conv_type == "SD"
+            # a second prompt on the same (now SD-conv) model reuses the lanes and still agrees with itself
+            again = gi.generate_lanes(model, ae, diffusion, batch, ctx, uc, lanes=lanes, steps=S, guidance_scale=5.0, alpha_type=[0.3, 0.0, 0.7],
+                                      starting_noise=x_T.clone(), grounding_extra_input=extra, grounding_input=gin)
+            assert torch.isfinite(again).all()
+        model._drop_engine()
+    ref = out[(1, False)]
+    assert torch.isfinite(ref).all()
+    for key, val in out.items():
+        rel = mse(val, ref) / float(ref.float().var())
+        REPORT[f"lanes_gate_off_{modality}_{key[0]}_{int(key[1])}"] = dict(rel_mse_vs_one_lane=rel)
+        assert rel < 2e-3, (key, rel)
+    ae._drop_engine()
