@@ -16,7 +16,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 INCLUDE = HERE.parent / "include"
 LIB = HERE / "libgligen_amd.so"
-SOURCES = ["gemm.hip", "ffn.hip", "attention.hip", "norm.hip", "misc.hip", "convnext.hip", "engine.hip", "capi.hip"]
+SOURCES = ["gemm.hip", "ffn.hip", "attention.hip", "norm.hip", "misc.hip", "convnext.hip", "train.hip", "engine.hip", "capi.hip"]
 # attention: keep MFMA accumulators in VGPRs (gfx950 has one unified register file); the default AGPR
 # form costs a v_accvgpr_read/write pair per accumulator per KV tile around the softmax rescale
 # ffn: the GEGLU micro-steps of the row-local feed-forward are plain fp32 on purpose (packed fp32 is dearer beside MFMAs): no SLP packing

@@ -1,5 +1,6 @@
 // extern "C" surface of libgligen_amd.so (see include/gligen_amd.h). Nothing throws across it.
 #include "engine.h"
+#include "train.h"
 
 #include <cstdlib>
 
@@ -458,6 +459,35 @@ int gl_op_feedforward(gl_ctx* ctx, const void* x, int M, int C, const float* gam
         ck(gemm_launch(A2, w2b, M, C, 4 * C, E2, eng.splitk_ws(), eng.splitk_ws_bytes(), S(s)));
         if (stats) HIPCK_API(hipMemsetAsync(stats, 0, (size_t)M * sizeof(float2), S(s)));
     }
+    GL_API_END
+}
+
+static const char* const k_train_block_names[GL_TRAIN_BLOCK_PARAMS] = {
+    "norm1.weight", "norm1.bias", "attn1.to_q.weight", "attn1.to_k.weight", "attn1.to_v.weight", "attn1.to_out.0.weight", "attn1.to_out.0.bias",
+    "fuser.linear.weight", "fuser.linear.bias", "fuser.norm1.weight", "fuser.norm1.bias", "fuser.attn.to_q.weight", "fuser.attn.to_k.weight",
+    "fuser.attn.to_v.weight", "fuser.attn.to_out.0.weight", "fuser.attn.to_out.0.bias", "fuser.norm2.weight", "fuser.norm2.bias",
+    "fuser.ff.net.0.proj.weight", "fuser.ff.net.0.proj.bias", "fuser.ff.net.2.weight", "fuser.ff.net.2.bias", "fuser.alpha_attn", "fuser.alpha_dense",
+    "norm2.weight", "norm2.bias", "attn2.to_q.weight", "attn2.to_k.weight", "attn2.to_v.weight", "attn2.to_out.0.weight", "attn2.to_out.0.bias",
+    "norm3.weight", "norm3.bias", "ff.net.0.proj.weight", "ff.net.0.proj.bias", "ff.net.2.weight", "ff.net.2.bias"};
+static_assert(GL_TRAIN_BLOCK_PARAMS == gl::TP_COUNT, "parameter table out of step with train.h");
+
+const char* const* gl_train_block_param_names(void) { return k_train_block_names; }
+
+int gl_op_block_train(gl_ctx* ctx, const gl_train_block_dims* dims, const float* const* params, const float* x, const float* objs,
+                      const float* context, const float* target, float* y, float* loss, float* dx, float* dobjs, float* const* grads,
+                      gl_stream s) {
+    NEED(ctx);
+    if (!dims || !params || !x || !objs || !context || !target || !y || !loss || !dx || !dobjs || !grads)
+        return gl::set_error(GL_ERR_ARG, "gl_op_block_train: null pointer");
+    for (int i = 0; i < GL_TRAIN_BLOCK_PARAMS; ++i)
+        if (grads[i] && !(i >= gl::TP_F_LIN_W && i <= gl::TP_F_ALPHA_DENSE))
+            return gl::set_error(GL_ERR_ARG, "gl_op_block_train: a gradient was asked for '%s', which the reference keeps frozen", k_train_block_names[i]);
+    GL_API_BEGIN
+    Engine& eng = *ctx->eng;
+    eng.arena().reset();
+    gl::TrainBlockDims d{dims->B, dims->N, dims->Ng, dims->C, dims->heads, dims->ctx_T, dims->ctx_dim, dims->fuser_scale};
+    int rc = gl::block_train_step(eng.arena(), eng.splitk_ws(), eng.splitk_ws_bytes(), d, params, x, objs, context, target, y, loss, dx, dobjs, grads, S(s));
+    if (rc != GL_OK) throw GlError(rc, gl::last_error());
     GL_API_END
 }
 

@@ -1,0 +1,33 @@
+// Training slice (second half): forward + backward of ONE BasicTransformerBlock with a gatedSA fuser
+// (reference ldm/modules/attention.py:333-338, 236-244) under the reference's loss, with the gradients the reference's trainer
+// asks for (trainer.py:217-245: the fuser.* parameters; the block input and the grounding tokens so that the step chains into
+// position_net and the blocks in front). See train.hip.
+#pragma once
+#include "common.h"
+
+namespace gl {
+
+struct TrainBlockDims {
+    int B, N, Ng, C, heads, ctx_T, ctx_dim;
+    float fuser_scale;      // GatedSelfAttentionDense.scale (attention.py:232)
+};
+
+// Parameter slots: the reference state_dict of BasicTransformerBlock(fuser_type="gatedSA"), fp32 device pointers
+enum {
+    TP_NORM1_W = 0, TP_NORM1_B, TP_A1_Q, TP_A1_K, TP_A1_V, TP_A1_O, TP_A1_OB,
+    TP_F_LIN_W, TP_F_LIN_B, TP_F_N1_W, TP_F_N1_B, TP_F_Q, TP_F_K, TP_F_V, TP_F_O, TP_F_OB,
+    TP_F_N2_W, TP_F_N2_B, TP_F_FF1_W, TP_F_FF1_B, TP_F_FF2_W, TP_F_FF2_B, TP_F_ALPHA_ATTN, TP_F_ALPHA_DENSE,
+    TP_NORM2_W, TP_NORM2_B, TP_A2_Q, TP_A2_K, TP_A2_V, TP_A2_O, TP_A2_OB,
+    TP_NORM3_W, TP_NORM3_B, TP_FF1_W, TP_FF1_B, TP_FF2_W, TP_FF2_B,
+    TP_COUNT
+};
+
+class Arena;
+// x [B][N][C], objs [B][Ng][ctx_dim], context [B][ctx_T][ctx_dim], target [B][N][C]: fp32 device. Outputs (fp32 device): y [B][N][C],
+// loss[1] = mse_loss(y, target) (trainer.py:366), dx, dobjs, and grads[slot] for every non-null slot among the fuser's
+// (TP_F_LIN_W .. TP_F_ALPHA_DENSE), each shaped like its parameter. bf16 GEMM operands, fp32 accumulation and fp32 elsewhere.
+int block_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainBlockDims& d, const float* const* params, const float* x,
+                     const float* objs, const float* context, const float* target, float* y, float* loss, float* dx, float* dobjs,
+                     float* const* grads, hipStream_t s);
+
+}  // namespace gl

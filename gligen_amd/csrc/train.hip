@@ -1,0 +1,492 @@
+// Training slice for gfx950: forward + backward of one BasicTransformerBlock with a gatedSA fuser under the reference's loss.
+//
+// Reference: ldm/modules/attention.py:333-338 (BasicTransformerBlock._forward), :236-244 (GatedSelfAttentionDense.forward),
+// :127-186 (CrossAttention / SelfAttention), :37-64 (GEGLU / FeedForward); trainer.py:353-371 (run_one_step: mse_loss(model_output,
+// noise)), :217-245 (what is trainable: fuser.*, position_net, downsample_net), :375-392 (loss.backward(); opt.step()).
+//
+// What runs where: every matrix product of the forward and of the backward (dgrad  dX = dY W,  wgrad  dW = dY^T X) goes through
+// the bf16 MFMA GEMM of gemm.hip with fp32 output (operands are cast / transposed to bf16 by the kernels below; accumulation and
+// everything else is fp32, as the reference trains in fp32). LayerNorm, attention (forward with the row log-sum-exp saved,
+// backward with the probabilities RECOMPUTED from q, k and that log-sum-exp -- nothing of size Nq x Nk is ever stored), GEGLU,
+// the tanh gates and the loss have their own fp32 kernels. Gradients are produced for the fuser.* parameters only (weight
+// gradients of the frozen SD layers are never formed -- trainer.py:217-245 leaves them out of the optimizer), for the block's
+// input and for the grounding tokens, so the step chains into position_net and the blocks in front of this one.
+// This is the first slice of the training path (DESIGN.md section 9 has the rest of the plan): op-level, held to gradients of the
+// reference's own autograd (tests/golden/block_backward_gatedsa.npz), not yet tuned.
+#include "train.h"
+
+#include "engine.h"
+
+#include <cstdarg>
+#include <cstdio>
+
+namespace gl {
+
+namespace {
+
+std::string fmt(const char* f, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, f);
+    vsnprintf(buf, sizeof buf, f, ap);
+    va_end(ap);
+    return buf;
+}
+
+__global__ void transpose_f32_bf16_kernel(const float* __restrict__ src, int R, int Cc, int ld, bf16* __restrict__ dst, int Rpad) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + threadIdx.x;
+        tile[i][threadIdx.x] = (r < R && c < Cc) ? src[(size_t)r * ld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + threadIdx.x;
+        if (c < Cc && r < Rpad) dst[(size_t)c * Rpad + r] = f2bf(tile[threadIdx.x][i]);
+    }
+}
+
+// out[c] = sum_r a[r][c] (* b[r][c])   -- one thread per column, rows in order: deterministic
+__global__ void colsum_kernel(const float* __restrict__ a, const float* __restrict__ b, int R, int Cc, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cc) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += b ? a[(size_t)r * Cc + c] * b[(size_t)r * Cc + c] : a[(size_t)r * Cc + c];
+    out[c] = s;
+}
+
+// LayerNorm over C per row (eps 1e-5, nn.LayerNorm): one wave per row
+__global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b, int R, int Cc,
+                              float* __restrict__ y, float* __restrict__ xhat, float* __restrict__ rstd_out) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const float* xr = x + (size_t)row * Cc;
+    float s = 0.f, ss = 0.f;
+    for (int c = lane; c < Cc; c += 64) { const float v = xr[c]; s += v; ss += v * v; }
+    s = wave_sum(s); ss = wave_sum(ss);
+    const float mean = s / Cc, var = fmaxf(ss / Cc - mean * mean, 0.f), rstd = rsqrtf(var + 1e-5f);
+    for (int c = lane; c < Cc; c += 64) {
+        const float h = (xr[c] - mean) * rstd;
+        xhat[(size_t)row * Cc + c] = h;
+        y[(size_t)row * Cc + c] = h * g[c] + b[c];
+    }
+    if (lane == 0) rstd_out[row] = rstd;
+}
+// dx (+)= rstd (g - mean(g) - xhat mean(g xhat)),  g = dy gamma
+__global__ void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ rstd, const float* __restrict__ gam,
+                              int R, int Cc, float* __restrict__ dx, int accumulate) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const float* dr = dy + (size_t)row * Cc;
+    const float* hr = xhat + (size_t)row * Cc;
+    float m1 = 0.f, m2 = 0.f;
+    for (int c = lane; c < Cc; c += 64) { const float gv = dr[c] * gam[c]; m1 += gv; m2 += gv * hr[c]; }
+    m1 = wave_sum(m1) / Cc; m2 = wave_sum(m2) / Cc;
+    const float rs = rstd[row];
+    for (int c = lane; c < Cc; c += 64) {
+        const float v = rs * (dr[c] * gam[c] - m1 - hr[c] * m2);
+        float* o = dx + (size_t)row * Cc + c;
+        *o = accumulate ? *o + v : v;
+    }
+}
+
+// ---- attention on row-major q [B][Nq][H d], k / v [B][Nk][H d]: one thread per (batch, head, query) / (batch, head, key)
+template <int D>
+__global__ void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int H, int Nq, int Nk, float scale,
+                                float* __restrict__ o, float* __restrict__ lse) {
+    const int bh = blockIdx.y, b = bh / H, h = bh % H, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nq) return;
+    const int ld = H * D;
+    float qi[D], acc[D];
+    const float* qp = q + ((size_t)b * Nq + i) * ld + h * D;
+#pragma unroll
+    for (int c = 0; c < D; ++c) { qi[c] = qp[c] * scale; acc[c] = 0.f; }
+    float m = -1e30f, l = 0.f;
+    for (int j = 0; j < Nk; ++j) {
+        const float* kp = k + ((size_t)b * Nk + j) * ld + h * D;
+        const float* vp = v + ((size_t)b * Nk + j) * ld + h * D;
+        float sc = 0.f;
+#pragma unroll
+        for (int c = 0; c < D; ++c) sc = fmaf(qi[c], kp[c], sc);
+        const float mn = fmaxf(m, sc), corr = __expf(m - mn), p = __expf(sc - mn);
+        l = l * corr + p;
+#pragma unroll
+        for (int c = 0; c < D; ++c) acc[c] = fmaf(acc[c], corr, p * vp[c]);
+        m = mn;
+    }
+    float* op = o + ((size_t)b * Nq + i) * ld + h * D;
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int c = 0; c < D; ++c) op[c] = acc[c] * inv;
+    lse[(size_t)bh * Nq + i] = m + __logf(l);
+}
+// dq and the row terms delta_i = do_i . o_i; the probabilities are recomputed from q, k and the saved log-sum-exp
+template <int D>
+__global__ void attn_bwd_q_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, const float* __restrict__ o,
+                                  const float* __restrict__ dout, const float* __restrict__ lse, int H, int Nq, int Nk, float scale,
+                                  float* __restrict__ dq, float* __restrict__ delta) {
+    const int bh = blockIdx.y, b = bh / H, h = bh % H, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nq) return;
+    const int ld = H * D;
+    const size_t off = ((size_t)b * Nq + i) * ld + h * D;
+    float qi[D], di[D], acc[D];
+    float dl = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) { qi[c] = q[off + c] * scale; di[c] = dout[off + c]; dl = fmaf(di[c], o[off + c], dl); acc[c] = 0.f; }
+    const float L = lse[(size_t)bh * Nq + i];
+    for (int j = 0; j < Nk; ++j) {
+        const float* kp = k + ((size_t)b * Nk + j) * ld + h * D;
+        const float* vp = v + ((size_t)b * Nk + j) * ld + h * D;
+        float sc = 0.f, dp = 0.f;
+#pragma unroll
+        for (int c = 0; c < D; ++c) { sc = fmaf(qi[c], kp[c], sc); dp = fmaf(di[c], vp[c], dp); }
+        const float ds = __expf(sc - L) * (dp - dl);
+#pragma unroll
+        for (int c = 0; c < D; ++c) acc[c] = fmaf(ds, kp[c], acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < D; ++c) dq[off + c] = acc[c] * scale;
+    delta[(size_t)bh * Nq + i] = dl;
+}
+template <int D>
+__global__ void attn_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, const float* __restrict__ dout,
+                                   const float* __restrict__ lse, const float* __restrict__ delta, int H, int Nq, int Nk, float scale,
+                                   float* __restrict__ dk, float* __restrict__ dv) {
+    const int bh = blockIdx.y, b = bh / H, h = bh % H, j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Nk) return;
+    const int ld = H * D;
+    const size_t off = ((size_t)b * Nk + j) * ld + h * D;
+    float kj[D], vj[D], ak[D], av[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) { kj[c] = k[off + c]; vj[c] = v[off + c]; ak[c] = 0.f; av[c] = 0.f; }
+    for (int i = 0; i < Nq; ++i) {
+        const float* qp = q + ((size_t)b * Nq + i) * ld + h * D;
+        const float* dp_ = dout + ((size_t)b * Nq + i) * ld + h * D;
+        float sc = 0.f, dp = 0.f;
+#pragma unroll
+        for (int c = 0; c < D; ++c) { sc = fmaf(qp[c], kj[c], sc); dp = fmaf(dp_[c], vj[c], dp); }
+        const float p = __expf(sc * scale - lse[(size_t)bh * Nq + i]);
+        const float ds = p * (dp - delta[(size_t)bh * Nq + i]);
+#pragma unroll
+        for (int c = 0; c < D; ++c) { av[c] = fmaf(p, dp_[c], av[c]); ak[c] = fmaf(ds, qp[c], ak[c]); }
+    }
+#pragma unroll
+    for (int c = 0; c < D; ++c) { dk[off + c] = ak[c] * scale; dv[off + c] = av[c]; }
+}
+
+// GEGLU (attention.py:37-44): h = val * gelu(gate), u = [val | gate] of width 2 I (erf GELU, F.gelu default)
+__global__ void geglu_fwd_kernel(const float* __restrict__ u, int R, int I, float* __restrict__ h) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)R * I) return;
+    const size_t r = idx / I, c = idx % I;
+    const float val = u[r * 2 * I + c], g = u[r * 2 * I + I + c];
+    h[idx] = val * 0.5f * g * (1.f + erff(g * 0.70710678118654752440f));
+}
+__global__ void geglu_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ u, int R, int I, float* __restrict__ du) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)R * I) return;
+    const size_t r = idx / I, c = idx % I;
+    const float val = u[r * 2 * I + c], g = u[r * 2 * I + I + c], d = dh[idx];
+    const float Phi = 0.5f * (1.f + erff(g * 0.70710678118654752440f));
+    const float phi = 0.3989422804014327f * __expf(-0.5f * g * g);
+    du[r * 2 * I + c] = d * g * Phi;
+    du[r * 2 * I + I + c] = d * val * (Phi + g * phi);
+}
+
+// out = a + gate * b, gate = scale * tanh(*alpha) (alpha null: gate 1)
+__global__ void gated_add_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ alpha, float scale, size_t n,
+                                 float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float g = alpha ? scale * tanhf(*alpha) : 1.f;
+    out[i] = a[i] + g * b[i];
+}
+// out = gate * a
+__global__ void gated_scale_kernel(const float* __restrict__ a, const float* __restrict__ alpha, float scale, size_t n, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = scale * tanhf(*alpha) * a[i];
+}
+__global__ void add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+// out[0] = coef(alpha) * sum_i a[i] b[i]: one block, fixed order.  mode 0: coef = scale (1 - tanh^2 alpha) (the gate's derivative);
+// mode 1: coef = 1 / n and out = mean((a - b)^2) (the loss)
+__global__ void __launch_bounds__(1024) dot_reduce_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, const float* __restrict__ alpha,
+                                                          float scale, int mode, float* __restrict__ out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += 1024) s += mode ? (a[i] - b[i]) * (a[i] - b[i]) : a[i] * b[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        if (mode) out[0] = t / (float)n;
+        else { const float th = tanhf(*alpha); out[0] = scale * (1.f - th * th) * t; }
+    }
+}
+// dy = 2 (y - t) / n   (d mse_loss / dy)
+__global__ void mse_grad_kernel(const float* __restrict__ y, const float* __restrict__ t, size_t n, float* __restrict__ dy) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dy[i] = 2.f * (y[i] - t[i]) / (float)n;
+}
+
+struct Ctx {
+    Arena& ar;
+    float* ws;
+    size_t ws_bytes;
+    hipStream_t s;
+    void ck(int rc) const { if (rc != GL_OK) throw GlError(rc, gl::last_error()); }
+    void hip(hipError_t e, const char* what) const { if (e != hipSuccess) throw GlError(GL_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
+    float* f32(size_t n) const { return ar.get<float>(n); }
+    static dim3 g1(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+    bf16* to_bf16(const float* src, size_t n) const {
+        bf16* d = ar.get<bf16>(n);
+        ck(cast_f32_bf16_launch(src, d, (int64_t)n, s));
+        return d;
+    }
+    // [R][Cc] fp32 -> [Cc][Rpad] bf16, columns R..Rpad zero (Rpad: the contraction length of the GEMM that reads it, a multiple of 64)
+    bf16* transposed(const float* src, int R, int Cc, int Rpad) const {
+        bf16* d = ar.get<bf16>((size_t)Cc * Rpad);
+        hipLaunchKernelGGL(transpose_f32_bf16_kernel, dim3(cdiv(Cc, 32), cdiv(Rpad, 32)), dim3(32, 8), 0, s, src, R, Cc, Cc, d, Rpad);
+        return d;
+    }
+    // out [M][N] fp32 = a [M][K] w[N][K]^T (+ bias)
+    void mm(const bf16* a, const bf16* w, int M, int N, int K, const float* bias, float* out) const {
+        AOperand A;
+        aoperand_rows(A, a, K, K);
+        Epilogue E;
+        epilogue_defaults(E);
+        E.out = out; E.ldo = N; E.out_f32 = 1; E.bias = bias;
+        ck(gemm_launch(A, w, M, N, K, E, ws, ws_bytes, s));
+    }
+    // y = x W^T + b
+    float* lin_fwd(const float* x, int M, int K, const float* W, const float* b, int N) const {
+        float* y = f32((size_t)M * N);
+        mm(to_bf16(x, (size_t)M * K), to_bf16(W, (size_t)N * K), M, N, K, b, y);
+        return y;
+    }
+    // dgrad: dx [M][K] = dy [M][N] W [N][K]   (the GEMM's "weight" operand is W^T, contraction over N)
+    float* lin_dgrad(const float* dy, int M, int N, const float* W, int K) const {
+        float* dx = f32((size_t)M * K);
+        mm(to_bf16(dy, (size_t)M * N), transposed(W, N, K, N), M, K, N, nullptr, dx);
+        return dx;
+    }
+    // wgrad: dW [N][K] = dy^T x (contraction over the M rows, zero-padded to a multiple of 64), db [N] = column sums of dy
+    void lin_wgrad(const float* dy, const float* x, int M, int N, int K, float* dW, float* db) const {
+        const int Mp = round_up(M, 64);
+        if (dW) mm(transposed(dy, M, N, Mp), transposed(x, M, K, Mp), N, K, Mp, nullptr, dW);
+        if (db) hipLaunchKernelGGL(colsum_kernel, g1(N), dim3(256), 0, s, dy, (const float*)nullptr, M, N, db);
+    }
+    struct LN { float* y; float* xhat; float* rstd; };
+    LN ln_fwd(const float* x, int R, int Cc, const float* g, const float* b) const {
+        LN r{f32((size_t)R * Cc), f32((size_t)R * Cc), f32(R)};
+        hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, x, g, b, R, Cc, r.y, r.xhat, r.rstd);
+        return r;
+    }
+    void ln_bwd(const float* dy, const LN& f, const float* g, int R, int Cc, float* dx, bool accumulate, float* dgamma, float* dbeta) const {
+        hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, dy, f.xhat, f.rstd, g, R, Cc, dx, accumulate ? 1 : 0);
+        if (dgamma) hipLaunchKernelGGL(colsum_kernel, g1(Cc), dim3(256), 0, s, dy, (const float*)f.xhat, R, Cc, dgamma);
+        if (dbeta) hipLaunchKernelGGL(colsum_kernel, g1(Cc), dim3(256), 0, s, dy, (const float*)nullptr, R, Cc, dbeta);
+    }
+    struct Attn { float* o; float* lse; };
+    template <int D>
+    Attn attn_fwd_d(const float* q, const float* k, const float* v, int B, int H, int Nq, int Nk) const {
+        Attn a{f32((size_t)B * Nq * H * D), f32((size_t)B * H * Nq)};
+        hipLaunchKernelGGL(attn_fwd_kernel<D>, dim3(cdiv(Nq, 64), B * H), dim3(64), 0, s, q, k, v, H, Nq, Nk, 1.f / sqrtf((float)D), a.o, a.lse);
+        return a;
+    }
+    template <int D>
+    void attn_bwd_d(const float* q, const float* k, const float* v, const Attn& f, const float* dout, int B, int H, int Nq, int Nk, float* dq,
+                    float* dk, float* dv) const {
+        float* delta = f32((size_t)B * H * Nq);
+        const float sc = 1.f / sqrtf((float)D);
+        hipLaunchKernelGGL(attn_bwd_q_kernel<D>, dim3(cdiv(Nq, 64), B * H), dim3(64), 0, s, q, k, v, (const float*)f.o, dout, (const float*)f.lse, H, Nq, Nk, sc,
+                           dq, delta);
+        if (dk && dv)
+            hipLaunchKernelGGL(attn_bwd_kv_kernel<D>, dim3(cdiv(Nk, 64), B * H), dim3(64), 0, s, q, k, v, dout, (const float*)f.lse, (const float*)delta, H, Nq,
+                               Nk, sc, dk, dv);
+    }
+    Attn attn_fwd(int D, const float* q, const float* k, const float* v, int B, int H, int Nq, int Nk) const {
+        switch (D) {
+            case 32: return attn_fwd_d<32>(q, k, v, B, H, Nq, Nk);
+            case 40: return attn_fwd_d<40>(q, k, v, B, H, Nq, Nk);
+            case 64: return attn_fwd_d<64>(q, k, v, B, H, Nq, Nk);
+            case 80: return attn_fwd_d<80>(q, k, v, B, H, Nq, Nk);
+            default: throw GlError(GL_ERR_UNSUPPORTED, fmt("training slice: head dim %d (32, 40, 64, 80 are built)", D));
+        }
+    }
+    void attn_bwd(int D, const float* q, const float* k, const float* v, const Attn& f, const float* dout, int B, int H, int Nq, int Nk, float* dq,
+                  float* dk, float* dv) const {
+        switch (D) {
+            case 32: return attn_bwd_d<32>(q, k, v, f, dout, B, H, Nq, Nk, dq, dk, dv);
+            case 40: return attn_bwd_d<40>(q, k, v, f, dout, B, H, Nq, Nk, dq, dk, dv);
+            case 64: return attn_bwd_d<64>(q, k, v, f, dout, B, H, Nq, Nk, dq, dk, dv);
+            case 80: return attn_bwd_d<80>(q, k, v, f, dout, B, H, Nq, Nk, dq, dk, dv);
+            default: throw GlError(GL_ERR_UNSUPPORTED, "training slice: head dim");
+        }
+    }
+    void add(float* dst, const float* src, size_t n) const { hipLaunchKernelGGL(add_inplace_kernel, g1(n), dim3(256), 0, s, dst, src, n); }
+    // rows [B][rows_per_b][Cc] of a [B][stride_rows][Cc] tensor starting at row0 -> a packed copy, and back
+    float* slice_rows(const float* src, int B, int stride_rows, int row0, int rows, int Cc) const {
+        float* d = f32((size_t)B * rows * Cc);
+        hip(hipMemcpy2DAsync(d, (size_t)rows * Cc * 4, src + (size_t)row0 * Cc, (size_t)stride_rows * Cc * 4, (size_t)rows * Cc * 4, B, hipMemcpyDeviceToDevice, s),
+            "hipMemcpy2DAsync");
+        return d;
+    }
+    void put_rows(float* dst, int B, int stride_rows, int row0, const float* src, int rows, int Cc) const {
+        hip(hipMemcpy2DAsync(dst + (size_t)row0 * Cc, (size_t)stride_rows * Cc * 4, src, (size_t)rows * Cc * 4, (size_t)rows * Cc * 4, B, hipMemcpyDeviceToDevice, s),
+            "hipMemcpy2DAsync");
+    }
+};
+
+}  // namespace
+
+int block_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainBlockDims& d, const float* const* P, const float* x, const float* objs,
+                     const float* context, const float* target, float* y, float* loss, float* dx, float* dobjs, float* const* G, hipStream_t s) {
+    try {
+        const int B = d.B, N = d.N, Ng = d.Ng, C = d.C, H = d.heads, D = C / H, T = N + Ng, M = B * N, MT = B * T, MC = B * d.ctx_T, KD = d.ctx_dim;
+        if (C % 64 || KD % 64 || C % H || B < 1 || N < 1 || Ng < 1) throw GlError(GL_ERR_ARG, "block_train_step: C and ctx_dim must be multiples of 64");
+        for (int i = 0; i < TP_COUNT; ++i)
+            if (!P[i]) throw GlError(GL_ERR_ARG, fmt("block_train_step: parameter slot %d is null", i));
+        Ctx c{ar, ws, ws_bytes, s};
+        const size_t nx = (size_t)M * C;
+
+        // ================= forward (attention.py:333-338), everything the backward needs kept in the arena
+        // x1 = attn1(norm1(x)) + x
+        const Ctx::LN n1 = c.ln_fwd(x, M, C, P[TP_NORM1_W], P[TP_NORM1_B]);
+        float* q1 = c.lin_fwd(n1.y, M, C, P[TP_A1_Q], nullptr, C);
+        float* k1 = c.lin_fwd(n1.y, M, C, P[TP_A1_K], nullptr, C);
+        float* v1 = c.lin_fwd(n1.y, M, C, P[TP_A1_V], nullptr, C);
+        const Ctx::Attn a1 = c.attn_fwd(D, q1, k1, v1, B, H, N, N);
+        float* o1 = c.lin_fwd(a1.o, M, C, P[TP_A1_O], P[TP_A1_OB], C);
+        float* x1 = c.f32(nx);
+        hipLaunchKernelGGL(gated_add_kernel, Ctx::g1(nx), dim3(256), 0, s, x, (const float*)o1, (const float*)nullptr, 1.f, nx, x1);
+        // fuser (attention.py:236-244): x2 = x1 + scale tanh(alpha_attn) attn(norm1([x1 ; linear(objs)]))[:, :N]
+        float* ol = c.lin_fwd(objs, B * Ng, KD, P[TP_F_LIN_W], P[TP_F_LIN_B], C);
+        float* cat = c.f32((size_t)MT * C);
+        c.put_rows(cat, B, T, 0, x1, N, C);
+        c.put_rows(cat, B, T, N, ol, Ng, C);
+        const Ctx::LN nf1 = c.ln_fwd(cat, MT, C, P[TP_F_N1_W], P[TP_F_N1_B]);
+        float* qf = c.lin_fwd(nf1.y, MT, C, P[TP_F_Q], nullptr, C);
+        float* kf = c.lin_fwd(nf1.y, MT, C, P[TP_F_K], nullptr, C);
+        float* vf = c.lin_fwd(nf1.y, MT, C, P[TP_F_V], nullptr, C);
+        const Ctx::Attn af = c.attn_fwd(D, qf, kf, vf, B, H, T, T);
+        float* af_vis = c.slice_rows(af.o, B, T, 0, N, C);
+        float* of = c.lin_fwd(af_vis, M, C, P[TP_F_O], P[TP_F_OB], C);
+        float* x2 = c.f32(nx);
+        hipLaunchKernelGGL(gated_add_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)x1, (const float*)of, P[TP_F_ALPHA_ATTN], d.fuser_scale, nx, x2);
+        //        x3 = x2 + scale tanh(alpha_dense) ff(norm2(x2))
+        const Ctx::LN nf2 = c.ln_fwd(x2, M, C, P[TP_F_N2_W], P[TP_F_N2_B]);
+        float* uf = c.lin_fwd(nf2.y, M, C, P[TP_F_FF1_W], P[TP_F_FF1_B], 8 * C);
+        float* hf = c.f32((size_t)M * 4 * C);
+        hipLaunchKernelGGL(geglu_fwd_kernel, Ctx::g1((size_t)M * 4 * C), dim3(256), 0, s, (const float*)uf, M, 4 * C, hf);
+        float* ff_f = c.lin_fwd(hf, M, 4 * C, P[TP_F_FF2_W], P[TP_F_FF2_B], C);
+        float* x3 = c.f32(nx);
+        hipLaunchKernelGGL(gated_add_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)x2, (const float*)ff_f, P[TP_F_ALPHA_DENSE], d.fuser_scale, nx, x3);
+        // x4 = attn2(norm2(x3), context) + x3
+        const Ctx::LN n2 = c.ln_fwd(x3, M, C, P[TP_NORM2_W], P[TP_NORM2_B]);
+        float* q2 = c.lin_fwd(n2.y, M, C, P[TP_A2_Q], nullptr, C);
+        float* k2 = c.lin_fwd(context, MC, KD, P[TP_A2_K], nullptr, C);
+        float* v2 = c.lin_fwd(context, MC, KD, P[TP_A2_V], nullptr, C);
+        const Ctx::Attn a2 = c.attn_fwd(D, q2, k2, v2, B, H, N, d.ctx_T);
+        float* o2 = c.lin_fwd(a2.o, M, C, P[TP_A2_O], P[TP_A2_OB], C);
+        float* x4 = c.f32(nx);
+        hipLaunchKernelGGL(gated_add_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)x3, (const float*)o2, (const float*)nullptr, 1.f, nx, x4);
+        // y = ff(norm3(x4)) + x4
+        const Ctx::LN n3 = c.ln_fwd(x4, M, C, P[TP_NORM3_W], P[TP_NORM3_B]);
+        float* u3 = c.lin_fwd(n3.y, M, C, P[TP_FF1_W], P[TP_FF1_B], 8 * C);
+        float* h3 = c.f32((size_t)M * 4 * C);
+        hipLaunchKernelGGL(geglu_fwd_kernel, Ctx::g1((size_t)M * 4 * C), dim3(256), 0, s, (const float*)u3, M, 4 * C, h3);
+        float* ff3 = c.lin_fwd(h3, M, 4 * C, P[TP_FF2_W], P[TP_FF2_B], C);
+        hipLaunchKernelGGL(gated_add_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)x4, (const float*)ff3, (const float*)nullptr, 1.f, nx, y);
+
+        // ================= loss (trainer.py:366) and its gradient
+        hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)y, target, nx, (const float*)nullptr, 1.f, 1, loss);
+        float* g = c.f32(nx);   // the running gradient of the residual stream: dL/dy -> dL/dx4 -> ... -> dL/dx
+        hipLaunchKernelGGL(mse_grad_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)y, target, nx, g);
+
+        // ================= backward
+        {   // y = x4 + ff(norm3(x4)): frozen weights, data gradients only
+            float* g_h3 = c.lin_dgrad(g, M, C, P[TP_FF2_W], 4 * C);
+            float* g_u3 = c.f32((size_t)M * 8 * C);
+            hipLaunchKernelGGL(geglu_bwd_kernel, Ctx::g1((size_t)M * 4 * C), dim3(256), 0, s, (const float*)g_h3, (const float*)u3, M, 4 * C, g_u3);
+            float* g_n3 = c.lin_dgrad(g_u3, M, 8 * C, P[TP_FF1_W], C);
+            c.ln_bwd(g_n3, n3, P[TP_NORM3_W], M, C, g, true, nullptr, nullptr);
+        }
+        {   // x4 = x3 + attn2(norm2(x3), context): the context comes from the frozen text encoder, no dK / dV
+            float* g_a2 = c.lin_dgrad(g, M, C, P[TP_A2_O], C);
+            float* g_q2 = c.f32(nx);
+            c.attn_bwd(D, q2, k2, v2, a2, g_a2, B, H, N, d.ctx_T, g_q2, nullptr, nullptr);
+            float* g_n2 = c.lin_dgrad(g_q2, M, C, P[TP_A2_Q], C);
+            c.ln_bwd(g_n2, n2, P[TP_NORM2_W], M, C, g, true, nullptr, nullptr);
+        }
+        {   // x3 = x2 + g_d ff(norm2(x2)), g_d = scale tanh(alpha_dense): the fuser's feed-forward, TRAINABLE
+            if (G[TP_F_ALPHA_DENSE])
+                hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)g, (const float*)ff_f, nx, P[TP_F_ALPHA_DENSE], d.fuser_scale, 0,
+                                   G[TP_F_ALPHA_DENSE]);
+            float* g_ff = c.f32(nx);
+            hipLaunchKernelGGL(gated_scale_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)g, P[TP_F_ALPHA_DENSE], d.fuser_scale, nx, g_ff);
+            c.lin_wgrad(g_ff, hf, M, C, 4 * C, G[TP_F_FF2_W], G[TP_F_FF2_B]);
+            float* g_hf = c.lin_dgrad(g_ff, M, C, P[TP_F_FF2_W], 4 * C);
+            float* g_uf = c.f32((size_t)M * 8 * C);
+            hipLaunchKernelGGL(geglu_bwd_kernel, Ctx::g1((size_t)M * 4 * C), dim3(256), 0, s, (const float*)g_hf, (const float*)uf, M, 4 * C, g_uf);
+            c.lin_wgrad(g_uf, nf2.y, M, 8 * C, C, G[TP_F_FF1_W], G[TP_F_FF1_B]);
+            float* g_nf2 = c.lin_dgrad(g_uf, M, 8 * C, P[TP_F_FF1_W], C);
+            c.ln_bwd(g_nf2, nf2, P[TP_F_N2_W], M, C, g, true, G[TP_F_N2_W], G[TP_F_N2_B]);
+        }
+        float* g_ol = nullptr;
+        {   // x2 = x1 + g_a attn(norm1([x1 ; linear(objs)]))[:, :N]: the fuser's attention, TRAINABLE
+            if (G[TP_F_ALPHA_ATTN])
+                hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)g, (const float*)of, nx, P[TP_F_ALPHA_ATTN], d.fuser_scale, 0,
+                                   G[TP_F_ALPHA_ATTN]);
+            float* g_of = c.f32(nx);
+            hipLaunchKernelGGL(gated_scale_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)g, P[TP_F_ALPHA_ATTN], d.fuser_scale, nx, g_of);
+            c.lin_wgrad(g_of, af_vis, M, C, C, G[TP_F_O], G[TP_F_OB]);
+            float* g_af_vis = c.lin_dgrad(g_of, M, C, P[TP_F_O], C);
+            float* g_af = c.f32((size_t)MT * C);      // the grounding-token rows of the attention output are dropped by [:, :N]: zero gradient
+            c.hip(hipMemsetAsync(g_af, 0, (size_t)MT * C * 4, s), "hipMemsetAsync");
+            c.put_rows(g_af, B, T, 0, g_af_vis, N, C);
+            float* g_qf = c.f32((size_t)MT * C);
+            float* g_kf = c.f32((size_t)MT * C);
+            float* g_vf = c.f32((size_t)MT * C);
+            c.attn_bwd(D, qf, kf, vf, af, g_af, B, H, T, T, g_qf, g_kf, g_vf);
+            c.lin_wgrad(g_qf, nf1.y, MT, C, C, G[TP_F_Q], nullptr);
+            c.lin_wgrad(g_kf, nf1.y, MT, C, C, G[TP_F_K], nullptr);
+            c.lin_wgrad(g_vf, nf1.y, MT, C, C, G[TP_F_V], nullptr);
+            float* g_nf1 = c.lin_dgrad(g_qf, MT, C, P[TP_F_Q], C);
+            c.add(g_nf1, c.lin_dgrad(g_kf, MT, C, P[TP_F_K], C), (size_t)MT * C);
+            c.add(g_nf1, c.lin_dgrad(g_vf, MT, C, P[TP_F_V], C), (size_t)MT * C);
+            float* g_cat = c.f32((size_t)MT * C);
+            c.ln_bwd(g_nf1, nf1, P[TP_F_N1_W], MT, C, g_cat, false, G[TP_F_N1_W], G[TP_F_N1_B]);
+            c.add(g, c.slice_rows(g_cat, B, T, 0, N, C), nx);
+            g_ol = c.slice_rows(g_cat, B, T, N, Ng, C);
+            c.lin_wgrad(g_ol, objs, B * Ng, C, KD, G[TP_F_LIN_W], G[TP_F_LIN_B]);
+            float* g_objs = c.lin_dgrad(g_ol, B * Ng, C, P[TP_F_LIN_W], KD);
+            c.hip(hipMemcpyAsync(dobjs, g_objs, (size_t)B * Ng * KD * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+        }
+        {   // x1 = x + attn1(norm1(x)): frozen
+            float* g_a1 = c.lin_dgrad(g, M, C, P[TP_A1_O], C);
+            float* g_q1 = c.f32(nx);
+            float* g_k1 = c.f32(nx);
+            float* g_v1 = c.f32(nx);
+            c.attn_bwd(D, q1, k1, v1, a1, g_a1, B, H, N, N, g_q1, g_k1, g_v1);
+            float* g_n1 = c.lin_dgrad(g_q1, M, C, P[TP_A1_Q], C);
+            c.add(g_n1, c.lin_dgrad(g_k1, M, C, P[TP_A1_K], C), nx);
+            c.add(g_n1, c.lin_dgrad(g_v1, M, C, P[TP_A1_V], C), nx);
+            c.ln_bwd(g_n1, n1, P[TP_NORM1_W], M, C, g, true, nullptr, nullptr);
+        }
+        c.hip(hipMemcpyAsync(dx, g, nx * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+        c.hip(hipGetLastError(), "training slice kernel launch");
+    } catch (const GlError& e) {
+        return set_error(e.code, "%s", e.what());
+    }
+    return GL_OK;
+}
+
+}  // namespace gl

@@ -30,6 +30,11 @@ def _f32(t: torch.Tensor, device) -> torch.Tensor:
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
+class TrainBlockDims(C.Structure):
+    _fields_ = [("B", C.c_int), ("N", C.c_int), ("Ng", C.c_int), ("C", C.c_int), ("heads", C.c_int), ("ctx_T", C.c_int), ("ctx_dim", C.c_int),
+                ("fuser_scale", C.c_float)]
+
+
 class Engine:
     """One engine per device; owns packed bf16 weights, workspace arena and cached conditioning."""
 
@@ -374,6 +379,29 @@ class Engine:
         check(self.lib.gl_op_feedforward(self._ctx, _ptr(x), M, Cc, _ptr(gamma), _ptr(beta), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2),
                                          _ptr(res), _ptr(gate), _ptr(y), _ptr(stats), C.byref(used), _stream(self.device)))
         return y, stats, int(used.value)
+
+    def block_train_param_names(self):
+        names = self.lib.gl_train_block_param_names()
+        return [names[i].decode() for i in range(37)]
+
+    def op_block_train(self, state_dict, x, objs, context, target, heads, fuser_scale=1.0):
+        """Training slice (gl_op_block_train): forward + backward of one BasicTransformerBlock (gatedSA fuser) under
+        mse_loss(y, target). state_dict: the block's reference state_dict (fp32). Returns (y, loss, dx, dobjs, grads) with grads
+        a dict over the fuser.* parameter names."""
+        dev = self.device
+        names = self.block_train_param_names()
+        params = [_f32(state_dict[n], dev) for n in names]
+        x, objs, context, target = (_f32(t, dev) for t in (x, objs, context, target))
+        B, N, Cc = x.shape
+        dims = TrainBlockDims(int(B), int(N), int(objs.shape[1]), int(Cc), int(heads), int(context.shape[1]), int(context.shape[2]), float(fuser_scale))
+        y, dx, dobjs = torch.empty_like(x), torch.empty_like(x), torch.empty_like(objs)
+        loss = torch.zeros(1, device=dev, dtype=torch.float32)
+        grads = {n: torch.zeros_like(p) for n, p in zip(names, params) if n.startswith("fuser.")}
+        parr = (C.c_void_p * 37)(*[p.data_ptr() for p in params])
+        garr = (C.c_void_p * 37)(*[(grads[n].data_ptr() if n in grads else None) for n in names])
+        check(self.lib.gl_op_block_train(self._ctx, C.byref(dims), parr, _ptr(x), _ptr(objs), _ptr(context), _ptr(target), _ptr(y), _ptr(loss),
+                                         _ptr(dx), _ptr(dobjs), garr, _stream(self.device)))
+        return y, loss, dx, dobjs, grads
 
     def op_conv3x3(self, x0, w_oihw, bias, x1=None, stride=1, ups=0, pad_lo=1, res=None):
         B, H, W, C0 = x0.shape

@@ -222,6 +222,25 @@ int gl_op_ln_linear(gl_ctx* ctx, const void* a, int M, int K0, const float* w0, 
 int gl_op_feedforward(gl_ctx* ctx, const void* x, int M, int C, const float* gamma, const float* beta, const float* w1, const float* b1,
                       const float* w2, const float* b2, const void* res, const float* gate, void* y, void* stats, int* used_rows,
                       gl_stream s);
+/* ---- training slice: one BasicTransformerBlock, forward + backward ---------------------------------
+ * Forward of the reference's BasicTransformerBlock with a gatedSA fuser (ldm/modules/attention.py:333-338, 236-244), the
+ * reference's loss on its output (trainer.py:366: mse_loss(model_output, noise)) and the backward pass, with the gradients the
+ * reference's optimizer holds for this block (trainer.py:217-245: every fuser.* parameter) plus d loss / d x and d loss / d objs
+ * so that the step chains into position_net and the blocks in front. All tensors fp32 on the device:
+ *   x [B][N][C], objs [B][Ng][ctx_dim], context [B][ctx_T][ctx_dim], target [B][N][C]  ->  y [B][N][C], loss[1], dx, dobjs.
+ * params[GL_TRAIN_BLOCK_PARAMS]: the block's state_dict in the order of gl_train_block_param_names(); grads[]: same order, one
+ * buffer shaped like the parameter for every fuser.* entry wanted (NULL: not computed; non-fuser entries must be NULL -- those
+ * layers are frozen in the reference and their weight gradients are never formed). */
+#define GL_TRAIN_BLOCK_PARAMS 37
+typedef struct gl_train_block_dims {
+    int B, N, Ng, C, heads, ctx_T, ctx_dim;
+    float fuser_scale;               /* GatedSelfAttentionDense.scale */
+} gl_train_block_dims;
+const char* const* gl_train_block_param_names(void);   /* GL_TRAIN_BLOCK_PARAMS reference state_dict keys, e.g. "fuser.attn.to_q.weight" */
+int gl_op_block_train(gl_ctx* ctx, const gl_train_block_dims* dims, const float* const* params, const float* x, const float* objs,
+                      const float* context, const float* target, float* y, float* loss, float* dx, float* dobjs, float* const* grads,
+                      gl_stream s);
+
 /* 3x3 conv over NHWC bf16 (channel-concat of x0,x1), weight OIHW fp32, stride 1|2, optional
  * nearest 2x upsample of the input, pad_lo 1 (symmetric) or 0 (VAE-encoder style). y NHWC bf16. */
 int gl_op_conv3x3(gl_ctx* ctx, const void* x0, int C0, const void* x1, int C1, int B, int H, int W,

@@ -462,6 +462,45 @@ def misc_case():
     print("misc: ok")
 
 
+def block_backward_case(name="block_backward_gatedsa", B=2, hw=16, Ng=30, C=320, heads=8, ctx_dim=768, ctx_T=77):
+    """Training slice (second half): gradients of the reference's loss -- mse_loss(model_output, noise),
+    trainer.py:353-371 -- through ONE BasicTransformerBlock (attention.py:333-338) from the reference's own autograd: with
+    respect to the block's input, the grounding tokens and every trainable (fuser.*) parameter of trainer.py:217-245. The
+    block's output plays the role of model_output, `target` of the noise."""
+    from ldm.modules.attention import BasicTransformerBlock
+    blk = BasicTransformerBlock(C, ctx_dim, ctx_dim, heads, C // heads, "gatedSA", use_checkpoint=False)
+    syn.fill_module_(blk, 77)
+    with torch.no_grad():   # the gates start at tanh(0) = 0 (attention.py:229-230), where the fuser gets no gradient but alpha: open them
+        blk.fuser.alpha_attn.fill_(0.6)
+        blk.fuser.alpha_dense.fill_(-0.4)
+    g = torch.Generator().manual_seed(4242)
+    N = hw * hw
+    x = torch.randn(B, N, C, generator=g).requires_grad_(True)
+    objs = (torch.randn(B, Ng, ctx_dim, generator=g) * 0.5).requires_grad_(True)
+    context = torch.randn(B, ctx_T, ctx_dim, generator=g)
+    target = torch.randn(B, N, C, generator=g)
+    for p_name, p_ in blk.named_parameters():
+        p_.requires_grad_(p_name.startswith("fuser."))
+    y = blk(x, context, objs)
+    loss = torch.nn.functional.mse_loss(y, target)
+    loss.backward()
+    # inputs are not stored: the test regenerates them from the same seeded CPU generator (block_backward_inputs in tests/helpers.py
+    # repeats the four draws above); the big weight gradients are stored as fp16 of g / max|g| + the scale (2^-11 relative per entry)
+    out = dict(y=y.detach().numpy(), loss=np.float64(loss.item()), dx=x.grad.numpy(), dobjs=objs.grad.numpy(),
+               x_sum=np.float64(x.detach().double().sum().item()), target_sum=np.float64(target.double().sum().item()))
+    for p_name, p_ in blk.named_parameters():
+        if p_name.startswith("fuser."):
+            gq = p_.grad.numpy()
+            sc = float(np.abs(gq).max()) or 1.0
+            out["grad." + p_name] = (gq / sc).astype(np.float16)
+            out["scale." + p_name] = np.float64(sc)
+    out["meta"] = np.frombuffer(json.dumps(dict(B=B, hw=hw, Ng=Ng, C=C, heads=heads, ctx_dim=ctx_dim, ctx_T=ctx_T, seed=77,
+                                                alpha_attn=0.6, alpha_dense=-0.4)).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss {loss.item():.6f}, |dx| {x.grad.abs().mean():.3e}, {sum(1 for k in out if k.startswith('grad.'))} fuser gradients")
+    return {k: list(v.shape) for k, v in blk.state_dict().items()}
+
+
 CASES = {
     "unet_small_text": lambda: unet_case("unet_small_text", syn.UNET_CFG_SMALL, "text", 2, 16),
     "unet_small_text_image": lambda: unet_case("unet_small_text_image", syn.UNET_CFG_SMALL, "text_image", 2, 16),
@@ -508,6 +547,8 @@ CASES = {
     "unet_full_64_text_image_b4": lambda: unet_pair_case("unet_full_64_text_image_b4", "text_image", 4, 64),
     "unet_full_64_keypoint_b4": lambda: unet_pair_case("unet_full_64_keypoint_b4", "keypoint", 4, 64),
     "c2_end_to_end": c2_case,
+    # ---- round 4: the training slice (gradients through one transformer block, from the reference's autograd)
+    "block_backward_gatedsa": block_backward_case,
 }
 
 if __name__ == "__main__":

@@ -104,3 +104,16 @@ def scripted_randn_like(noise, multistep=True):
             state["step"], state["slot"] = i + 1, 0
         return out
     return fn
+
+
+def block_backward_inputs(meta):
+    """The inputs of the training-slice golden (oracle/make_golden.py: block_backward_case), regenerated from the same seeded
+    CPU generator in the same order: x, objs, context, target."""
+    import torch
+    g = torch.Generator().manual_seed(4242)
+    B, N, C, Ng, D, T = meta["B"], meta["hw"] ** 2, meta["C"], meta["Ng"], meta["ctx_dim"], meta["ctx_T"]
+    x = torch.randn(B, N, C, generator=g)
+    objs = torch.randn(B, Ng, D, generator=g) * 0.5
+    context = torch.randn(B, T, D, generator=g)
+    target = torch.randn(B, N, C, generator=g)
+    return x, objs, context, target

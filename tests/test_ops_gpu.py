@@ -3,6 +3,8 @@ reference of the same op on the same (bf16-rounded) inputs. Tolerances are relat
 reference's max magnitude: bf16 output rounding is 2^-8 = 3.9e-3."""
 import math
 
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -342,3 +344,56 @@ def test_feedforward_rows_large_gate_inputs(engine):
     assert used == 1 and bool(torch.isfinite(y.float()).all())
     ref = (F.gelu(b1[4 * C:]).view(4, C).sum(0) / 4.0).expand(M, C)
     assert rel_err(y, ref) < TOL
+
+
+# ---- training slice (second half): forward + backward of one BasicTransformerBlock (gatedSA fuser) under
+# the reference's loss, against gradients from the reference's own autograd (tests/golden/block_backward_gatedsa.npz, made by
+# oracle/make_golden.py from /root/reference: trainer.py:353-371 loss, attention.py:333-338 block, trainer.py:217-245 trainable set)
+def test_fuser_block_backward_vs_reference(engine):
+    import json
+    import numpy as np
+    from gligen_amd import synthetic as syn
+    from helpers import GOLDEN, block_backward_inputs
+    from ldm.modules.attention import BasicTransformerBlock
+    g = np.load(os.path.join(GOLDEN, "block_backward_gatedsa.npz"))
+    meta = json.loads(bytes(g["meta"]).decode())
+    x, objs, context, target = block_backward_inputs(meta)
+    assert abs(float(x.double().sum()) - float(g["x_sum"])) < 1e-6 and abs(float(target.double().sum()) - float(g["target_sum"])) < 1e-6
+    blk = BasicTransformerBlock(meta["C"], meta["ctx_dim"], meta["ctx_dim"], meta["heads"], meta["C"] // meta["heads"], "gatedSA")
+    sd = syn.seeded_state_dict({k: tuple(v.shape) for k, v in blk.state_dict().items()}, meta["seed"])
+    sd["fuser.alpha_attn"] = torch.tensor(meta["alpha_attn"])
+    sd["fuser.alpha_dense"] = torch.tensor(meta["alpha_dense"])
+    assert sorted(engine.block_train_param_names()) == sorted(sd.keys())
+    y, loss, dx, dobjs, grads = engine.op_block_train(sd, x, objs, context, target, meta["heads"])
+
+    def rel_mse(a, ref):
+        a, ref = a.detach().float().cpu(), torch.as_tensor(ref).float()
+        return float(((a - ref) ** 2).mean() / (ref ** 2).mean().clamp_min(1e-30))
+
+    report = {"y": rel_mse(y, g["y"]), "loss": abs(float(loss) - float(g["loss"])) / float(g["loss"]), "dx": rel_mse(dx, g["dx"]), "dobjs": rel_mse(dobjs, g["dobjs"])}
+    names = sorted(k[5:] for k in g.files if k.startswith("grad."))
+    assert names == sorted(grads.keys()) and len(names) == 17
+    for n in names:
+        ref = torch.from_numpy(g["grad." + n].astype(np.float32)) * float(g["scale." + n])
+        report["grad." + n] = rel_mse(grads[n], ref)
+    worst = max(report, key=report.get)
+    print("training slice: worst", worst, report[worst])
+    assert report["loss"] < 1e-3 and report["y"] < 1e-4, report
+    assert all(v < 1e-3 for v in report.values()), {k: v for k, v in report.items() if v >= 1e-3}
+    # a frozen layer's weight gradient cannot be asked for
+    import ctypes as C
+    from gligen_amd import _lib
+    with pytest.raises(_lib.GligenAmdError):
+        dev = x.device
+        dims = type("D", (), {})
+        names_all = engine.block_train_param_names()
+        params = [sd[n].float().cuda().contiguous() for n in names_all]
+        parr = (C.c_void_p * 37)(*[p.data_ptr() for p in params])
+        bad = torch.zeros_like(params[names_all.index("attn1.to_q.weight")])
+        garr = (C.c_void_p * 37)(*[(bad.data_ptr() if n == "attn1.to_q.weight" else None) for n in names_all])
+        from gligen_amd.engine import TrainBlockDims
+        d = TrainBlockDims(meta["B"], meta["hw"] ** 2, meta["Ng"], meta["C"], meta["heads"], meta["ctx_T"], meta["ctx_dim"], 1.0)
+        xs = [t.float().cuda().contiguous() for t in (x, objs, context, target)]
+        outs = [torch.empty_like(xs[0]), torch.zeros(1, device="cuda"), torch.empty_like(xs[0]), torch.empty_like(xs[1])]
+        _lib.check(engine.lib.gl_op_block_train(engine._ctx, C.byref(d), parr, *[C.c_void_p(t.data_ptr()) for t in xs],
+                                                *[C.c_void_p(t.data_ptr()) for t in outs], garr, None))
