@@ -462,6 +462,13 @@ int gl_op_feedforward(gl_ctx* ctx, const void* x, int M, int C, const float* gam
     GL_API_END
 }
 
+int gl_op_adamw_step(gl_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int step, gl_stream s) {
+    NEED(ctx);
+    if (!p || !g || !m || !v || n < 0) return gl::set_error(GL_ERR_ARG, "gl_op_adamw_step: null pointer");
+    return gl::adamw_step(p, g, m, v, (size_t)n, lr, beta1, beta2, eps, weight_decay, step, S(s));
+}
+
 static const char* const k_train_block_names[GL_TRAIN_BLOCK_PARAMS] = {
     "norm1.weight", "norm1.bias", "attn1.to_q.weight", "attn1.to_k.weight", "attn1.to_v.weight", "attn1.to_out.0.weight", "attn1.to_out.0.bias",
     "fuser.linear.weight", "fuser.linear.bias", "fuser.norm1.weight", "fuser.norm1.bias", "fuser.attn.to_q.weight", "fuser.attn.to_k.weight",

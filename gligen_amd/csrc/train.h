@@ -30,4 +30,7 @@ int block_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainBlockDims
                      const float* objs, const float* context, const float* target, float* y, float* loss, float* dx, float* dobjs,
                      float* const* grads, hipStream_t s);
 
+// One AdamW update of a flat fp32 parameter range, in place (torch.optim.AdamW semantics: trainer.py:245, :384 opt.step()); step = 1, 2, ...
+int adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd, int step, hipStream_t s);
+
 }  // namespace gl

@@ -235,6 +235,20 @@ __global__ void mse_grad_kernel(const float* __restrict__ y, const float* __rest
     if (i < n) dy[i] = 2.f * (y[i] - t[i]) / (float)n;
 }
 
+// torch.optim.AdamW (trainer.py:245, one step of opt.step()): decoupled weight decay, bias-corrected moments, in place
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
+                             float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] * (1.f - lr * wd) - (lr / bc1) * (mi / denom);
+}
+
 struct Ctx {
     Arena& ar;
     float* ws;
@@ -346,6 +360,14 @@ struct Ctx {
 };
 
 }  // namespace
+
+int adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd, int step, hipStream_t s) {
+    if (step < 1) return set_error(GL_ERR_ARG, "adamw_step: step counts from 1");
+    const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, sqrtf(bc2));
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
 
 int block_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainBlockDims& d, const float* const* P, const float* x, const float* objs,
                      const float* context, const float* target, float* y, float* loss, float* dx, float* dobjs, float* const* G, hipStream_t s) {

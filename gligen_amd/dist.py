@@ -1,5 +1,6 @@
 """One process per GPU. The denoising path shards by sample (independent trajectories, no exchange
-step — SURVEY.md §8e), so the only collectives are the benchmark's barrier and max-over-ranks clock."""
+step — SURVEY.md §8e), so the only collectives there are the benchmark's barrier and max-over-ranks clock.
+The training path has one real exchange: the gradients of the trainable set, GradBuckets below."""
 from __future__ import annotations
 
 import os
@@ -62,3 +63,65 @@ def shutdown() -> None:
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+class GradBuckets:
+    """Gradient exchange of the training path (reference trainer.py:321-322: DistributedDataParallel over the trainable set --
+    16 fusers + position_net, ~209 M fp32 values = 836 MB per step; distributed.py:53-62). The gradients live IN a few large flat
+    buffers from the start -- `views[name]` is the tensor the backward kernels write (gl_op_block_train takes its pointer), so
+    there is no pack / unpack pass -- and every buffer is exchanged as one collective: xGMI is point-to-point (7 links x ~153 GB/s
+    per GPU), a ring collective is per-link bound, and few large transfers amortise its latency where DDP's default 25 MB buckets
+    would pay it 34 times. On RCCL each bucket is a reduce-scatter + all-gather pair (the halves of a ring all-reduce, so an
+    optimizer that is sharded over the ranks later only drops the second half); gloo (CPU tests) uses all_reduce.
+    A tensor is never split across buckets; bucket lengths are padded to a multiple of the world size."""
+
+    def __init__(self, named_shapes, bucket_mb: float = 128.0, world: int | None = None, device="cpu", dtype=torch.float32):
+        self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        limit = max(1, int(bucket_mb * (1 << 20)) // torch.empty((), dtype=dtype).element_size())
+        self.layout = []          # per bucket: [(name, offset, numel, shape)]
+        cur, used = [], 0
+        for name, shape in named_shapes.items():
+            n = 1
+            for d in shape:
+                n *= int(d)
+            if cur and used + n > limit:
+                self.layout.append(cur)
+                cur, used = [], 0
+            cur.append((name, used, n, tuple(int(d) for d in shape)))
+            used += n
+        if cur:
+            self.layout.append(cur)
+        self.buckets, self.views = [], {}
+        for items in self.layout:
+            total = items[-1][1] + items[-1][2]
+            padded = (total + self.world - 1) // self.world * self.world
+            buf = torch.zeros(padded, dtype=dtype, device=device)
+            self.buckets.append(buf)
+            for name, off, n, shape in items:
+                self.views[name] = buf[off:off + n].view(shape)
+
+    def zero_(self):
+        for b in self.buckets:
+            b.zero_()
+
+    def all_reduce(self, average: bool = True):
+        """Sum (or mean) of every bucket over the ranks, in place. Returns the number of collectives issued."""
+        if not dist.is_initialized() or self.world == 1:
+            return 0
+        n = 0
+        nccl = dist.get_backend() == "nccl"
+        for buf in self.buckets:
+            if nccl:
+                shard = buf.numel() // self.world
+                mine = torch.empty(shard, dtype=buf.dtype, device=buf.device)
+                dist.reduce_scatter_tensor(mine, buf, op=dist.ReduceOp.SUM)
+                if average:
+                    mine.div_(self.world)
+                dist.all_gather_into_tensor(buf, mine)
+                n += 2
+            else:
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+                if average:
+                    buf.div_(self.world)
+                n += 1
+        return n

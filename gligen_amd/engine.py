@@ -380,6 +380,13 @@ class Engine:
                                          _ptr(res), _ptr(gate), _ptr(y), _ptr(stats), C.byref(used), _stream(self.device)))
         return y, stats, int(used.value)
 
+    def op_adamw_step(self, p, g, m, v, step, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        """In-place AdamW update of a flat fp32 tensor (gl_op_adamw_step; torch.optim.AdamW semantics)."""
+        for t in (p, g, m, v):
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
+        check(self.lib.gl_op_adamw_step(self._ctx, _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(betas[0]), float(betas[1]),
+                                        float(eps), float(weight_decay), int(step), _stream(self.device)))
+
     def block_train_param_names(self):
         names = self.lib.gl_train_block_param_names()
         return [names[i].decode() for i in range(37)]

@@ -241,6 +241,11 @@ int gl_op_block_train(gl_ctx* ctx, const gl_train_block_dims* dims, const float*
                       const float* context, const float* target, float* y, float* loss, float* dx, float* dobjs, float* const* grads,
                       gl_stream s);
 
+/* One AdamW step over a flat fp32 range, in place: p, exp_avg m, exp_avg_sq v [n]; g the (all-reduced) gradient; step counts from 1.
+ * torch.optim.AdamW semantics -- the reference's optimizer over the trainable set (trainer.py:245, opt.step() at :384). */
+int gl_op_adamw_step(gl_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int step, gl_stream s);
+
 /* 3x3 conv over NHWC bf16 (channel-concat of x0,x1), weight OIHW fp32, stride 1|2, optional
  * nearest 2x upsample of the input, pad_lo 1 (symmetric) or 0 (VAE-encoder style). y NHWC bf16. */
 int gl_op_conv3x3(gl_ctx* ctx, const void* x0, int C0, const void* x1, int C1, int B, int H, int W,

@@ -103,3 +103,69 @@ def test_bench_spawns_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
                          capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert bad.returncode != 0 and "must agree" in (bad.stderr + bad.stdout)
+
+
+# ---- the one exchange of the training path: the trainable set's gradients, gligen_amd.dist.GradBuckets
+GRAD_WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, {root!r})
+    import torch
+    from gligen_amd import dist as gdist
+    from ldm.modules.attention import BasicTransformerBlock
+    rank, local_rank, world = gdist.init_from_env(backend="gloo")
+    blk = BasicTransformerBlock(64, 96, 96, 2, 32, "gatedSA")
+    shapes = {{k: tuple(v.shape) for k, v in blk.state_dict().items() if k.startswith("fuser.")}}   # trainer.py:217-245
+    gb = gdist.GradBuckets(shapes, bucket_mb=0.05, world=world)    # small buckets: several of them, tensors of very different sizes
+    g = torch.Generator().manual_seed(100 + rank)
+    for name, v in gb.views.items():
+        v.copy_(torch.randn(v.shape, generator=g))
+    n_coll = gb.all_reduce(average=True)
+    # what every rank must hold now: the mean of the two ranks' seeded gradients
+    ref = {{}}
+    for r in range(world):
+        gr = torch.Generator().manual_seed(100 + r)
+        for name, shape in shapes.items():
+            t = torch.randn(shape, generator=gr)
+            ref[name] = ref.get(name, 0) + t / world
+    err = max(float((gb.views[n] - ref[n]).abs().max()) for n in shapes)
+    pads = [int(b.numel()) % world for b in gb.buckets]
+    split = sum(1 for items in gb.layout for (_, off, n, _) in items if off + n > gb.buckets[gb.layout.index(items)].numel())
+    print("RESULT " + json.dumps(dict(rank=rank, err=err, n_buckets=len(gb.buckets), n_coll=n_coll, pads=pads, split=split,
+                                      n_tensors=len(shapes), total=sum(int(v.numel()) for v in gb.views.values()))))
+    gdist.shutdown()
+""")
+
+
+def test_two_rank_gloo_gradient_buckets(tmp_path):
+    import json
+    port = _free_port()
+    script = tmp_path / "grad_worker.py"
+    script.write_text(GRAD_WORKER.format(root=ROOT))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = {}
+    for p in procs:
+        out, err = p.communicate(timeout=180)
+        assert p.returncode == 0, err[-2000:]
+        r = json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][-1][7:])
+        res[r["rank"]] = r
+    for r in res.values():
+        assert r["err"] < 1e-6                      # both ranks hold the mean gradient of every tensor
+        assert r["n_tensors"] == 17 and r["n_buckets"] > 1 and r["n_coll"] == r["n_buckets"]    # one collective per bucket
+        assert r["pads"] == [0] * r["n_buckets"] and r["split"] == 0     # bucket lengths divide by the world size, no tensor is split
+    assert res[0]["total"] == res[1]["total"]
+
+
+def test_gradient_buckets_layout_is_zero_copy():
+    """The views handed to the backward kernels ARE the bucket memory (no pack pass), in declaration order, one bucket for the
+    whole set when it fits."""
+    from gligen_amd.dist import GradBuckets
+    shapes = {"a.weight": (8, 4), "a.bias": (8,), "b.weight": (16, 8)}
+    gb = GradBuckets(shapes, bucket_mb=1.0, world=8)
+    assert len(gb.buckets) == 1 and gb.buckets[0].numel() % 8 == 0 and gb.buckets[0].numel() >= 32 + 8 + 128
+    gb.views["a.bias"].fill_(3.0)
+    assert float(gb.buckets[0][32:40].sum()) == 24.0 and float(gb.buckets[0].sum()) == 24.0
+    assert [n for items in gb.layout for (n, *_rest) in items] == list(shapes)
+    assert GradBuckets(shapes, bucket_mb=1e-4, world=2).all_reduce() == 0      # no process group: nothing to exchange

@@ -397,3 +397,18 @@ def test_fuser_block_backward_vs_reference(engine):
         outs = [torch.empty_like(xs[0]), torch.zeros(1, device="cuda"), torch.empty_like(xs[0]), torch.empty_like(xs[1])]
         _lib.check(engine.lib.gl_op_block_train(engine._ctx, C.byref(d), parr, *[C.c_void_p(t.data_ptr()) for t in xs],
                                                 *[C.c_void_p(t.data_ptr()) for t in outs], garr, None))
+
+
+def test_adamw_step_matches_torch(engine):
+    """gl_op_adamw_step against torch.optim.AdamW (the reference's optimizer over the trainable set, trainer.py:245) for three steps."""
+    n = 100003
+    p0 = rnd(n, seed=1)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in (1, 2, 3):
+        g = rnd(n, seed=10 + step) * (0.1 ** step)
+        ref.grad = g.clone()
+        opt.step()
+        engine.op_adamw_step(p, g, m, v, step, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+        assert torch.allclose(p, ref.detach(), rtol=1e-5, atol=1e-6), step
