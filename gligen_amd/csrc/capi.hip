@@ -462,6 +462,32 @@ int gl_op_feedforward(gl_ctx* ctx, const void* x, int M, int C, const float* gam
     GL_API_END
 }
 
+int gl_op_ff_chain(gl_ctx* ctx, const void* x, int M, int C, const float* pre_w, const float* pre_b, const void* pre_res, const float* pre_gate,
+                   const float* gamma, const float* beta, const float* w1, const float* b1, const float* w2, const float* b2, const float* gate,
+                   const float* post_w, const float* post_b, const void* post_res, void* y, gl_stream s) {
+    NEED(ctx);
+    if (!x || !pre_w || !pre_b || !pre_res || !gamma || !beta || !w1 || !b1 || !w2 || !b2 || !y) return gl::set_error(GL_ERR_ARG, "gl_op_ff_chain: null pointer");
+    if (post_w && (!post_b || !post_res)) return gl::set_error(GL_ERR_ARG, "gl_op_ff_chain: the trailing projection needs its bias and residual");
+    GL_API_BEGIN
+    Engine& eng = *ctx->eng;
+    Arena& ar = eng.arena();
+    ar.reset();
+    auto ck = [&](int rc) { if (rc != GL_OK) throw GlError(rc, gl::last_error()); };
+    if (!ff_rows_supported(M, C)) throw GlError(GL_ERR_UNSUPPORTED, "gl_op_ff_chain: no row-local kernel for this shape (C = 320, M % 128 == 0)");
+    float* wf = ar.get<float>((size_t)8 * C * C);
+    float* bf = ar.get<float>((size_t)8 * C);
+    ck(ln_fold_launch(w1, b1, gamma, beta, wf, bf, 8 * C, C, S(s)));
+    void* st = ar.alloc(ff_chain_stream_bytes(C, true, post_w != nullptr));
+    ck(ff_chain_pack_launch(wf, bf, w2, pre_w, post_w, st, C, S(s)));
+    FFRowsParams P{};
+    P.x = (const bf16*)x; P.ldx = C; P.normalize = 1; P.eps = 1e-5f; P.stream = st; P.b2 = b2; P.gate = gate; P.out = (bf16*)y; P.ldo = C; P.M = M;
+    P.pre = 1; P.pre_b = pre_b; P.pre_res = (const bf16*)pre_res; P.ld_pre_res = C; P.pre_gate = pre_gate;
+    P.mid_out = ar.get<bf16>((size_t)M * C); P.ld_mid = C;
+    if (post_w) { P.post = 1; P.post_b = post_b; P.post_res = (const bf16*)post_res; P.ld_post_res = C; }
+    ck(ff_rows_launch(P, C, S(s)));
+    GL_API_END
+}
+
 int gl_op_adamw_step(gl_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int step, gl_stream s) {
     NEED(ctx);

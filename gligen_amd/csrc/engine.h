@@ -86,6 +86,9 @@ struct CrossAttnW { LinW q; const bf16* wk = nullptr; const bf16* wv = nullptr; 
 struct FFW {
     const bf16* w1 = nullptr; const float* b1 = nullptr; LinW w2; int C = 0; int geglu16 = 0; bool folded = false; const float* csum1 = nullptr;
     const void* rows_stream = nullptr;   // the same weights as the fragment stream of the row-local kernel (ffn.hip), where one exists for C
+    // the chained form (ffn.h FFRowsParams::pre / post): [projection in front][this feed-forward][projection behind] as ONE stream
+    const void* chain_stream = nullptr;
+    bool chain_post = false;
 };
 // partial row statistics written by the GEMM that produced a residual-stream tensor (nb = 0: none)
 struct RowStats { float2* p = nullptr; int nb = 0, ld = 0; };
@@ -210,13 +213,15 @@ class Engine {
     ConvW conv3(const std::string& prefix, int Npad = 0);
     LinW conv1(const std::string& prefix);
     const bf16* cast_rows(const std::vector<std::string>& weight_keys);
-    FFW ffw(const std::string& prefix, int C, const NormW* fold = nullptr);
+    // pre_key / post_key: weights of the C x C projections chained in front of / behind this feed-forward ("" = none)
+    FFW ffw(const std::string& prefix, int C, const NormW* fold = nullptr, const std::string& pre_key = "", const std::string& post_key = "");
     // fp32 temporaries W * gamma, b + W beta of one linear layer (freed at the end of build_unet)
     struct FoldTmp { float* w = nullptr; float* b = nullptr; int N = 0, K = 0; };
     FoldTmp fold_ln(const std::string& weight_key, const float* bias, const NormW& n);
     std::vector<void*> fold_tmps_;
     bool ln_fold_ = false;       // LayerNorms folded into their consumers (GL_LN_FOLD=0: off)
     bool ff_rows_ = true;        // row-local feed-forward kernel where it exists (GL_FF_ROWS=0: off)
+    int ff_chain_ = 2;           // its chained forms: 1 = attn2.to_out -> ff -> proj_out, 2 = also fuser.attn.to_out -> fuser.ff (GL_FF_CHAIN)
     ResW resw(const std::string& prefix, int Cin, int Cout, bool unet);
     void build_unet();
     void build_vae();
@@ -236,6 +241,9 @@ class Engine {
     bf16* feedforward(const FFW& f, const bf16* ln, int M, const bf16* res, const float* gate, hipStream_t s, const RowStats* in_stats = nullptr,
                       RowStats* out_stats = nullptr, bool raw_rows = false);
     bool ff_rows(const FFW& f, int M) const;
+    // the chained launch: t = pre_res + pre_gate (x Wpre^T + pre_b); y = t + gate ff(LN(t)); out = y, or post_res + y Wpost^T + post_b
+    bf16* feedforward_chain(const FFW& f, const bf16* x, int M, const LinW& pre, const bf16* pre_res, const float* pre_gate, const float* gate,
+                            const LinW* post, const bf16* post_res, bf16* out, hipStream_t s, RowStats* out_stats);
     void self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, int Nq, int Nk, int C, int d, bf16* o, hipStream_t s,
                         const RowStats* in_stats = nullptr);
     bf16* vae_attn(const VaeAttnW& a, const bf16* x, int B, int HW, hipStream_t s);

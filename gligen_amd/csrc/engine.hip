@@ -359,7 +359,7 @@ Engine::FoldTmp Engine::fold_ln(const std::string& wkey, const float* bias, cons
     return t;
 }
 
-FFW Engine::ffw(const std::string& p, int C, const NormW* fold) {
+FFW Engine::ffw(const std::string& p, int C, const NormW* fold, const std::string& pre_key, const std::string& post_key) {
     FFW f;
     f.C = C;
     const RawTensor& w = raw(p + ".net.0.proj.weight");
@@ -389,6 +389,13 @@ FFW Engine::ffw(const std::string& p, int C, const NormW* fold) {
         void* st = persist(ff_stream_bytes(C), false);
         CK(ff_pack_launch(wsrc, bsrc, raw(p + ".net.2.weight").p, st, C, 0));
         f.rows_stream = st;
+        if (fold && !pre_key.empty()) {      // chained form: the projections around this feed-forward ride in the same stream
+            const bool post = !post_key.empty();
+            void* cs = persist(ff_chain_stream_bytes(C, true, post), false);
+            CK(ff_chain_pack_launch(wsrc, bsrc, raw(p + ".net.2.weight").p, raw(pre_key).p, post ? raw(post_key).p : nullptr, cs, C, 0));
+            f.chain_stream = cs;
+            f.chain_post = post;
+        }
     }
     return f;
 }
@@ -484,6 +491,7 @@ void Engine::build_unet() {
         const bool fold = fuse_qkv && !(dev_env("GL_LN_FOLD") && atoi(dev_env("GL_LN_FOLD")) == 0);
         ln_fold_ = fold;
         ff_rows_ = !(dev_env("GL_FF_ROWS") && atoi(dev_env("GL_FF_ROWS")) == 0);   // row-local feed-forward kernel (ffn.hip) where it exists
+        ff_chain_ = dev_env("GL_FF_CHAIN") ? atoi(dev_env("GL_FF_CHAIN")) : 2;
         auto self_attn_w = [&](const std::string& a, const NormW* ln) {
             SelfAttnW w;
             w.fused = fuse_qkv;
@@ -527,7 +535,7 @@ void Engine::build_unet() {
         t.a2.wv = cast_rows({tb + ".attn2.to_v.weight"});
         t.a2.ctx_dim = (int)raw(tb + ".attn2.to_k.weight").shape[1];
         t.a2.out = linear(tb + ".attn2.to_out.0");
-        t.ff = ffw(tb + ".ff", C, fold ? &t.ln3 : nullptr);
+        t.ff = ffw(tb + ".ff", C, fold ? &t.ln3 : nullptr, ff_chain_ >= 1 ? tb + ".attn2.to_out.0.weight" : "", ff_chain_ >= 1 ? p + ".proj_out.weight" : "");
         if (has(tb + ".fuser.linear.weight") != (c.fuser_kind != 2))
             throw GlError(GL_ERR_ARG, "fuser weights do not match fuser_kind (gatedSA has fuser.linear, gatedCA does not)");
         t.fn1 = norm(tb + ".fuser.norm1");
@@ -545,7 +553,7 @@ void Engine::build_unet() {
                 throw GlError(GL_ERR_ARG, "gatedCA: fuser.attn key / value dim must equal the grounding-token dim");
             t.fca.out = linear(tb + ".fuser.attn.to_out.0");
         }
-        t.fff = ffw(tb + ".fuser.ff", C, fold ? &t.fn2 : nullptr);
+        t.fff = ffw(tb + ".fuser.ff", C, fold ? &t.fn2 : nullptr, (ff_chain_ >= 2 && c.fuser_kind == 0) ? tb + ".fuser.attn.to_out.0.weight" : "");
         raw(tb + ".fuser.alpha_attn");
         raw(tb + ".fuser.alpha_dense");
         st_.push_back(t);
@@ -1168,6 +1176,36 @@ void Engine::self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, in
     ++n_launches;
 }
 
+bf16* Engine::feedforward_chain(const FFW& f, const bf16* x, int M, const LinW& pre, const bf16* pre_res, const float* pre_gate, const float* gate,
+                                const LinW* post, const bf16* post_res, bf16* out, hipStream_t s, RowStats* out_stats) {
+    const int C = f.C;
+    if (!f.chain_stream || !ff_rows_supported(M, C) || (post != nullptr) != f.chain_post) throw GlError(GL_ERR_STATE, "feedforward_chain: no chained stream of this shape");
+    if (!out) out = arena_.get<bf16>((size_t)M * C);
+    FFRowsParams P{};
+    P.x = x; P.ldx = C; P.normalize = 1; P.eps = 1e-5f; P.stream = f.chain_stream; P.b2 = f.w2.b; P.gate = gate; P.out = out; P.ldo = C; P.M = M;
+    P.pre = 1; P.pre_b = pre.b; P.pre_res = pre_res; P.ld_pre_res = C; P.pre_gate = pre_gate;
+    P.mid_out = arena_.get<bf16>((size_t)M * C);     // (only written when the gate is too small for the residual to ride in the accumulator)
+    P.ld_mid = C;
+    if (post) { P.post = 1; P.post_b = post->b; P.post_res = post_res; P.ld_post_res = C; }
+    if (out_stats) {
+        *out_stats = RowStats{};
+        if (ln_fold_) {
+            out_stats->ld = 1; out_stats->nb = 1;
+            out_stats->p = arena_.get<float2>((size_t)M);
+            P.stats_out = out_stats->p; P.stats_ld = 1;
+        }
+    }
+    ProfScope ps(this, s, post ? "ff_rows_kernel<pre, post>" : "ff_rows_kernel<pre>", (24.0 + (post ? 4.0 : 2.0)) * M * (double)C * C, 0.0);
+    CK(ff_rows_launch(P, C, s));
+    FILE* launch_log = launch_log_file();
+    if (launch_log) {
+        fprintf(launch_log, "ff_rows_kernel|%d|%d|%d|0|%.0f\n", M, C, 4 * C, (double)ff_chain_stream_bytes(C, true, post != nullptr) + (post ? 8.0 : 6.0) * M * C);
+        fflush(launch_log);
+    }
+    ++n_launches;
+    return out;
+}
+
 bool Engine::ff_rows(const FFW& f, int M) const { return f.rows_stream && ff_rows_supported(M, f.C); }
 
 bf16* Engine::feedforward(const FFW& f, const bf16* ln, int M, const bf16* res, const float* gate, hipStream_t s, const RowStats* in_stats,
@@ -1254,8 +1292,9 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
     bf16* t1 = linear_rows(o, M, t.a1.out, ACT_NONE, t0, nullptr, s, &st1);
 
     const int Ng = cond_.Ng;
-    bf16* t2;
+    bf16* t2 = nullptr;
     bf16* t3;
+    bool fuser_chained = false;
     if (fuser_off_) {
         t3 = t1;
         st3 = st1;
@@ -1296,7 +1335,13 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
             ++n_launches;
         }
         self_attention(t.fa, lnc, B, Tf, HW, HW + Ng, C, d, o, s);
-        t2 = linear_rows(o, M, t.fa.out, ACT_NONE, t1, gates_ + 2 * t.idx, s, r2 ? nullptr : &st2);
+        if (r2 && t.fff.chain_stream && !t.fff.chain_post) {
+            // fuser.attn.to_out + gated residual, LayerNorm, fuser.ff + gated residual: one row-local launch
+            t3 = feedforward_chain(t.fff, o, M, t.fa.out, t1, gates_ + 2 * t.idx, gates_ + 2 * t.idx + 1, nullptr, nullptr, nullptr, s, &st3);
+            fuser_chained = true;
+        } else {
+            t2 = linear_rows(o, M, t.fa.out, ACT_NONE, t1, gates_ + 2 * t.idx, s, r2 ? nullptr : &st2);
+        }
     } else {
         // fuser (gatedCA, attention.py:207-212): x = x + scale*tanh(alpha_attn) * attn(norm1(x), objs, objs)
         ln = layernorm(t1, B, HW, C, t.fn1, true, s);
@@ -1324,9 +1369,11 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
         t2 = linear_rows(o, M, t.fca.out, ACT_NONE, t1, gates_ + 2 * t.idx, s, r2 ? nullptr : &st2);
     }
     //        x = x + scale*tanh(alpha_dense) * ff(norm2(x))
+    if (!fuser_chained) {
     const bool f2 = r2 || (t.fff.folded && can_fold(st2, 8 * C, EPI_ROWMAJOR, ACT_GEGLU));
     ln = normed(t2, t.fn2, t.fff.folded, f2, false);
     t3 = feedforward(t.fff, ln, M, t2, gates_ + 2 * t.idx + 1, s, (f2 && !r2) ? &st2 : nullptr, &st3, r2);
+    }
     }
 
     // x = attn2(norm2(x), context) + x
@@ -1359,6 +1406,12 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
             log_attention(attn_kernel_name(d, cond_.ctx_T), B, heads, HW, cond_.ctx_T, d);
         }
         ++n_launches;
+    }
+    if (r4 && t.ff.chain_stream && t.ff.chain_post) {
+        // attn2.to_out + residual, LayerNorm, ff + residual, proj_out + x_in: one row-local launch (attention.py:337-338, 374-376)
+        feedforward_chain(t.ff, o, M, t.a2.out, t3, nullptr, nullptr, &t.proj_out, x, out, s, nullptr);
+        arena_.release(mk);
+        return out;
     }
     bf16* t4 = linear_rows(o, M, t.a2.out, ACT_NONE, t3, nullptr, s, r4 ? nullptr : &st4);
 

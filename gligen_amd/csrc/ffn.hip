@@ -54,6 +54,13 @@ struct FFGeom {
     static constexpr size_t STREAM_BYTES = (size_t)NSTAGE * STAGE;
     static constexpr int LDS_BYTES = 2 * STAGE;
     static_assert(NCH % 2 == 0, "chunk parity of the last chunk");
+    // a chained C x C projection: KS k-steps x NCB feature blocks = KS * NCB blocks, in PJ_ST stages of PJ_BLK (k-step major inside a stage)
+    static constexpr int PJ_KS = 4;                   // k-steps per stage
+    static constexpr int PJ_BLK = PJ_KS * NCB;        // 40 blocks per stage
+    static constexpr int PJ_ST = KS / PJ_KS;          // 5 stages
+    static_assert(KS % PJ_KS == 0 && PJ_BLK % 4 == 0 && PJ_ST % 2 == 1, "projection stage geometry (an odd stage count flips the LDS buffer parity)");
+    static constexpr size_t PJ_BYTES = (size_t)PJ_ST * PJ_BLK * 1024;
+    static constexpr size_t chain_bytes(bool pre, bool post) { return STREAM_BYTES + (pre ? PJ_BYTES : 0) + (post ? PJ_BYTES : 0); }
 };
 
 // Fragment layouts (v_mfma_f32_32x32x16_bf16, weights as the A operand): A lane L holds row L & 31, k-slots 8 (L >> 5) .. + 7;
@@ -62,26 +69,46 @@ struct FFGeom {
 //    x, gate = proj(x).chunk(2)), so a lane's registers 0..7 are 8 values and 8..15 the gates of the same 8 hidden features
 //    f = 8 jj + 4 h + e (jj = 0, 1);
 //  * P^T operand of FF-out k-step nb: k-slot 8 h + 4 jj + e  <->  hidden feature c 32 + nb 16 + 8 jj + 4 h + e.
+// KPERM: the B operand of this product comes out of accumulator registers (a projection or the feed-forward behind another stage):
+// its k-slot 8 h + 4 jj + e holds feature 16 ks + 8 jj + 4 h + e instead of 16 ks + 8 h + (4 jj + e) -- the weights' columns follow
+__device__ __forceinline__ int ff_kidx(int ks, int h, int e, bool kperm) { return kperm ? 16 * ks + 8 * (e >> 2) + 4 * h + (e & 3) : 16 * ks + 8 * h + e; }
+
 template <int C>
 __global__ void __launch_bounds__(256) ff_pack_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                                      const float* __restrict__ pre_w, const float* __restrict__ post_w,
                                                       unsigned char* __restrict__ stream) {
     using G = FFGeom<C>;
-    const size_t n_pieces = G::STREAM_BYTES / 16;
+    const size_t pre_bytes = pre_w ? G::PJ_BYTES : 0, ff_end = pre_bytes + G::STREAM_BYTES;
+    const size_t n_pieces = (ff_end + (post_w ? G::PJ_BYTES : 0)) / 16;
     for (size_t pc = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pc < n_pieces; pc += (size_t)gridDim.x * blockDim.x) {
         U4BF8 o;
         o.u = make_uint4(0, 0, 0, 0);
         const size_t byte = pc * 16;
-        const int st = (int)(byte / G::STAGE);
-        const int in = (int)(byte % G::STAGE);
-        const int blk = in >> 10, L = (in >> 4) & 63, r = L & 31, h = L >> 5;
+        const int L = (int)(byte >> 4) & 63, r = L & 31, h = L >> 5;
+        if (byte < pre_bytes || byte >= ff_end) {
+            // projection segment: block b = stage * PJ_BLK + (k-step inside the stage) * NCB + feature block
+            const bool post = byte >= ff_end;
+            const float* w = post ? post_w : pre_w;
+            const int b = (int)((byte - (post ? ff_end : 0)) >> 10);
+            const int st = b / G::PJ_BLK, i = b % G::PJ_BLK, ks = st * G::PJ_KS + i / G::NCB, cb = i % G::NCB;
+            const float* src = w + (size_t)(cb * 32 + r) * C;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.e[e] = f2bf(src[ff_kidx(ks, h, e, post)]);
+            *reinterpret_cast<uint4*>(stream + byte) = o.u;
+            continue;
+        }
+        const size_t fb = byte - pre_bytes;
+        const int st = (int)(fb / G::STAGE);
+        const int in = (int)(fb % G::STAGE);
+        const int blk = in >> 10;
         if (blk < G::NPB) {
             const int ks = blk >> 1, nb = blk & 1;
             if (st < G::NCH) {
                 const int row = (r >> 4) * 4 * C + st * 32 + nb * 16 + (r & 15);
                 if (ks < G::KS) {
-                    const float* src = w1 + (size_t)row * C + ks * 16 + h * 8;
+                    const float* src = w1 + (size_t)row * C;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o.e[e] = f2bf(src[e]);
+                    for (int e = 0; e < 8; ++e) o.e[e] = f2bf(src[ff_kidx(ks, h, e, pre_w != nullptr)]);
                 } else if (h == 0) {
                     o.e[0] = f2bf(b1[row]);      // the bias step multiplies k-slot 0 by one (bf16 bias: the accumulator is rounded to bf16 anyway)
                 }
@@ -171,6 +198,21 @@ __device__ __forceinline__ void mfma_acc_aa(f32x16& d, const bf16x8& a, const u3
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %5, %6, %0" FFR_PAD : "+a"(d), FFR_GS(s) : "v"(a), "v"(b));
 }
 
+__device__ __forceinline__ void mfma_acc_aab(f32x16& d, const bf16x8& a, const bf16x8& b) {                       // accumulator and B in the AGPR half
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" FFR_PAD : "+a"(d) : "v"(a), "a"(b));
+}
+
+// The last MFMAs' results before hipcc's own reads of the accumulators: 32 wait states, and EVERY tuple is an in/out operand of the
+// statement -- a tuple whose last MFMA sits earlier in the stream is otherwise "defined" by that earlier statement, and hipcc is free
+// to hoist the epilogue's v_accvgpr_read of it right behind that MFMA's ISSUE, 30 cycles before its result lands (seen: one stale
+// register per row, off by exactly the last chunk's contribution)
+template <int N>
+__device__ __forceinline__ void ffr_settle(f32x16 (&acc)[N]) {
+    static_assert(N == 10, "operand list written for 10 tuples");
+    asm volatile("s_nop 15\n\ts_nop 15"
+                 : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]), "+a"(acc[8]), "+a"(acc[9]));
+}
+
 // erf-GELU of the gate times the value for one pair of hidden features, in 7 micro-steps of 1-4 plain fp32 VALU instructions
 // (packed fp32 costs a wait state per dependent pair on gfx950 and is dearer than two plain ops beside MFMAs, MI355X_MICROARCH.md):
 //   gelu(x) = x Phi(x) = max(x, 0) - |x| h(|x|),   h(a) = erfc(a / sqrt2) / 2 = 2^L(a),
@@ -213,10 +255,13 @@ __device__ __forceinline__ void geglu_step(GegluState& s, float v0, float v1, fl
 
 // ABL: developer ablation bits (tools/gpu_r4b.sh; only ABL = 0 is in the product library): 1 no GEGLU arithmetic, 2 no DMA behind the
 // prologue's, 8 no projection MFMAs, 16 no FF-out MFMAs, 32 no barrier
-template <int C, int ABL = 0>
+// PRE / POST: a row-local C x C projection in front of / behind the feed-forward in the same launch (FFRowsParams::pre / post)
+template <int C, int ABL = 0, bool PRE = false, bool POST = false>
 __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
     using G = FFGeom<C>;
     constexpr int KS = G::KS, NKP = G::NKP, NCB = G::NCB, NCH = G::NCH, NPB = G::NPB, NBLK = G::NBLK, STAGE = G::STAGE;
+    constexpr int PJ_BLK = G::PJ_BLK, PJ_ST = G::PJ_ST, PJ_KS = G::PJ_KS;
+    constexpr int FB = PRE ? 1 : 0;     // LDS buffer of the feed-forward's chunk 0 (the leading projection's PJ_ST stages flip the parity)
     constexpr int NR = 12;      // fragment ring (blocks): the read of block i + RD is issued behind MFMA i
     constexpr int RD = 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -234,7 +279,7 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
         const unsigned long long a = (unsigned long long)(uintptr_t)p.stream;
         rs.x = (unsigned)a;
         rs.y = (unsigned)(a >> 32);           // base[47:32], stride 0
-        rs.z = (unsigned)G::STREAM_BYTES;     // num_records
+        rs.z = (unsigned)G::chain_bytes(PRE, POST);     // num_records
         rs.w = 0x00020000u;                   // raw buffer, dword format (as __builtin_amdgcn_make_buffer_rsrc builds it for gfx950)
     }
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -243,7 +288,7 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
     unsigned dma_lds = lds_w;
     unsigned dma_off = (unsigned)wave * 1024u;
 #pragma unroll
-    for (int i = 0; i < G::NBS / 4; ++i) ffr_dma<true>(rs, lane16, dma_lds, dma_off);
+    for (int i = 0; i < (PRE ? PJ_BLK : G::NBS) / 4; ++i) ffr_dma<true>(rs, lane16, dma_lds, dma_off);
 
     // ---- the wave's rows as B-operand fragments: lane holds x[row][16 ks + 8 h .. + 7]
     bf16x8 xf[KS];
@@ -252,8 +297,10 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(src + ks * 16);
     }
-    const float gate = (p.res && p.gate) ? *p.gate : 1.f;
-    if (p.normalize) {
+    const float gate = ((p.res || PRE) && p.gate) ? *p.gate : 1.f;
+    const float pre_gate = (PRE && p.pre_gate) ? *p.pre_gate : 1.f;
+    const float res_in_acc = (PRE && fabsf(gate) > 1e-20f) ? 1.f / gate : 0.f;   // chained form: the feed-forward's residual rides in its accumulator
+    if (!PRE && p.normalize) {
         float s = 0.f, ss = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
@@ -294,6 +341,47 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
     gs.l0 = gs.l1 = gs.m0 = gs.m1 = 0.f;
     const unsigned ra_st[2] = {lds0 + lane16, lds0 + (unsigned)STAGE + lane16};
 
+    // A chained projection: acc[cb] += W-block(ks, cb) x xin[ks] over PJ_ST stages of PJ_BLK blocks; buffer parity of its first stage
+    // BUF0; NEXT = blocks per wave of whatever follows its last stage in the stream (0: nothing), fetched under that last stage
+    auto proj_phase = [&](f32x16 (&acc)[NCB], bf16x8 (&xin)[KS], auto buf0_c, auto next_c) {
+        constexpr int BUF0 = decltype(buf0_c)::value, NEXT = decltype(next_c)::value;
+        static_for<PJ_ST>([&](auto sc) {
+            constexpr int st = decltype(sc)::value, BUF = (BUF0 + st) & 1;
+            constexpr int pieces = st + 1 < PJ_ST ? PJ_BLK / 4 : NEXT;
+            constexpr int every = pieces > PJ_BLK / 4 ? 2 : 4;      // (16 blocks of a feed-forward stage do not fit one per four gaps)
+            asm volatile("s_waitcnt vmcnt(0)");
+            if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
+            const unsigned ra = ra_st[BUF];
+            dma_lds = lds_w + (BUF ? 0u : (unsigned)STAGE);
+            bf16x8 fr[NR];
+            static_for<RD>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                ffr_rd16<i * 1024>(fr[i % NR], ra);
+            });
+            static_for<PJ_BLK>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i % 4 == 0) {
+                    constexpr int last = (i + RD - 1 < PJ_BLK - 1) ? i + RD - 1 : PJ_BLK - 1;
+                    constexpr int need = (i + 3 < PJ_BLK - 1) ? i + 3 : PJ_BLK - 1;
+                    ffr_wait_lgkm<last - need>();
+                }
+                constexpr int ks = st * PJ_KS + i / NCB, cb = i % NCB;
+                mfma_acc_aab(acc[cb], fr[i % NR], xin[ks]);
+                if constexpr (i + RD < PJ_BLK) ffr_rd16<(i + RD) * 1024>(fr[(i + RD) % NR], ra);
+                if constexpr (i % every == 1 && i / every < pieces && !(ABL & 2)) ffr_dma(rs, lane16, dma_lds, dma_off);
+            });
+        });
+        ffr_settle(acc);
+    };
+    // rows in accumulator layout (register 4 j + e of block cb = feature 32 cb + 8 j + 4 h + e) -> B operand fragments in the
+    // permuted k-slot order (ff_kidx): slot 4 jj + e of k-step ks = register 4 (2 (ks & 1) + jj) + e of block ks >> 1
+    auto to_fragments = [&](const float (&v)[NCB][16], bf16x8 (&dst)[KS], float scale, float shift) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dst[ks][e] = f2bf(fmaf(v[ks >> 1][4 * (2 * (ks & 1) + (e >> 2)) + (e & 3)], scale, shift));
+    };
+
     // micro-step u (0..55) of the GEGLU of one chunk: call k = u / 7 handles block nb = k >> 2, feature pair (jj, pr); source = that
     // chunk's projection accumulators, destination dword 2 jj + pr of its P^T operand
     auto gstep = [&](auto uc, f32x16 (&src)[2], u32x4 (&dst)[2]) {
@@ -331,8 +419,9 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
         __builtin_amdgcn_s_barrier();
 #endif
-        const unsigned ra = ra_st[PAR];
-        dma_lds = lds_w + (PAR ? 0u : (unsigned)STAGE);   // the next stage goes where the previous one was
+        constexpr int BUF = PAR ^ FB;
+        const unsigned ra = ra_st[BUF];
+        dma_lds = lds_w + (BUF ? 0u : (unsigned)STAGE);   // the next stage goes where the previous one was
         bf16x8 fr[NR];
         static_for<RD>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
@@ -378,6 +467,53 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) asm volatile("" : "+a"(acc2[cb]));
     asm volatile("s_nop 7" : "+v"(xb));
+    if constexpr (PRE) {
+        // leading projection: t = pre_res + pre_gate (x Wpre^T + pre_b), written to mid_out, normalised into the feed-forward's operand
+        proj_phase(acc2, xf, std::integral_constant<int, 0>{}, std::integral_constant<int, G::NBS / 4>{});
+        // The feed-forward's residual is t itself. It rides in the accumulator -- Y^T starts at t / gate, so gate (Y^T + b2) is
+        // t + gate (ff + b2) -- and t is neither stored nor read back; only when the gate is too small to divide by does t take the
+        // way through mid_out (fp32 accumulation: the detour through t / gate costs ~2^-24 |t| per chunk, nothing next to bf16).
+        float tv[NCB][16];
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            float4 bv[4];
+            uint2 rv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bv[j] = *reinterpret_cast<const float4*>(p.pre_b + cb * 32 + j * 8 + h * 4);
+                rv[j] = *reinterpret_cast<const uint2*>(p.pre_res + (size_t)row * p.ld_pre_res + cb * 32 + j * 8 + h * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                U2BF4 r, o;
+                r.u = rv[j];
+                const float bj[4] = {bv[j].x, bv[j].y, bv[j].z, bv[j].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o.e[e] = f2bf(bf2f(r.e[e]) + pre_gate * (acc2[cb][4 * j + e] + bj[e]));
+                    const float t_ = bf2f(o.e[e]);
+                    tv[cb][4 * j + e] = t_;
+                    s += t_;
+                    ss = fmaf(t_, t_, ss);
+                    acc2[cb][4 * j + e] = t_ * res_in_acc;   // (0 when the residual goes through mid_out)
+                }
+                if (res_in_acc == 0.f) *reinterpret_cast<uint2*>(p.mid_out + (size_t)row * p.ld_mid + cb * 32 + j * 8 + h * 4) = o.u;
+            }
+        }
+        s += __shfl_xor(s, 32, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        const float mean = s * (1.f / C);
+        const float var = fmaxf(ss * (1.f / C) - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + p.eps);
+        to_fragments(tv, xf, rstd, -mean * rstd);
+        __builtin_amdgcn_s_waitcnt(0x0F70);        // hipcc's loads and stores above are done before the next asm DMA (its waits do not count those)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(xf[ks]));
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) asm volatile("" : "+a"(acc2[cb]));
+        asm volatile("s_nop 7" : "+v"(xb));
+    }
     chunk(std::true_type{}, std::integral_constant<int, 0>{});
 #pragma unroll 1
     for (int it = 1; it + 1 < NCH; it += 2) {
@@ -387,11 +523,12 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
     chunk(std::false_type{}, std::integral_constant<int, 1>{});
     {
         // last stage (index NCH, even): the rest of the GEGLU of the last chunk, then its FF-out product; nothing left to fetch
-        constexpr int PAR = NCH & 1;
+        constexpr int PAR = NCH & 1, BUF = PAR ^ FB;
         f32x16 (&S)[2] = a1[PAR ^ 1];
         asm volatile("s_waitcnt vmcnt(0)");
         if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
-        const unsigned ra = ra_st[PAR];
+        const unsigned ra = ra_st[BUF];
+        dma_lds = lds_w + (BUF ? 0u : (unsigned)STAGE);
         bf16x8 fr[NR];
         static_for<RD>([&](auto ic) {
             constexpr int i = NPB + decltype(ic)::value;
@@ -408,14 +545,19 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
             }
             if constexpr (!(ABL & 16)) mfma_acc_aa(acc2[cb], fr[i % NR], P[PAR ^ 1][nb], gs);
             if constexpr (i + RD < NBLK) ffr_rd16<(i + RD) * 1024>(fr[(i + RD) % NR], ra);
+            if constexpr (POST && ob % 2 == 1 && !(ABL & 2)) ffr_dma(rs, lane16, dma_lds, dma_off);   // the trailing projection's first stage: 10 blocks per wave
         });
-        asm volatile("s_nop 15\n\ts_nop 15");      // the last MFMAs' results before hipcc's own reads of the accumulators
+        ffr_settle(acc2);
     }
+    static_assert(!POST || (NBLK - NPB) / 2 == PJ_BLK / 4, "the last feed-forward stage fetches the trailing projection's first stage");
 
-    // ---- epilogue: lane holds features 32 cb + 8 j + 4 h + e of its row. Two copies under one uniform branch
+    // ---- epilogue: lane holds features 32 cb + 8 j + 4 h + e of its row. Copies under uniform branches
     // (a residual load behind a per-use guard is waited for in place)
-    auto epilogue = [&](auto res_c) {
-        constexpr bool RES = decltype(res_c)::value;
+    // y = res + gate (acc2 + b2); FINAL: stored to out (+ statistics); else kept (bf16-rounded) for the trailing projection
+    auto ff_result = [&](auto res_c, auto final_c, float (&yv)[NCB][16]) {
+        constexpr bool RES = decltype(res_c)::value, FINAL = decltype(final_c)::value;
+        const bf16* resp = PRE ? p.mid_out : p.res;
+        const int ldr = PRE ? p.ld_mid : p.ldres;
         float s = 0.f, ss = 0.f;
         bf16* dst = p.out + (size_t)row * p.ldo + h * 4;
 #pragma unroll
@@ -425,7 +567,7 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 bv[j] = *reinterpret_cast<const float4*>(p.b2 + cb * 32 + j * 8 + h * 4);
-                if constexpr (RES) rv[j] = *reinterpret_cast<const uint2*>(p.res + (size_t)row * p.ldres + cb * 32 + j * 8 + h * 4);
+                if constexpr (RES) rv[j] = *reinterpret_cast<const uint2*>(resp + (size_t)row * ldr + cb * 32 + j * 8 + h * 4);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -435,14 +577,67 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
                     r.u = rv[j];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = bf2f(r.e[e]) + gate * v[e];
+                } else if constexpr (PRE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= gate;      // the residual was in the accumulator (t / gate)
                 }
                 U2BF4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     o.e[e] = f2bf(v[e]);
                     const float r = bf2f(o.e[e]);
-                    s += r;
-                    ss = fmaf(r, r, ss);
+                    if constexpr (FINAL) { s += r; ss = fmaf(r, r, ss); }
+                    else { yv[cb][4 * j + e] = r; acc2[cb][4 * j + e] = 0.f; }
+                }
+                if constexpr (FINAL) *reinterpret_cast<uint2*>(dst + cb * 32 + j * 8) = o.u;
+            }
+        }
+        if constexpr (FINAL)
+            if (p.stats_out) {
+                s += __shfl_xor(s, 32, 64);
+                ss += __shfl_xor(ss, 32, 64);
+                if (h == 0) p.stats_out[(size_t)row * p.stats_ld] = make_float2(s, ss);
+            }
+    };
+    if constexpr (!POST) {
+        float unused[NCB][16];
+        if (PRE ? res_in_acc == 0.f : p.res != nullptr) ff_result(std::true_type{}, std::true_type{}, unused);
+        else ff_result(std::false_type{}, std::true_type{}, unused);
+    } else {
+        // trailing projection: out = post_res + (y Wpost^T + post_b)
+        float yv[NCB][16];
+        if (PRE ? res_in_acc == 0.f : p.res != nullptr) ff_result(std::true_type{}, std::false_type{}, yv);
+        else ff_result(std::false_type{}, std::false_type{}, yv);
+        to_fragments(yv, xf, 1.f, 0.f);
+        __builtin_amdgcn_s_waitcnt(0x0F70);        // (hipcc's loads above before the next asm DMA)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(xf[ks]));
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) asm volatile("" : "+a"(acc2[cb]));
+        asm volatile("s_nop 7" : "+v"(xb));
+        proj_phase(acc2, xf, std::integral_constant<int, ((NCH & 1) ^ FB) ^ 1>{}, std::integral_constant<int, 0>{});
+        float s = 0.f, ss = 0.f;
+        bf16* dst = p.out + (size_t)row * p.ldo + h * 4;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            float4 bv[4];
+            uint2 rv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bv[j] = *reinterpret_cast<const float4*>(p.post_b + cb * 32 + j * 8 + h * 4);
+                rv[j] = *reinterpret_cast<const uint2*>(p.post_res + (size_t)row * p.ld_post_res + cb * 32 + j * 8 + h * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                U2BF4 r, o;
+                r.u = rv[j];
+                const float bj[4] = {bv[j].x, bv[j].y, bv[j].z, bv[j].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o.e[e] = f2bf(bf2f(r.e[e]) + acc2[cb][4 * j + e] + bj[e]);
+                    const float q_ = bf2f(o.e[e]);
+                    s += q_;
+                    ss = fmaf(q_, q_, ss);
                 }
                 *reinterpret_cast<uint2*>(dst + cb * 32 + j * 8) = o.u;
             }
@@ -452,9 +647,7 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
             ss += __shfl_xor(ss, 32, 64);
             if (h == 0) p.stats_out[(size_t)row * p.stats_ld] = make_float2(s, ss);
         }
-    };
-    if (p.res) epilogue(std::true_type{});
-    else epilogue(std::false_type{});
+    }
 }
 
 }  // namespace
@@ -466,11 +659,21 @@ size_t ff_stream_bytes(int C) {
     return 0;
 }
 
-int ff_pack_launch(const float* w1, const float* b1, const float* w2, void* stream, int C, hipStream_t s) {
+size_t ff_chain_stream_bytes(int C, bool pre, bool post) {
+    if (C == 320) return FFGeom<320>::chain_bytes(pre, post);
+    return 0;
+}
+
+int ff_chain_pack_launch(const float* w1, const float* b1, const float* w2, const float* pre_w, const float* post_w, void* stream, int C, hipStream_t s) {
     if (C != 320) return set_error(GL_ERR_UNSUPPORTED, "ff_pack: no row-local feed-forward kernel for C = %d", C);
-    hipLaunchKernelGGL(ff_pack_kernel<320>, dim3(1024), dim3(256), 0, s, w1, b1, w2, reinterpret_cast<unsigned char*>(stream));
+    if (post_w && !pre_w) return set_error(GL_ERR_UNSUPPORTED, "ff_pack: a trailing projection is built only together with a leading one");
+    hipLaunchKernelGGL(ff_pack_kernel<320>, dim3(1024), dim3(256), 0, s, w1, b1, w2, pre_w, post_w, reinterpret_cast<unsigned char*>(stream));
     GL_LAUNCH_CHECK();
     return GL_OK;
+}
+
+int ff_pack_launch(const float* w1, const float* b1, const float* w2, void* stream, int C, hipStream_t s) {
+    return ff_chain_pack_launch(w1, b1, w2, nullptr, nullptr, stream, C, s);
 }
 
 #ifdef GL_FFN_ABLATE
@@ -508,13 +711,25 @@ int ff_rows_launch(const FFRowsParams& p, int C, hipStream_t s) {
     if (!ff_rows_supported(p.M, C)) return set_error(GL_ERR_UNSUPPORTED, "ff_rows: M = %d, C = %d has no row-local kernel", p.M, C);
     if (p.ldx % 8 || p.ldo % 4 || (p.res && p.ldres % 4)) return set_error(GL_ERR_ARG, "ff_rows: row strides must keep 16-byte loads / 8-byte stores aligned");
     using G = FFGeom<320>;
-    auto kfn = ff_rows_kernel<320>;
-    static bool attr_done = false;   // once per process; never inside a stream capture (the first call is an eager one)
-    if (!attr_done) {
-        GL_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(kfn, dim3(p.M / 128), dim3(256), G::LDS_BYTES, s, p);
+    if (p.post && !p.pre) return set_error(GL_ERR_UNSUPPORTED, "ff_rows: a trailing projection is built only together with a leading one");
+    if (p.pre && (!p.normalize || !p.pre_b || !p.pre_res || !p.mid_out || p.ld_pre_res % 4 || p.ld_mid % 4))
+        return set_error(GL_ERR_ARG, "ff_rows: the leading projection needs normalize = 1, its bias, residual and the buffer for its result");
+    if (p.post && (!p.post_b || !p.post_res || p.ld_post_res % 4)) return set_error(GL_ERR_ARG, "ff_rows: the trailing projection needs its bias and residual");
+    // once per process and kernel; never inside a stream capture (the first call of each form is an eager one)
+#define FF_LAUNCH(PRE_, POST_)                                                                                               \
+    do {                                                                                                                     \
+        auto kfn = ff_rows_kernel<320, 0, PRE_, POST_>;                                                                      \
+        static bool attr_done = false;                                                                                       \
+        if (!attr_done) {                                                                                                    \
+            GL_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));         \
+            attr_done = true;                                                                                                \
+        }                                                                                                                    \
+        hipLaunchKernelGGL(kfn, dim3(p.M / 128), dim3(256), G::LDS_BYTES, s, p);                                             \
+    } while (0)
+    if (p.pre && p.post) FF_LAUNCH(true, true);
+    else if (p.pre) FF_LAUNCH(true, false);
+    else FF_LAUNCH(false, false);
+#undef FF_LAUNCH
     GL_LAUNCH_CHECK();
     return GL_OK;
 }

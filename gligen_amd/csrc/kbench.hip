@@ -334,6 +334,96 @@ int main(int argc, char** argv) {
                 printf("FFN M%d C%d norm%d: fused %.1f us (%.0f TF/s) vs two GEMMs%s %.1f us; maxdiff %g of %g %s\n", M, C, norm, us, flop / us * 1e-6,
                        norm ? " + ln_kernel" : "", us_ref, d, m, ok ? "ok" : "MISMATCH");
             }
+        } else if (!strcmp(kind, "ffnc")) {
+            // chained row-local kernel (ffn.hip): ffnc M C post count -- leading projection + LayerNorm + feed-forward (+ trailing
+            // projection) in one launch against the separate launches it replaces
+            const int M = v[0], C = v[1], post = v[2];
+            count = v[3]; c = 0;
+            flop = (24.0 + 2.0 * (1 + post)) * M * (double)C * C;
+            static float *fw1 = nullptr, *fb1, *fw2, *fb2, *fgate, *fpre, *fpost, *fbpre, *fbpost;
+            static bf16 *wp1, *w2b, *hid, *xn, *preb, *postb, *tmid, *t3, *mid2;
+            static float* bp1;
+            static void* strm[2];
+            if (!fw1) {
+                fw1 = dev_f32((size_t)8 * 320 * 320, 21, 0.05f);
+                fb1 = dev_f32(8 * 320, 22, 0.1f);
+                fw2 = dev_f32((size_t)320 * 4 * 320, 23, 0.03f);
+                fb2 = dev_f32(320, 24, 0.1f);
+                fgate = dev_f32(4, 25, 0.7f);
+                fpre = dev_f32((size_t)320 * 320, 26, 0.06f);
+                fpost = dev_f32((size_t)320 * 320, 27, 0.06f);
+                fbpre = dev_f32(320, 28, 0.1f);
+                fbpost = dev_f32(320, 29, 0.1f);
+                HC(hipMalloc(&wp1, (size_t)8 * 320 * 320 * 2));
+                HC(hipMalloc(&bp1, 8 * 320 * 4));
+                HC(hipMalloc(&w2b, (size_t)320 * 4 * 320 * 2));
+                HC(hipMalloc(&preb, (size_t)320 * 320 * 2));
+                HC(hipMalloc(&postb, (size_t)320 * 320 * 2));
+                HC(hipMalloc(&strm[0], ff_chain_stream_bytes(320, true, false)));
+                HC(hipMalloc(&strm[1], ff_chain_stream_bytes(320, true, true)));
+                HC(hipMalloc(&hid, (size_t)65536 * 4 * 320 * 2));
+                HC(hipMalloc(&xn, (size_t)65536 * 320 * 2));
+                HC(hipMalloc(&tmid, (size_t)65536 * 320 * 2));
+                HC(hipMalloc(&t3, (size_t)65536 * 320 * 2));
+                HC(hipMalloc(&mid2, (size_t)65536 * 320 * 2));
+            }
+            if (!ff_rows_supported(M, C) || M > 65536) { printf("ffnc: unsupported %d %d\n", M, C); continue; }
+            GC(pack_geglu_launch(fw1, fb1, wp1, bp1, 4 * C, C, gemm_geglu_layout(), s));
+            GC(cast_f32_bf16_launch(fw2, w2b, (int64_t)C * 4 * C, s));
+            GC(cast_f32_bf16_launch(fpre, preb, (int64_t)C * C, s));
+            GC(cast_f32_bf16_launch(fpost, postb, (int64_t)C * C, s));
+            GC(ff_chain_pack_launch(fw1, fb1, fw2, fpre, post ? fpost : nullptr, strm[post], C, s));
+            bf16* xres = a1 + ((size_t)64 << 20);     // x_in of the trailing projection
+            FFRowsParams P{};
+            P.x = a0; P.ldx = C; P.normalize = 1; P.eps = 1e-5f; P.stream = strm[post]; P.b2 = fb2; P.gate = fgate; P.out = a2; P.ldo = C; P.M = M;
+            P.pre = 1; P.pre_b = fbpre; P.pre_res = a1; P.ld_pre_res = C; P.pre_gate = fgate + 1; P.mid_out = mid2; P.ld_mid = C;
+            P.post = post; P.post_b = fbpost; P.post_res = xres; P.ld_post_res = C;
+            relaunch = [=] { GC(ff_rows_launch(P, C, cur_s)); };
+            bf16* refout = a2 + ((size_t)100 << 20);
+            auto separate = [=] {
+                {   // t = res + g1 (x Wpre^T + bpre)
+                    AOperand A;
+                    aoperand_rows(A, a0, C, C);
+                    Epilogue E;
+                    epilogue_defaults(E);
+                    E.out = tmid; E.ldo = C; E.bias = fbpre; E.res = a1; E.ldres = C; E.gate = fgate + 1;
+                    GC(gemm_launch(A, preb, M, C, C, E, ws, ws_bytes, cur_s));
+                }
+                LNParams L{};
+                L.x = tmid; L.B = 1; L.N1 = M; L.N2 = 0; L.Tpad = M; L.C = C; L.eps = 1e-5f; L.y = xn;
+                GC(layernorm_launch(L, cur_s));
+                AOperand A;
+                aoperand_rows(A, xn, C, C);
+                Epilogue E;
+                epilogue_defaults(E);
+                E.act = ACT_GEGLU; E.geglu16 = gemm_geglu_layout(); E.out = hid; E.ldo = 4 * C; E.bias = bp1;
+                GC(gemm_launch(A, wp1, M, 8 * C, C, E, ws, ws_bytes, cur_s));
+                AOperand A2;
+                aoperand_rows(A2, hid, 4 * C, 4 * C);
+                Epilogue E2;
+                epilogue_defaults(E2);
+                E2.out = post ? t3 : refout; E2.ldo = C; E2.bias = fb2; E2.res = tmid; E2.ldres = C; E2.gate = fgate;
+                GC(gemm_launch(A2, w2b, M, C, 4 * C, E2, ws, ws_bytes, cur_s));
+                if (post) {
+                    AOperand A3;
+                    aoperand_rows(A3, t3, C, C);
+                    Epilogue E3;
+                    epilogue_defaults(E3);
+                    E3.out = refout; E3.ldo = C; E3.bias = fbpost; E3.res = xres; E3.ldres = C;
+                    GC(gemm_launch(A3, postb, M, C, C, E3, ws, ws_bytes, cur_s));
+                }
+            };
+            const float us_ref = time_us(separate, reps, s);
+            us = time_us(relaunch, reps, s);
+            {
+                float d, m, d2, m2;
+                maxdiff(a2, refout, (size_t)M * C, s, &d, &m);
+                d2 = m2 = 0.f;     // (t is no longer written: the feed-forward's residual rides in its accumulator)
+                const bool ok = d <= 0.03f * m + 1e-6f;
+                if (!ok) ++n_bad;
+                printf("FFNC M%d C%d post%d: one launch %.1f us (%.0f TF/s) vs %d separate launches %.1f us; maxdiff out %g of %g, mid %g of %g %s\n", M, C, post, us,
+                       flop / us * 1e-6, 4 + post, us_ref, d, m, d2, m2, ok ? "ok" : "MISMATCH");
+            }
         } else if (!strcmp(kind, "conv")) {
             const int B = v[0], H = v[1], W = v[2], C0 = v[3], C1 = v[4], Cout = v[5], stride = v[6], ups = v[7];
             count = v[8]; c = 1;

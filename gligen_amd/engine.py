@@ -380,6 +380,16 @@ class Engine:
                                          _ptr(res), _ptr(gate), _ptr(y), _ptr(stats), C.byref(used), _stream(self.device)))
         return y, stats, int(used.value)
 
+    def op_ff_chain(self, x, pre_w, pre_b, pre_res, gamma, beta, w1, b1, w2, b2, pre_gate=None, gate=None, post_w=None, post_b=None, post_res=None):
+        """Leading projection + residual, LayerNorm, feed-forward + residual (, trailing projection + residual) in one row-local
+        launch (gl_op_ff_chain)."""
+        M, Cc = x.shape
+        y = torch.empty((M, Cc), device=x.device, dtype=torch.bfloat16)
+        check(self.lib.gl_op_ff_chain(self._ctx, _ptr(x), M, Cc, _ptr(pre_w), _ptr(pre_b), _ptr(pre_res), _ptr(pre_gate), _ptr(gamma), _ptr(beta),
+                                      _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(gate), _ptr(post_w), _ptr(post_b), _ptr(post_res), _ptr(y),
+                                      _stream(self.device)))
+        return y
+
     def op_adamw_step(self, p, g, m, v, step, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         """In-place AdamW update of a flat fp32 tensor (gl_op_adamw_step; torch.optim.AdamW semantics)."""
         for t in (p, g, m, v):

@@ -222,6 +222,16 @@ int gl_op_ln_linear(gl_ctx* ctx, const void* a, int M, int K0, const float* w0, 
 int gl_op_feedforward(gl_ctx* ctx, const void* x, int M, int C, const float* gamma, const float* beta, const float* w1, const float* b1,
                       const float* w2, const float* b2, const void* res, const float* gate, void* y, void* stats, int* used_rows,
                       gl_stream s);
+/* The chained row-local launch of a transformer block's tail (reference attention.py:236-244 fuser, :337-338 + :374-376):
+ *   t = pre_res + pre_gate * (x Wpre^T + pre_b)         (an attention's to_out + (gated) residual)
+ *   u = t + gate * ( GEGLU( LN(t) W1^T + b1 ) W2^T + b2 )
+ *   y = u,  or with post_w:  post_res + (u Wpost^T + post_b)          (SpatialTransformer.proj_out + x_in)
+ * x / pre_res / post_res / y [M][C] bf16, Wpre / Wpost [C][C] fp32, the feed-forward as in gl_op_feedforward (gamma / beta required),
+ * pre_gate / gate device scalars or NULL (1). Needs the row-local kernel (C = 320, M % 128 == 0): GL_ERR_UNSUPPORTED otherwise. */
+int gl_op_ff_chain(gl_ctx* ctx, const void* x, int M, int C, const float* pre_w, const float* pre_b, const void* pre_res, const float* pre_gate,
+                   const float* gamma, const float* beta, const float* w1, const float* b1, const float* w2, const float* b2, const float* gate,
+                   const float* post_w, const float* post_b, const void* post_res, void* y, gl_stream s);
+
 /* ---- training slice: one BasicTransformerBlock, forward + backward ---------------------------------
  * Forward of the reference's BasicTransformerBlock with a gatedSA fuser (ldm/modules/attention.py:333-338, 236-244), the
  * reference's loss on its output (trainer.py:366: mse_loss(model_output, noise)) and the backward pass, with the gradients the

@@ -412,3 +412,31 @@ def test_adamw_step_matches_torch(engine):
         opt.step()
         engine.op_adamw_step(p, g, m, v, step, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
         assert torch.allclose(p, ref.detach(), rtol=1e-5, atol=1e-6), step
+
+
+# ---- the chained row-local launch (ffn.hip FFRowsParams::pre / post): an attention's to_out + (gated) residual, LayerNorm,
+# feed-forward + (gated) residual and -- behind the block's last feed-forward -- proj_out + x_in, against fp32 torch
+# (reference attention.py:236-244, 333-338, 374-376). gate 1e-30: the residual cannot ride in the accumulator (t / gate overflows).
+@pytest.mark.parametrize("M", [128, 4096])
+@pytest.mark.parametrize("post,gates", [(False, (0.37, -0.6)), (True, (None, None)), (False, (0.5, 1e-30))])
+def test_ff_chain(engine, M, post, gates):
+    C = 320
+    x = bf(rnd(M, C, seed=1))
+    pre_w, pre_b = rnd(C, C, scale=C ** -0.5, seed=2), 0.1 * rnd(C, seed=3)
+    pre_res = bf(rnd(M, C, seed=4) * 1.3 + 0.2)
+    gamma, beta = 1.0 + 0.3 * rnd(C, seed=5), 0.2 * rnd(C, seed=6)
+    w1, b1 = rnd(8 * C, C, scale=C ** -0.5, seed=7), 0.5 * rnd(8 * C, seed=8)
+    w2, b2 = rnd(C, 4 * C, scale=(4 * C) ** -0.5, seed=9), 0.1 * rnd(C, seed=10)
+    post_w, post_b, post_res = (rnd(C, C, scale=C ** -0.5, seed=11), 0.1 * rnd(C, seed=12), bf(rnd(M, C, seed=13))) if post else (None, None, None)
+    g1 = None if gates[0] is None else torch.tensor([gates[0]], device="cuda")
+    g2 = None if gates[1] is None else torch.tensor([gates[1]], device="cuda")
+    y = engine.op_ff_chain(x, pre_w, pre_b, pre_res, gamma, beta, w1, b1, w2, b2, pre_gate=g1, gate=g2, post_w=post_w, post_b=post_b, post_res=post_res)
+    t = bf(pre_res.float() + (gates[0] or 1.0) * (x.float() @ bf(pre_w).float().t() + pre_b)).float()     # the kernel rounds t to bf16 too
+    h = F.layer_norm(t, (C,), gamma, beta, 1e-5) @ w1.t() + b1
+    val, g = h.chunk(2, dim=-1)
+    u = t + (1.0 if gates[1] is None else gates[1]) * ((val * F.gelu(g)) @ w2.t() + b2)
+    ref = (post_res.float() + bf(u).float() @ bf(post_w).float().t() + post_b) if post else u
+    assert torch.isfinite(y.float()).all()
+    assert rel_err(y, ref) < TOL, rel_err(y, ref)
+    y2 = engine.op_ff_chain(x, pre_w, pre_b, pre_res, gamma, beta, w1, b1, w2, b2, pre_gate=g1, gate=g2, post_w=post_w, post_b=post_b, post_res=post_res)
+    assert torch.equal(y, y2)
