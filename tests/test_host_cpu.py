@@ -609,3 +609,26 @@ def test_lds_swizzles_are_conflict_free_where_they_are_used():
         assert _fragment_read_conflicts(aligned, 1, k) > 0 and _fragment_read_conflicts(aligned, 2, k) > 0   # why the halo buffer needed its own
     src = open(os.path.join(str(ROOT), "gligen_amd", "csrc", "gemm.hip")).read()
     assert "(((unsigned)q ^ (hr & 6u)) << 4)" in src and "((t & 7) ^ (r0 & 6)) * 16" in src   # read side and DMA side agree
+
+
+def test_row_local_kernel_gelu_constants():
+    """The cubic exp2 form of erf-GELU in gligen_amd/csrc/ffn.hip (FFR_GELU_C0..C3; tools/fit_gelu.py is the fit): evaluated in fp32
+    as the kernel does, against the erf GELU of F.gelu (reference attention.py:44), over a range far beyond what it was fitted on."""
+    import re
+    import numpy as np
+    from scipy.special import erf
+    src = open(os.path.join(ROOT, "gligen_amd", "csrc", "ffn.hip")).read()
+    c = [float(re.search(rf"#define FFR_GELU_C{i} (-?[0-9.eE+-]+)f", src).group(1)) for i in (3, 2, 1, 0)]
+    assert all(v < 0 for v in c)          # h = 2^L decreases monotonically: no clamp needed beyond the fitted range
+    x = np.concatenate([np.linspace(-40, 40, 400001), np.array([-1e4, -300.0, 300.0, 1e4, 3e38, -3e38])]).astype(np.float32)
+    a = np.abs(x)
+    with np.errstate(over="ignore"):
+        L = np.float32(c[0])
+        for k in c[1:]:
+            L = (L * a + np.float32(k)).astype(np.float32)
+        h = np.exp2(L.astype(np.float64)).astype(np.float32)
+        got = np.maximum(x, 0) - a * h
+    ref = 0.5 * x.astype(np.float64) * (1 + erf(x.astype(np.float64) / np.sqrt(2)))
+    assert np.isfinite(got).all()
+    err = np.abs(got.astype(np.float64) - ref)
+    assert err.max() < 1e-4, err.max()    # 2^-9 relative is what the bf16 P^T operand keeps of values of order 1

@@ -229,3 +229,117 @@ def test_gemm_epilogues_wait_once_before_their_stores(gemm_asm):
         assert stores >= 8 and after <= 1, (name, stores, after)
     for name, (loads, imm, stores, after) in rows.items():
         assert imm == 0, (name, loads, imm)
+
+
+# ---- the row-local feed-forward kernel (ffn.hip): one wave per SIMD, the main loop a fixed asm-ordered stream. What is pinned here
+# are the properties whose absence no numerical test on a lucky box shows (each was a real bug on the way):
+@pytest.fixture(scope="module")
+def ffn_asm(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = tmp_path_factory.mktemp("isa") / "ffn.s"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-I", str(ROOT / "include"), "--offload-device-only", "-S",
+           str(ROOT / "gligen_amd" / "csrc" / "ffn.hip"), "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return out.read_text()
+
+
+def _ffn_kernels(asm):
+    for name in re.findall(r"^(_ZN2gl12_GLOBAL__N_114ff_rows_kernelI[^:\s]*):", asm, re.M):
+        a = asm.index(name + ":")
+        b = asm.index(".end_amdhsa_kernel", a)
+        meta = asm[a:b]
+        body = [l.strip() for l in meta.split("\n") if l.strip() and not l.strip().startswith(";") and not l.strip().startswith(".")]
+        yield name, meta, body
+
+
+def _regs(tok):
+    m = re.match(r"([av])\[(\d+):(\d+)\]", tok)
+    if m:
+        return m.group(1), set(range(int(m.group(2)), int(m.group(3)) + 1))
+    m = re.match(r"([av])(\d+)$", tok)
+    return (m.group(1), {int(m.group(2))}) if m else (None, set())
+
+
+def test_ffn_kernels_fit_the_register_file_without_scratch(ffn_asm):
+    names = [n for n, _, _ in _ffn_kernels(ffn_asm)]
+    assert len(names) == 3, names          # plain, leading projection, leading + trailing projection
+    for name, meta, _ in _ffn_kernels(ffn_asm):
+        assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", meta) or "scratch_" not in meta, name
+        assert "scratch_load" not in meta and "scratch_store" not in meta, name
+        nv = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1))
+        assert nv <= 512, (name, nv)
+
+
+def test_ffn_main_loop_is_the_stream_it_was_written_as(ffn_asm):
+    """Two chunks per loop iteration: 124 MFMAs (32x32x16), one fragment read behind each, 32 DMA blocks, two barriers, and nothing
+    else that could stall the lone wave of a SIMD: no accumulator moves, no packed fp32 (a wait state per dependent pair), no
+    compiler-inserted vmcnt wait inside the stream (its counted waits do not see the asm DMAs)."""
+    for name, meta, body in _ffn_kernels(ffn_asm):
+        # the steady-state loop: a label and the backward branch to it with 124 MFMAs in between
+        lines = [l.strip() for l in meta.split("\n") if l.strip() and not l.strip().startswith(";")]
+        labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+        seg = None
+        for i, l in enumerate(lines):
+            m = re.search(r"s_cbranch_\w+ (\.LBB\d+_\d+)", l)
+            if m and labels.get(m.group(1), 1 << 30) < i:
+                cand = [x for x in lines[labels[m.group(1)]:i] if not x.startswith(".")]
+                if sum(1 for x in cand if x.startswith("v_mfma")) == 124:
+                    seg = cand
+        assert seg, name
+        assert all("32x32x16_bf16" in x for x in seg if x.startswith("v_mfma")), name
+        cnt = lambda p: sum(1 for l in seg if re.match(p, l))
+        assert cnt(r"v_mfma") == 124, (name, cnt(r"v_mfma"))
+        assert cnt(r"ds_read_b128") == 124, (name, cnt(r"ds_read_b128"))
+        assert cnt(r"buffer_load_dwordx4 .* lds") == 32, (name, cnt(r"buffer_load_dwordx4 .* lds"))
+        assert cnt(r"v_accvgpr_") == 0, (name, cnt(r"v_accvgpr_"))
+        assert cnt(r"v_pk_") == 0, name
+        assert cnt(r"v_exp_f32") == 32 and cnt(r"v_rcp_f32") == 0, name      # one transcendental per hidden feature (the exp2 form of erf-GELU)
+        assert cnt(r"global_load|global_store") == 0, name
+        waits = [l for l in seg if l.startswith("s_waitcnt") and "vmcnt" in l]
+        assert all(w.replace(" ", "") == "s_waitcntvmcnt(0)" for w in waits) and len(waits) <= 3, (name, waits)
+        assert len(seg) < 900, (name, len(seg))     # ~6 issue slots per 32-cycle MFMA
+
+
+def test_ffn_accumulators_are_never_touched_next_to_their_mfmas(ffn_asm):
+    """(1) No v_accvgpr_write lands within six instructions in front of an MFMA that reads that register (hipcc pads that hazard
+    for its own MFMAs, not for an asm statement: the x fragments are pinned into the AGPR half before the stream starts).
+    (2) No v_accvgpr_read of an accumulator tuple sits between that tuple's last MFMA and the settle nops (hipcc is free to hoist
+    the epilogue's reads of a tuple right behind the ISSUE of its last MFMA unless every tuple is an operand of the settle statement)."""
+    for name, _, body in _ffn_kernels(ffn_asm):
+        acc = set()
+        for l in body:
+            if l.startswith("v_mfma"):
+                c, r = _regs(l.split(None, 1)[1].split(",")[0].strip())
+                if c == "a":
+                    acc |= r
+        nops = [i for i, l in enumerate(body) if l.startswith("s_nop 15")]
+        for i, l in enumerate(body):
+            if l.startswith("v_mfma"):
+                srcs = set()
+                for tok in l.split(None, 1)[1].split(",")[1:]:
+                    c, r = _regs(tok.strip())
+                    if c == "a":
+                        srcs |= r
+                for j in range(max(0, i - 6), i):
+                    if body[j].startswith("v_accvgpr_write"):
+                        c, r = _regs(body[j].split()[1].rstrip(","))
+                        assert not (r & srcs), (name, body[j], l)
+            if l.startswith("v_accvgpr_read"):
+                c, r = _regs(l.split(",")[1].strip())
+                if r & acc:
+                    for j in range(i - 1, max(0, i - 40), -1):
+                        if body[j].startswith("v_mfma"):
+                            c2, r2 = _regs(body[j].split(None, 1)[1].split(",")[0].strip())
+                            if c2 == "a" and (r & r2):
+                                assert any(j < n < i for n in nops), (name, body[j], l)
+                                break
+
+
+def test_ffn_dma_statements_declare_what_they_clobber():
+    """The LDS-DMA asm steps its cursors with s_add_u32: SCC has to be in the clobber list (without it hipcc kept the loop
+    condition in SCC across the statement and the loop ran until the 32-bit stream offset overflowed)."""
+    src = (ROOT / "gligen_amd" / "csrc" / "ffn.hip").read_text()
+    stmts = re.findall(r'asm volatile\("(?:s_nop 4\\n\\t)?s_mov_b32 m0.*?;', src, re.S)
+    assert len(stmts) == 2
+    assert all('"scc"' in st for st in stmts)
