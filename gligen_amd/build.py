@@ -20,7 +20,7 @@ SOURCES = ["gemm.hip", "ffn.hip", "attention.hip", "norm.hip", "misc.hip", "conv
 # attention: keep MFMA accumulators in VGPRs (gfx950 has one unified register file); the default AGPR
 # form costs a v_accvgpr_read/write pair per accumulator per KV tile around the softmax rescale
 # ffn: the GEGLU micro-steps of the row-local feed-forward are plain fp32 on purpose (packed fp32 is dearer beside MFMAs): no SLP packing
-EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "ffn.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "ffn.hip": ["-fno-slp-vectorize", "-fno-honor-nans"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

@@ -235,7 +235,7 @@ __device__ __forceinline__ void geglu_step(GegluState& s, float v0, float v1, fl
     } else if constexpr (J == 2) {
         s.l0 = fmaf(a0, s.l0, FFR_GELU_C0);
         s.l1 = fmaf(a1, s.l1, FFR_GELU_C0);
-        s.m0 = fmaxf(x0, 0.f);
+        s.m0 = fmaxf(x0, 0.f);     // (one v_max each: ffn.hip is built with -fno-honor-nans, else hipcc canonicalises the operand first)
         s.m1 = fmaxf(x1, 0.f);
     } else if constexpr (J == 3) {
         s.l0 = __builtin_amdgcn_exp2f(s.l0);
@@ -262,8 +262,15 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
     constexpr int KS = G::KS, NKP = G::NKP, NCB = G::NCB, NCH = G::NCH, NPB = G::NPB, NBLK = G::NBLK, STAGE = G::STAGE;
     constexpr int PJ_BLK = G::PJ_BLK, PJ_ST = G::PJ_ST, PJ_KS = G::PJ_KS;
     constexpr int FB = PRE ? 1 : 0;     // LDS buffer of the feed-forward's chunk 0 (the leading projection's PJ_ST stages flip the parity)
-    constexpr int NR = 12;      // fragment ring (blocks): the read of block i + RD is issued behind MFMA i
-    constexpr int RD = 8;
+#ifndef GL_FFN_RD
+#define GL_FFN_RD 8
+#endif
+#ifndef GL_FFN_DMA_EVERY
+#define GL_FFN_DMA_EVERY 3
+#endif
+    constexpr int RD = GL_FFN_RD;      // fragment ring (blocks): the read of block i + RD is issued behind MFMA i
+    constexpr int NR = RD + 4;
+    constexpr int DEV = GL_FFN_DMA_EVERY;   // the next stage's 16 DMA pieces per wave: one behind every DEV-th MFMA of the chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int t = threadIdx.x;
@@ -348,7 +355,7 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
         static_for<PJ_ST>([&](auto sc) {
             constexpr int st = decltype(sc)::value, BUF = (BUF0 + st) & 1;
             constexpr int pieces = st + 1 < PJ_ST ? PJ_BLK / 4 : NEXT;
-            constexpr int every = pieces > PJ_BLK / 4 ? 2 : 4;      // (16 blocks of a feed-forward stage do not fit one per four gaps)
+            constexpr int every = pieces > PJ_BLK / 4 ? 2 : (DEV < 4 ? 2 : 4);      // (16 blocks of a feed-forward stage do not fit one per four gaps)
             asm volatile("s_waitcnt vmcnt(0)");
             if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
             const unsigned ra = ra_st[BUF];
@@ -447,7 +454,7 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
                 if constexpr (!(ABL & 16)) mfma_acc_aa(acc2[cb], fr[i % NR], P[PAR ^ 1][nb], gs);
             }
             if constexpr (i + RD < NBLK) ffr_rd16<(i + RD) * 1024>(fr[(i + RD) % NR], ra);
-            if constexpr (i % 4 == 1 && !(ABL & 2)) ffr_dma(rs, lane16, dma_lds, dma_off);
+            if constexpr (i >= 1 && (i - 1) % DEV == 0 && (i - 1) / DEV < G::NBS / 4 && !(ABL & 2)) ffr_dma(rs, lane16, dma_lds, dma_off);
             if constexpr (i < 37) {
                 if constexpr (!FIRST) gstep(std::integral_constant<int, 19 + i>{}, S, P[PAR ^ 1]);
             } else if constexpr (i > NPB) {
