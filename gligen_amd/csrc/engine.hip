@@ -1199,7 +1199,8 @@ bf16* Engine::feedforward_chain(const FFW& f, const bf16* x, int M, const LinW& 
     CK(ff_rows_launch(P, C, s));
     FILE* launch_log = launch_log_file();
     if (launch_log) {
-        fprintf(launch_log, "ff_rows_kernel|%d|%d|%d|0|%.0f\n", M, C, 4 * C, (double)ff_chain_stream_bytes(C, true, post != nullptr) + (post ? 8.0 : 6.0) * M * C);
+        fprintf(launch_log, "ff_rows_kernel<320, 0, true, %s>|%d|%d|%d|0|%.0f\n", post ? "true" : "false", M, C, 4 * C,
+                (double)ff_chain_stream_bytes(C, true, post != nullptr) + (post ? 8.0 : 6.0) * M * C);   // (the symbol as rocprofv3 prints it: pmc_summarize.py joins on it)
         fflush(launch_log);
     }
     ++n_launches;
@@ -1230,7 +1231,7 @@ bf16* Engine::feedforward(const FFW& f, const bf16* ln, int M, const bf16* res, 
         CK(ff_rows_launch(P, C, s));
         FILE* launch_log = launch_log_file();
         if (launch_log) {
-            fprintf(launch_log, "ff_rows_kernel|%d|%d|%d|0|%.0f\n", M, C, 4 * C, (double)ff_stream_bytes(C) + (res ? 6.0 : 4.0) * M * C);
+            fprintf(launch_log, "ff_rows_kernel<320, 0, false, false>|%d|%d|%d|0|%.0f\n", M, C, 4 * C, (double)ff_stream_bytes(C) + (res ? 6.0 : 4.0) * M * C);
             fflush(launch_log);
         }
         ++n_launches;

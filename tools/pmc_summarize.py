@@ -20,7 +20,7 @@ out, dirs = args[0], args[1:]
 
 
 def clean(name):
-    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
     return re.sub(r"\(.*$", "", name).replace("gl::", "")
 
 
