@@ -524,6 +524,26 @@ int gl_op_block_train(gl_ctx* ctx, const gl_train_block_dims* dims, const float*
     GL_API_END
 }
 
+static const char* const k_train_resblock_names[GL_TRAIN_RESBLOCK_PARAMS] = {
+    "in_layers.0.weight", "in_layers.0.bias", "in_layers.2.weight", "in_layers.2.bias", "emb_layers.1.weight", "emb_layers.1.bias",
+    "out_layers.0.weight", "out_layers.0.bias", "out_layers.3.weight", "out_layers.3.bias", "skip_connection.weight", "skip_connection.bias"};
+static_assert(GL_TRAIN_RESBLOCK_PARAMS == gl::RP_COUNT, "parameter table out of step with train.h");
+
+const char* const* gl_train_resblock_param_names(void) { return k_train_resblock_names; }
+
+int gl_op_resblock_train(gl_ctx* ctx, const gl_train_resblock_dims* dims, const float* const* params, const float* x, const float* emb,
+                         const float* target, float* y, float* loss, float* dx, gl_stream s) {
+    NEED(ctx);
+    if (!dims || !params || !x || !emb || !target || !y || !loss || !dx) return gl::set_error(GL_ERR_ARG, "gl_op_resblock_train: null pointer");
+    GL_API_BEGIN
+    Engine& eng = *ctx->eng;
+    eng.arena().reset();
+    gl::TrainResDims d{dims->B, dims->H, dims->W, dims->Cin, dims->Cout, dims->emb_dim};
+    int rc = gl::resblock_train_step(eng.arena(), eng.splitk_ws(), eng.splitk_ws_bytes(), d, params, x, emb, target, y, loss, dx, S(s));
+    if (rc != GL_OK) throw GlError(rc, gl::last_error());
+    GL_API_END
+}
+
 int gl_op_conv3x3(gl_ctx* ctx, const void* x0, int C0, const void* x1, int C1, int B, int H, int W,
                   const float* w_oihw, const float* bias, int Cout, int stride, int ups, int pad_lo,
                   const void* res, void* y, gl_stream s) {

@@ -30,6 +30,19 @@ int block_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainBlockDims
                      const float* objs, const float* context, const float* target, float* y, float* loss, float* dx, float* dobjs,
                      float* const* grads, hipStream_t s);
 
+// ---- ResBlock (openaimodel.py:154-232): the second block type of the UNet. Frozen in the reference's trainer, so its backward is the
+// input gradient only. Parameter slots = its state_dict (skip_connection.* null when Cin == Cout: nn.Identity), fp32 device pointers
+struct TrainResDims {
+    int B, H, W, Cin, Cout, emb_dim;
+};
+enum {
+    RP_GN1_W = 0, RP_GN1_B, RP_C1_W, RP_C1_B, RP_EMB_W, RP_EMB_B, RP_GN2_W, RP_GN2_B, RP_C2_W, RP_C2_B, RP_SKIP_W, RP_SKIP_B,
+    RP_COUNT
+};
+// x [B][H*W][Cin], emb [B][emb_dim], target [B][H*W][Cout] fp32 device (pixel rows) -> y [B][H*W][Cout], loss[1] = mse_loss(y, target), dx
+int resblock_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainResDims& d, const float* const* params, const float* x, const float* emb,
+                        const float* target, float* y, float* loss, float* dx, hipStream_t s);
+
 // One AdamW update of a flat fp32 parameter range, in place (torch.optim.AdamW semantics: trainer.py:245, :384 opt.step()); step = 1, 2, ...
 int adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd, int step, hipStream_t s);
 

@@ -249,6 +249,82 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     p[i] = p[i] * (1.f - lr * wd) - (lr / bc1) * (mi / denom);
 }
 
+
+// ---- ResBlock pieces (openaimodel.py:154-232): GroupNorm32 + SiLU over pixel rows [B][HW][C] (fp32), and their backward.
+// One workgroup per (group, sample); the group's HW x cpg slab is read twice (statistics, then apply), sums in a fixed order.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+// xhat = (x - mean) * rstd per (sample, group); a = silu(xhat * gamma + beta)   (util.py:223-226 GroupNorm32, eps 1e-5; nn.SiLU)
+__global__ void __launch_bounds__(256) gn_silu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gam, const float* __restrict__ bet, int HW, int Cc,
+                                                          float* __restrict__ xhat, float* __restrict__ rstd_out, float* __restrict__ a) {
+    __shared__ float red[4];
+    const int g = blockIdx.x, b = blockIdx.y, cpg = Cc / 32, n = HW * cpg;
+    const float* xb = x + (size_t)b * HW * Cc + g * cpg;
+    float s = 0.f, q = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { const float v = xb[(size_t)(i / cpg) * Cc + i % cpg]; s += v; q += v * v; }
+    s = block_sum_256(s, red);
+    q = block_sum_256(q, red);
+    const float mean = s / n, rstd = rsqrtf(fmaxf(q / n - mean * mean, 0.f) + 1e-5f);
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int c = g * cpg + i % cpg;
+        const size_t o = ((size_t)b * HW + i / cpg) * Cc + c;
+        const float h = (x[o] - mean) * rstd, u = h * gam[c] + bet[c];
+        xhat[o] = h;
+        a[o] = u / (1.f + __expf(-u));
+    }
+    if (threadIdx.x == 0) rstd_out[b * 32 + g] = rstd;
+}
+// da (gradient w.r.t. a = silu(u), u = xhat gamma + beta)  ->  dx of the GroupNorm's input:
+//   du = da sigma(u) (1 + u (1 - sigma(u))),  t = du gamma,  dx = rstd (t - mean_g(t) - xhat mean_g(t xhat))      (dx (+)= when accumulate)
+__global__ void __launch_bounds__(256) gn_silu_bwd_kernel(const float* __restrict__ da, const float* __restrict__ xhat, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gam, const float* __restrict__ bet, int HW, int Cc,
+                                                          float* __restrict__ dx, int accumulate) {
+    __shared__ float red[4];
+    const int g = blockIdx.x, b = blockIdx.y, cpg = Cc / 32, n = HW * cpg;
+    auto t_of = [&](int i, float& h) {
+        const int c = g * cpg + i % cpg;
+        const size_t o = ((size_t)b * HW + i / cpg) * Cc + c;
+        h = xhat[o];
+        const float u = h * gam[c] + bet[c], sg = 1.f / (1.f + __expf(-u));
+        return da[o] * sg * (1.f + u * (1.f - sg)) * gam[c];
+    };
+    float m1 = 0.f, m2 = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { float h; const float t = t_of(i, h); m1 += t; m2 += t * h; }
+    m1 = block_sum_256(m1, red) / n;
+    m2 = block_sum_256(m2, red) / n;
+    const float rs = rstd[b * 32 + g];
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float h;
+        const float t = t_of(i, h);
+        const size_t o = ((size_t)b * HW + i / cpg) * Cc + g * cpg + i % cpg;
+        const float v = rs * (t - m1 - h * m2);
+        dx[o] = accumulate ? dx[o] + v : v;
+    }
+}
+// out[b][p][c] = a[b][p][c] + e[b][c]   (h + emb_out[..., None, None], openaimodel.py:230)
+__global__ void add_per_sample_kernel(const float* __restrict__ a, const float* __restrict__ e, int HW, int Cc, size_t n, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = a[i] + e[(i / ((size_t)HW * Cc)) * Cc + i % Cc];
+}
+__global__ void silu_kernel(const float* __restrict__ x, size_t n, float* __restrict__ y) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = x[i] / (1.f + __expf(-x[i]));
+}
+// The weights of the data-gradient conv: dX = conv3x3(dY, W'), W'[i][o][ky][kx] = W[o][i][2 - ky][2 - kx] (stride 1, pad 1: the
+// transposed convolution of a 3x3 / pad 1 conv is a 3x3 / pad 1 conv with the filter flipped and the channel roles exchanged)
+__global__ void conv_dgrad_weight_kernel(const float* __restrict__ w, int O, int I, float* __restrict__ wt) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= O * I * 9) return;
+    const int t = idx % 9, i = (idx / 9) % I, o = idx / (9 * I);
+    wt[((size_t)i * O + o) * 9 + (8 - t)] = w[idx];
+}
+
 struct Ctx {
     Arena& ar;
     float* ws;
@@ -344,6 +420,38 @@ struct Ctx {
             case 80: return attn_bwd_d<80>(q, k, v, f, dout, B, H, Nq, Nk, dq, dk, dv);
             default: throw GlError(GL_ERR_UNSUPPORTED, "training slice: head dim");
         }
+    }
+
+    // 3x3 conv, stride 1, pad 1, over pixel rows a [B][H*W][Cin] (fp32; cast to bf16 for the implicit-GEMM kernel of gemm.hip) with
+    // an OIHW fp32 weight -> [B][H*W][Cout] fp32 (+ bias). dgrad = true: the data gradient of that conv, a [..][Cout] -> [..][Cin].
+    float* conv3(const float* a, int B, int H, int W, const float* w_oihw, const float* bias, int Cin, int Cout, bool dgrad) const {
+        const int Ci = dgrad ? Cout : Cin, Co = dgrad ? Cin : Cout, M = B * H * W;
+        const float* wsrc = w_oihw;
+        if (dgrad) {
+            float* wt = f32((size_t)Cin * Cout * 9);
+            hipLaunchKernelGGL(conv_dgrad_weight_kernel, g1((size_t)Cin * Cout * 9), dim3(256), 0, s, w_oihw, Cout, Cin, wt);
+            wsrc = wt;
+        }
+        bf16* wp = ar.get<bf16>((size_t)Co * 9 * Ci);
+        ck(pack_conv_weight_launch(wsrc, wp, Co, Ci, 3, 3, Co, s));
+        float* out = f32((size_t)M * Co);
+        AOperand A{};
+        A.p0 = to_bf16(a, (size_t)M * Ci); A.C0 = Ci; A.ld0 = Ci; A.mode = A_CONV3;
+        A.Hin = H; A.Win = W; A.Ho = H; A.Wo = W; A.stride = 1; A.ups = 0; A.pad_lo = 1;
+        Epilogue E;
+        epilogue_defaults(E);
+        E.out = out; E.ldo = Co; E.out_f32 = 1; E.bias = bias;
+        ck(gemm_launch(A, wp, M, Co, 9 * Ci, E, ws, ws_bytes, s));
+        return out;
+    }
+    struct GN { float* a; float* xhat; float* rstd; };
+    GN gn_silu_fwd(const float* x, int B, int HW, int Cc, const float* g, const float* b) const {
+        GN r{f32((size_t)B * HW * Cc), f32((size_t)B * HW * Cc), f32((size_t)B * 32)};
+        hipLaunchKernelGGL(gn_silu_fwd_kernel, dim3(32, B), dim3(256), 0, s, x, g, b, HW, Cc, r.xhat, r.rstd, r.a);
+        return r;
+    }
+    void gn_silu_bwd(const float* da, const GN& f, const float* g, const float* b, int B, int HW, int Cc, float* dx, bool accumulate) const {
+        hipLaunchKernelGGL(gn_silu_bwd_kernel, dim3(32, B), dim3(256), 0, s, da, (const float*)f.xhat, (const float*)f.rstd, g, b, HW, Cc, dx, accumulate ? 1 : 0);
     }
     void add(float* dst, const float* src, size_t n) const { hipLaunchKernelGGL(add_inplace_kernel, g1(n), dim3(256), 0, s, dst, src, n); }
     // rows [B][rows_per_b][Cc] of a [B][stride_rows][Cc] tensor starting at row0 -> a packed copy, and back
@@ -504,6 +612,53 @@ int block_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainBlockDims
             c.ln_bwd(g_n1, n1, P[TP_NORM1_W], M, C, g, true, nullptr, nullptr);
         }
         c.hip(hipMemcpyAsync(dx, g, nx * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+        c.hip(hipGetLastError(), "training slice kernel launch");
+    } catch (const GlError& e) {
+        return set_error(e.code, "%s", e.what());
+    }
+    return GL_OK;
+}
+
+// Forward + backward of one ResBlock (openaimodel.py:154-232, no up / down, no scale-shift norm) under mse_loss(y, target): every
+// parameter of it is frozen in the reference's trainer (trainer.py:217-245), so what the training step needs from a ResBlock is the
+// gradient w.r.t. its INPUT -- the path by which the loss reaches the fusers in front of it. Rows are pixels ([B][H*W][C], the
+// layout of this library; the reference's NCHW is a permutation of it).
+int resblock_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainResDims& d, const float* const* P, const float* x, const float* emb,
+                        const float* target, float* y, float* loss, float* dx, hipStream_t s) {
+    try {
+        const int B = d.B, HW = d.H * d.W, Cin = d.Cin, Cout = d.Cout, M = B * HW;
+        if (Cin % 64 || Cout % 64 || d.emb_dim % 64 || B < 1 || HW < 1) throw GlError(GL_ERR_ARG, "resblock_train_step: Cin, Cout and emb_dim must be multiples of 64");
+        const bool skip_conv = Cin != Cout;
+        for (int i = 0; i < RP_COUNT; ++i)
+            if (!P[i] && !(i >= RP_SKIP_W && !skip_conv)) throw GlError(GL_ERR_ARG, fmt("resblock_train_step: parameter slot %d is null", i));
+        if (!skip_conv && (P[RP_SKIP_W] || P[RP_SKIP_B])) throw GlError(GL_ERR_ARG, "resblock_train_step: skip_connection is nn.Identity when Cin == Cout");
+        Ctx c{ar, ws, ws_bytes, s};
+        const size_t ny = (size_t)M * Cout;
+        // ---- forward: h = conv(silu(gn(x))) + emb_layers(emb);  y = skip(x) + conv(silu(gn(h)))
+        const Ctx::GN n1 = c.gn_silu_fwd(x, B, HW, Cin, P[RP_GN1_W], P[RP_GN1_B]);
+        float* h1 = c.conv3(n1.a, B, d.H, d.W, P[RP_C1_W], P[RP_C1_B], Cin, Cout, false);
+        float* se = c.f32((size_t)B * d.emb_dim);
+        hipLaunchKernelGGL(silu_kernel, Ctx::g1((size_t)B * d.emb_dim), dim3(256), 0, s, emb, (size_t)B * d.emb_dim, se);
+        float* eo = c.lin_fwd(se, B, d.emb_dim, P[RP_EMB_W], P[RP_EMB_B], Cout);
+        float* h2 = c.f32(ny);
+        hipLaunchKernelGGL(add_per_sample_kernel, Ctx::g1(ny), dim3(256), 0, s, (const float*)h1, (const float*)eo, HW, Cout, ny, h2);
+        const Ctx::GN n2 = c.gn_silu_fwd(h2, B, HW, Cout, P[RP_GN2_W], P[RP_GN2_B]);
+        float* h3 = c.conv3(n2.a, B, d.H, d.W, P[RP_C2_W], P[RP_C2_B], Cout, Cout, false);
+        const float* sk = x;
+        if (skip_conv) sk = c.lin_fwd(x, M, Cin, P[RP_SKIP_W], P[RP_SKIP_B], Cout);      // the 1 x 1 conv is a Linear over pixel rows
+        hipLaunchKernelGGL(gated_add_kernel, Ctx::g1(ny), dim3(256), 0, s, sk, (const float*)h3, (const float*)nullptr, 1.f, ny, y);
+        // ---- loss and its gradient
+        hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)y, target, ny, (const float*)nullptr, 1.f, 1, loss);
+        float* g = c.f32(ny);
+        hipLaunchKernelGGL(mse_grad_kernel, Ctx::g1(ny), dim3(256), 0, s, (const float*)y, target, ny, g);
+        // ---- backward: data gradients only
+        float* g_a2 = c.conv3(g, B, d.H, d.W, P[RP_C2_W], nullptr, Cout, Cout, true);
+        float* g_h2 = c.f32(ny);
+        c.gn_silu_bwd(g_a2, n2, P[RP_GN2_W], P[RP_GN2_B], B, HW, Cout, g_h2, false);      // = dL/dh1 (the emb path has nothing trainable upstream)
+        float* g_a1 = c.conv3(g_h2, B, d.H, d.W, P[RP_C1_W], nullptr, Cin, Cout, true);
+        float* g_x = skip_conv ? c.lin_dgrad(g, M, Cout, P[RP_SKIP_W], Cin) : g;           // through the skip connection
+        c.gn_silu_bwd(g_a1, n1, P[RP_GN1_W], P[RP_GN1_B], B, HW, Cin, g_x, true);
+        c.hip(hipMemcpyAsync(dx, g_x, (size_t)M * Cin * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
         c.hip(hipGetLastError(), "training slice kernel launch");
     } catch (const GlError& e) {
         return set_error(e.code, "%s", e.what());

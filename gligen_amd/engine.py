@@ -30,6 +30,10 @@ def _f32(t: torch.Tensor, device) -> torch.Tensor:
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
+class TrainResDims(C.Structure):   # = gl_train_resblock_dims
+    _fields_ = [(n, C.c_int) for n in ("B", "H", "W", "Cin", "Cout", "emb_dim")]
+
+
 class TrainBlockDims(C.Structure):
     _fields_ = [("B", C.c_int), ("N", C.c_int), ("Ng", C.c_int), ("C", C.c_int), ("heads", C.c_int), ("ctx_T", C.c_int), ("ctx_dim", C.c_int),
                 ("fuser_scale", C.c_float)]
@@ -396,6 +400,31 @@ class Engine:
             assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
         check(self.lib.gl_op_adamw_step(self._ctx, _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(betas[0]), float(betas[1]),
                                         float(eps), float(weight_decay), int(step), _stream(self.device)))
+
+    def resblock_train_param_names(self):
+        names = self.lib.gl_train_resblock_param_names()
+        return [names[i].decode() for i in range(12)]
+
+    def op_resblock_train(self, state_dict, x, emb, target):
+        """Training slice (gl_op_resblock_train): forward + backward of one ResBlock under mse_loss(y, target). x [B, Cin, H, W],
+        emb [B, emb_dim], target [B, Cout, H, W] as the reference passes them (NCHW; the library's pixel-row layout is a permutation);
+        state_dict: the block's reference state_dict. Returns (y [B, Cout, H, W], loss, dx [B, Cin, H, W])."""
+        dev = self.device
+        names = self.resblock_train_param_names()
+        params = [(_f32(state_dict[n], dev) if n in state_dict else None) for n in names]
+        B, Cin, H, W = x.shape
+        Cout = target.shape[1]
+        rows = lambda t: _f32(t, dev).permute(0, 2, 3, 1).reshape(t.shape[0], H * W, t.shape[1]).contiguous()
+        xr, tr, e = rows(x), rows(target), _f32(emb, dev)
+        dims = TrainResDims(int(B), int(H), int(W), int(Cin), int(Cout), int(e.shape[1]))
+        y = torch.empty((B, H * W, Cout), device=dev, dtype=torch.float32)
+        dx = torch.empty((B, H * W, Cin), device=dev, dtype=torch.float32)
+        loss = torch.zeros(1, device=dev, dtype=torch.float32)
+        parr = (C.c_void_p * 12)(*[(p.data_ptr() if p is not None else None) for p in params])
+        check(self.lib.gl_op_resblock_train(self._ctx, C.byref(dims), parr, _ptr(xr), _ptr(e), _ptr(tr), _ptr(y), _ptr(loss), _ptr(dx),
+                                            _stream(dev)))
+        back = lambda t, Cc: t.reshape(B, H, W, Cc).permute(0, 3, 1, 2).contiguous()
+        return back(y, Cout), loss, back(dx, Cin)
 
     def block_train_param_names(self):
         names = self.lib.gl_train_block_param_names()

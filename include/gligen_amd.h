@@ -251,6 +251,21 @@ int gl_op_block_train(gl_ctx* ctx, const gl_train_block_dims* dims, const float*
                       const float* context, const float* target, float* y, float* loss, float* dx, float* dobjs, float* const* grads,
                       gl_stream s);
 
+/* The UNet's other block type: forward + backward of one ResBlock (reference ldm/modules/diffusionmodules/openaimodel.py:154-232,
+ * no up / down, no scale-shift norm) under the same loss. Every ResBlock parameter is frozen in the reference's trainer
+ * (trainer.py:217-245), so its backward is the gradient w.r.t. its input -- the path by which the loss reaches the fusers in front.
+ * Tensors fp32 on the device, rows = pixels (this library's layout; the reference's NCHW is a permutation of it):
+ *   x [B][H*W][Cin], emb [B][emb_dim], target [B][H*W][Cout]  ->  y [B][H*W][Cout], loss[1] = mse_loss(y, target), dx [B][H*W][Cin].
+ * params[GL_TRAIN_RESBLOCK_PARAMS]: the block's state_dict in the order of gl_train_resblock_param_names(); the two
+ * skip_connection.* entries are NULL when Cin == Cout (nn.Identity) and required otherwise (1 x 1 conv: weight [Cout][Cin][1][1]). */
+#define GL_TRAIN_RESBLOCK_PARAMS 12
+typedef struct gl_train_resblock_dims {
+    int B, H, W, Cin, Cout, emb_dim;
+} gl_train_resblock_dims;
+const char* const* gl_train_resblock_param_names(void);
+int gl_op_resblock_train(gl_ctx* ctx, const gl_train_resblock_dims* dims, const float* const* params, const float* x, const float* emb,
+                         const float* target, float* y, float* loss, float* dx, gl_stream s);
+
 /* One AdamW step over a flat fp32 range, in place: p, exp_avg m, exp_avg_sq v [n]; g the (all-reduced) gradient; step counts from 1.
  * torch.optim.AdamW semantics -- the reference's optimizer over the trainable set (trainer.py:245, opt.step() at :384). */
 int gl_op_adamw_step(gl_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,

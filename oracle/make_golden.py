@@ -501,6 +501,31 @@ def block_backward_case(name="block_backward_gatedsa", B=2, hw=16, Ng=30, C=320,
     return {k: list(v.shape) for k, v in blk.state_dict().items()}
 
 
+def resblock_backward_case(name, Cin, Cout, B=2, hw=16, emb_dim=256):
+    """Training slice, second block type: gradient of the reference's loss w.r.t. the INPUT of one ResBlock
+    (openaimodel.py:154-232) from the reference's own autograd. Every ResBlock parameter is frozen in the reference's trainer
+    (trainer.py:217-245), so dL/dx -- the path to the fusers in front -- is all a training step needs from it. out_layers' last
+    conv is zero-initialised in the reference (zero_module); the seeded fill gives it real weights, as a trained checkpoint has."""
+    from ldm.modules.diffusionmodules.openaimodel import ResBlock
+    blk = ResBlock(Cin, emb_dim, 0.0, out_channels=Cout, use_checkpoint=False)
+    syn.fill_module_(blk, 78)
+    for p_ in blk.parameters():
+        p_.requires_grad_(False)
+    g = torch.Generator().manual_seed(4343)
+    x = torch.randn(B, Cin, hw, hw, generator=g).requires_grad_(True)
+    emb = torch.randn(B, emb_dim, generator=g)
+    target = torch.randn(B, Cout, hw, hw, generator=g)
+    y = blk(x, emb)
+    loss = torch.nn.functional.mse_loss(y, target)
+    loss.backward()
+    out = dict(y=y.detach().numpy(), loss=np.float64(loss.item()), dx=x.grad.numpy(), x_sum=np.float64(x.detach().double().sum().item()),
+               target_sum=np.float64(target.double().sum().item()))
+    out["meta"] = np.frombuffer(json.dumps(dict(B=B, hw=hw, Cin=Cin, Cout=Cout, emb_dim=emb_dim, seed=78)).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss {loss.item():.6f}, |dx| {x.grad.abs().mean():.3e}, keys {sorted(blk.state_dict().keys())}")
+    return {k: list(v.shape) for k, v in blk.state_dict().items()}
+
+
 CASES = {
     "unet_small_text": lambda: unet_case("unet_small_text", syn.UNET_CFG_SMALL, "text", 2, 16),
     "unet_small_text_image": lambda: unet_case("unet_small_text_image", syn.UNET_CFG_SMALL, "text_image", 2, 16),
@@ -549,6 +574,8 @@ CASES = {
     "c2_end_to_end": c2_case,
     # ---- round 4: the training slice (gradients through one transformer block, from the reference's autograd)
     "block_backward_gatedsa": block_backward_case,
+    "resblock_backward_skipconv": lambda: resblock_backward_case("resblock_backward_skipconv", 64, 128),
+    "resblock_backward_identity": lambda: resblock_backward_case("resblock_backward_identity", 128, 128),
 }
 
 if __name__ == "__main__":

@@ -117,3 +117,15 @@ def block_backward_inputs(meta):
     context = torch.randn(B, T, D, generator=g)
     target = torch.randn(B, N, C, generator=g)
     return x, objs, context, target
+
+
+def resblock_backward_inputs(meta):
+    """The inputs of the ResBlock training-slice goldens (oracle/make_golden.py: resblock_backward_case), regenerated from the same
+    seeded CPU generator in the same order: x, emb, target."""
+    import torch
+    g = torch.Generator().manual_seed(4343)
+    B, hw = meta["B"], meta["hw"]
+    x = torch.randn(B, meta["Cin"], hw, hw, generator=g)
+    emb = torch.randn(B, meta["emb_dim"], generator=g)
+    target = torch.randn(B, meta["Cout"], hw, hw, generator=g)
+    return x, emb, target

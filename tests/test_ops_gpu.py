@@ -399,6 +399,39 @@ def test_fuser_block_backward_vs_reference(engine):
                                                 *[C.c_void_p(t.data_ptr()) for t in outs], garr, None))
 
 
+@pytest.mark.parametrize("name", ["resblock_backward_skipconv", "resblock_backward_identity"])
+def test_resblock_backward_vs_reference(engine, name):
+    """Training slice, second block type (gl_op_resblock_train): forward + input gradient of one ResBlock under the reference's loss,
+    against the reference's own autograd (oracle/make_golden.py: resblock_backward_case). Bar as for the transformer block: rel-MSE
+    <= 1e-3 per tensor (bf16 conv operands, fp32 accumulation and fp32 everywhere else)."""
+    import json
+    import numpy as np
+    from gligen_amd import synthetic as syn
+    from helpers import GOLDEN, golden_shapes, resblock_backward_inputs
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(bytes(g["meta"]).decode())
+    x, emb, target = resblock_backward_inputs(meta)
+    assert abs(float(x.double().sum()) - float(g["x_sum"])) < 1e-6
+    sd = syn.seeded_state_dict({k: tuple(v) for k, v in golden_shapes(name).items()}, meta["seed"])
+    assert set(sd.keys()) <= set(engine.resblock_train_param_names())
+    y, loss, dx = engine.op_resblock_train(sd, x, emb, target)
+
+    def rel_mse(a, ref):
+        a, ref = a.detach().float().cpu(), torch.as_tensor(ref).float()
+        return float(((a - ref) ** 2).mean() / (ref ** 2).mean().clamp_min(1e-30))
+
+    report = {"y": rel_mse(y, g["y"]), "loss": abs(float(loss) - float(g["loss"])) / float(g["loss"]), "dx": rel_mse(dx, g["dx"])}
+    print("resblock training slice", name, report)
+    assert report["loss"] < 1e-3 and report["y"] < 1e-4 and report["dx"] < 1e-3, report
+    if meta["Cin"] == meta["Cout"]:      # nn.Identity has no parameters: a skip weight with equal channel counts is a caller error
+        from gligen_amd import _lib
+        bad = dict(sd)
+        bad["skip_connection.weight"] = torch.zeros(meta["Cout"], meta["Cin"], 1, 1)
+        bad["skip_connection.bias"] = torch.zeros(meta["Cout"])
+        with pytest.raises(_lib.GligenAmdError):
+            engine.op_resblock_train(bad, x, emb, target)
+
+
 def test_adamw_step_matches_torch(engine):
     """gl_op_adamw_step against torch.optim.AdamW (the reference's optimizer over the trainable set, trainer.py:245) for three steps."""
     n = 100003

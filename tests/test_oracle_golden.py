@@ -1,5 +1,7 @@
 """Pin the CPU oracle (oracle/gligen_oracle.py) to outputs of the REAL reference stored under
 tests/golden/ by oracle/make_golden.py. No GPU. fp32 vs fp32: only op-ordering noise is allowed."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -268,3 +270,24 @@ def test_spatial_modalities(modality):
         inp_null = dict(inp, grounding_input=dict(image=torch.zeros_like(img), mask=torch.zeros(B)))
         assert mse(orc.unet_forward(sd, cfg, inp_null), g["eps_null"]) < FP32_TOL
     assert mse(g["eps"], g["eps_null"]) > 1e-5
+
+
+@pytest.mark.parametrize("name", ["resblock_backward_skipconv", "resblock_backward_identity"])
+def test_resblock_backward_golden(name):
+    """The ResBlock training-slice goldens (the reference's autograd): the oracle's ResBlock reproduces the forward, and autograd
+    through the oracle reproduces dL/dx -- which pins the oracle as a checker for the backward as well."""
+    import json
+    from helpers import GOLDEN, golden_shapes, resblock_backward_inputs
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(bytes(g["meta"]).decode())
+    x, emb, target = resblock_backward_inputs(meta)
+    assert abs(float(x.double().sum()) - float(g["x_sum"])) < 1e-6 and abs(float(target.double().sum()) - float(g["target_sum"])) < 1e-6
+    sd = {"rb." + k: v for k, v in syn.seeded_state_dict({k: tuple(v) for k, v in golden_shapes(name).items()}, meta["seed"]).items()}
+    x = x.requires_grad_(True)
+    y = orc.unet_resblock(sd, "rb", x, emb)
+    loss = torch.nn.functional.mse_loss(y, target)
+    loss.backward()
+    assert float((y.detach() - torch.from_numpy(g["y"])).abs().max()) < 1e-4
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    ref = torch.from_numpy(g["dx"])
+    assert float(((x.grad - ref) ** 2).mean() / (ref ** 2).mean()) < 1e-8
