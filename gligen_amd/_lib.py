@@ -94,8 +94,11 @@ SYMBOLS = {
     "gl_op_feedforward": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_I), _P]),
     "gl_train_block_param_names": (C.POINTER(C.c_char_p), []),
     "gl_op_block_train": (_I, [_P, _P, C.POINTER(_P), _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_P), _P]),
+    "gl_train_st_param_names": (C.POINTER(C.c_char_p), []),
+    "gl_op_st_train": (_I, [_P, _P, C.POINTER(_P), _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_P), _P]),
     "gl_train_resblock_param_names": (C.POINTER(C.c_char_p), []),
     "gl_op_resblock_train": (_I, [_P, _P, C.POINTER(_P), _P, _P, _P, _P, _P, _P, _P]),
+    "gl_op_resample_train": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gl_op_adamw_step": (_I, [_P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I, _P]),
     "gl_op_ff_chain": (_I, [_P, _P, _I, _I] + [_P] * 16),
     "gl_op_conv3x3": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),

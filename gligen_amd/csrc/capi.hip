@@ -524,6 +524,41 @@ int gl_op_block_train(gl_ctx* ctx, const gl_train_block_dims* dims, const float*
     GL_API_END
 }
 
+static_assert(GL_TRAIN_ST_PARAMS == gl::ST_COUNT, "parameter table out of step with train.h");
+const char* const* gl_train_st_param_names(void) {
+    static std::string store[GL_TRAIN_ST_PARAMS];
+    static const char* names[GL_TRAIN_ST_PARAMS];
+    static const bool once = [] {
+        store[gl::ST_NORM_W] = "norm.weight"; store[gl::ST_NORM_B] = "norm.bias";
+        store[gl::ST_PIN_W] = "proj_in.weight"; store[gl::ST_PIN_B] = "proj_in.bias";
+        for (int i = 0; i < GL_TRAIN_BLOCK_PARAMS; ++i) store[gl::ST_BLOCK0 + i] = std::string("transformer_blocks.0.") + k_train_block_names[i];
+        store[gl::ST_POUT_W] = "proj_out.weight"; store[gl::ST_POUT_B] = "proj_out.bias";
+        for (int i = 0; i < GL_TRAIN_ST_PARAMS; ++i) names[i] = store[i].c_str();
+        return true;
+    }();
+    (void)once;
+    return names;
+}
+
+int gl_op_st_train(gl_ctx* ctx, const gl_train_block_dims* dims, const float* const* params, const float* x, const float* objs,
+                   const float* context, const float* target, float* y, float* loss, float* dx, float* dobjs, float* const* grads, gl_stream s) {
+    NEED(ctx);
+    if (!dims || !params || !x || !objs || !context || !target || !y || !loss || !dx || !dobjs || !grads)
+        return gl::set_error(GL_ERR_ARG, "gl_op_st_train: null pointer");
+    for (int i = 0; i < GL_TRAIN_ST_PARAMS; ++i) {
+        const int bi = i - gl::ST_BLOCK0;
+        if (grads[i] && !(bi >= gl::TP_F_LIN_W && bi <= gl::TP_F_ALPHA_DENSE))
+            return gl::set_error(GL_ERR_ARG, "gl_op_st_train: a gradient was asked for '%s', which the reference keeps frozen", gl_train_st_param_names()[i]);
+    }
+    GL_API_BEGIN
+    Engine& eng = *ctx->eng;
+    eng.arena().reset();
+    gl::TrainBlockDims d{dims->B, dims->N, dims->Ng, dims->C, dims->heads, dims->ctx_T, dims->ctx_dim, dims->fuser_scale};
+    int rc = gl::st_train_step(eng.arena(), eng.splitk_ws(), eng.splitk_ws_bytes(), d, params, x, objs, context, target, y, loss, dx, dobjs, grads, S(s));
+    if (rc != GL_OK) throw GlError(rc, gl::last_error());
+    GL_API_END
+}
+
 static const char* const k_train_resblock_names[GL_TRAIN_RESBLOCK_PARAMS] = {
     "in_layers.0.weight", "in_layers.0.bias", "in_layers.2.weight", "in_layers.2.bias", "emb_layers.1.weight", "emb_layers.1.bias",
     "out_layers.0.weight", "out_layers.0.bias", "out_layers.3.weight", "out_layers.3.bias", "skip_connection.weight", "skip_connection.bias"};
@@ -540,6 +575,18 @@ int gl_op_resblock_train(gl_ctx* ctx, const gl_train_resblock_dims* dims, const 
     eng.arena().reset();
     gl::TrainResDims d{dims->B, dims->H, dims->W, dims->Cin, dims->Cout, dims->emb_dim};
     int rc = gl::resblock_train_step(eng.arena(), eng.splitk_ws(), eng.splitk_ws_bytes(), d, params, x, emb, target, y, loss, dx, S(s));
+    if (rc != GL_OK) throw GlError(rc, gl::last_error());
+    GL_API_END
+}
+
+int gl_op_resample_train(gl_ctx* ctx, int mode, int B, int H, int W, int C, const float* w_oihw, const float* bias, const float* x,
+                         const float* target, float* y, float* loss, float* dx, gl_stream s) {
+    NEED(ctx);
+    if (!w_oihw || !x || !target || !y || !loss || !dx) return gl::set_error(GL_ERR_ARG, "gl_op_resample_train: null pointer");
+    GL_API_BEGIN
+    Engine& eng = *ctx->eng;
+    eng.arena().reset();
+    int rc = gl::resample_train_step(eng.arena(), eng.splitk_ws(), eng.splitk_ws_bytes(), mode, B, H, W, C, w_oihw, bias, x, target, y, loss, dx, S(s));
     if (rc != GL_OK) throw GlError(rc, gl::last_error());
     GL_API_END
 }

@@ -30,6 +30,12 @@ int block_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainBlockDims
                      const float* objs, const float* context, const float* target, float* y, float* loss, float* dx, float* dobjs,
                      float* const* grads, hipStream_t s);
 
+// SpatialTransformer (attention.py:340-376) with one BasicTransformerBlock: slots = [norm.weight, norm.bias, proj_in.weight, proj_in.bias,
+// the block's TP_* slots, proj_out.weight, proj_out.bias]; d.N = H * W pixels, d.C = in_channels = heads * d_head
+enum { ST_NORM_W = 0, ST_NORM_B, ST_PIN_W, ST_PIN_B, ST_BLOCK0, ST_POUT_W = ST_BLOCK0 + TP_COUNT, ST_POUT_B, ST_COUNT };
+int st_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainBlockDims& d, const float* const* params, const float* x, const float* objs,
+                  const float* context, const float* target, float* y, float* loss, float* dx, float* dobjs, float* const* grads, hipStream_t s);
+
 // ---- ResBlock (openaimodel.py:154-232): the second block type of the UNet. Frozen in the reference's trainer, so its backward is the
 // input gradient only. Parameter slots = its state_dict (skip_connection.* null when Cin == Cout: nn.Identity), fp32 device pointers
 struct TrainResDims {
@@ -41,6 +47,11 @@ enum {
 };
 // x [B][H*W][Cin], emb [B][emb_dim], target [B][H*W][Cout] fp32 device (pixel rows) -> y [B][H*W][Cout], loss[1] = mse_loss(y, target), dx
 int resblock_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainResDims& d, const float* const* params, const float* x, const float* emb,
+                        const float* target, float* y, float* loss, float* dx, hipStream_t s);
+
+// Downsample (mode 0: conv3x3 stride 2) / Upsample (mode 1: nearest 2x + conv3x3) of C channels (openaimodel.py:64-124): forward, loss, dx.
+// x [B][H*W][C], y / target [B][Ho*Wo][C] pixel rows
+int resample_train_step(Arena& ar, float* ws, size_t ws_bytes, int mode, int B, int H, int W, int C, const float* w_oihw, const float* bias, const float* x,
                         const float* target, float* y, float* loss, float* dx, hipStream_t s);
 
 // One AdamW update of a flat fp32 parameter range, in place (torch.optim.AdamW semantics: trainer.py:245, :384 opt.step()); step = 1, 2, ...

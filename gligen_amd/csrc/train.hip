@@ -261,7 +261,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 }
 // xhat = (x - mean) * rstd per (sample, group); a = silu(xhat * gamma + beta)   (util.py:223-226 GroupNorm32, eps 1e-5; nn.SiLU)
 __global__ void __launch_bounds__(256) gn_silu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gam, const float* __restrict__ bet, int HW, int Cc,
-                                                          float* __restrict__ xhat, float* __restrict__ rstd_out, float* __restrict__ a) {
+                                                          float* __restrict__ xhat, float* __restrict__ rstd_out, float* __restrict__ a, int silu, float eps) {
     __shared__ float red[4];
     const int g = blockIdx.x, b = blockIdx.y, cpg = Cc / 32, n = HW * cpg;
     const float* xb = x + (size_t)b * HW * Cc + g * cpg;
@@ -269,13 +269,13 @@ __global__ void __launch_bounds__(256) gn_silu_fwd_kernel(const float* __restric
     for (int i = threadIdx.x; i < n; i += 256) { const float v = xb[(size_t)(i / cpg) * Cc + i % cpg]; s += v; q += v * v; }
     s = block_sum_256(s, red);
     q = block_sum_256(q, red);
-    const float mean = s / n, rstd = rsqrtf(fmaxf(q / n - mean * mean, 0.f) + 1e-5f);
+    const float mean = s / n, rstd = rsqrtf(fmaxf(q / n - mean * mean, 0.f) + eps);
     for (int i = threadIdx.x; i < n; i += 256) {
         const int c = g * cpg + i % cpg;
         const size_t o = ((size_t)b * HW + i / cpg) * Cc + c;
         const float h = (x[o] - mean) * rstd, u = h * gam[c] + bet[c];
         xhat[o] = h;
-        a[o] = u / (1.f + __expf(-u));
+        a[o] = silu ? u / (1.f + __expf(-u)) : u;
     }
     if (threadIdx.x == 0) rstd_out[b * 32 + g] = rstd;
 }
@@ -283,13 +283,14 @@ __global__ void __launch_bounds__(256) gn_silu_fwd_kernel(const float* __restric
 //   du = da sigma(u) (1 + u (1 - sigma(u))),  t = du gamma,  dx = rstd (t - mean_g(t) - xhat mean_g(t xhat))      (dx (+)= when accumulate)
 __global__ void __launch_bounds__(256) gn_silu_bwd_kernel(const float* __restrict__ da, const float* __restrict__ xhat, const float* __restrict__ rstd,
                                                           const float* __restrict__ gam, const float* __restrict__ bet, int HW, int Cc,
-                                                          float* __restrict__ dx, int accumulate) {
+                                                          float* __restrict__ dx, int accumulate, int silu) {
     __shared__ float red[4];
     const int g = blockIdx.x, b = blockIdx.y, cpg = Cc / 32, n = HW * cpg;
     auto t_of = [&](int i, float& h) {
         const int c = g * cpg + i % cpg;
         const size_t o = ((size_t)b * HW + i / cpg) * Cc + c;
         h = xhat[o];
+        if (!silu) return da[o] * gam[c];
         const float u = h * gam[c] + bet[c], sg = 1.f / (1.f + __expf(-u));
         return da[o] * sg * (1.f + u * (1.f - sg)) * gam[c];
     };
@@ -323,6 +324,25 @@ __global__ void conv_dgrad_weight_kernel(const float* __restrict__ w, int O, int
     if (idx >= O * I * 9) return;
     const int t = idx % 9, i = (idx / 9) % I, o = idx / (9 * I);
     wt[((size_t)i * O + o) * 9 + (8 - t)] = w[idx];
+}
+
+// Downsample backward: z [B][H][W][C] = dy [B][H/2][W/2][C] at the even positions, zeros elsewhere (the transposed stride-2 conv is
+// the stride-1 conv of this with the flipped filter). Upsample backward: dx [B][H][W][C] = 2 x 2 block sums of du [B][2H][2W][C]
+// (the adjoint of nearest-neighbour doubling).
+__global__ void zero_insert2_kernel(const float* __restrict__ dy, int H, int W, int Cc, size_t n, float* __restrict__ z) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % Cc), xw = (int)((i / Cc) % W), yh = (int)((i / ((size_t)Cc * W)) % H);
+    const size_t b = i / ((size_t)Cc * W * H);
+    z[i] = ((xw | yh) & 1) ? 0.f : dy[((b * (H / 2) + yh / 2) * (W / 2) + xw / 2) * Cc + c];
+}
+__global__ void sum2x2_kernel(const float* __restrict__ du, int H, int W, int Cc, size_t n, float* __restrict__ dx) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % Cc), xw = (int)((i / Cc) % W), yh = (int)((i / ((size_t)Cc * W)) % H);
+    const size_t b = i / ((size_t)Cc * W * H);
+    const float* p = du + ((b * 2 * H + 2 * yh) * 2 * W + 2 * xw) * Cc + c;
+    dx[i] = (p[0] + p[Cc]) + (p[(size_t)2 * W * Cc] + p[(size_t)2 * W * Cc + Cc]);
 }
 
 struct Ctx {
@@ -424,8 +444,10 @@ struct Ctx {
 
     // 3x3 conv, stride 1, pad 1, over pixel rows a [B][H*W][Cin] (fp32; cast to bf16 for the implicit-GEMM kernel of gemm.hip) with
     // an OIHW fp32 weight -> [B][H*W][Cout] fp32 (+ bias). dgrad = true: the data gradient of that conv, a [..][Cout] -> [..][Cin].
-    float* conv3(const float* a, int B, int H, int W, const float* w_oihw, const float* bias, int Cin, int Cout, bool dgrad) const {
-        const int Ci = dgrad ? Cout : Cin, Co = dgrad ? Cin : Cout, M = B * H * W;
+    // stride 2 (Downsample: output (H/2) x (W/2)) and ups = 1 (Upsample: nearest 2x in the loader, output 2H x 2W) for the forward only
+    float* conv3(const float* a, int B, int H, int W, const float* w_oihw, const float* bias, int Cin, int Cout, bool dgrad, int stride = 1, int ups = 0) const {
+        const int Ho = stride == 2 ? H / 2 : H << ups, Wo = stride == 2 ? W / 2 : W << ups;
+        const int Ci = dgrad ? Cout : Cin, Co = dgrad ? Cin : Cout, M = B * Ho * Wo;
         const float* wsrc = w_oihw;
         if (dgrad) {
             float* wt = f32((size_t)Cin * Cout * 9);
@@ -436,22 +458,23 @@ struct Ctx {
         ck(pack_conv_weight_launch(wsrc, wp, Co, Ci, 3, 3, Co, s));
         float* out = f32((size_t)M * Co);
         AOperand A{};
-        A.p0 = to_bf16(a, (size_t)M * Ci); A.C0 = Ci; A.ld0 = Ci; A.mode = A_CONV3;
-        A.Hin = H; A.Win = W; A.Ho = H; A.Wo = W; A.stride = 1; A.ups = 0; A.pad_lo = 1;
+        A.p0 = to_bf16(a, (size_t)B * H * W * Ci); A.C0 = Ci; A.ld0 = Ci; A.mode = A_CONV3;
+        A.Hin = H; A.Win = W; A.Ho = Ho; A.Wo = Wo; A.stride = stride; A.ups = ups; A.pad_lo = 1;
         Epilogue E;
         epilogue_defaults(E);
-        E.out = out; E.ldo = Co; E.out_f32 = 1; E.bias = bias;
+        E.out = out; E.ldo = Co; E.out_f32 = 1; E.bias = bias; E.rows_per_b = Ho * Wo;
         ck(gemm_launch(A, wp, M, Co, 9 * Ci, E, ws, ws_bytes, s));
         return out;
     }
     struct GN { float* a; float* xhat; float* rstd; };
-    GN gn_silu_fwd(const float* x, int B, int HW, int Cc, const float* g, const float* b) const {
+    GN gn_silu_fwd(const float* x, int B, int HW, int Cc, const float* g, const float* b, bool silu = true, float eps = 1e-5f) const {
         GN r{f32((size_t)B * HW * Cc), f32((size_t)B * HW * Cc), f32((size_t)B * 32)};
-        hipLaunchKernelGGL(gn_silu_fwd_kernel, dim3(32, B), dim3(256), 0, s, x, g, b, HW, Cc, r.xhat, r.rstd, r.a);
+        hipLaunchKernelGGL(gn_silu_fwd_kernel, dim3(32, B), dim3(256), 0, s, x, g, b, HW, Cc, r.xhat, r.rstd, r.a, silu ? 1 : 0, eps);
         return r;
     }
-    void gn_silu_bwd(const float* da, const GN& f, const float* g, const float* b, int B, int HW, int Cc, float* dx, bool accumulate) const {
-        hipLaunchKernelGGL(gn_silu_bwd_kernel, dim3(32, B), dim3(256), 0, s, da, (const float*)f.xhat, (const float*)f.rstd, g, b, HW, Cc, dx, accumulate ? 1 : 0);
+    void gn_silu_bwd(const float* da, const GN& f, const float* g, const float* b, int B, int HW, int Cc, float* dx, bool accumulate, bool silu = true) const {
+        hipLaunchKernelGGL(gn_silu_bwd_kernel, dim3(32, B), dim3(256), 0, s, da, (const float*)f.xhat, (const float*)f.rstd, g, b, HW, Cc, dx, accumulate ? 1 : 0,
+                           silu ? 1 : 0);
     }
     void add(float* dst, const float* src, size_t n) const { hipLaunchKernelGGL(add_inplace_kernel, g1(n), dim3(256), 0, s, dst, src, n); }
     // rows [B][rows_per_b][Cc] of a [B][stride_rows][Cc] tensor starting at row0 -> a packed copy, and back
@@ -477,140 +500,198 @@ int adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr,
     return GL_OK;
 }
 
+// Everything the backward of a BasicTransformerBlock needs from its forward (all in the arena)
+struct BlockSaved {
+    Ctx::LN n1, nf1, nf2, n2, n3;
+    Ctx::Attn a1, af, a2;
+    float *q1, *k1, *v1, *qf, *kf, *vf, *q2, *k2, *v2;
+    float *af_vis, *of, *uf, *hf, *ff_f, *u3;
+};
+
+// y = BasicTransformerBlock(x, context, objs) (attention.py:333-338), everything the backward needs kept in the arena
+static BlockSaved block_forward(const Ctx& c, const TrainBlockDims& d, const float* const* P, const float* x, const float* objs, const float* context, float* y) {
+    hipStream_t s = c.s;
+    const int B = d.B, N = d.N, Ng = d.Ng, C = d.C, H = d.heads, D = C / H, T = N + Ng, M = B * N, MT = B * T, MC = B * d.ctx_T, KD = d.ctx_dim;
+    const size_t nx = (size_t)M * C;
+    BlockSaved S;
+    // x1 = attn1(norm1(x)) + x
+    S.n1 = c.ln_fwd(x, M, C, P[TP_NORM1_W], P[TP_NORM1_B]);
+    S.q1 = c.lin_fwd(S.n1.y, M, C, P[TP_A1_Q], nullptr, C);
+    S.k1 = c.lin_fwd(S.n1.y, M, C, P[TP_A1_K], nullptr, C);
+    S.v1 = c.lin_fwd(S.n1.y, M, C, P[TP_A1_V], nullptr, C);
+    S.a1 = c.attn_fwd(D, S.q1, S.k1, S.v1, B, H, N, N);
+    float* o1 = c.lin_fwd(S.a1.o, M, C, P[TP_A1_O], P[TP_A1_OB], C);
+    float* x1 = c.f32(nx);
+    hipLaunchKernelGGL(gated_add_kernel, Ctx::g1(nx), dim3(256), 0, s, x, (const float*)o1, (const float*)nullptr, 1.f, nx, x1);
+    // fuser (attention.py:236-244): x2 = x1 + scale tanh(alpha_attn) attn(norm1([x1 ; linear(objs)]))[:, :N]
+    float* ol = c.lin_fwd(objs, B * Ng, KD, P[TP_F_LIN_W], P[TP_F_LIN_B], C);
+    float* cat = c.f32((size_t)MT * C);
+    c.put_rows(cat, B, T, 0, x1, N, C);
+    c.put_rows(cat, B, T, N, ol, Ng, C);
+    S.nf1 = c.ln_fwd(cat, MT, C, P[TP_F_N1_W], P[TP_F_N1_B]);
+    S.qf = c.lin_fwd(S.nf1.y, MT, C, P[TP_F_Q], nullptr, C);
+    S.kf = c.lin_fwd(S.nf1.y, MT, C, P[TP_F_K], nullptr, C);
+    S.vf = c.lin_fwd(S.nf1.y, MT, C, P[TP_F_V], nullptr, C);
+    S.af = c.attn_fwd(D, S.qf, S.kf, S.vf, B, H, T, T);
+    S.af_vis = c.slice_rows(S.af.o, B, T, 0, N, C);
+    S.of = c.lin_fwd(S.af_vis, M, C, P[TP_F_O], P[TP_F_OB], C);
+    float* x2 = c.f32(nx);
+    hipLaunchKernelGGL(gated_add_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)x1, (const float*)S.of, P[TP_F_ALPHA_ATTN], d.fuser_scale, nx, x2);
+    //        x3 = x2 + scale tanh(alpha_dense) ff(norm2(x2))
+    S.nf2 = c.ln_fwd(x2, M, C, P[TP_F_N2_W], P[TP_F_N2_B]);
+    S.uf = c.lin_fwd(S.nf2.y, M, C, P[TP_F_FF1_W], P[TP_F_FF1_B], 8 * C);
+    S.hf = c.f32((size_t)M * 4 * C);
+    hipLaunchKernelGGL(geglu_fwd_kernel, Ctx::g1((size_t)M * 4 * C), dim3(256), 0, s, (const float*)S.uf, M, 4 * C, S.hf);
+    S.ff_f = c.lin_fwd(S.hf, M, 4 * C, P[TP_F_FF2_W], P[TP_F_FF2_B], C);
+    float* x3 = c.f32(nx);
+    hipLaunchKernelGGL(gated_add_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)x2, (const float*)S.ff_f, P[TP_F_ALPHA_DENSE], d.fuser_scale, nx, x3);
+    // x4 = attn2(norm2(x3), context) + x3
+    S.n2 = c.ln_fwd(x3, M, C, P[TP_NORM2_W], P[TP_NORM2_B]);
+    S.q2 = c.lin_fwd(S.n2.y, M, C, P[TP_A2_Q], nullptr, C);
+    S.k2 = c.lin_fwd(context, MC, KD, P[TP_A2_K], nullptr, C);
+    S.v2 = c.lin_fwd(context, MC, KD, P[TP_A2_V], nullptr, C);
+    S.a2 = c.attn_fwd(D, S.q2, S.k2, S.v2, B, H, N, d.ctx_T);
+    float* o2 = c.lin_fwd(S.a2.o, M, C, P[TP_A2_O], P[TP_A2_OB], C);
+    float* x4 = c.f32(nx);
+    hipLaunchKernelGGL(gated_add_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)x3, (const float*)o2, (const float*)nullptr, 1.f, nx, x4);
+    // y = ff(norm3(x4)) + x4
+    S.n3 = c.ln_fwd(x4, M, C, P[TP_NORM3_W], P[TP_NORM3_B]);
+    S.u3 = c.lin_fwd(S.n3.y, M, C, P[TP_FF1_W], P[TP_FF1_B], 8 * C);
+    float* h3 = c.f32((size_t)M * 4 * C);
+    hipLaunchKernelGGL(geglu_fwd_kernel, Ctx::g1((size_t)M * 4 * C), dim3(256), 0, s, (const float*)S.u3, M, 4 * C, h3);
+    float* ff3 = c.lin_fwd(h3, M, 4 * C, P[TP_FF2_W], P[TP_FF2_B], C);
+    hipLaunchKernelGGL(gated_add_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)x4, (const float*)ff3, (const float*)nullptr, 1.f, nx, y);
+    return S;
+}
+
+// g: dL/dy on entry, dL/dx on return (the running gradient of the residual stream). dobjs and G[slot] (fuser.* only) are written.
+static void block_backward(const Ctx& c, const TrainBlockDims& d, const float* const* P, const BlockSaved& S, const float* objs, float* g, float* dobjs,
+                           float* const* G) {
+    hipStream_t s = c.s;
+    const int B = d.B, N = d.N, Ng = d.Ng, C = d.C, H = d.heads, D = C / H, T = N + Ng, M = B * N, MT = B * T, KD = d.ctx_dim;
+    const size_t nx = (size_t)M * C;
+    {   // y = x4 + ff(norm3(x4)): frozen weights, data gradients only
+        float* g_h3 = c.lin_dgrad(g, M, C, P[TP_FF2_W], 4 * C);
+        float* g_u3 = c.f32((size_t)M * 8 * C);
+        hipLaunchKernelGGL(geglu_bwd_kernel, Ctx::g1((size_t)M * 4 * C), dim3(256), 0, s, (const float*)g_h3, (const float*)S.u3, M, 4 * C, g_u3);
+        float* g_n3 = c.lin_dgrad(g_u3, M, 8 * C, P[TP_FF1_W], C);
+        c.ln_bwd(g_n3, S.n3, P[TP_NORM3_W], M, C, g, true, nullptr, nullptr);
+    }
+    {   // x4 = x3 + attn2(norm2(x3), context): the context comes from the frozen text encoder, no dK / dV
+        float* g_a2 = c.lin_dgrad(g, M, C, P[TP_A2_O], C);
+        float* g_q2 = c.f32(nx);
+        c.attn_bwd(D, S.q2, S.k2, S.v2, S.a2, g_a2, B, H, N, d.ctx_T, g_q2, nullptr, nullptr);
+        float* g_n2 = c.lin_dgrad(g_q2, M, C, P[TP_A2_Q], C);
+        c.ln_bwd(g_n2, S.n2, P[TP_NORM2_W], M, C, g, true, nullptr, nullptr);
+    }
+    {   // x3 = x2 + g_d ff(norm2(x2)), g_d = scale tanh(alpha_dense): the fuser's feed-forward, TRAINABLE
+        if (G[TP_F_ALPHA_DENSE])
+            hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)g, (const float*)S.ff_f, nx, P[TP_F_ALPHA_DENSE], d.fuser_scale, 0,
+                               G[TP_F_ALPHA_DENSE]);
+        float* g_ff = c.f32(nx);
+        hipLaunchKernelGGL(gated_scale_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)g, P[TP_F_ALPHA_DENSE], d.fuser_scale, nx, g_ff);
+        c.lin_wgrad(g_ff, S.hf, M, C, 4 * C, G[TP_F_FF2_W], G[TP_F_FF2_B]);
+        float* g_hf = c.lin_dgrad(g_ff, M, C, P[TP_F_FF2_W], 4 * C);
+        float* g_uf = c.f32((size_t)M * 8 * C);
+        hipLaunchKernelGGL(geglu_bwd_kernel, Ctx::g1((size_t)M * 4 * C), dim3(256), 0, s, (const float*)g_hf, (const float*)S.uf, M, 4 * C, g_uf);
+        c.lin_wgrad(g_uf, S.nf2.y, M, 8 * C, C, G[TP_F_FF1_W], G[TP_F_FF1_B]);
+        float* g_nf2 = c.lin_dgrad(g_uf, M, 8 * C, P[TP_F_FF1_W], C);
+        c.ln_bwd(g_nf2, S.nf2, P[TP_F_N2_W], M, C, g, true, G[TP_F_N2_W], G[TP_F_N2_B]);
+    }
+    {   // x2 = x1 + g_a attn(norm1([x1 ; linear(objs)]))[:, :N]: the fuser's attention, TRAINABLE
+        if (G[TP_F_ALPHA_ATTN])
+            hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)g, (const float*)S.of, nx, P[TP_F_ALPHA_ATTN], d.fuser_scale, 0,
+                               G[TP_F_ALPHA_ATTN]);
+        float* g_of = c.f32(nx);
+        hipLaunchKernelGGL(gated_scale_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)g, P[TP_F_ALPHA_ATTN], d.fuser_scale, nx, g_of);
+        c.lin_wgrad(g_of, S.af_vis, M, C, C, G[TP_F_O], G[TP_F_OB]);
+        float* g_af_vis = c.lin_dgrad(g_of, M, C, P[TP_F_O], C);
+        float* g_af = c.f32((size_t)MT * C);      // the grounding-token rows of the attention output are dropped by [:, :N]: zero gradient
+        c.hip(hipMemsetAsync(g_af, 0, (size_t)MT * C * 4, s), "hipMemsetAsync");
+        c.put_rows(g_af, B, T, 0, g_af_vis, N, C);
+        float* g_qf = c.f32((size_t)MT * C);
+        float* g_kf = c.f32((size_t)MT * C);
+        float* g_vf = c.f32((size_t)MT * C);
+        c.attn_bwd(D, S.qf, S.kf, S.vf, S.af, g_af, B, H, T, T, g_qf, g_kf, g_vf);
+        c.lin_wgrad(g_qf, S.nf1.y, MT, C, C, G[TP_F_Q], nullptr);
+        c.lin_wgrad(g_kf, S.nf1.y, MT, C, C, G[TP_F_K], nullptr);
+        c.lin_wgrad(g_vf, S.nf1.y, MT, C, C, G[TP_F_V], nullptr);
+        float* g_nf1 = c.lin_dgrad(g_qf, MT, C, P[TP_F_Q], C);
+        c.add(g_nf1, c.lin_dgrad(g_kf, MT, C, P[TP_F_K], C), (size_t)MT * C);
+        c.add(g_nf1, c.lin_dgrad(g_vf, MT, C, P[TP_F_V], C), (size_t)MT * C);
+        float* g_cat = c.f32((size_t)MT * C);
+        c.ln_bwd(g_nf1, S.nf1, P[TP_F_N1_W], MT, C, g_cat, false, G[TP_F_N1_W], G[TP_F_N1_B]);
+        c.add(g, c.slice_rows(g_cat, B, T, 0, N, C), nx);
+        float* g_ol = c.slice_rows(g_cat, B, T, N, Ng, C);
+        c.lin_wgrad(g_ol, objs, B * Ng, C, KD, G[TP_F_LIN_W], G[TP_F_LIN_B]);
+        float* g_objs = c.lin_dgrad(g_ol, B * Ng, C, P[TP_F_LIN_W], KD);
+        c.hip(hipMemcpyAsync(dobjs, g_objs, (size_t)B * Ng * KD * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+    }
+    {   // x1 = x + attn1(norm1(x)): frozen
+        float* g_a1 = c.lin_dgrad(g, M, C, P[TP_A1_O], C);
+        float* g_q1 = c.f32(nx);
+        float* g_k1 = c.f32(nx);
+        float* g_v1 = c.f32(nx);
+        c.attn_bwd(D, S.q1, S.k1, S.v1, S.a1, g_a1, B, H, N, N, g_q1, g_k1, g_v1);
+        float* g_n1 = c.lin_dgrad(g_q1, M, C, P[TP_A1_Q], C);
+        c.add(g_n1, c.lin_dgrad(g_k1, M, C, P[TP_A1_K], C), nx);
+        c.add(g_n1, c.lin_dgrad(g_v1, M, C, P[TP_A1_V], C), nx);
+        c.ln_bwd(g_n1, S.n1, P[TP_NORM1_W], M, C, g, true, nullptr, nullptr);
+    }
+}
+
+static void block_check(const TrainBlockDims& d, const float* const* P) {
+    if (d.C % 64 || d.ctx_dim % 64 || d.C % d.heads || d.B < 1 || d.N < 1 || d.Ng < 1) throw GlError(GL_ERR_ARG, "block_train_step: C and ctx_dim must be multiples of 64");
+    for (int i = 0; i < TP_COUNT; ++i)
+        if (!P[i]) throw GlError(GL_ERR_ARG, fmt("block_train_step: parameter slot %d is null", i));
+}
+
 int block_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainBlockDims& d, const float* const* P, const float* x, const float* objs,
                      const float* context, const float* target, float* y, float* loss, float* dx, float* dobjs, float* const* G, hipStream_t s) {
     try {
-        const int B = d.B, N = d.N, Ng = d.Ng, C = d.C, H = d.heads, D = C / H, T = N + Ng, M = B * N, MT = B * T, MC = B * d.ctx_T, KD = d.ctx_dim;
-        if (C % 64 || KD % 64 || C % H || B < 1 || N < 1 || Ng < 1) throw GlError(GL_ERR_ARG, "block_train_step: C and ctx_dim must be multiples of 64");
-        for (int i = 0; i < TP_COUNT; ++i)
-            if (!P[i]) throw GlError(GL_ERR_ARG, fmt("block_train_step: parameter slot %d is null", i));
+        block_check(d, P);
         Ctx c{ar, ws, ws_bytes, s};
-        const size_t nx = (size_t)M * C;
-
-        // ================= forward (attention.py:333-338), everything the backward needs kept in the arena
-        // x1 = attn1(norm1(x)) + x
-        const Ctx::LN n1 = c.ln_fwd(x, M, C, P[TP_NORM1_W], P[TP_NORM1_B]);
-        float* q1 = c.lin_fwd(n1.y, M, C, P[TP_A1_Q], nullptr, C);
-        float* k1 = c.lin_fwd(n1.y, M, C, P[TP_A1_K], nullptr, C);
-        float* v1 = c.lin_fwd(n1.y, M, C, P[TP_A1_V], nullptr, C);
-        const Ctx::Attn a1 = c.attn_fwd(D, q1, k1, v1, B, H, N, N);
-        float* o1 = c.lin_fwd(a1.o, M, C, P[TP_A1_O], P[TP_A1_OB], C);
-        float* x1 = c.f32(nx);
-        hipLaunchKernelGGL(gated_add_kernel, Ctx::g1(nx), dim3(256), 0, s, x, (const float*)o1, (const float*)nullptr, 1.f, nx, x1);
-        // fuser (attention.py:236-244): x2 = x1 + scale tanh(alpha_attn) attn(norm1([x1 ; linear(objs)]))[:, :N]
-        float* ol = c.lin_fwd(objs, B * Ng, KD, P[TP_F_LIN_W], P[TP_F_LIN_B], C);
-        float* cat = c.f32((size_t)MT * C);
-        c.put_rows(cat, B, T, 0, x1, N, C);
-        c.put_rows(cat, B, T, N, ol, Ng, C);
-        const Ctx::LN nf1 = c.ln_fwd(cat, MT, C, P[TP_F_N1_W], P[TP_F_N1_B]);
-        float* qf = c.lin_fwd(nf1.y, MT, C, P[TP_F_Q], nullptr, C);
-        float* kf = c.lin_fwd(nf1.y, MT, C, P[TP_F_K], nullptr, C);
-        float* vf = c.lin_fwd(nf1.y, MT, C, P[TP_F_V], nullptr, C);
-        const Ctx::Attn af = c.attn_fwd(D, qf, kf, vf, B, H, T, T);
-        float* af_vis = c.slice_rows(af.o, B, T, 0, N, C);
-        float* of = c.lin_fwd(af_vis, M, C, P[TP_F_O], P[TP_F_OB], C);
-        float* x2 = c.f32(nx);
-        hipLaunchKernelGGL(gated_add_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)x1, (const float*)of, P[TP_F_ALPHA_ATTN], d.fuser_scale, nx, x2);
-        //        x3 = x2 + scale tanh(alpha_dense) ff(norm2(x2))
-        const Ctx::LN nf2 = c.ln_fwd(x2, M, C, P[TP_F_N2_W], P[TP_F_N2_B]);
-        float* uf = c.lin_fwd(nf2.y, M, C, P[TP_F_FF1_W], P[TP_F_FF1_B], 8 * C);
-        float* hf = c.f32((size_t)M * 4 * C);
-        hipLaunchKernelGGL(geglu_fwd_kernel, Ctx::g1((size_t)M * 4 * C), dim3(256), 0, s, (const float*)uf, M, 4 * C, hf);
-        float* ff_f = c.lin_fwd(hf, M, 4 * C, P[TP_F_FF2_W], P[TP_F_FF2_B], C);
-        float* x3 = c.f32(nx);
-        hipLaunchKernelGGL(gated_add_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)x2, (const float*)ff_f, P[TP_F_ALPHA_DENSE], d.fuser_scale, nx, x3);
-        // x4 = attn2(norm2(x3), context) + x3
-        const Ctx::LN n2 = c.ln_fwd(x3, M, C, P[TP_NORM2_W], P[TP_NORM2_B]);
-        float* q2 = c.lin_fwd(n2.y, M, C, P[TP_A2_Q], nullptr, C);
-        float* k2 = c.lin_fwd(context, MC, KD, P[TP_A2_K], nullptr, C);
-        float* v2 = c.lin_fwd(context, MC, KD, P[TP_A2_V], nullptr, C);
-        const Ctx::Attn a2 = c.attn_fwd(D, q2, k2, v2, B, H, N, d.ctx_T);
-        float* o2 = c.lin_fwd(a2.o, M, C, P[TP_A2_O], P[TP_A2_OB], C);
-        float* x4 = c.f32(nx);
-        hipLaunchKernelGGL(gated_add_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)x3, (const float*)o2, (const float*)nullptr, 1.f, nx, x4);
-        // y = ff(norm3(x4)) + x4
-        const Ctx::LN n3 = c.ln_fwd(x4, M, C, P[TP_NORM3_W], P[TP_NORM3_B]);
-        float* u3 = c.lin_fwd(n3.y, M, C, P[TP_FF1_W], P[TP_FF1_B], 8 * C);
-        float* h3 = c.f32((size_t)M * 4 * C);
-        hipLaunchKernelGGL(geglu_fwd_kernel, Ctx::g1((size_t)M * 4 * C), dim3(256), 0, s, (const float*)u3, M, 4 * C, h3);
-        float* ff3 = c.lin_fwd(h3, M, 4 * C, P[TP_FF2_W], P[TP_FF2_B], C);
-        hipLaunchKernelGGL(gated_add_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)x4, (const float*)ff3, (const float*)nullptr, 1.f, nx, y);
-
-        // ================= loss (trainer.py:366) and its gradient
+        const size_t nx = (size_t)d.B * d.N * d.C;
+        const BlockSaved S = block_forward(c, d, P, x, objs, context, y);
+        // loss (trainer.py:366) and its gradient
         hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)y, target, nx, (const float*)nullptr, 1.f, 1, loss);
-        float* g = c.f32(nx);   // the running gradient of the residual stream: dL/dy -> dL/dx4 -> ... -> dL/dx
+        float* g = c.f32(nx);
         hipLaunchKernelGGL(mse_grad_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)y, target, nx, g);
+        block_backward(c, d, P, S, objs, g, dobjs, G);
+        c.hip(hipMemcpyAsync(dx, g, nx * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+        c.hip(hipGetLastError(), "training slice kernel launch");
+    } catch (const GlError& e) {
+        return set_error(e.code, "%s", e.what());
+    }
+    return GL_OK;
+}
 
-        // ================= backward
-        {   // y = x4 + ff(norm3(x4)): frozen weights, data gradients only
-            float* g_h3 = c.lin_dgrad(g, M, C, P[TP_FF2_W], 4 * C);
-            float* g_u3 = c.f32((size_t)M * 8 * C);
-            hipLaunchKernelGGL(geglu_bwd_kernel, Ctx::g1((size_t)M * 4 * C), dim3(256), 0, s, (const float*)g_h3, (const float*)u3, M, 4 * C, g_u3);
-            float* g_n3 = c.lin_dgrad(g_u3, M, 8 * C, P[TP_FF1_W], C);
-            c.ln_bwd(g_n3, n3, P[TP_NORM3_W], M, C, g, true, nullptr, nullptr);
-        }
-        {   // x4 = x3 + attn2(norm2(x3), context): the context comes from the frozen text encoder, no dK / dV
-            float* g_a2 = c.lin_dgrad(g, M, C, P[TP_A2_O], C);
-            float* g_q2 = c.f32(nx);
-            c.attn_bwd(D, q2, k2, v2, a2, g_a2, B, H, N, d.ctx_T, g_q2, nullptr, nullptr);
-            float* g_n2 = c.lin_dgrad(g_q2, M, C, P[TP_A2_Q], C);
-            c.ln_bwd(g_n2, n2, P[TP_NORM2_W], M, C, g, true, nullptr, nullptr);
-        }
-        {   // x3 = x2 + g_d ff(norm2(x2)), g_d = scale tanh(alpha_dense): the fuser's feed-forward, TRAINABLE
-            if (G[TP_F_ALPHA_DENSE])
-                hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)g, (const float*)ff_f, nx, P[TP_F_ALPHA_DENSE], d.fuser_scale, 0,
-                                   G[TP_F_ALPHA_DENSE]);
-            float* g_ff = c.f32(nx);
-            hipLaunchKernelGGL(gated_scale_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)g, P[TP_F_ALPHA_DENSE], d.fuser_scale, nx, g_ff);
-            c.lin_wgrad(g_ff, hf, M, C, 4 * C, G[TP_F_FF2_W], G[TP_F_FF2_B]);
-            float* g_hf = c.lin_dgrad(g_ff, M, C, P[TP_F_FF2_W], 4 * C);
-            float* g_uf = c.f32((size_t)M * 8 * C);
-            hipLaunchKernelGGL(geglu_bwd_kernel, Ctx::g1((size_t)M * 4 * C), dim3(256), 0, s, (const float*)g_hf, (const float*)uf, M, 4 * C, g_uf);
-            c.lin_wgrad(g_uf, nf2.y, M, 8 * C, C, G[TP_F_FF1_W], G[TP_F_FF1_B]);
-            float* g_nf2 = c.lin_dgrad(g_uf, M, 8 * C, P[TP_F_FF1_W], C);
-            c.ln_bwd(g_nf2, nf2, P[TP_F_N2_W], M, C, g, true, G[TP_F_N2_W], G[TP_F_N2_B]);
-        }
-        float* g_ol = nullptr;
-        {   // x2 = x1 + g_a attn(norm1([x1 ; linear(objs)]))[:, :N]: the fuser's attention, TRAINABLE
-            if (G[TP_F_ALPHA_ATTN])
-                hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)g, (const float*)of, nx, P[TP_F_ALPHA_ATTN], d.fuser_scale, 0,
-                                   G[TP_F_ALPHA_ATTN]);
-            float* g_of = c.f32(nx);
-            hipLaunchKernelGGL(gated_scale_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)g, P[TP_F_ALPHA_ATTN], d.fuser_scale, nx, g_of);
-            c.lin_wgrad(g_of, af_vis, M, C, C, G[TP_F_O], G[TP_F_OB]);
-            float* g_af_vis = c.lin_dgrad(g_of, M, C, P[TP_F_O], C);
-            float* g_af = c.f32((size_t)MT * C);      // the grounding-token rows of the attention output are dropped by [:, :N]: zero gradient
-            c.hip(hipMemsetAsync(g_af, 0, (size_t)MT * C * 4, s), "hipMemsetAsync");
-            c.put_rows(g_af, B, T, 0, g_af_vis, N, C);
-            float* g_qf = c.f32((size_t)MT * C);
-            float* g_kf = c.f32((size_t)MT * C);
-            float* g_vf = c.f32((size_t)MT * C);
-            c.attn_bwd(D, qf, kf, vf, af, g_af, B, H, T, T, g_qf, g_kf, g_vf);
-            c.lin_wgrad(g_qf, nf1.y, MT, C, C, G[TP_F_Q], nullptr);
-            c.lin_wgrad(g_kf, nf1.y, MT, C, C, G[TP_F_K], nullptr);
-            c.lin_wgrad(g_vf, nf1.y, MT, C, C, G[TP_F_V], nullptr);
-            float* g_nf1 = c.lin_dgrad(g_qf, MT, C, P[TP_F_Q], C);
-            c.add(g_nf1, c.lin_dgrad(g_kf, MT, C, P[TP_F_K], C), (size_t)MT * C);
-            c.add(g_nf1, c.lin_dgrad(g_vf, MT, C, P[TP_F_V], C), (size_t)MT * C);
-            float* g_cat = c.f32((size_t)MT * C);
-            c.ln_bwd(g_nf1, nf1, P[TP_F_N1_W], MT, C, g_cat, false, G[TP_F_N1_W], G[TP_F_N1_B]);
-            c.add(g, c.slice_rows(g_cat, B, T, 0, N, C), nx);
-            g_ol = c.slice_rows(g_cat, B, T, N, Ng, C);
-            c.lin_wgrad(g_ol, objs, B * Ng, C, KD, G[TP_F_LIN_W], G[TP_F_LIN_B]);
-            float* g_objs = c.lin_dgrad(g_ol, B * Ng, C, P[TP_F_LIN_W], KD);
-            c.hip(hipMemcpyAsync(dobjs, g_objs, (size_t)B * Ng * KD * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
-        }
-        {   // x1 = x + attn1(norm1(x)): frozen
-            float* g_a1 = c.lin_dgrad(g, M, C, P[TP_A1_O], C);
-            float* g_q1 = c.f32(nx);
-            float* g_k1 = c.f32(nx);
-            float* g_v1 = c.f32(nx);
-            c.attn_bwd(D, q1, k1, v1, a1, g_a1, B, H, N, N, g_q1, g_k1, g_v1);
-            float* g_n1 = c.lin_dgrad(g_q1, M, C, P[TP_A1_Q], C);
-            c.add(g_n1, c.lin_dgrad(g_k1, M, C, P[TP_A1_K], C), nx);
-            c.add(g_n1, c.lin_dgrad(g_v1, M, C, P[TP_A1_V], C), nx);
-            c.ln_bwd(g_n1, n1, P[TP_NORM1_W], M, C, g, true, nullptr, nullptr);
-        }
+// SpatialTransformer.forward (attention.py:366-376) around one BasicTransformerBlock: x + proj_out(block(proj_in(norm(x)))), norm =
+// GroupNorm(32, eps 1e-6) without activation, proj_in / proj_out 1 x 1 convs = Linears over pixel rows. norm / proj_* are SD layers
+// (frozen); gradients: the block's fuser.* parameters, dx, dobjs. P / G: [norm.w, norm.b, proj_in.w, proj_in.b, <37 block slots>,
+// proj_out.w, proj_out.b].
+int st_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainBlockDims& d, const float* const* P, const float* x, const float* objs,
+                  const float* context, const float* target, float* y, float* loss, float* dx, float* dobjs, float* const* G, hipStream_t s) {
+    try {
+        for (int i = 0; i < ST_COUNT; ++i)
+            if (!P[i]) throw GlError(GL_ERR_ARG, fmt("st_train_step: parameter slot %d is null", i));
+        block_check(d, P + ST_BLOCK0);
+        Ctx c{ar, ws, ws_bytes, s};
+        const int B = d.B, N = d.N, C = d.C, M = B * N;
+        const size_t nx = (size_t)M * C;
+        const Ctx::GN n0 = c.gn_silu_fwd(x, B, N, C, P[ST_NORM_W], P[ST_NORM_B], false, 1e-6f);
+        float* t0 = c.lin_fwd(n0.a, M, C, P[ST_PIN_W], P[ST_PIN_B], C);
+        float* yb = c.f32(nx);
+        const BlockSaved S = block_forward(c, d, P + ST_BLOCK0, t0, objs, context, yb);
+        float* po = c.lin_fwd(yb, M, C, P[ST_POUT_W], P[ST_POUT_B], C);
+        hipLaunchKernelGGL(gated_add_kernel, Ctx::g1(nx), dim3(256), 0, s, x, (const float*)po, (const float*)nullptr, 1.f, nx, y);
+        hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)y, target, nx, (const float*)nullptr, 1.f, 1, loss);
+        float* g = c.f32(nx);
+        hipLaunchKernelGGL(mse_grad_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)y, target, nx, g);
+        float* g_b = c.lin_dgrad(g, M, C, P[ST_POUT_W], C);                     // through proj_out
+        block_backward(c, d, P + ST_BLOCK0, S, objs, g_b, dobjs, G + ST_BLOCK0);   // g_b: dL/d(block output) -> dL/d(block input)
+        float* g_a = c.lin_dgrad(g_b, M, C, P[ST_PIN_W], C);                    // through proj_in
+        c.gn_silu_bwd(g_a, n0, P[ST_NORM_W], P[ST_NORM_B], B, N, C, g, true, false);   // + the residual x_in: g already holds dL/dy
         c.hip(hipMemcpyAsync(dx, g, nx * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
         c.hip(hipGetLastError(), "training slice kernel launch");
     } catch (const GlError& e) {
@@ -659,6 +740,36 @@ int resblock_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainResDim
         float* g_x = skip_conv ? c.lin_dgrad(g, M, Cout, P[RP_SKIP_W], Cin) : g;           // through the skip connection
         c.gn_silu_bwd(g_a1, n1, P[RP_GN1_W], P[RP_GN1_B], B, HW, Cin, g_x, true);
         c.hip(hipMemcpyAsync(dx, g_x, (size_t)M * Cin * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+        c.hip(hipGetLastError(), "training slice kernel launch");
+    } catch (const GlError& e) {
+        return set_error(e.code, "%s", e.what());
+    }
+    return GL_OK;
+}
+
+// Downsample (mode 0: conv3x3 stride 2, openaimodel.py:99-124) / Upsample (mode 1: nearest 2x + conv3x3, openaimodel.py:64-96) of C
+// channels: forward, mse_loss(y, target) and the gradient w.r.t. the input (the conv is a frozen SD layer).
+int resample_train_step(Arena& ar, float* ws, size_t ws_bytes, int mode, int B, int H, int W, int C, const float* w_oihw, const float* bias, const float* x,
+                        const float* target, float* y, float* loss, float* dx, hipStream_t s) {
+    try {
+        if (C % 64 || (mode == 0 && ((H | W) & 1)) || B < 1 || mode < 0 || mode > 1) throw GlError(GL_ERR_ARG, "resample_train_step: C % 64, even H / W for mode 0");
+        Ctx c{ar, ws, ws_bytes, s};
+        const int Ho = mode ? 2 * H : H / 2, Wo = mode ? 2 * W : W / 2;
+        const size_t ny = (size_t)B * Ho * Wo * C, nx = (size_t)B * H * W * C;
+        float* yv = c.conv3(x, B, H, W, w_oihw, bias, C, C, false, mode ? 1 : 2, mode ? 1 : 0);
+        c.hip(hipMemcpyAsync(y, yv, ny * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+        hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)y, target, ny, (const float*)nullptr, 1.f, 1, loss);
+        float* g = c.f32(ny);
+        hipLaunchKernelGGL(mse_grad_kernel, Ctx::g1(ny), dim3(256), 0, s, (const float*)y, target, ny, g);
+        if (mode == 0) {
+            float* z = c.f32(nx);
+            hipLaunchKernelGGL(zero_insert2_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)g, H, W, C, nx, z);
+            float* gx = c.conv3(z, B, H, W, w_oihw, nullptr, C, C, true);
+            c.hip(hipMemcpyAsync(dx, gx, nx * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+        } else {
+            float* gu = c.conv3(g, B, Ho, Wo, w_oihw, nullptr, C, C, true);
+            hipLaunchKernelGGL(sum2x2_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)gu, H, W, C, nx, dx);
+        }
         c.hip(hipGetLastError(), "training slice kernel launch");
     } catch (const GlError& e) {
         return set_error(e.code, "%s", e.what());

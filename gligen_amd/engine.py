@@ -401,6 +401,48 @@ class Engine:
         check(self.lib.gl_op_adamw_step(self._ctx, _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(betas[0]), float(betas[1]),
                                         float(eps), float(weight_decay), int(step), _stream(self.device)))
 
+    def st_train_param_names(self):
+        names = self.lib.gl_train_st_param_names()
+        return [names[i].decode() for i in range(43)]
+
+    def op_st_train(self, state_dict, x, objs, context, target, heads, fuser_scale=1.0):
+        """Training slice (gl_op_st_train): forward + backward of one SpatialTransformer (GroupNorm, proj_in, one gatedSA
+        BasicTransformerBlock, proj_out, residual) under mse_loss(y, target). x / target [B, C, H, W] as the reference passes them;
+        state_dict: the module's reference state_dict. Returns (y, loss, dx, dobjs, grads) with grads keyed by the trainable
+        (transformer_blocks.0.fuser.*) names."""
+        dev = self.device
+        names = self.st_train_param_names()
+        params = [_f32(state_dict[n], dev) for n in names]
+        B, Cc, H, W = x.shape
+        rows = lambda t: _f32(t, dev).permute(0, 2, 3, 1).reshape(B, H * W, Cc).contiguous()
+        xr, tr = rows(x), rows(target)
+        objs, context = _f32(objs, dev), _f32(context, dev)
+        dims = TrainBlockDims(int(B), int(H * W), int(objs.shape[1]), int(Cc), int(heads), int(context.shape[1]), int(context.shape[2]), float(fuser_scale))
+        y, dx, dobjs = torch.empty_like(xr), torch.empty_like(xr), torch.empty_like(objs)
+        loss = torch.zeros(1, device=dev, dtype=torch.float32)
+        grads = {n: torch.zeros_like(p) for n, p in zip(names, params) if n.startswith("transformer_blocks.0.fuser.")}
+        parr = (C.c_void_p * 43)(*[p.data_ptr() for p in params])
+        garr = (C.c_void_p * 43)(*[(grads[n].data_ptr() if n in grads else None) for n in names])
+        check(self.lib.gl_op_st_train(self._ctx, C.byref(dims), parr, _ptr(xr), _ptr(objs), _ptr(context), _ptr(tr), _ptr(y), _ptr(loss), _ptr(dx),
+                                      _ptr(dobjs), garr, _stream(dev)))
+        back = lambda t: t.reshape(B, H, W, Cc).permute(0, 3, 1, 2).contiguous()
+        return back(y), loss, back(dx), dobjs, grads
+
+    def op_resample_train(self, mode, weight, bias, x, target):
+        """Training slice (gl_op_resample_train): Downsample (mode "down": conv3x3 stride 2) or Upsample (mode "up": nearest 2x +
+        conv3x3) forward, mse_loss(y, target) and the input gradient. x [B, C, H, W], target [B, C, Ho, Wo] (reference layout)."""
+        dev = self.device
+        B, Cc, H, W = x.shape
+        Ho, Wo = target.shape[2], target.shape[3]
+        rows = lambda t: _f32(t, dev).permute(0, 2, 3, 1).reshape(B, -1, Cc).contiguous()
+        xr, tr = rows(x), rows(target)
+        y, dx = torch.empty_like(tr), torch.empty_like(xr)
+        loss = torch.zeros(1, device=dev, dtype=torch.float32)
+        w, b = _f32(weight, dev), _f32(bias, dev)
+        check(self.lib.gl_op_resample_train(self._ctx, 0 if mode == "down" else 1, int(B), int(H), int(W), int(Cc), _ptr(w), _ptr(b), _ptr(xr), _ptr(tr),
+                                            _ptr(y), _ptr(loss), _ptr(dx), _stream(dev)))
+        return (y.reshape(B, Ho, Wo, Cc).permute(0, 3, 1, 2).contiguous(), loss, dx.reshape(B, H, W, Cc).permute(0, 3, 1, 2).contiguous())
+
     def resblock_train_param_names(self):
         names = self.lib.gl_train_resblock_param_names()
         return [names[i].decode() for i in range(12)]

@@ -251,6 +251,15 @@ int gl_op_block_train(gl_ctx* ctx, const gl_train_block_dims* dims, const float*
                       const float* context, const float* target, float* y, float* loss, float* dx, float* dobjs, float* const* grads,
                       gl_stream s);
 
+/* SpatialTransformer.forward (reference ldm/modules/attention.py:340-376) around that block: x + proj_out(block(proj_in(norm(x)))),
+ * same tensors and gradients as gl_op_block_train with x / target / y / dx as pixel rows [B][H*W][C] (dims->N = H*W, dims->C =
+ * in_channels = heads * d_head). params / grads [GL_TRAIN_ST_PARAMS] in the order of gl_train_st_param_names(): norm.*, proj_in.*,
+ * transformer_blocks.0.<the block's names>, proj_out.*; gradients only for transformer_blocks.0.fuser.* entries. */
+#define GL_TRAIN_ST_PARAMS (GL_TRAIN_BLOCK_PARAMS + 6)
+const char* const* gl_train_st_param_names(void);
+int gl_op_st_train(gl_ctx* ctx, const gl_train_block_dims* dims, const float* const* params, const float* x, const float* objs,
+                   const float* context, const float* target, float* y, float* loss, float* dx, float* dobjs, float* const* grads, gl_stream s);
+
 /* The UNet's other block type: forward + backward of one ResBlock (reference ldm/modules/diffusionmodules/openaimodel.py:154-232,
  * no up / down, no scale-shift norm) under the same loss. Every ResBlock parameter is frozen in the reference's trainer
  * (trainer.py:217-245), so its backward is the gradient w.r.t. its input -- the path by which the loss reaches the fusers in front.
@@ -264,6 +273,12 @@ typedef struct gl_train_resblock_dims {
 } gl_train_resblock_dims;
 const char* const* gl_train_resblock_param_names(void);
 int gl_op_resblock_train(gl_ctx* ctx, const gl_train_resblock_dims* dims, const float* const* params, const float* x, const float* emb,
+                         const float* target, float* y, float* loss, float* dx, gl_stream s);
+
+/* Downsample (mode 0: conv3x3 stride 2, reference openaimodel.py:99-124) / Upsample (mode 1: nearest 2x + conv3x3, :64-96) of C channels:
+ * forward, mse_loss(y, target) and the gradient w.r.t. the input (the conv is a frozen SD layer; w OIHW fp32 [C][C][3][3]).
+ * x / dx [B][H*W][C], y / target [B][Ho*Wo][C] fp32 pixel rows, Ho = H/2 (mode 0) or 2H (mode 1). */
+int gl_op_resample_train(gl_ctx* ctx, int mode, int B, int H, int W, int C, const float* w_oihw, const float* bias, const float* x,
                          const float* target, float* y, float* loss, float* dx, gl_stream s);
 
 /* One AdamW step over a flat fp32 range, in place: p, exp_avg m, exp_avg_sq v [n]; g the (all-reduced) gradient; step counts from 1.

@@ -526,6 +526,63 @@ def resblock_backward_case(name, Cin, Cout, B=2, hw=16, emb_dim=256):
     return {k: list(v.shape) for k, v in blk.state_dict().items()}
 
 
+def st_backward_case(name="st_backward_gatedsa", B=2, hw=16, Ng=30, C=128, heads=4, ctx_dim=768, ctx_T=77):
+    """Training slice: one SpatialTransformer (attention.py:340-376: GroupNorm, proj_in, a gatedSA BasicTransformerBlock, proj_out,
+    residual) under the reference's loss, gradients from the reference's autograd for its trainable parameters
+    (transformer_blocks.0.fuser.*, trainer.py:217-245), its input and the grounding tokens."""
+    from ldm.modules.attention import SpatialTransformer
+    st = SpatialTransformer(C, ctx_dim, ctx_dim, heads, C // heads, depth=1, fuser_type="gatedSA", use_checkpoint=False)
+    syn.fill_module_(st, 79)
+    with torch.no_grad():
+        st.transformer_blocks[0].fuser.alpha_attn.fill_(0.5)
+        st.transformer_blocks[0].fuser.alpha_dense.fill_(-0.7)
+    g = torch.Generator().manual_seed(4444)
+    x = torch.randn(B, C, hw, hw, generator=g).requires_grad_(True)
+    objs = (torch.randn(B, Ng, ctx_dim, generator=g) * 0.5).requires_grad_(True)
+    context = torch.randn(B, ctx_T, ctx_dim, generator=g)
+    target = torch.randn(B, C, hw, hw, generator=g)
+    for p_name, p_ in st.named_parameters():
+        p_.requires_grad_(".fuser." in p_name)
+    y = st(x, context, objs)
+    loss = torch.nn.functional.mse_loss(y, target)
+    loss.backward()
+    out = dict(y=y.detach().numpy(), loss=np.float64(loss.item()), dx=x.grad.numpy(), dobjs=objs.grad.numpy(),
+               x_sum=np.float64(x.detach().double().sum().item()), target_sum=np.float64(target.double().sum().item()))
+    for p_name, p_ in st.named_parameters():
+        if ".fuser." in p_name:
+            gq = p_.grad.numpy()
+            sc = float(np.abs(gq).max()) or 1.0
+            out["grad." + p_name] = (gq / sc).astype(np.float16)
+            out["scale." + p_name] = np.float64(sc)
+    out["meta"] = np.frombuffer(json.dumps(dict(B=B, hw=hw, Ng=Ng, C=C, heads=heads, ctx_dim=ctx_dim, ctx_T=ctx_T, seed=79,
+                                                alpha_attn=0.5, alpha_dense=-0.7)).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss {loss.item():.6f}, |dx| {x.grad.abs().mean():.3e}, {sum(1 for k in out if k.startswith('grad.'))} fuser gradients")
+    return {k: list(v.shape) for k, v in st.state_dict().items()}
+
+
+def resample_backward_case(name="resample_backward", B=2, hw=16, C=64):
+    """Training slice: Downsample (conv3x3 stride 2, openaimodel.py:99-124) and Upsample (nearest 2x + conv3x3, :64-96): forward and the
+    gradient of mse_loss w.r.t. the input from the reference's autograd (the convs are frozen SD layers)."""
+    from ldm.modules.diffusionmodules.openaimodel import Downsample, Upsample
+    out = {}
+    g = torch.Generator().manual_seed(4545)
+    for key, mod, ho in (("down", Downsample(C, True, dims=2), hw // 2), ("up", Upsample(C, True, dims=2), hw * 2)):
+        syn.fill_module_(mod, 80)
+        for p_ in mod.parameters():
+            p_.requires_grad_(False)
+        x = torch.randn(B, C, hw, hw, generator=g).requires_grad_(True)
+        target = torch.randn(B, C, ho, ho, generator=g)
+        y = mod(x)
+        loss = torch.nn.functional.mse_loss(y, target)
+        loss.backward()
+        out.update({key + "_y": y.detach().numpy(), key + "_loss": np.float64(loss.item()), key + "_dx": x.grad.numpy(),
+                    key + "_x_sum": np.float64(x.detach().double().sum().item())})
+        print(f"{name}/{key}: loss {loss.item():.6f}, |dx| {x.grad.abs().mean():.3e}, keys {sorted(mod.state_dict().keys())}")
+    out["meta"] = np.frombuffer(json.dumps(dict(B=B, hw=hw, C=C, seed=80)).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+
 CASES = {
     "unet_small_text": lambda: unet_case("unet_small_text", syn.UNET_CFG_SMALL, "text", 2, 16),
     "unet_small_text_image": lambda: unet_case("unet_small_text_image", syn.UNET_CFG_SMALL, "text_image", 2, 16),
@@ -574,6 +631,8 @@ CASES = {
     "c2_end_to_end": c2_case,
     # ---- round 4: the training slice (gradients through one transformer block, from the reference's autograd)
     "block_backward_gatedsa": block_backward_case,
+    "st_backward_gatedsa": st_backward_case,
+    "resample_backward": resample_backward_case,
     "resblock_backward_skipconv": lambda: resblock_backward_case("resblock_backward_skipconv", 64, 128),
     "resblock_backward_identity": lambda: resblock_backward_case("resblock_backward_identity", 128, 128),
 }

@@ -129,3 +129,15 @@ def resblock_backward_inputs(meta):
     emb = torch.randn(B, meta["emb_dim"], generator=g)
     target = torch.randn(B, meta["Cout"], hw, hw, generator=g)
     return x, emb, target
+
+
+def st_backward_inputs(meta):
+    """The inputs of the SpatialTransformer training-slice golden (oracle/make_golden.py: st_backward_case): x, objs, context, target."""
+    import torch
+    g = torch.Generator().manual_seed(4444)
+    B, hw, C, Ng, D, T = meta["B"], meta["hw"], meta["C"], meta["Ng"], meta["ctx_dim"], meta["ctx_T"]
+    x = torch.randn(B, C, hw, hw, generator=g)
+    objs = torch.randn(B, Ng, D, generator=g) * 0.5
+    context = torch.randn(B, T, D, generator=g)
+    target = torch.randn(B, C, hw, hw, generator=g)
+    return x, objs, context, target

@@ -399,6 +399,72 @@ def test_fuser_block_backward_vs_reference(engine):
                                                 *[C.c_void_p(t.data_ptr()) for t in outs], garr, None))
 
 
+def test_spatial_transformer_backward_vs_reference(engine):
+    """Training slice (gl_op_st_train): GroupNorm + proj_in + gatedSA block + proj_out + residual, forward and backward, against the
+    reference's autograd (oracle/make_golden.py: st_backward_case); rel-MSE <= 1e-3 per tensor."""
+    import json
+    import numpy as np
+    from gligen_amd import synthetic as syn
+    from helpers import GOLDEN, golden_shapes, st_backward_inputs
+    g = np.load(os.path.join(GOLDEN, "st_backward_gatedsa.npz"))
+    meta = json.loads(bytes(g["meta"]).decode())
+    x, objs, context, target = st_backward_inputs(meta)
+    assert abs(float(x.double().sum()) - float(g["x_sum"])) < 1e-6
+    sd = syn.seeded_state_dict({k: tuple(v) for k, v in golden_shapes("st_backward_gatedsa").items()}, meta["seed"])
+    sd["transformer_blocks.0.fuser.alpha_attn"] = torch.tensor(meta["alpha_attn"])
+    sd["transformer_blocks.0.fuser.alpha_dense"] = torch.tensor(meta["alpha_dense"])
+    assert sorted(engine.st_train_param_names()) == sorted(sd.keys())
+    y, loss, dx, dobjs, grads = engine.op_st_train(sd, x, objs, context, target, meta["heads"])
+
+    def rel_mse(a, ref):
+        a, ref = a.detach().float().cpu(), torch.as_tensor(ref).float()
+        return float(((a - ref) ** 2).mean() / (ref ** 2).mean().clamp_min(1e-30))
+
+    report = {"y": rel_mse(y, g["y"]), "loss": abs(float(loss) - float(g["loss"])) / float(g["loss"]), "dx": rel_mse(dx, g["dx"]), "dobjs": rel_mse(dobjs, g["dobjs"])}
+    names = sorted(k[5:] for k in g.files if k.startswith("grad."))
+    assert names == sorted(grads.keys()) and len(names) == 17
+    for n in names:
+        ref = torch.from_numpy(g["grad." + n].astype(np.float32)) * float(g["scale." + n])
+        report["grad." + n] = rel_mse(grads[n], ref)
+    worst = max(report, key=report.get)
+    print("spatial transformer training slice: worst", worst, report[worst])
+    assert report["loss"] < 1e-3 and report["y"] < 1e-4, report
+    assert all(v < 1e-3 for v in report.values()), {k: v for k, v in report.items() if v >= 1e-3}
+
+
+@pytest.mark.parametrize("mode", ["down", "up"])
+def test_resample_backward_vs_reference(engine, mode):
+    """Training slice (gl_op_resample_train): Downsample / Upsample forward + input gradient against the reference's autograd
+    (oracle/make_golden.py: resample_backward_case): the transposed stride-2 conv as zero insertion + the stride-1 conv with the
+    flipped filter, the adjoint of nearest doubling as 2 x 2 block sums."""
+    import json
+    import numpy as np
+    from gligen_amd import synthetic as syn
+    from helpers import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "resample_backward.npz"))
+    meta = json.loads(bytes(g["meta"]).decode())
+    B, hw, Cc = meta["B"], meta["hw"], meta["C"]
+    gen = torch.Generator().manual_seed(4545)
+    for key, ho in (("down", hw // 2), ("up", hw * 2)):      # the generator order of the golden: down's x, target, then up's
+        x = torch.randn(B, Cc, hw, hw, generator=gen)
+        target = torch.randn(B, Cc, ho, ho, generator=gen)
+        if key == mode:
+            break
+    assert abs(float(x.double().sum()) - float(g[mode + "_x_sum"])) < 1e-6
+    sd = syn.seeded_state_dict({"op.weight" if mode == "down" else "conv.weight": (Cc, Cc, 3, 3), "op.bias" if mode == "down" else "conv.bias": (Cc,)}, meta["seed"])
+    w = sd["op.weight" if mode == "down" else "conv.weight"]
+    b = sd["op.bias" if mode == "down" else "conv.bias"]
+    y, loss, dx = engine.op_resample_train(mode, w, b, x, target)
+
+    def rel_mse(a, ref):
+        a, ref = a.detach().float().cpu(), torch.as_tensor(ref).float()
+        return float(((a - ref) ** 2).mean() / (ref ** 2).mean().clamp_min(1e-30))
+
+    report = {"y": rel_mse(y, g[mode + "_y"]), "loss": abs(float(loss) - float(g[mode + "_loss"])) / float(g[mode + "_loss"]), "dx": rel_mse(dx, g[mode + "_dx"])}
+    print("resample training slice", mode, report)
+    assert report["loss"] < 1e-3 and report["y"] < 1e-4 and report["dx"] < 1e-3, report
+
+
 @pytest.mark.parametrize("name", ["resblock_backward_skipconv", "resblock_backward_identity"])
 def test_resblock_backward_vs_reference(engine, name):
     """Training slice, second block type (gl_op_resblock_train): forward + input gradient of one ResBlock under the reference's loss,
