@@ -55,6 +55,11 @@ class PlmsArgs(C.Structure):
     ]
 
 
+class TrainUNetIn(C.Structure):   # = gl_train_unet_in
+    _fields_ = [(n, C.c_int) for n in ("B", "H", "W", "ctx_T", "Ng")] + \
+               [(n, C.c_void_p) for n in ("x", "timesteps", "context", "boxes", "masks", "positive_embeddings", "target")] + [("fuser_scale", C.c_float)]
+
+
 class ProfRec(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("calls", C.c_int), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
 
@@ -99,6 +104,7 @@ SYMBOLS = {
     "gl_train_resblock_param_names": (C.POINTER(C.c_char_p), []),
     "gl_op_resblock_train": (_I, [_P, _P, C.POINTER(_P), _P, _P, _P, _P, _P, _P, _P]),
     "gl_op_resample_train": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gl_unet_train_step": (_I, [_P, C.POINTER(UNetConfig), C.POINTER(TrainUNetIn), _I, C.POINTER(C.c_char_p), C.POINTER(_P), C.POINTER(_P), _P, _P, _P]),
     "gl_op_adamw_step": (_I, [_P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I, _P]),
     "gl_op_ff_chain": (_I, [_P, _P, _I, _I] + [_P] * 16),
     "gl_op_conv3x3": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),

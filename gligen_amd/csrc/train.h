@@ -54,6 +54,27 @@ int resblock_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainResDim
 int resample_train_step(Arena& ar, float* ws, size_t ws_bytes, int mode, int B, int H, int W, int C, const float* w_oihw, const float* bias, const float* x,
                         const float* target, float* y, float* loss, float* dx, hipStream_t s);
 
+// ---- the whole training iteration for a UNetModel with the text grounding tokenizer and gatedSA fusers (openaimodel.py:237-464)
+struct TrainUNetCfg {
+    int in_channels, out_channels, model_channels, num_res_blocks, num_heads, context_dim, gr_dim;
+    int n_mult, channel_mult[8], n_attn, attention_resolutions[8];
+};
+struct TrainUNetIn {
+    int B, H, W, ctx_T, Ng;
+    const float* x;                     // [B][H*W][in_channels] pixel rows: the noised latent
+    const float* timesteps;             // [B]
+    const float* context;               // [B][ctx_T][context_dim]
+    const float* boxes;                 // [B][Ng][4]
+    const float* masks;                 // [B][Ng]
+    const float* positive_embeddings;   // [B][Ng][gr_dim]
+    const float* target;                // [B][H*W][out_channels]: the noise
+    float fuser_scale;
+};
+// names / params / grads: the model's state_dict (fp32 device pointers; grads[i] non-null only for fuser.* and position_net.* entries:
+// the reference's trainable set, trainer.py:217-245). block_names: the TP_* state_dict keys. eps_out (optional) [B][H*W][out_channels].
+int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& cfg, const TrainUNetIn& in, int n_params, const char* const* names,
+                    const float* const* params, float* const* grads, const char* const* block_names, float* eps_out, float* loss, hipStream_t s);
+
 // One AdamW update of a flat fp32 parameter range, in place (torch.optim.AdamW semantics: trainer.py:245, :384 opt.step()); step = 1, 2, ...
 int adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd, int step, hipStream_t s);
 

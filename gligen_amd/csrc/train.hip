@@ -19,6 +19,10 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
 
 namespace gl {
 
@@ -670,28 +674,48 @@ int block_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainBlockDims
 // GroupNorm(32, eps 1e-6) without activation, proj_in / proj_out 1 x 1 convs = Linears over pixel rows. norm / proj_* are SD layers
 // (frozen); gradients: the block's fuser.* parameters, dx, dobjs. P / G: [norm.w, norm.b, proj_in.w, proj_in.b, <37 block slots>,
 // proj_out.w, proj_out.b].
+struct STSaved {
+    Ctx::GN n0;
+    BlockSaved blk;
+};
+static void st_check(const TrainBlockDims& d, const float* const* P) {
+    for (int i = 0; i < ST_COUNT; ++i)
+        if (!P[i]) throw GlError(GL_ERR_ARG, fmt("st_train_step: parameter slot %d is null", i));
+    block_check(d, P + ST_BLOCK0);
+}
+static STSaved st_forward(const Ctx& c, const TrainBlockDims& d, const float* const* P, const float* x, const float* objs, const float* context, float* y) {
+    const int B = d.B, N = d.N, C = d.C, M = B * N;
+    const size_t nx = (size_t)M * C;
+    STSaved S;
+    S.n0 = c.gn_silu_fwd(x, B, N, C, P[ST_NORM_W], P[ST_NORM_B], false, 1e-6f);
+    float* t0 = c.lin_fwd(S.n0.a, M, C, P[ST_PIN_W], P[ST_PIN_B], C);
+    float* yb = c.f32(nx);
+    S.blk = block_forward(c, d, P + ST_BLOCK0, t0, objs, context, yb);
+    float* po = c.lin_fwd(yb, M, C, P[ST_POUT_W], P[ST_POUT_B], C);
+    hipLaunchKernelGGL(gated_add_kernel, Ctx::g1(nx), dim3(256), 0, c.s, x, (const float*)po, (const float*)nullptr, 1.f, nx, y);
+    return S;
+}
+// g: dL/dy on entry, dL/dx on return
+static void st_backward(const Ctx& c, const TrainBlockDims& d, const float* const* P, const STSaved& S, const float* objs, float* g, float* dobjs,
+                        float* const* G) {
+    const int B = d.B, N = d.N, C = d.C, M = B * N;
+    float* g_b = c.lin_dgrad(g, M, C, P[ST_POUT_W], C);                              // through proj_out
+    block_backward(c, d, P + ST_BLOCK0, S.blk, objs, g_b, dobjs, G + ST_BLOCK0);     // g_b: dL/d(block output) -> dL/d(block input)
+    float* g_a = c.lin_dgrad(g_b, M, C, P[ST_PIN_W], C);                             // through proj_in
+    c.gn_silu_bwd(g_a, S.n0, P[ST_NORM_W], P[ST_NORM_B], B, N, C, g, true, false);   // + the residual x_in: g already holds dL/dy
+}
+
 int st_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainBlockDims& d, const float* const* P, const float* x, const float* objs,
                   const float* context, const float* target, float* y, float* loss, float* dx, float* dobjs, float* const* G, hipStream_t s) {
     try {
-        for (int i = 0; i < ST_COUNT; ++i)
-            if (!P[i]) throw GlError(GL_ERR_ARG, fmt("st_train_step: parameter slot %d is null", i));
-        block_check(d, P + ST_BLOCK0);
+        st_check(d, P);
         Ctx c{ar, ws, ws_bytes, s};
-        const int B = d.B, N = d.N, C = d.C, M = B * N;
-        const size_t nx = (size_t)M * C;
-        const Ctx::GN n0 = c.gn_silu_fwd(x, B, N, C, P[ST_NORM_W], P[ST_NORM_B], false, 1e-6f);
-        float* t0 = c.lin_fwd(n0.a, M, C, P[ST_PIN_W], P[ST_PIN_B], C);
-        float* yb = c.f32(nx);
-        const BlockSaved S = block_forward(c, d, P + ST_BLOCK0, t0, objs, context, yb);
-        float* po = c.lin_fwd(yb, M, C, P[ST_POUT_W], P[ST_POUT_B], C);
-        hipLaunchKernelGGL(gated_add_kernel, Ctx::g1(nx), dim3(256), 0, s, x, (const float*)po, (const float*)nullptr, 1.f, nx, y);
+        const size_t nx = (size_t)d.B * d.N * d.C;
+        const STSaved S = st_forward(c, d, P, x, objs, context, y);
         hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)y, target, nx, (const float*)nullptr, 1.f, 1, loss);
         float* g = c.f32(nx);
         hipLaunchKernelGGL(mse_grad_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)y, target, nx, g);
-        float* g_b = c.lin_dgrad(g, M, C, P[ST_POUT_W], C);                     // through proj_out
-        block_backward(c, d, P + ST_BLOCK0, S, objs, g_b, dobjs, G + ST_BLOCK0);   // g_b: dL/d(block output) -> dL/d(block input)
-        float* g_a = c.lin_dgrad(g_b, M, C, P[ST_PIN_W], C);                    // through proj_in
-        c.gn_silu_bwd(g_a, n0, P[ST_NORM_W], P[ST_NORM_B], B, N, C, g, true, false);   // + the residual x_in: g already holds dL/dy
+        st_backward(c, d, P, S, objs, g, dobjs, G);
         c.hip(hipMemcpyAsync(dx, g, nx * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
         c.hip(hipGetLastError(), "training slice kernel launch");
     } catch (const GlError& e) {
@@ -704,42 +728,61 @@ int st_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainBlockDims& d
 // parameter of it is frozen in the reference's trainer (trainer.py:217-245), so what the training step needs from a ResBlock is the
 // gradient w.r.t. its INPUT -- the path by which the loss reaches the fusers in front of it. Rows are pixels ([B][H*W][C], the
 // layout of this library; the reference's NCHW is a permutation of it).
+struct ResSaved {
+    Ctx::GN n1, n2;
+};
+static void res_check(const TrainResDims& d, const float* const* P) {
+    if (d.Cin % 64 || d.Cout % 64 || d.emb_dim % 64 || d.B < 1 || d.H < 1 || d.W < 1)
+        throw GlError(GL_ERR_ARG, "resblock_train_step: Cin, Cout and emb_dim must be multiples of 64");
+    const bool skip_conv = d.Cin != d.Cout;
+    for (int i = 0; i < RP_COUNT; ++i)
+        if (!P[i] && !(i >= RP_SKIP_W && !skip_conv)) throw GlError(GL_ERR_ARG, fmt("resblock_train_step: parameter slot %d is null", i));
+    if (!skip_conv && (P[RP_SKIP_W] || P[RP_SKIP_B])) throw GlError(GL_ERR_ARG, "resblock_train_step: skip_connection is nn.Identity when Cin == Cout");
+}
+// silu_emb: SiLU(emb) [B][emb_dim] (emb_layers.0, shared by every ResBlock of a step).  h = conv(silu(gn(x))) + emb_layers(emb);
+// y = skip(x) + conv(silu(gn(h)))
+static ResSaved res_forward(const Ctx& c, const TrainResDims& d, const float* const* P, const float* x, const float* silu_emb, float* y) {
+    const int B = d.B, HW = d.H * d.W, Cin = d.Cin, Cout = d.Cout, M = B * HW;
+    const size_t ny = (size_t)M * Cout;
+    ResSaved S;
+    S.n1 = c.gn_silu_fwd(x, B, HW, Cin, P[RP_GN1_W], P[RP_GN1_B]);
+    float* h1 = c.conv3(S.n1.a, B, d.H, d.W, P[RP_C1_W], P[RP_C1_B], Cin, Cout, false);
+    float* eo = c.lin_fwd(silu_emb, B, d.emb_dim, P[RP_EMB_W], P[RP_EMB_B], Cout);
+    float* h2 = c.f32(ny);
+    hipLaunchKernelGGL(add_per_sample_kernel, Ctx::g1(ny), dim3(256), 0, c.s, (const float*)h1, (const float*)eo, HW, Cout, ny, h2);
+    S.n2 = c.gn_silu_fwd(h2, B, HW, Cout, P[RP_GN2_W], P[RP_GN2_B]);
+    float* h3 = c.conv3(S.n2.a, B, d.H, d.W, P[RP_C2_W], P[RP_C2_B], Cout, Cout, false);
+    const float* sk = x;
+    if (Cin != Cout) sk = c.lin_fwd(x, M, Cin, P[RP_SKIP_W], P[RP_SKIP_B], Cout);      // the 1 x 1 conv is a Linear over pixel rows
+    hipLaunchKernelGGL(gated_add_kernel, Ctx::g1(ny), dim3(256), 0, c.s, sk, (const float*)h3, (const float*)nullptr, 1.f, ny, y);
+    return S;
+}
+// g [.][Cout]: dL/dy (left untouched when Cin != Cout). Returns dL/dx [.][Cin] (g itself, updated in place, when Cin == Cout)
+static float* res_backward(const Ctx& c, const TrainResDims& d, const float* const* P, const ResSaved& S, float* g) {
+    const int B = d.B, HW = d.H * d.W, Cin = d.Cin, Cout = d.Cout, M = B * HW;
+    float* g_a2 = c.conv3(g, B, d.H, d.W, P[RP_C2_W], nullptr, Cout, Cout, true);
+    float* g_h2 = c.f32((size_t)M * Cout);
+    c.gn_silu_bwd(g_a2, S.n2, P[RP_GN2_W], P[RP_GN2_B], B, HW, Cout, g_h2, false);    // = dL/dh1 (the emb path has nothing trainable upstream)
+    float* g_a1 = c.conv3(g_h2, B, d.H, d.W, P[RP_C1_W], nullptr, Cin, Cout, true);
+    float* g_x = Cin != Cout ? c.lin_dgrad(g, M, Cout, P[RP_SKIP_W], Cin) : g;         // through the skip connection
+    c.gn_silu_bwd(g_a1, S.n1, P[RP_GN1_W], P[RP_GN1_B], B, HW, Cin, g_x, true);
+    return g_x;
+}
+
 int resblock_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainResDims& d, const float* const* P, const float* x, const float* emb,
                         const float* target, float* y, float* loss, float* dx, hipStream_t s) {
     try {
-        const int B = d.B, HW = d.H * d.W, Cin = d.Cin, Cout = d.Cout, M = B * HW;
-        if (Cin % 64 || Cout % 64 || d.emb_dim % 64 || B < 1 || HW < 1) throw GlError(GL_ERR_ARG, "resblock_train_step: Cin, Cout and emb_dim must be multiples of 64");
-        const bool skip_conv = Cin != Cout;
-        for (int i = 0; i < RP_COUNT; ++i)
-            if (!P[i] && !(i >= RP_SKIP_W && !skip_conv)) throw GlError(GL_ERR_ARG, fmt("resblock_train_step: parameter slot %d is null", i));
-        if (!skip_conv && (P[RP_SKIP_W] || P[RP_SKIP_B])) throw GlError(GL_ERR_ARG, "resblock_train_step: skip_connection is nn.Identity when Cin == Cout");
+        res_check(d, P);
         Ctx c{ar, ws, ws_bytes, s};
-        const size_t ny = (size_t)M * Cout;
-        // ---- forward: h = conv(silu(gn(x))) + emb_layers(emb);  y = skip(x) + conv(silu(gn(h)))
-        const Ctx::GN n1 = c.gn_silu_fwd(x, B, HW, Cin, P[RP_GN1_W], P[RP_GN1_B]);
-        float* h1 = c.conv3(n1.a, B, d.H, d.W, P[RP_C1_W], P[RP_C1_B], Cin, Cout, false);
-        float* se = c.f32((size_t)B * d.emb_dim);
-        hipLaunchKernelGGL(silu_kernel, Ctx::g1((size_t)B * d.emb_dim), dim3(256), 0, s, emb, (size_t)B * d.emb_dim, se);
-        float* eo = c.lin_fwd(se, B, d.emb_dim, P[RP_EMB_W], P[RP_EMB_B], Cout);
-        float* h2 = c.f32(ny);
-        hipLaunchKernelGGL(add_per_sample_kernel, Ctx::g1(ny), dim3(256), 0, s, (const float*)h1, (const float*)eo, HW, Cout, ny, h2);
-        const Ctx::GN n2 = c.gn_silu_fwd(h2, B, HW, Cout, P[RP_GN2_W], P[RP_GN2_B]);
-        float* h3 = c.conv3(n2.a, B, d.H, d.W, P[RP_C2_W], P[RP_C2_B], Cout, Cout, false);
-        const float* sk = x;
-        if (skip_conv) sk = c.lin_fwd(x, M, Cin, P[RP_SKIP_W], P[RP_SKIP_B], Cout);      // the 1 x 1 conv is a Linear over pixel rows
-        hipLaunchKernelGGL(gated_add_kernel, Ctx::g1(ny), dim3(256), 0, s, sk, (const float*)h3, (const float*)nullptr, 1.f, ny, y);
-        // ---- loss and its gradient
+        const size_t ny = (size_t)d.B * d.H * d.W * d.Cout;
+        float* se = c.f32((size_t)d.B * d.emb_dim);
+        hipLaunchKernelGGL(silu_kernel, Ctx::g1((size_t)d.B * d.emb_dim), dim3(256), 0, s, emb, (size_t)d.B * d.emb_dim, se);
+        const ResSaved S = res_forward(c, d, P, x, se, y);
         hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)y, target, ny, (const float*)nullptr, 1.f, 1, loss);
         float* g = c.f32(ny);
         hipLaunchKernelGGL(mse_grad_kernel, Ctx::g1(ny), dim3(256), 0, s, (const float*)y, target, ny, g);
-        // ---- backward: data gradients only
-        float* g_a2 = c.conv3(g, B, d.H, d.W, P[RP_C2_W], nullptr, Cout, Cout, true);
-        float* g_h2 = c.f32(ny);
-        c.gn_silu_bwd(g_a2, n2, P[RP_GN2_W], P[RP_GN2_B], B, HW, Cout, g_h2, false);      // = dL/dh1 (the emb path has nothing trainable upstream)
-        float* g_a1 = c.conv3(g_h2, B, d.H, d.W, P[RP_C1_W], nullptr, Cin, Cout, true);
-        float* g_x = skip_conv ? c.lin_dgrad(g, M, Cout, P[RP_SKIP_W], Cin) : g;           // through the skip connection
-        c.gn_silu_bwd(g_a1, n1, P[RP_GN1_W], P[RP_GN1_B], B, HW, Cin, g_x, true);
-        c.hip(hipMemcpyAsync(dx, g_x, (size_t)M * Cin * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+        float* g_x = res_backward(c, d, P, S, g);
+        c.hip(hipMemcpyAsync(dx, g_x, (size_t)d.B * d.H * d.W * d.Cin * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
         c.hip(hipGetLastError(), "training slice kernel launch");
     } catch (const GlError& e) {
         return set_error(e.code, "%s", e.what());
@@ -748,7 +791,24 @@ int resblock_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainResDim
 }
 
 // Downsample (mode 0: conv3x3 stride 2, openaimodel.py:99-124) / Upsample (mode 1: nearest 2x + conv3x3, openaimodel.py:64-96) of C
-// channels: forward, mse_loss(y, target) and the gradient w.r.t. the input (the conv is a frozen SD layer).
+// channels; the conv is a frozen SD layer: forward, and the gradient w.r.t. the input.
+static float* resample_forward(const Ctx& c, int mode, int B, int H, int W, int C, const float* w_oihw, const float* bias, const float* x) {
+    return c.conv3(x, B, H, W, w_oihw, bias, C, C, false, mode ? 1 : 2, mode ? 1 : 0);
+}
+// g: dL/dy [B][Ho*Wo][C] -> dL/dx [B][H*W][C]
+static float* resample_backward(const Ctx& c, int mode, int B, int H, int W, int C, const float* w_oihw, const float* g) {
+    const size_t nx = (size_t)B * H * W * C;
+    if (mode == 0) {
+        float* z = c.f32(nx);
+        hipLaunchKernelGGL(zero_insert2_kernel, Ctx::g1(nx), dim3(256), 0, c.s, g, H, W, C, nx, z);
+        return c.conv3(z, B, H, W, w_oihw, nullptr, C, C, true);
+    }
+    float* gu = c.conv3(g, B, 2 * H, 2 * W, w_oihw, nullptr, C, C, true);
+    float* dx = c.f32(nx);
+    hipLaunchKernelGGL(sum2x2_kernel, Ctx::g1(nx), dim3(256), 0, c.s, (const float*)gu, H, W, C, nx, dx);
+    return dx;
+}
+
 int resample_train_step(Arena& ar, float* ws, size_t ws_bytes, int mode, int B, int H, int W, int C, const float* w_oihw, const float* bias, const float* x,
                         const float* target, float* y, float* loss, float* dx, hipStream_t s) {
     try {
@@ -756,21 +816,359 @@ int resample_train_step(Arena& ar, float* ws, size_t ws_bytes, int mode, int B, 
         Ctx c{ar, ws, ws_bytes, s};
         const int Ho = mode ? 2 * H : H / 2, Wo = mode ? 2 * W : W / 2;
         const size_t ny = (size_t)B * Ho * Wo * C, nx = (size_t)B * H * W * C;
-        float* yv = c.conv3(x, B, H, W, w_oihw, bias, C, C, false, mode ? 1 : 2, mode ? 1 : 0);
+        float* yv = resample_forward(c, mode, B, H, W, C, w_oihw, bias, x);
         c.hip(hipMemcpyAsync(y, yv, ny * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
         hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)y, target, ny, (const float*)nullptr, 1.f, 1, loss);
         float* g = c.f32(ny);
         hipLaunchKernelGGL(mse_grad_kernel, Ctx::g1(ny), dim3(256), 0, s, (const float*)y, target, ny, g);
-        if (mode == 0) {
-            float* z = c.f32(nx);
-            hipLaunchKernelGGL(zero_insert2_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)g, H, W, C, nx, z);
-            float* gx = c.conv3(z, B, H, W, w_oihw, nullptr, C, C, true);
-            c.hip(hipMemcpyAsync(dx, gx, nx * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
-        } else {
-            float* gu = c.conv3(g, B, Ho, Wo, w_oihw, nullptr, C, C, true);
-            hipLaunchKernelGGL(sum2x2_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)gu, H, W, C, nx, dx);
-        }
+        float* gx = resample_backward(c, mode, B, H, W, C, w_oihw, g);
+        c.hip(hipMemcpyAsync(dx, gx, nx * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
         c.hip(hipGetLastError(), "training slice kernel launch");
+    } catch (const GlError& e) {
+        return set_error(e.code, "%s", e.what());
+    }
+    return GL_OK;
+}
+
+// ======================================================================================================================
+// The whole training iteration of the reference (trainer.py:353-392: model(input) -> mse_loss(model_output, noise) -> backward) for a
+// UNetModel with the text grounding tokenizer and gatedSA fusers (openaimodel.py:237-464), composed of the slices above:
+//   objs = position_net(boxes, masks, positive_embeddings)          text_grounding_net.py:30-52      TRAINABLE
+//   emb  = time_embed(timestep_embedding(t))                         openaimodel.py:436-437           frozen, no backward needed
+//   input_blocks / middle_block / output_blocks (skip concats) / out openaimodel.py:452-464
+// Gradients for every fuser.* parameter of every SpatialTransformer and for position_net.*; nothing else is trainable in the
+// reference (trainer.py:217-245), and no input gradient is needed in front of the first fuser. All activations of the forward stay
+// in the arena (no recomputation at this size; DESIGN.md section 9 has the checkpointing plan for the full model).
+namespace {
+
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, int dim, float* __restrict__ out) {   // util.py:160-180
+    const int b = blockIdx.x, half = dim / 2;
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        const float a = t[b] * __expf(-9.210340371976184f * (float)i / (float)half);   // ln(10000)
+        out[(size_t)b * dim + i] = cosf(a);
+        out[(size_t)b * dim + half + i] = sinf(a);
+    }
+}
+// PositionNet input rows (text_grounding_net.py:33-48): [pe * m + (1 - m) * null_positive | fourier(boxes) * m + (1 - m) * null_position],
+// fourier = for k in 0..7: sin(f_k x) (4 values), cos(f_k x) (4 values), f_k = 100^(k / 8)   (util.py:12-26)
+__global__ void posnet_input_kernel_f32(const float* __restrict__ boxes, const float* __restrict__ masks, const float* __restrict__ pe,
+                                        const float* __restrict__ null_pos_feat, const float* __restrict__ null_xyxy, int D, float* __restrict__ out) {
+    const int row = blockIdx.x, W = D + 64;
+    const float m = masks[row];
+    for (int c = threadIdx.x; c < W; c += blockDim.x) {
+        float v, nul;
+        if (c < D) { v = pe[(size_t)row * D + c]; nul = null_pos_feat[c]; }
+        else {
+            const int j = c - D, k = j >> 3, r = j & 7;
+            const float a = powf(100.f, (float)k / 8.f) * boxes[(size_t)row * 4 + (r & 3)];
+            v = r < 4 ? sinf(a) : cosf(a);
+            nul = null_xyxy[j];
+        }
+        out[(size_t)row * W + c] = v * m + (1.f - m) * nul;
+    }
+}
+// out[c] = sum_rows (1 - m[row]) g[row][c0 + c]   (the gradient of a learnable null embedding)
+__global__ void null_grad_kernel(const float* __restrict__ g, const float* __restrict__ masks, int R, int ld, int c0, int n, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += (1.f - masks[r]) * g[(size_t)r * ld + c0 + c];
+    out[c] = s;
+}
+__global__ void silu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, size_t n, float* __restrict__ dx) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float sg = 1.f / (1.f + __expf(-x[i]));
+    dx[i] = dy[i] * sg * (1.f + x[i] * (1.f - sg));
+}
+// fp32 direct 3x3 conv, stride 1, pad 1, over pixel rows, for the two convs with 4 channels on one side (conv_in 4 -> C, out C -> 4):
+// one thread per output element. w OIHW.
+__global__ void conv3x3_direct_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, int H, int W, int Cin,
+                                      int Cout, size_t n, float* __restrict__ y) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int co = (int)(i % Cout), xw = (int)((i / Cout) % W), yh = (int)((i / ((size_t)Cout * W)) % H);
+    const size_t b = i / ((size_t)Cout * W * H);
+    float acc = bias ? bias[co] : 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yy = yh + ky - 1;
+        if (yy < 0 || yy >= H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int xx = xw + kx - 1;
+            if (xx < 0 || xx >= W) continue;
+            const float* xp = x + ((b * H + yy) * W + xx) * Cin;
+            const float* wp = w + (size_t)co * Cin * 9 + ky * 3 + kx;
+            for (int ci = 0; ci < Cin; ++ci) acc = fmaf(xp[ci], wp[(size_t)ci * 9], acc);
+        }
+    }
+    y[i] = acc;
+}
+__global__ void concat_kernel(const float* __restrict__ a, int C0, const float* __restrict__ b, int C1, size_t rows, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int C = C0 + C1;
+    if (i >= rows * C) return;
+    const size_t r = i / C;
+    const int c = (int)(i % C);
+    out[i] = c < C0 ? a[r * C0 + c] : b[r * C1 + (c - C0)];
+}
+// dst[r][c] (+)= src[r][c0 + c]
+__global__ void split_kernel(const float* __restrict__ src, int ld, int c0, int Cc, size_t rows, float* __restrict__ dst, int accumulate) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * Cc) return;
+    const size_t r = i / Cc;
+    const int c = (int)(i % Cc);
+    const float v = src[r * ld + c0 + c];
+    dst[i] = accumulate ? dst[i] + v : v;
+}
+
+struct Names {
+    std::unordered_map<std::string, int> idx;
+    const float* const* params;
+    float* const* grads;
+    const float* w(const std::string& k) const {
+        auto it = idx.find(k);
+        if (it == idx.end() || !params[it->second]) throw GlError(GL_ERR_MISSING, "unet_train_step: missing parameter '" + k + "'");
+        return params[it->second];
+    }
+    bool has(const std::string& k) const { auto it = idx.find(k); return it != idx.end() && params[it->second]; }
+    float* g(const std::string& k) const {
+        auto it = idx.find(k);
+        return it == idx.end() ? nullptr : grads[it->second];
+    }
+};
+
+}  // namespace
+
+int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& cfg, const TrainUNetIn& in, int n_params, const char* const* names,
+                    const float* const* params, float* const* grads, const char* const* block_names, float* eps_out, float* loss, hipStream_t s) {
+    try {
+        Names nm;
+        nm.params = params;
+        nm.grads = grads;
+        for (int i = 0; i < n_params; ++i) nm.idx[names[i]] = i;
+        for (int i = 0; i < n_params; ++i)
+            if (grads[i] && !(strstr(names[i], ".fuser.") || !strncmp(names[i], "position_net.", 13)))
+                throw GlError(GL_ERR_ARG, fmt("unet_train_step: a gradient was asked for '%s', which the reference keeps frozen", names[i]));
+        Ctx c{ar, ws, ws_bytes, s};
+        const int B = in.B, H0 = in.H, W0 = in.W, mc = cfg.model_channels, ED = 4 * mc, KD = cfg.context_dim, Ng = in.Ng;
+        if (mc % 64 || KD % 64 || cfg.gr_dim % 64 || B < 1) throw GlError(GL_ERR_ARG, "unet_train_step: model_channels / context_dim / grounding dim must be multiples of 64");
+        auto in_attn = [&](int ds) { for (int i = 0; i < cfg.n_attn; ++i) if (cfg.attention_resolutions[i] == ds) return true; return false; };
+
+        // ---- grounding tokens (trainable)
+        const int MR = B * Ng, PW = cfg.gr_dim + 64;
+        float* pcat = c.f32((size_t)MR * PW);
+        hipLaunchKernelGGL(posnet_input_kernel_f32, dim3(MR), dim3(256), 0, s, in.boxes, in.masks, in.positive_embeddings,
+                           nm.w("position_net.null_positive_feature"), nm.w("position_net.null_position_feature"), cfg.gr_dim, pcat);
+        float* pl0 = c.lin_fwd(pcat, MR, PW, nm.w("position_net.linears.0.weight"), nm.w("position_net.linears.0.bias"), 512);
+        float* pa0 = c.f32((size_t)MR * 512);
+        hipLaunchKernelGGL(silu_kernel, Ctx::g1((size_t)MR * 512), dim3(256), 0, s, (const float*)pl0, (size_t)MR * 512, pa0);
+        float* pl1 = c.lin_fwd(pa0, MR, 512, nm.w("position_net.linears.2.weight"), nm.w("position_net.linears.2.bias"), 512);
+        float* pa1 = c.f32((size_t)MR * 512);
+        hipLaunchKernelGGL(silu_kernel, Ctx::g1((size_t)MR * 512), dim3(256), 0, s, (const float*)pl1, (size_t)MR * 512, pa1);
+        float* objs = c.lin_fwd(pa1, MR, 512, nm.w("position_net.linears.4.weight"), nm.w("position_net.linears.4.bias"), KD);
+        // ---- time embedding (frozen): silu(emb) is what every ResBlock's emb_layers starts with
+        float* te = c.f32((size_t)B * mc);
+        hipLaunchKernelGGL(timestep_embedding_kernel, dim3(B), dim3(256), 0, s, in.timesteps, mc, te);
+        float* e0 = c.lin_fwd(te, B, mc, nm.w("time_embed.0.weight"), nm.w("time_embed.0.bias"), ED);
+        float* e0s = c.f32((size_t)B * ED);
+        hipLaunchKernelGGL(silu_kernel, Ctx::g1((size_t)B * ED), dim3(256), 0, s, (const float*)e0, (size_t)B * ED, e0s);
+        float* emb = c.lin_fwd(e0s, B, ED, nm.w("time_embed.2.weight"), nm.w("time_embed.2.bias"), ED);
+        float* semb = c.f32((size_t)B * ED);
+        hipLaunchKernelGGL(silu_kernel, Ctx::g1((size_t)B * ED), dim3(256), 0, s, (const float*)emb, (size_t)B * ED, semb);
+
+        // ---- the layers, in forward order, each remembering what its backward needs
+        struct Act { float* p; int C, H, W; };
+        enum Kind { K_RES, K_ST, K_DOWN, K_UP, K_CAT };
+        struct Layer {
+            Kind kind;
+            std::string prefix;
+            int Cin, Cout, H, W, C0;                  // K_CAT: C0 = channels of h, Cin - C0 = channels of the skip; skip_idx = its producer
+            int skip_idx;
+            std::vector<const float*> P;
+            std::vector<float*> G;
+            ResSaved rs;
+            STSaved ss;
+        };
+        std::vector<Layer> L;
+        auto res_layer = [&](const std::string& p, int Cin, int Cout, int H, int W) {
+            Layer l{K_RES, p, Cin, Cout, H, W, 0, -1, {}, {}, {}, {}};
+            static const char* k[RP_COUNT] = {"in_layers.0.weight", "in_layers.0.bias", "in_layers.2.weight", "in_layers.2.bias", "emb_layers.1.weight",
+                                              "emb_layers.1.bias", "out_layers.0.weight", "out_layers.0.bias", "out_layers.3.weight", "out_layers.3.bias",
+                                              "skip_connection.weight", "skip_connection.bias"};
+            for (int i = 0; i < RP_COUNT; ++i) l.P.push_back((i >= RP_SKIP_W && Cin == Cout) ? nullptr : nm.w(p + "." + k[i]));
+            return l;
+        };
+        auto st_layer = [&](const std::string& p, int C, int H, int W) {
+            Layer l{K_ST, p, C, C, H, W, 0, -1, {}, {}, {}, {}};
+            l.P.resize(ST_COUNT);
+            l.G.assign(ST_COUNT, nullptr);
+            l.P[ST_NORM_W] = nm.w(p + ".norm.weight"); l.P[ST_NORM_B] = nm.w(p + ".norm.bias");
+            l.P[ST_PIN_W] = nm.w(p + ".proj_in.weight"); l.P[ST_PIN_B] = nm.w(p + ".proj_in.bias");
+            l.P[ST_POUT_W] = nm.w(p + ".proj_out.weight"); l.P[ST_POUT_B] = nm.w(p + ".proj_out.bias");
+            for (int i = 0; i < TP_COUNT; ++i) {
+                const std::string k = p + ".transformer_blocks.0." + block_names[i];
+                l.P[ST_BLOCK0 + i] = nm.w(k);
+                l.G[ST_BLOCK0 + i] = nm.g(k);
+            }
+            return l;
+        };
+        const int Cx = cfg.in_channels;
+        const size_t M0 = (size_t)B * H0 * W0;
+        // conv_in (frozen, in front of every trainable parameter: forward only)
+        float* h0 = c.f32(M0 * mc);
+        hipLaunchKernelGGL(conv3x3_direct_kernel, Ctx::g1(M0 * mc), dim3(256), 0, s, in.x, nm.w("input_blocks.0.0.weight"), nm.w("input_blocks.0.0.bias"), H0, W0,
+                           Cx, mc, M0 * mc, h0);
+        Act h{h0, mc, H0, W0};
+        std::vector<Act> hs{h};
+        std::vector<int> hs_layer{-1};          // which layer produced each skip (-1: conv_in)
+        auto run = [&](Layer l) {
+            const TrainBlockDims bd{B, l.H * l.W, Ng, l.Cout, cfg.num_heads, in.ctx_T, KD, in.fuser_scale};
+            const size_t rows = (size_t)B * l.H * l.W;
+            float* y = nullptr;
+            if (l.kind == K_RES) {
+                const TrainResDims rd{B, l.H, l.W, l.Cin, l.Cout, ED};
+                res_check(rd, l.P.data());
+                y = c.f32(rows * l.Cout);
+                l.rs = res_forward(c, rd, l.P.data(), h.p, semb, y);
+            } else if (l.kind == K_ST) {
+                st_check(bd, l.P.data());
+                y = c.f32(rows * l.Cout);
+                l.ss = st_forward(c, bd, l.P.data(), h.p, objs, in.context, y);
+            } else if (l.kind == K_DOWN) {
+                y = resample_forward(c, 0, B, l.H, l.W, l.Cin, l.P[0], l.P[1], h.p);
+                h.H = l.H / 2; h.W = l.W / 2;
+            } else if (l.kind == K_UP) {
+                y = resample_forward(c, 1, B, l.H, l.W, l.Cin, l.P[0], l.P[1], h.p);
+                h.H = l.H * 2; h.W = l.W * 2;
+            }
+            h.p = y; h.C = l.Cout;
+            L.push_back(std::move(l));
+        };
+        int ch = mc, ds = 1, n = 1;
+        for (int level = 0; level < cfg.n_mult; ++level) {
+            const int mult = cfg.channel_mult[level];
+            for (int r = 0; r < cfg.num_res_blocks; ++r) {
+                const std::string p = fmt("input_blocks.%d", n);
+                run(res_layer(p + ".0", ch, mult * mc, h.H, h.W));
+                ch = mult * mc;
+                if (in_attn(ds)) run(st_layer(p + ".1", ch, h.H, h.W));
+                hs.push_back(h); hs_layer.push_back((int)L.size() - 1);
+                ++n;
+            }
+            if (level != cfg.n_mult - 1) {
+                const std::string p = fmt("input_blocks.%d.0.op", n);
+                Layer l{K_DOWN, p, ch, ch, h.H, h.W, 0, -1, {nm.w(p + ".weight"), nm.w(p + ".bias")}, {}, {}, {}};
+                run(l);
+                hs.push_back(h); hs_layer.push_back((int)L.size() - 1);
+                ds *= 2;
+                ++n;
+            }
+        }
+        run(res_layer("middle_block.0", ch, ch, h.H, h.W));
+        run(st_layer("middle_block.1", ch, h.H, h.W));
+        run(res_layer("middle_block.2", ch, ch, h.H, h.W));
+        n = 0;
+        for (int level = cfg.n_mult - 1; level >= 0; --level) {
+            const int mult = cfg.channel_mult[level];
+            for (int i = 0; i <= cfg.num_res_blocks; ++i) {
+                const Act sk = hs.back();
+                const int sk_layer = hs_layer.back();
+                hs.pop_back(); hs_layer.pop_back();
+                if (sk.H != h.H || sk.W != h.W) throw GlError(GL_ERR_STATE, "unet_train_step: skip / stream size mismatch");
+                {   // h = cat([h, hs.pop()], dim = 1)
+                    const size_t rows = (size_t)B * h.H * h.W;
+                    float* cat = c.f32(rows * (h.C + sk.C));
+                    hipLaunchKernelGGL(concat_kernel, Ctx::g1(rows * (h.C + sk.C)), dim3(256), 0, s, (const float*)h.p, h.C, (const float*)sk.p, sk.C, rows, cat);
+                    Layer l{K_CAT, "", h.C + sk.C, h.C + sk.C, h.H, h.W, h.C, sk_layer, {}, {}, {}, {}};
+                    h.p = cat; h.C += sk.C;
+                    L.push_back(l);
+                }
+                const std::string p = fmt("output_blocks.%d", n);
+                run(res_layer(p + ".0", h.C, mc * mult, h.H, h.W));
+                ch = mc * mult;
+                int j = 1;
+                if (in_attn(ds)) { run(st_layer(p + ".1", ch, h.H, h.W)); j = 2; }
+                if (level && i == cfg.num_res_blocks) {
+                    const std::string q = p + fmt(".%d.conv", j);
+                    Layer l{K_UP, q, ch, ch, h.H, h.W, 0, -1, {nm.w(q + ".weight"), nm.w(q + ".bias")}, {}, {}, {}};
+                    run(l);
+                    ds /= 2;
+                }
+                ++n;
+            }
+        }
+        // out = conv(silu(gn(h)))  (openaimodel.py:389-393)
+        const Ctx::GN on = c.gn_silu_fwd(h.p, B, H0 * W0, mc, nm.w("out.0.weight"), nm.w("out.0.bias"));
+        const int Co = cfg.out_channels;
+        const size_t ny = M0 * Co;
+        float* y = c.f32(ny);
+        hipLaunchKernelGGL(conv3x3_direct_kernel, Ctx::g1(ny), dim3(256), 0, s, (const float*)on.a, nm.w("out.2.weight"), nm.w("out.2.bias"), H0, W0, mc, Co, ny, y);
+        if (eps_out) c.hip(hipMemcpyAsync(eps_out, y, ny * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+        hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)y, in.target, ny, (const float*)nullptr, 1.f, 1, loss);
+
+        // ---- backward
+        float* gy = c.f32(ny);
+        hipLaunchKernelGGL(mse_grad_kernel, Ctx::g1(ny), dim3(256), 0, s, (const float*)y, in.target, ny, gy);
+        float* wt = c.f32((size_t)mc * Co * 9);       // out conv dgrad: the same direct conv on the flipped / transposed weight
+        hipLaunchKernelGGL(conv_dgrad_weight_kernel, Ctx::g1((size_t)mc * Co * 9), dim3(256), 0, s, nm.w("out.2.weight"), Co, mc, wt);
+        float* g_a = c.f32(M0 * mc);
+        hipLaunchKernelGGL(conv3x3_direct_kernel, Ctx::g1(M0 * mc), dim3(256), 0, s, (const float*)gy, (const float*)wt, (const float*)nullptr, H0, W0, Co, mc,
+                           M0 * mc, g_a);
+        float* g = c.f32(M0 * mc);
+        c.gn_silu_bwd(g_a, on, nm.w("out.0.weight"), nm.w("out.0.bias"), B, H0 * W0, mc, g, false);
+        float* g_objs = c.f32((size_t)MR * KD);
+        c.hip(hipMemsetAsync(g_objs, 0, (size_t)MR * KD * 4, s), "hipMemsetAsync");
+        std::vector<float*> skip_grad(L.size(), nullptr);     // dL/d(output of layer i) arriving through a skip connection
+        int first_st = -1;
+        for (size_t i = 0; i < L.size(); ++i)
+            if (L[i].kind == K_ST) { first_st = (int)i; break; }
+        for (int i = (int)L.size() - 1; i >= 0 && i >= first_st; --i) {
+            Layer& l = L[i];
+            const size_t rows = (size_t)B * l.H * l.W;
+            if (skip_grad[i]) {     // this layer's output also went into a skip connection (l.H, l.W are its INPUT size)
+                const size_t out_rows = l.kind == K_DOWN ? rows / 4 : l.kind == K_UP ? rows * 4 : rows;
+                c.add(g, skip_grad[i], out_rows * l.Cout);
+            }
+            if (l.kind == K_CAT) {
+                float* gh = c.f32(rows * l.C0);
+                hipLaunchKernelGGL(split_kernel, Ctx::g1(rows * l.C0), dim3(256), 0, s, (const float*)g, l.Cin, 0, l.C0, rows, gh, 0);
+                const int C1 = l.Cin - l.C0;
+                if (l.skip_idx >= first_st) {       // (a skip produced in front of the first fuser carries no gradient anybody needs)
+                    float* gs = c.f32(rows * C1);
+                    hipLaunchKernelGGL(split_kernel, Ctx::g1(rows * C1), dim3(256), 0, s, (const float*)g, l.Cin, l.C0, C1, rows, gs, 0);
+                    skip_grad[l.skip_idx] = gs;
+                }
+                g = gh;
+            } else if (l.kind == K_RES) {
+                const TrainResDims rd{B, l.H, l.W, l.Cin, l.Cout, ED};
+                g = res_backward(c, rd, l.P.data(), l.rs, g);
+            } else if (l.kind == K_ST) {
+                const TrainBlockDims bd{B, l.H * l.W, Ng, l.Cout, cfg.num_heads, in.ctx_T, KD, in.fuser_scale};
+                float* d_o = c.f32((size_t)MR * KD);
+                st_backward(c, bd, l.P.data(), l.ss, objs, g, d_o, l.G.data());
+                c.add(g_objs, d_o, (size_t)MR * KD);
+            } else if (l.kind == K_DOWN) {
+                g = resample_backward(c, 0, B, l.H, l.W, l.Cin, l.P[0], g);
+            } else if (l.kind == K_UP) {
+                g = resample_backward(c, 1, B, l.H, l.W, l.Cin, l.P[0], g);
+            }
+        }
+        // ---- position_net backward (text_grounding_net.py:17-27: Linear, SiLU, Linear, SiLU, Linear; the two learnable null embeddings)
+        c.lin_wgrad(g_objs, pa1, MR, KD, 512, nm.g("position_net.linears.4.weight"), nm.g("position_net.linears.4.bias"));
+        float* g_a1 = c.lin_dgrad(g_objs, MR, KD, nm.w("position_net.linears.4.weight"), 512);
+        float* g_l1 = c.f32((size_t)MR * 512);
+        hipLaunchKernelGGL(silu_bwd_kernel, Ctx::g1((size_t)MR * 512), dim3(256), 0, s, (const float*)g_a1, (const float*)pl1, (size_t)MR * 512, g_l1);
+        c.lin_wgrad(g_l1, pa0, MR, 512, 512, nm.g("position_net.linears.2.weight"), nm.g("position_net.linears.2.bias"));
+        float* g_a0 = c.lin_dgrad(g_l1, MR, 512, nm.w("position_net.linears.2.weight"), 512);
+        float* g_l0 = c.f32((size_t)MR * 512);
+        hipLaunchKernelGGL(silu_bwd_kernel, Ctx::g1((size_t)MR * 512), dim3(256), 0, s, (const float*)g_a0, (const float*)pl0, (size_t)MR * 512, g_l0);
+        c.lin_wgrad(g_l0, pcat, MR, 512, PW, nm.g("position_net.linears.0.weight"), nm.g("position_net.linears.0.bias"));
+        float* g_cat = c.lin_dgrad(g_l0, MR, 512, nm.w("position_net.linears.0.weight"), PW);
+        if (float* gp = nm.g("position_net.null_positive_feature"))
+            hipLaunchKernelGGL(null_grad_kernel, Ctx::g1(cfg.gr_dim), dim3(256), 0, s, (const float*)g_cat, in.masks, MR, PW, 0, cfg.gr_dim, gp);
+        if (float* gp = nm.g("position_net.null_position_feature"))
+            hipLaunchKernelGGL(null_grad_kernel, Ctx::g1(64), dim3(256), 0, s, (const float*)g_cat, in.masks, MR, PW, cfg.gr_dim, 64, gp);
+        c.hip(hipGetLastError(), "training step kernel launch");
     } catch (const GlError& e) {
         return set_error(e.code, "%s", e.what());
     }

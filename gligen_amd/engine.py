@@ -401,6 +401,47 @@ class Engine:
         check(self.lib.gl_op_adamw_step(self._ctx, _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(betas[0]), float(betas[1]),
                                         float(eps), float(weight_decay), int(step), _stream(self.device)))
 
+    def unet_train_step(self, cfg: Mapping, state_dict: Mapping[str, torch.Tensor], batch: Mapping[str, torch.Tensor], fuser_scale: float = 1.0,
+                        trainable=None):
+        """One training iteration of the reference (trainer.py:353-392: model(input), mse_loss(model_output, noise), backward) on the
+        device (gl_unet_train_step). cfg: UNetModel kwargs (text tokenizer, gatedSA); state_dict: the model's parameters (fp32, on this
+        device: they are used in place); batch: x [B, 4, H, W] (noised latent), timesteps [B], context [B, 77, 768], boxes, masks,
+        positive_embeddings, target [B, 4, H, W] (the noise). Returns (loss, eps [B, 4, H, W], grads) with grads over the reference's
+        trainable set (trainer.py:217-245: '*.fuser.*' and 'position_net.*' keys) or the `trainable` names given."""
+        dev = self.device
+        c = UNetConfig()
+        c.in_channels, c.out_channels, c.model_channels = cfg["in_channels"], cfg["out_channels"], cfg["model_channels"]
+        c.num_res_blocks, c.num_heads, c.context_dim = cfg["num_res_blocks"], cfg["num_heads"], cfg["context_dim"]
+        c.n_mult = len(cfg["channel_mult"])
+        for i, v in enumerate(cfg["channel_mult"]):
+            c.channel_mult[i] = int(v)
+        c.n_attn = len(cfg["attention_resolutions"])
+        for i, v in enumerate(cfg["attention_resolutions"]):
+            c.attention_resolutions[i] = int(v)
+        c.grounding_kind, c.fuser_kind = 0, 0
+        c.gr_in_dim = c.gr_out_dim = 768
+        names = [k for k in state_dict.keys()]
+        params = [_f32(state_dict[k], dev) for k in names]
+        if trainable is None:
+            trainable = [k for k in names if ".fuser." in k or k.startswith("position_net.")]
+        grads = {k: torch.zeros_like(p) for k, p in zip(names, params) if k in set(trainable)}
+        x, target = batch["x"], batch["target"]
+        B, Cx, H, W = x.shape
+        rows = lambda t: _f32(t, dev).permute(0, 2, 3, 1).reshape(B, H * W, t.shape[1]).contiguous()
+        keep = dict(x=rows(x), t=_f32(batch["timesteps"], dev), ctx=_f32(batch["context"], dev), boxes=_f32(batch["boxes"], dev),
+                    masks=_f32(batch["masks"], dev), pe=_f32(batch["positive_embeddings"], dev), target=rows(target))
+        u = _lib.TrainUNetIn(int(B), int(H), int(W), int(keep["ctx"].shape[1]), int(keep["boxes"].shape[1]), keep["x"].data_ptr(), keep["t"].data_ptr(),
+                             keep["ctx"].data_ptr(), keep["boxes"].data_ptr(), keep["masks"].data_ptr(), keep["pe"].data_ptr(), keep["target"].data_ptr(),
+                             float(fuser_scale))
+        n = len(names)
+        narr = (C.c_char_p * n)(*[k.encode() for k in names])
+        parr = (C.c_void_p * n)(*[p.data_ptr() for p in params])
+        garr = (C.c_void_p * n)(*[(grads[k].data_ptr() if k in grads else None) for k in names])
+        eps = torch.empty((B, H * W, c.out_channels), device=dev, dtype=torch.float32)
+        loss = torch.zeros(1, device=dev, dtype=torch.float32)
+        check(self.lib.gl_unet_train_step(self._ctx, C.byref(c), C.byref(u), n, narr, parr, garr, _ptr(eps), _ptr(loss), _stream(dev)))
+        return loss, eps.reshape(B, H, W, c.out_channels).permute(0, 3, 1, 2).contiguous(), grads
+
     def st_train_param_names(self):
         names = self.lib.gl_train_st_param_names()
         return [names[i].decode() for i in range(43)]

@@ -281,6 +281,27 @@ int gl_op_resblock_train(gl_ctx* ctx, const gl_train_resblock_dims* dims, const 
 int gl_op_resample_train(gl_ctx* ctx, int mode, int B, int H, int W, int C, const float* w_oihw, const float* bias, const float* x,
                          const float* target, float* y, float* loss, float* dx, gl_stream s);
 
+/* ---- one whole training iteration (reference trainer.py:353-392: model(input), mse_loss(model_output, noise), loss.backward()) for a
+ * UNetModel with the text grounding tokenizer and gatedSA fusers (openaimodel.py:237-464; gl_unet_config with grounding_kind 0,
+ * fuser_kind 0, no inpainting / extra channels). The model's parameters come as its state_dict: n_params names (the reference's
+ * keys, e.g. "input_blocks.1.1.transformer_blocks.0.fuser.linear.weight") with fp32 device pointers; grads[i] is a buffer shaped
+ * like parameter i for every trainable parameter wanted -- the reference's trainable set is every "*.fuser.*" key and "position_net.*"
+ * (trainer.py:217-245); any other non-NULL entry is rejected -- and NULL elsewhere. Tensors fp32 on the device, x / target / eps_out
+ * as pixel rows [B][H*W][channels] (eps_out optional). loss[1] = mse_loss(eps, target). */
+typedef struct gl_train_unet_in {
+    int B, H, W, ctx_T, Ng;
+    const float* x;                     /* [B][H*W][in_channels]: the noised latent */
+    const float* timesteps;             /* [B], as float */
+    const float* context;               /* [B][ctx_T][context_dim] */
+    const float* boxes;                 /* [B][Ng][4] */
+    const float* masks;                 /* [B][Ng] */
+    const float* positive_embeddings;   /* [B][Ng][gr_in_dim] */
+    const float* target;                /* [B][H*W][out_channels]: the noise */
+    float fuser_scale;
+} gl_train_unet_in;
+int gl_unet_train_step(gl_ctx* ctx, const gl_unet_config* cfg, const gl_train_unet_in* in, int n_params, const char* const* names,
+                       const float* const* params, float* const* grads, float* eps_out, float* loss, gl_stream s);
+
 /* One AdamW step over a flat fp32 range, in place: p, exp_avg m, exp_avg_sq v [n]; g the (all-reduced) gradient; step counts from 1.
  * torch.optim.AdamW semantics -- the reference's optimizer over the trainable set (trainer.py:245, opt.step() at :384). */
 int gl_op_adamw_step(gl_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,

@@ -583,6 +583,51 @@ def resample_backward_case(name="resample_backward", B=2, hw=16, C=64):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
 
 
+def _grad_sample(gq, n=4096):
+    """A gradient tensor as the golden stores it: the whole tensor when it has at most n elements, else n elements at a fixed
+    stride of the flattened tensor (the test computes the same indices); fp16 of g / max|g| + the scale, and the full L2 norm."""
+    flat = gq.reshape(-1)
+    stride = max(1, flat.size // n)
+    sub = flat[::stride][:n] if flat.size > n else flat
+    sc = float(np.abs(sub).max()) or 1.0
+    return (sub / sc).astype(np.float16), sc, float(np.sqrt((flat.astype(np.float64) ** 2).sum()))
+
+
+def unet_backward_case(name="unet_small_train_step", B=2, hw=16, n_valid=3):
+    """One whole training iteration of the reference on the small UNet (trainer.py:353-392): model(input) on a noised latent,
+    mse_loss(model_output, noise), loss.backward(), with requires_grad exactly as the trainer sets it (trainer.py:217-245: every
+    fuser.* parameter and position_net). Stored: loss, eps, and per trainable tensor a strided sample of its gradient + its norm
+    (34 M gradient values as a whole would be 70 MB)."""
+    cfg = dict(syn.UNET_CFG_SMALL, use_checkpoint=False)
+    model = build_unet(cfg, "text")
+    batch = syn.make_batch("text", B, n_valid=n_valid, seed=5)
+    g = model.grounding_tokenizer_input.prepare(batch)
+    x = syn.make_latent(B, 4, hw, hw, seed=6)
+    ctx = syn.make_context(B, seed=6)
+    t = torch.tensor([981, 441][:B], dtype=torch.long)
+    target = syn.make_latent(B, 4, hw, hw, seed=7)
+    trainable = []
+    for k, p_ in model.named_parameters():
+        on = ".fuser." in k or k.startswith("position_net.")
+        p_.requires_grad_(on)
+        if on:
+            trainable.append(k)
+    eps = model(dict(x=x, timesteps=t, context=ctx, grounding_input=g, inpainting_extra_input=None, grounding_extra_input=None))
+    loss = torch.nn.functional.mse_loss(eps, target)
+    loss.backward()
+    out = dict(eps=eps.detach().numpy(), loss=np.float64(loss.item()))
+    for k, p_ in model.named_parameters():
+        if k in trainable:
+            sub, sc, nrm = _grad_sample(p_.grad.numpy())
+            out["grad." + k] = sub
+            out["scale." + k] = np.float64(sc)
+            out["norm." + k] = np.float64(nrm)
+    meta = dict(cfg=cfg, B=B, hw=hw, n_valid=n_valid, weight_seed=1234, n_trainable=len(trainable), sample=4096)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), meta=json.dumps(meta), **out)
+    print(f"{name}: loss {loss.item():.6f}, {len(trainable)} trainable tensors, {sum(p.numel() for k, p in model.named_parameters() if k in trainable) / 1e6:.1f} M gradient values")
+    return {k: list(v.shape) for k, v in model.state_dict().items()}
+
+
 CASES = {
     "unet_small_text": lambda: unet_case("unet_small_text", syn.UNET_CFG_SMALL, "text", 2, 16),
     "unet_small_text_image": lambda: unet_case("unet_small_text_image", syn.UNET_CFG_SMALL, "text_image", 2, 16),
@@ -632,6 +677,7 @@ CASES = {
     # ---- round 4: the training slice (gradients through one transformer block, from the reference's autograd)
     "block_backward_gatedsa": block_backward_case,
     "st_backward_gatedsa": st_backward_case,
+    "unet_small_train_step": unet_backward_case,
     "resample_backward": resample_backward_case,
     "resblock_backward_skipconv": lambda: resblock_backward_case("resblock_backward_skipconv", 64, 128),
     "resblock_backward_identity": lambda: resblock_backward_case("resblock_backward_identity", 128, 128),
