@@ -402,12 +402,13 @@ class Engine:
                                         float(eps), float(weight_decay), int(step), _stream(self.device)))
 
     def unet_train_step(self, cfg: Mapping, state_dict: Mapping[str, torch.Tensor], batch: Mapping[str, torch.Tensor], fuser_scale: float = 1.0,
-                        trainable=None):
+                        trainable=None, grads: Optional[Mapping[str, torch.Tensor]] = None):
         """One training iteration of the reference (trainer.py:353-392: model(input), mse_loss(model_output, noise), backward) on the
         device (gl_unet_train_step). cfg: UNetModel kwargs (text tokenizer, gatedSA); state_dict: the model's parameters (fp32, on this
         device: they are used in place); batch: x [B, 4, H, W] (noised latent), timesteps [B], context [B, 77, 768], boxes, masks,
         positive_embeddings, target [B, 4, H, W] (the noise). Returns (loss, eps [B, 4, H, W], grads) with grads over the reference's
-        trainable set (trainer.py:217-245: '*.fuser.*' and 'position_net.*' keys) or the `trainable` names given."""
+        trainable set (trainer.py:217-245: '*.fuser.*' and 'position_net.*' keys) or the `trainable` names given; `grads`: buffers to
+        write into instead of fresh ones (every entry is overwritten)."""
         dev = self.device
         c = UNetConfig()
         c.in_channels, c.out_channels, c.model_channels = cfg["in_channels"], cfg["out_channels"], cfg["model_channels"]
@@ -424,7 +425,11 @@ class Engine:
         params = [_f32(state_dict[k], dev) for k in names]
         if trainable is None:
             trainable = [k for k in names if ".fuser." in k or k.startswith("position_net.")]
-        grads = {k: torch.zeros_like(p) for k, p in zip(names, params) if k in set(trainable)}
+        if grads is None:
+            grads = {k: torch.zeros_like(p) for k, p in zip(names, params) if k in set(trainable)}
+        else:       # caller-owned gradient buffers (gligen_amd.dist.GradBuckets.views: the backward writes straight into the flat buckets)
+            for k, gt in grads.items():
+                assert gt.is_cuda and gt.dtype == torch.float32 and gt.is_contiguous() and tuple(gt.shape) == tuple(state_dict[k].shape), k
         x, target = batch["x"], batch["target"]
         B, Cx, H, W = x.shape
         rows = lambda t: _f32(t, dev).permute(0, 2, 3, 1).reshape(B, H * W, t.shape[1]).contiguous()

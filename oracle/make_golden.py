@@ -628,6 +628,41 @@ def unet_backward_case(name="unet_small_train_step", B=2, hw=16, n_valid=3):
     return {k: list(v.shape) for k, v in model.state_dict().items()}
 
 
+def unet_train_2steps_case(name="unet_small_train_2steps", B=2, hw=16, n_valid=3, lr=1e-3):
+    """Two optimisation steps of the reference's trainer on the small UNet (trainer.py:217-245 trainable set + torch.optim.AdamW,
+    :353-392 run_one_step / backward / opt.step) on one fixed batch: the three losses (before, after one, after two updates) and
+    samples of two updated tensors. lr is larger than the reference's 5e-5 so that two steps move the loss visibly."""
+    cfg = dict(syn.UNET_CFG_SMALL, use_checkpoint=False)
+    model = build_unet(cfg, "text")
+    batch = syn.make_batch("text", B, n_valid=n_valid, seed=5)
+    g = model.grounding_tokenizer_input.prepare(batch)
+    x, ctx = syn.make_latent(B, 4, hw, hw, seed=6), syn.make_context(B, seed=6)
+    t = torch.tensor([981, 441][:B], dtype=torch.long)
+    target = syn.make_latent(B, 4, hw, hw, seed=7)
+    params = []
+    for k, p_ in model.named_parameters():
+        on = ".fuser." in k or k.startswith("position_net.")
+        p_.requires_grad_(on)
+        if on:
+            params.append(p_)
+    opt = torch.optim.AdamW(params, lr=lr, weight_decay=0.0)
+    inp = dict(x=x, timesteps=t, context=ctx, grounding_input=g, inpainting_extra_input=None, grounding_extra_input=None)
+    losses = []
+    for it in range(3):
+        loss = torch.nn.functional.mse_loss(model(inp), target)
+        losses.append(loss.item())
+        if it < 2:
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+    sd = model.state_dict()
+    out = dict(losses=np.asarray(losses, dtype=np.float64),
+               w_linear=sd["input_blocks.1.1.transformer_blocks.0.fuser.linear.weight"].numpy().reshape(-1)[::61][:4096].copy(),
+               w_pn=sd["position_net.linears.4.weight"].numpy().reshape(-1)[::97][:4096].copy())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), meta=json.dumps(dict(cfg=cfg, B=B, hw=hw, n_valid=n_valid, weight_seed=1234, lr=lr)), **out)
+    print(f"{name}: losses {losses}")
+
+
 CASES = {
     "unet_small_text": lambda: unet_case("unet_small_text", syn.UNET_CFG_SMALL, "text", 2, 16),
     "unet_small_text_image": lambda: unet_case("unet_small_text_image", syn.UNET_CFG_SMALL, "text_image", 2, 16),
@@ -678,6 +713,7 @@ CASES = {
     "block_backward_gatedsa": block_backward_case,
     "st_backward_gatedsa": st_backward_case,
     "unet_small_train_step": unet_backward_case,
+    "unet_small_train_2steps": unet_train_2steps_case,
     "resample_backward": resample_backward_case,
     "resblock_backward_skipconv": lambda: resblock_backward_case("resblock_backward_skipconv", 64, 128),
     "resblock_backward_identity": lambda: resblock_backward_case("resblock_backward_identity", 128, 128),

@@ -632,3 +632,43 @@ def test_row_local_kernel_gelu_constants():
     assert np.isfinite(got).all()
     err = np.abs(got.astype(np.float64) - ref)
     assert err.max() < 1e-4, err.max()    # 2^-9 relative is what the bf16 P^T operand keeps of values of order 1
+
+
+def test_train_step_bookkeeping_on_flat_buckets():
+    """gligen_amd.train.TrainStep without a device: a stand-in engine records what it is given. The trainable tensors are the
+    reference's set (trainer.py:217-245), they and their gradients are views into flat buckets (what the library writes is what the
+    collective reads and what AdamW updates), and one AdamW launch is issued per bucket with a step count from 1."""
+    import torch
+    from gligen_amd.train import TrainStep, trainable_names
+
+    class FakeEngine:
+        device = torch.device("cpu")
+
+        def __init__(self):
+            self.adamw_calls = []
+
+        def unet_train_step(self, cfg, params, batch, fuser_scale=1.0, trainable=None, grads=None):
+            assert set(grads) == set(trainable_names(params))
+            for i, (k, gt) in enumerate(sorted(grads.items())):
+                gt.fill_(float(i + 1))
+            return torch.tensor([1.0]), torch.zeros(1), grads
+
+        def op_adamw_step(self, p, g, m, v, step, lr, betas, eps, weight_decay):
+            self.adamw_calls.append((p.data_ptr(), g.data_ptr(), step, p.numel()))
+            p.sub_(lr * torch.sign(g))
+
+    sd = {"input_blocks.1.1.transformer_blocks.0.fuser.linear.weight": torch.ones(8, 4), "position_net.linears.0.bias": torch.ones(6),
+          "input_blocks.1.1.transformer_blocks.0.attn1.to_q.weight": torch.ones(4, 4), "out.2.weight": torch.ones(2, 2),
+          "middle_block.1.transformer_blocks.0.fuser.alpha_attn": torch.ones(())}
+    eng = FakeEngine()
+    ts = TrainStep(eng, {}, sd, lr=0.5, bucket_mb=1e-4, world=1)      # 26 floats per bucket: the three trainable tensors need two buckets
+    assert sorted(ts.gbuf.views) == sorted(k for k in sd if ".fuser." in k or k.startswith("position_net."))
+    assert len(ts.pbuf.buckets) == 2 and [len(x) for x in ts.pbuf.layout] == [len(x) for x in ts.gbuf.layout]
+    for k in ts.gbuf.views:         # the model's trainable tensors ARE the flat buffers
+        assert ts.params[k].data_ptr() == ts.pbuf.views[k].data_ptr()
+    ts.step({})
+    ts.step({})
+    assert [c[2] for c in eng.adamw_calls] == [1, 1, 2, 2]
+    assert {c[0] for c in eng.adamw_calls} == {b.data_ptr() for b in ts.pbuf.buckets}
+    out = ts.state_dict()
+    assert torch.all(out["position_net.linears.0.bias"] == 0.0) and torch.all(out["out.2.weight"] == 1.0)      # 1 - 2 * 0.5; frozen untouched
