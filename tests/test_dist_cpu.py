@@ -158,6 +158,75 @@ def test_two_rank_gloo_gradient_buckets(tmp_path):
     assert res[0]["total"] == res[1]["total"]
 
 
+# ---- the trainer's step over two ranks: gligen_amd.train.TrainStep with a stand-in engine (rank-dependent gradients, a plain AdamW)
+TRAIN_WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, {root!r})
+    import torch
+    from gligen_amd import dist as gdist
+    from gligen_amd.train import TrainStep, trainable_names
+    rank, local_rank, world = gdist.init_from_env(backend="gloo")
+
+    class Eng:      # what Engine.unet_train_step / op_adamw_step do, on the CPU: every rank sees other data, hence other gradients
+        device = torch.device("cpu")
+        def unet_train_step(self, cfg, params, batch, fuser_scale=1.0, trainable=None, grads=None):
+            g = torch.Generator().manual_seed(7 * batch["it"] + rank)
+            for k in sorted(grads):
+                grads[k].copy_(torch.randn(grads[k].shape, generator=g))
+            return torch.tensor([float(rank)]), torch.zeros(1), grads
+        def op_adamw_step(self, p, g, m, v, step, lr, betas, eps, weight_decay):
+            m.mul_(betas[0]).add_(g, alpha=1 - betas[0]); v.mul_(betas[1]).addcmul_(g, g, value=1 - betas[1])
+            p.mul_(1 - lr * weight_decay).addcdiv_(m / (1 - betas[0] ** step), (v / (1 - betas[1] ** step)).sqrt() + eps, value=-lr)
+
+    gw = torch.Generator().manual_seed(3)
+    sd = {{"input_blocks.1.1.transformer_blocks.0.fuser.linear.weight": torch.randn(16, 8, generator=gw),
+          "input_blocks.1.1.transformer_blocks.0.fuser.alpha_attn": torch.randn((), generator=gw),
+          "position_net.linears.0.weight": torch.randn(12, 5, generator=gw), "out.2.weight": torch.randn(4, 4, generator=gw)}}
+    ts = TrainStep(Eng(), {{}}, sd, lr=0.1, weight_decay=0.01, bucket_mb=4e-4, world=world)
+    for it in range(3):
+        ts.step(dict(it=it))
+    # the same three steps in one process on the MEAN gradient of the two ranks
+    names = trainable_names(sd)
+    ref = {{k: sd[k].clone() for k in names}}
+    opt = torch.optim.AdamW([ref[k].requires_grad_(True) for k in names], lr=0.1, weight_decay=0.01)
+    for it in range(3):
+        gs = []
+        for r in range(world):
+            g = torch.Generator().manual_seed(7 * it + r)
+            gs.append({{k: torch.randn(ref[k].shape, generator=g) for k in sorted(names)}})
+        for k in names:
+            ref[k].grad = sum(x[k] for x in gs) / world
+        opt.step()
+    out = ts.state_dict()
+    err = max(float((out[k] - ref[k].detach()).abs().max()) for k in names)
+    print("RESULT " + json.dumps(dict(rank=rank, err=err, n_buckets=len(ts.gbuf.buckets), frozen_same=bool(torch.equal(out["out.2.weight"], sd["out.2.weight"])),
+                                      digest=float(sum(out[k].double().sum() for k in names)))))
+    gdist.shutdown()
+""")
+
+
+def test_two_rank_gloo_train_step(tmp_path):
+    """Two ranks with different gradients end every step with the same parameters: those of AdamW on the mean gradient
+    (the reference's DDP + torch.optim.AdamW, trainer.py:245, 321-322, 384), over several flat buckets."""
+    import json
+    port = _free_port()
+    script = tmp_path / "train_worker.py"
+    script.write_text(TRAIN_WORKER.format(root=ROOT))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = {}
+    for p in procs:
+        out, err = p.communicate(timeout=180)
+        assert p.returncode == 0, err[-2000:]
+        r = json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][-1][7:])
+        res[r["rank"]] = r
+    for r in res.values():
+        assert r["err"] < 1e-5 and r["frozen_same"] and r["n_buckets"] >= 2, r
+    assert res[0]["digest"] == res[1]["digest"]      # bit-identical replicas
+
+
 def test_gradient_buckets_layout_is_zero_copy():
     """The views handed to the backward kernels ARE the bucket memory (no pack pass), in declaration order, one bucket for the
     whole set when it fits."""
