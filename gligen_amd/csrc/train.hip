@@ -37,7 +37,12 @@ std::string fmt(const char* f, ...) {
     return buf;
 }
 
-__global__ void transpose_f32_bf16_kernel(const float* __restrict__ src, int R, int Cc, int ld, bf16* __restrict__ dst, int Rpad) {
+// The training path's matrix products run on the bf16 MFMA kernels at fp32-like precision: an fp32 operand x is the pair
+// (hi = bf16(x), lo = bf16(x - hi)) and a product A W^T is  hi_A hi_W^T + lo_A hi_W^T + hi_A lo_W^T  (three GEMMs with fp32 accumulation;
+// the dropped lo lo term is 2^-16 relative). The reference trains in fp32 (trainer.py: no autocast); single-pass bf16 is ~2^-9 per
+// operand element, which through the 40-odd layers of the full UNet's backward reached 8e-4 rel-MSE on the deepest gradient
+// (developer switch GL_TRAIN_BF16X1=1: one pass).
+__global__ void transpose_f32_bf16_kernel(const float* __restrict__ src, int R, int Cc, int ld, bf16* __restrict__ dst, bf16* __restrict__ dst_lo, int Rpad) {
     __shared__ float tile[32][33];
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
     for (int i = threadIdx.y; i < 32; i += 8) {
@@ -47,8 +52,30 @@ __global__ void transpose_f32_bf16_kernel(const float* __restrict__ src, int R, 
     __syncthreads();
     for (int i = threadIdx.y; i < 32; i += 8) {
         const int c = c0 + i, r = r0 + threadIdx.x;
-        if (c < Cc && r < Rpad) dst[(size_t)c * Rpad + r] = f2bf(tile[threadIdx.x][i]);
+        if (c < Cc && r < Rpad) {
+            const float v = tile[threadIdx.x][i];
+            const bf16 h = f2bf(v);
+            dst[(size_t)c * Rpad + r] = h;
+            if (dst_lo) dst_lo[(size_t)c * Rpad + r] = f2bf(v - bf2f(h));
+        }
     }
+}
+__global__ void split_bf16_kernel(const float* __restrict__ src, size_t n, bf16* __restrict__ hi, bf16* __restrict__ lo) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = src[i];
+    const bf16 h = f2bf(v);
+    hi[i] = h;
+    lo[i] = f2bf(v - bf2f(h));
+}
+// res = src - float(bf16(src))   (the low half of a conv weight, packed like the high half by pack_conv_weight_launch)
+__global__ void bf16_residual_kernel(const float* __restrict__ src, size_t n, float* __restrict__ res) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) res[i] = src[i] - bf2f(f2bf(src[i]));
+}
+__global__ void add3_kernel(float* __restrict__ dst, const float* __restrict__ a, const float* __restrict__ b, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += a[i] + b[i];
 }
 
 // out[c] = sum_r a[r][c] (* b[r][c])   -- one thread per column, rows in order: deterministic
@@ -359,25 +386,47 @@ struct Ctx {
     float* f32(size_t n) const { return ar.get<float>(n); }
     static dim3 g1(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
-    bf16* to_bf16(const float* src, size_t n) const {
-        bf16* d = ar.get<bf16>(n);
-        ck(cast_f32_bf16_launch(src, d, (int64_t)n, s));
+    static bool split_precision() {
+        static const bool one_pass = dev_env("GL_TRAIN_BF16X1") && atoi(dev_env("GL_TRAIN_BF16X1")) != 0;
+        return !one_pass;
+    }
+    struct Split { bf16* hi; bf16* lo; };      // lo null: single-pass bf16
+    Split to_bf16(const float* src, size_t n) const {
+        Split d{ar.get<bf16>(n), nullptr};
+        if (split_precision()) {
+            d.lo = ar.get<bf16>(n);
+            hipLaunchKernelGGL(split_bf16_kernel, g1(n), dim3(256), 0, s, src, n, d.hi, d.lo);
+        } else {
+            ck(cast_f32_bf16_launch(src, d.hi, (int64_t)n, s));
+        }
         return d;
     }
     // [R][Cc] fp32 -> [Cc][Rpad] bf16, columns R..Rpad zero (Rpad: the contraction length of the GEMM that reads it, a multiple of 64)
-    bf16* transposed(const float* src, int R, int Cc, int Rpad) const {
-        bf16* d = ar.get<bf16>((size_t)Cc * Rpad);
-        hipLaunchKernelGGL(transpose_f32_bf16_kernel, dim3(cdiv(Cc, 32), cdiv(Rpad, 32)), dim3(32, 8), 0, s, src, R, Cc, Cc, d, Rpad);
+    Split transposed(const float* src, int R, int Cc, int Rpad) const {
+        Split d{ar.get<bf16>((size_t)Cc * Rpad), split_precision() ? ar.get<bf16>((size_t)Cc * Rpad) : nullptr};
+        hipLaunchKernelGGL(transpose_f32_bf16_kernel, dim3(cdiv(Cc, 32), cdiv(Rpad, 32)), dim3(32, 8), 0, s, src, R, Cc, Cc, d.hi, d.lo, Rpad);
         return d;
     }
-    // out [M][N] fp32 = a [M][K] w[N][K]^T (+ bias)
-    void mm(const bf16* a, const bf16* w, int M, int N, int K, const float* bias, float* out) const {
+    void mm1(const bf16* a, const bf16* w, int M, int N, int K, const float* bias, float* out) const {
         AOperand A;
         aoperand_rows(A, a, K, K);
         Epilogue E;
         epilogue_defaults(E);
         E.out = out; E.ldo = N; E.out_f32 = 1; E.bias = bias;
         ck(gemm_launch(A, w, M, N, K, E, ws, ws_bytes, s));
+    }
+    // out [M][N] fp32 = a [M][K] w[N][K]^T (+ bias)
+    void mm(const Split& a, const Split& w, int M, int N, int K, const float* bias, float* out) const {
+        mm1(a.hi, w.hi, M, N, K, bias, out);
+        if (a.lo && w.lo) {
+            const size_t mk = ar.mark();
+            float* t1 = f32((size_t)M * N);
+            float* t2 = f32((size_t)M * N);
+            mm1(a.lo, w.hi, M, N, K, nullptr, t1);
+            mm1(a.hi, w.lo, M, N, K, nullptr, t2);
+            hipLaunchKernelGGL(add3_kernel, g1((size_t)M * N), dim3(256), 0, s, out, (const float*)t1, (const float*)t2, (size_t)M * N);
+            ar.release(mk);
+        }
     }
     // y = x W^T + b
     float* lin_fwd(const float* x, int M, int K, const float* W, const float* b, int N) const {
@@ -432,7 +481,8 @@ struct Ctx {
             case 40: return attn_fwd_d<40>(q, k, v, B, H, Nq, Nk);
             case 64: return attn_fwd_d<64>(q, k, v, B, H, Nq, Nk);
             case 80: return attn_fwd_d<80>(q, k, v, B, H, Nq, Nk);
-            default: throw GlError(GL_ERR_UNSUPPORTED, fmt("training slice: head dim %d (32, 40, 64, 80 are built)", D));
+            case 160: return attn_fwd_d<160>(q, k, v, B, H, Nq, Nk);
+            default: throw GlError(GL_ERR_UNSUPPORTED, fmt("training slice: head dim %d (32, 40, 64, 80, 160 are built)", D));
         }
     }
     void attn_bwd(int D, const float* q, const float* k, const float* v, const Attn& f, const float* dout, int B, int H, int Nq, int Nk, float* dq,
@@ -442,6 +492,7 @@ struct Ctx {
             case 40: return attn_bwd_d<40>(q, k, v, f, dout, B, H, Nq, Nk, dq, dk, dv);
             case 64: return attn_bwd_d<64>(q, k, v, f, dout, B, H, Nq, Nk, dq, dk, dv);
             case 80: return attn_bwd_d<80>(q, k, v, f, dout, B, H, Nq, Nk, dq, dk, dv);
+            case 160: return attn_bwd_d<160>(q, k, v, f, dout, B, H, Nq, Nk, dq, dk, dv);
             default: throw GlError(GL_ERR_UNSUPPORTED, "training slice: head dim");
         }
     }
@@ -460,14 +511,35 @@ struct Ctx {
         }
         bf16* wp = ar.get<bf16>((size_t)Co * 9 * Ci);
         ck(pack_conv_weight_launch(wsrc, wp, Co, Ci, 3, 3, Co, s));
+        bf16* wp_lo = nullptr;
+        if (split_precision()) {
+            const size_t nw = (size_t)Co * 9 * Ci;
+            float* wres = f32(nw);
+            hipLaunchKernelGGL(bf16_residual_kernel, g1(nw), dim3(256), 0, s, wsrc, nw, wres);
+            wp_lo = ar.get<bf16>(nw);
+            ck(pack_conv_weight_launch(wres, wp_lo, Co, Ci, 3, 3, Co, s));
+        }
         float* out = f32((size_t)M * Co);
-        AOperand A{};
-        A.p0 = to_bf16(a, (size_t)B * H * W * Ci); A.C0 = Ci; A.ld0 = Ci; A.mode = A_CONV3;
-        A.Hin = H; A.Win = W; A.Ho = Ho; A.Wo = Wo; A.stride = stride; A.ups = ups; A.pad_lo = 1;
-        Epilogue E;
-        epilogue_defaults(E);
-        E.out = out; E.ldo = Co; E.out_f32 = 1; E.bias = bias; E.rows_per_b = Ho * Wo;
-        ck(gemm_launch(A, wp, M, Co, 9 * Ci, E, ws, ws_bytes, s));
+        const Split av = to_bf16(a, (size_t)B * H * W * Ci);
+        auto one = [&](const bf16* ap, const bf16* wq, const float* bb, float* o) {
+            AOperand A{};
+            A.p0 = ap; A.C0 = Ci; A.ld0 = Ci; A.mode = A_CONV3;
+            A.Hin = H; A.Win = W; A.Ho = Ho; A.Wo = Wo; A.stride = stride; A.ups = ups; A.pad_lo = 1;
+            Epilogue E;
+            epilogue_defaults(E);
+            E.out = o; E.ldo = Co; E.out_f32 = 1; E.bias = bb; E.rows_per_b = Ho * Wo;
+            ck(gemm_launch(A, wq, M, Co, 9 * Ci, E, ws, ws_bytes, s));
+        };
+        one(av.hi, wp, bias, out);
+        if (av.lo && wp_lo) {
+            const size_t mk = ar.mark();
+            float* t1 = f32((size_t)M * Co);
+            float* t2 = f32((size_t)M * Co);
+            one(av.lo, wp, nullptr, t1);
+            one(av.hi, wp_lo, nullptr, t2);
+            hipLaunchKernelGGL(add3_kernel, g1((size_t)M * Co), dim3(256), 0, s, out, (const float*)t1, (const float*)t2, (size_t)M * Co);
+            ar.release(mk);
+        }
         return out;
     }
     struct GN { float* a; float* xhat; float* rstd; };

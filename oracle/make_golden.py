@@ -593,12 +593,12 @@ def _grad_sample(gq, n=4096):
     return (sub / sc).astype(np.float16), sc, float(np.sqrt((flat.astype(np.float64) ** 2).sum()))
 
 
-def unet_backward_case(name="unet_small_train_step", B=2, hw=16, n_valid=3):
+def unet_backward_case(name="unet_small_train_step", B=2, hw=16, n_valid=3, base_cfg=None):
     """One whole training iteration of the reference on the small UNet (trainer.py:353-392): model(input) on a noised latent,
     mse_loss(model_output, noise), loss.backward(), with requires_grad exactly as the trainer sets it (trainer.py:217-245: every
     fuser.* parameter and position_net). Stored: loss, eps, and per trainable tensor a strided sample of its gradient + its norm
     (34 M gradient values as a whole would be 70 MB)."""
-    cfg = dict(syn.UNET_CFG_SMALL, use_checkpoint=False)
+    cfg = dict(base_cfg or syn.UNET_CFG_SMALL, use_checkpoint=False)
     model = build_unet(cfg, "text")
     batch = syn.make_batch("text", B, n_valid=n_valid, seed=5)
     g = model.grounding_tokenizer_input.prepare(batch)
@@ -714,6 +714,8 @@ CASES = {
     "st_backward_gatedsa": st_backward_case,
     "unet_small_train_step": unet_backward_case,
     "unet_small_train_2steps": unet_train_2steps_case,
+    # the shipped topology (4 levels, 16 fusers, head dims 40 / 80 / 160; 966 tensors) at a 16 x 16 latent
+    "unet_full_train_step": lambda: unet_backward_case("unet_full_train_step", B=1, hw=16, base_cfg=syn.UNET_CFG),
     "resample_backward": resample_backward_case,
     "resblock_backward_skipconv": lambda: resblock_backward_case("resblock_backward_skipconv", 64, 128),
     "resblock_backward_identity": lambda: resblock_backward_case("resblock_backward_identity", 128, 128),
