@@ -291,3 +291,36 @@ def test_resblock_backward_golden(name):
     assert abs(float(loss) - float(g["loss"])) < 1e-5
     ref = torch.from_numpy(g["dx"])
     assert float(((x.grad - ref) ** 2).mean() / (ref ** 2).mean()) < 1e-8
+
+
+def test_unet_train_step_golden_through_the_oracle():
+    """The whole-iteration golden (the reference's loss.backward() on the small UNet): torch autograd THROUGH the oracle's
+    unet_forward reproduces the loss and the sampled gradients of all 127 trainable tensors -- the oracle is a pinned checker for the
+    training path too (smoke() uses it that way)."""
+    g = load_golden("unet_small_train_step")
+    meta = g["meta"]
+    B, hw = meta["B"], meta["hw"]
+    sd = syn.seeded_state_dict(golden_shapes("unet_small_train_step"), meta["weight_seed"])
+    train = [k for k in sd if ".fuser." in k or k.startswith("position_net.")]
+    assert len(train) == meta["n_trainable"]
+    for k in train:
+        sd[k].requires_grad_(True)
+    b = syn.make_batch("text", B, n_valid=meta["n_valid"], seed=5)
+    inp = dict(x=syn.make_latent(B, 4, hw, hw, seed=6), timesteps=torch.tensor([981, 441][:B]), context=syn.make_context(B, seed=6),
+               grounding_input=grounding_kwargs("text", b))
+    eps = orc.unet_forward(sd, oracle_cfg(meta["cfg"], "text"), inp)
+    loss = torch.nn.functional.mse_loss(eps, syn.make_latent(B, 4, hw, hw, seed=7))
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-6
+    n = meta["sample"]
+    worst = 0.0
+    for k in train:
+        flat = sd[k].grad.reshape(-1)
+        stride = max(1, flat.numel() // n)
+        sub = flat[::stride][:n] if flat.numel() > n else flat
+        ref = torch.from_numpy(g["grad." + k].astype(np.float32)) * float(g["scale." + k])
+        if ref.numel() == 1:
+            assert abs(float(sub) - float(ref)) < 2e-3 * max(abs(float(ref)), 1e-4), k
+            continue
+        worst = max(worst, float(((sub - ref) ** 2).mean() / (ref ** 2).mean()))
+    assert worst < 1e-5, worst        # (the golden stores fp16 samples: 1e-7)
