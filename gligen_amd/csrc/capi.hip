@@ -609,7 +609,7 @@ int gl_unet_train_step(gl_ctx* ctx, const gl_unet_config* cfg, const gl_train_un
     c.num_heads = cfg->num_heads; c.context_dim = cfg->context_dim; c.gr_dim = cfg->gr_in_dim; c.n_mult = cfg->n_mult; c.n_attn = cfg->n_attn;
     for (int i = 0; i < 8; ++i) { c.channel_mult[i] = cfg->channel_mult[i]; c.attention_resolutions[i] = cfg->attention_resolutions[i]; }
     gl::TrainUNetIn u{in->B, in->H, in->W, in->ctx_T, in->Ng, in->x, in->timesteps, in->context, in->boxes, in->masks, in->positive_embeddings, in->target,
-                      in->fuser_scale};
+                      in->fuser_scale, in->checkpoint};
     int rc = gl::unet_train_step(eng.arena(), eng.splitk_ws(), eng.splitk_ws_bytes(), c, u, n_params, names, params, grads, k_train_block_names, eps_out, loss, S(s));
     if (rc != GL_OK) throw GlError(rc, gl::last_error());
     GL_API_END

@@ -69,6 +69,7 @@ struct TrainUNetIn {
     const float* positive_embeddings;   // [B][Ng][gr_dim]
     const float* target;                // [B][H*W][out_channels]: the noise
     float fuser_scale;
+    int checkpoint;                     // 1: keep only every block's input and output; a block's backward recomputes its forward (same gradients, bit for bit)
 };
 // names / params / grads: the model's state_dict (fp32 device pointers; grads[i] non-null only for fuser.* and position_net.* entries:
 // the reference's trainable set, trainer.py:217-245). block_names: the TP_* state_dict keys. eps_out (optional) [B][H*W][out_channels].

@@ -1056,6 +1056,7 @@ int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& c
             std::string prefix;
             int Cin, Cout, H, W, C0;                  // K_CAT: C0 = channels of h, Cin - C0 = channels of the skip; skip_idx = its producer
             int skip_idx;
+            const float* x_in;                         // the layer's input (kept: with checkpointing the backward recomputes the forward from it)
             std::vector<const float*> P;
             std::vector<float*> G;
             ResSaved rs;
@@ -1063,7 +1064,7 @@ int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& c
         };
         std::vector<Layer> L;
         auto res_layer = [&](const std::string& p, int Cin, int Cout, int H, int W) {
-            Layer l{K_RES, p, Cin, Cout, H, W, 0, -1, {}, {}, {}, {}};
+            Layer l{K_RES, p, Cin, Cout, H, W, 0, -1, nullptr, {}, {}, {}, {}};
             static const char* k[RP_COUNT] = {"in_layers.0.weight", "in_layers.0.bias", "in_layers.2.weight", "in_layers.2.bias", "emb_layers.1.weight",
                                               "emb_layers.1.bias", "out_layers.0.weight", "out_layers.0.bias", "out_layers.3.weight", "out_layers.3.bias",
                                               "skip_connection.weight", "skip_connection.bias"};
@@ -1071,7 +1072,7 @@ int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& c
             return l;
         };
         auto st_layer = [&](const std::string& p, int C, int H, int W) {
-            Layer l{K_ST, p, C, C, H, W, 0, -1, {}, {}, {}, {}};
+            Layer l{K_ST, p, C, C, H, W, 0, -1, nullptr, {}, {}, {}, {}};
             l.P.resize(ST_COUNT);
             l.G.assign(ST_COUNT, nullptr);
             l.P[ST_NORM_W] = nm.w(p + ".norm.weight"); l.P[ST_NORM_B] = nm.w(p + ".norm.bias");
@@ -1097,15 +1098,22 @@ int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& c
             const TrainBlockDims bd{B, l.H * l.W, Ng, l.Cout, cfg.num_heads, in.ctx_T, KD, in.fuser_scale};
             const size_t rows = (size_t)B * l.H * l.W;
             float* y = nullptr;
+            l.x_in = h.p;
+            // checkpointing: a block's output is allocated first, everything its forward keeps (activations, statistics, the bf16
+            // operand copies) is given back to the arena behind it; the backward recomputes the forward from x_in
             if (l.kind == K_RES) {
                 const TrainResDims rd{B, l.H, l.W, l.Cin, l.Cout, ED};
                 res_check(rd, l.P.data());
                 y = c.f32(rows * l.Cout);
+                const size_t mk = ar.mark();
                 l.rs = res_forward(c, rd, l.P.data(), h.p, semb, y);
+                if (in.checkpoint) ar.release(mk);
             } else if (l.kind == K_ST) {
                 st_check(bd, l.P.data());
                 y = c.f32(rows * l.Cout);
+                const size_t mk = ar.mark();
                 l.ss = st_forward(c, bd, l.P.data(), h.p, objs, in.context, y);
+                if (in.checkpoint) ar.release(mk);
             } else if (l.kind == K_DOWN) {
                 y = resample_forward(c, 0, B, l.H, l.W, l.Cin, l.P[0], l.P[1], h.p);
                 h.H = l.H / 2; h.W = l.W / 2;
@@ -1129,7 +1137,7 @@ int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& c
             }
             if (level != cfg.n_mult - 1) {
                 const std::string p = fmt("input_blocks.%d.0.op", n);
-                Layer l{K_DOWN, p, ch, ch, h.H, h.W, 0, -1, {nm.w(p + ".weight"), nm.w(p + ".bias")}, {}, {}, {}};
+                Layer l{K_DOWN, p, ch, ch, h.H, h.W, 0, -1, nullptr, {nm.w(p + ".weight"), nm.w(p + ".bias")}, {}, {}, {}};
                 run(l);
                 hs.push_back(h); hs_layer.push_back((int)L.size() - 1);
                 ds *= 2;
@@ -1151,7 +1159,7 @@ int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& c
                     const size_t rows = (size_t)B * h.H * h.W;
                     float* cat = c.f32(rows * (h.C + sk.C));
                     hipLaunchKernelGGL(concat_kernel, Ctx::g1(rows * (h.C + sk.C)), dim3(256), 0, s, (const float*)h.p, h.C, (const float*)sk.p, sk.C, rows, cat);
-                    Layer l{K_CAT, "", h.C + sk.C, h.C + sk.C, h.H, h.W, h.C, sk_layer, {}, {}, {}, {}};
+                    Layer l{K_CAT, "", h.C + sk.C, h.C + sk.C, h.H, h.W, h.C, sk_layer, nullptr, {}, {}, {}, {}};
                     h.p = cat; h.C += sk.C;
                     L.push_back(l);
                 }
@@ -1162,7 +1170,7 @@ int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& c
                 if (in_attn(ds)) { run(st_layer(p + ".1", ch, h.H, h.W)); j = 2; }
                 if (level && i == cfg.num_res_blocks) {
                     const std::string q = p + fmt(".%d.conv", j);
-                    Layer l{K_UP, q, ch, ch, h.H, h.W, 0, -1, {nm.w(q + ".weight"), nm.w(q + ".bias")}, {}, {}, {}};
+                    Layer l{K_UP, q, ch, ch, h.H, h.W, 0, -1, nullptr, {nm.w(q + ".weight"), nm.w(q + ".bias")}, {}, {}, {}};
                     run(l);
                     ds /= 2;
                 }
@@ -1213,12 +1221,24 @@ int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& c
                 g = gh;
             } else if (l.kind == K_RES) {
                 const TrainResDims rd{B, l.H, l.W, l.Cin, l.Cout, ED};
-                g = res_backward(c, rd, l.P.data(), l.rs, g);
+                float* keep = (in.checkpoint && l.Cin != l.Cout) ? c.f32(rows * l.Cin) : nullptr;    // (allocated in front of the scope below)
+                const size_t mk = ar.mark();
+                if (in.checkpoint) l.rs = res_forward(c, rd, l.P.data(), l.x_in, semb, c.f32(rows * l.Cout));
+                float* gx = res_backward(c, rd, l.P.data(), l.rs, g);       // (g itself, updated in place, when Cin == Cout)
+                if (keep) {
+                    c.hip(hipMemcpyAsync(keep, gx, rows * l.Cin * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+                    gx = keep;
+                }
+                if (in.checkpoint) ar.release(mk);
+                g = gx;
             } else if (l.kind == K_ST) {
                 const TrainBlockDims bd{B, l.H * l.W, Ng, l.Cout, cfg.num_heads, in.ctx_T, KD, in.fuser_scale};
                 float* d_o = c.f32((size_t)MR * KD);
-                st_backward(c, bd, l.P.data(), l.ss, objs, g, d_o, l.G.data());
+                const size_t mk = ar.mark();
+                if (in.checkpoint) l.ss = st_forward(c, bd, l.P.data(), l.x_in, objs, in.context, c.f32(rows * l.Cout));
+                st_backward(c, bd, l.P.data(), l.ss, objs, g, d_o, l.G.data());      // g in place
                 c.add(g_objs, d_o, (size_t)MR * KD);
+                if (in.checkpoint) ar.release(mk);
             } else if (l.kind == K_DOWN) {
                 g = resample_backward(c, 0, B, l.H, l.W, l.Cin, l.P[0], g);
             } else if (l.kind == K_UP) {

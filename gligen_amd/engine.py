@@ -402,13 +402,14 @@ class Engine:
                                         float(eps), float(weight_decay), int(step), _stream(self.device)))
 
     def unet_train_step(self, cfg: Mapping, state_dict: Mapping[str, torch.Tensor], batch: Mapping[str, torch.Tensor], fuser_scale: float = 1.0,
-                        trainable=None, grads: Optional[Mapping[str, torch.Tensor]] = None):
+                        trainable=None, grads: Optional[Mapping[str, torch.Tensor]] = None, checkpoint: bool = False):
         """One training iteration of the reference (trainer.py:353-392: model(input), mse_loss(model_output, noise), backward) on the
         device (gl_unet_train_step). cfg: UNetModel kwargs (text tokenizer, gatedSA); state_dict: the model's parameters (fp32, on this
         device: they are used in place); batch: x [B, 4, H, W] (noised latent), timesteps [B], context [B, 77, 768], boxes, masks,
         positive_embeddings, target [B, 4, H, W] (the noise). Returns (loss, eps [B, 4, H, W], grads) with grads over the reference's
         trainable set (trainer.py:217-245: '*.fuser.*' and 'position_net.*' keys) or the `trainable` names given; `grads`: buffers to
-        write into instead of fresh ones (every entry is overwritten)."""
+        write into instead of fresh ones (every entry is overwritten); `checkpoint`: keep only block inputs / outputs and recompute each block's
+        forward in its backward (the same gradients bit for bit, a fraction of the arena)."""
         dev = self.device
         c = UNetConfig()
         c.in_channels, c.out_channels, c.model_channels = cfg["in_channels"], cfg["out_channels"], cfg["model_channels"]
@@ -437,7 +438,7 @@ class Engine:
                     masks=_f32(batch["masks"], dev), pe=_f32(batch["positive_embeddings"], dev), target=rows(target))
         u = _lib.TrainUNetIn(int(B), int(H), int(W), int(keep["ctx"].shape[1]), int(keep["boxes"].shape[1]), keep["x"].data_ptr(), keep["t"].data_ptr(),
                              keep["ctx"].data_ptr(), keep["boxes"].data_ptr(), keep["masks"].data_ptr(), keep["pe"].data_ptr(), keep["target"].data_ptr(),
-                             float(fuser_scale))
+                             float(fuser_scale), int(bool(checkpoint)))
         n = len(names)
         narr = (C.c_char_p * n)(*[k.encode() for k in names])
         parr = (C.c_void_p * n)(*[p.data_ptr() for p in params])

@@ -25,10 +25,11 @@ def trainable_names(state_dict: Mapping[str, torch.Tensor]):
 
 class TrainStep:
     def __init__(self, engine, cfg: Mapping, state_dict: Mapping[str, torch.Tensor], lr: float = 5e-5, weight_decay: float = 0.0,
-                 betas=(0.9, 0.999), eps: float = 1e-8, bucket_mb: float = 128.0, world: Optional[int] = None):
+                 betas=(0.9, 0.999), eps: float = 1e-8, bucket_mb: float = 128.0, world: Optional[int] = None, checkpoint: bool = True):
         self.engine, self.cfg = engine, dict(cfg)
         dev = engine.device
         self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), tuple(betas), float(eps)
+        self.checkpoint = bool(checkpoint)       # activation checkpointing per block (the reference: use_checkpoint=True in every shipped config)
         names = trainable_names(state_dict)
         shapes = {k: tuple(state_dict[k].shape) for k in names}
         # parameters, gradients and the two AdamW moments share one bucket layout
@@ -48,7 +49,7 @@ class TrainStep:
 
     def step(self, batch: Mapping[str, torch.Tensor], fuser_scale: float = 1.0):
         """One iteration: forward, loss, backward, gradient average over the ranks, AdamW. Returns (loss of this rank, eps)."""
-        loss, eps, _ = self.engine.unet_train_step(self.cfg, self.params, batch, fuser_scale=fuser_scale, grads=self.gbuf.views)
+        loss, eps, _ = self.engine.unet_train_step(self.cfg, self.params, batch, fuser_scale=fuser_scale, grads=self.gbuf.views, checkpoint=self.checkpoint)
         self.gbuf.all_reduce(average=True)
         self.steps += 1
         for p, g, m, v in zip(self.pbuf.buckets, self.gbuf.buckets, self.m, self.v):

@@ -298,6 +298,8 @@ typedef struct gl_train_unet_in {
     const float* positive_embeddings;   /* [B][Ng][gr_in_dim] */
     const float* target;                /* [B][H*W][out_channels]: the noise */
     float fuser_scale;
+    int checkpoint;                     /* activation checkpointing per ResBlock / SpatialTransformer: 1 = keep block inputs and outputs only and
+                                           recompute a block's forward in its backward (same gradients bit for bit, a fraction of the memory) */
 } gl_train_unet_in;
 int gl_unet_train_step(gl_ctx* ctx, const gl_unet_config* cfg, const gl_train_unet_in* in, int n_params, const char* const* names,
                        const float* const* params, float* const* grads, float* eps_out, float* loss, gl_stream s);

@@ -169,7 +169,7 @@ TRAIN_WORKER = textwrap.dedent("""
 
     class Eng:      # what Engine.unet_train_step / op_adamw_step do, on the CPU: every rank sees other data, hence other gradients
         device = torch.device("cpu")
-        def unet_train_step(self, cfg, params, batch, fuser_scale=1.0, trainable=None, grads=None):
+        def unet_train_step(self, cfg, params, batch, fuser_scale=1.0, trainable=None, grads=None, checkpoint=False):
             g = torch.Generator().manual_seed(7 * batch["it"] + rank)
             for k in sorted(grads):
                 grads[k].copy_(torch.randn(grads[k].shape, generator=g))

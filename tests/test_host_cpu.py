@@ -647,7 +647,7 @@ def test_train_step_bookkeeping_on_flat_buckets():
         def __init__(self):
             self.adamw_calls = []
 
-        def unet_train_step(self, cfg, params, batch, fuser_scale=1.0, trainable=None, grads=None):
+        def unet_train_step(self, cfg, params, batch, fuser_scale=1.0, trainable=None, grads=None, checkpoint=False):
             assert set(grads) == set(trainable_names(params))
             for i, (k, gt) in enumerate(sorted(grads.items())):
                 gt.fill_(float(i + 1))

@@ -458,6 +458,13 @@ def test_unet_train_step_vs_reference(engine, case, n_train, n_gates):
     bad = {k: v for k, v in report.items() if v >= 1e-5}
     assert not bad, bad
     assert all(abs(v - 1) < 1e-3 for v in norms.values()), {k: v for k, v in norms.items() if abs(v - 1) >= 1e-3}
+    # activation checkpointing (every block's forward recomputed in its backward): the same numbers, bit for bit, in a fraction of the arena
+    hw_full = engine.arena_high_water()
+    loss_c, eps_c, grads_c = engine.unet_train_step(cfg, sd, batch, checkpoint=True)
+    assert torch.equal(loss_c, loss) and torch.equal(eps_c, eps)
+    assert all(torch.equal(grads_c[k], grads[k]) for k in grads), [k for k in grads if not torch.equal(grads_c[k], grads[k])][:5]
+    if case == "unet_full_train_step":
+        print("unet training step: arena high water", round(hw_full / 2 ** 30, 2), "GB; the engine's later checkpointed run is in train_bench.txt")
     # a frozen parameter's gradient cannot be asked for
     from gligen_amd import _lib
     with pytest.raises(_lib.GligenAmdError):

@@ -11,7 +11,7 @@ from gligen_amd import synthetic as syn
 from gligen_amd.engine import Engine
 
 
-def run(name, cfg, B, hw, reps, eng):
+def run(name, cfg, B, hw, reps, eng, checkpoint=False):
     model_shapes = None
     from ldm.modules.diffusionmodules.openaimodel import UNetModel
     m = UNetModel(**dict(cfg, grounding_tokenizer=syn.GROUNDING_TOKENIZERS["text"], inpaint_mode=False))
@@ -21,14 +21,15 @@ def run(name, cfg, B, hw, reps, eng):
     batch = dict(x=syn.make_latent(B, 4, hw, hw, seed=6), timesteps=torch.tensor([981, 441, 300, 77][:B]).float(), context=syn.make_context(B, seed=6),
                  boxes=b["boxes"], masks=b["masks"], positive_embeddings=b["text_embeddings"], target=syn.make_latent(B, 4, hw, hw, seed=7))
     grads = {k: torch.zeros_like(v) for k, v in sd.items() if ".fuser." in k or k.startswith("position_net.")}
-    eng.unet_train_step(cfg, sd, batch, grads=grads)     # warm-up (GEMM tile selection)
+    eng = Engine(0, arena_gb=160.0)                      # a fresh arena per line: its high water is this configuration's
+    eng.unet_train_step(cfg, sd, batch, grads=grads, checkpoint=checkpoint)     # warm-up (GEMM tile selection)
     torch.cuda.synchronize()
     t0 = time.time()
     for _ in range(reps):
-        loss, _, _ = eng.unet_train_step(cfg, sd, batch, grads=grads)
+        loss, _, _ = eng.unet_train_step(cfg, sd, batch, grads=grads, checkpoint=checkpoint)
     torch.cuda.synchronize()
     dt = (time.time() - t0) / reps
-    print(json.dumps(dict(config=name, B=B, latent=hw, s_per_iteration=round(dt, 4), loss=float(loss), arena_high_water_gb=round(eng.arena_high_water() / 2 ** 30, 2),
+    print(json.dumps(dict(config=name, B=B, latent=hw, checkpoint=bool(checkpoint), s_per_iteration=round(dt, 4), loss=float(loss), arena_high_water_gb=round(eng.arena_high_water() / 2 ** 30, 2),
                           trainable_values=sum(int(g.numel()) for g in grads.values()))), flush=True)
 
 
@@ -38,3 +39,5 @@ if __name__ == "__main__":
     run("shipped topology", syn.UNET_CFG, 1, 16, 2, eng)
     if "--full64" in sys.argv:
         run("shipped topology", syn.UNET_CFG, 1, 64, 1, eng)
+        run("shipped topology", syn.UNET_CFG, 1, 64, 1, eng, checkpoint=True)
+        run("shipped topology", syn.UNET_CFG, 4, 64, 1, eng, checkpoint=True)
