@@ -58,7 +58,7 @@ class PlmsArgs(C.Structure):
 class TrainUNetIn(C.Structure):   # = gl_train_unet_in
     _fields_ = [(n, C.c_int) for n in ("B", "H", "W", "ctx_T", "Ng")] + \
                [(n, C.c_void_p) for n in ("x", "timesteps", "context", "boxes", "masks", "positive_embeddings", "target")] + \
-               [("fuser_scale", C.c_float), ("checkpoint", C.c_int)]
+               [("fuser_scale", C.c_float)] + [(n, C.c_void_p) for n in ("text_masks", "image_masks", "image_embeddings")] + [("checkpoint", C.c_int)]
 
 
 class ProfRec(C.Structure):

@@ -595,8 +595,10 @@ int gl_unet_train_step(gl_ctx* ctx, const gl_unet_config* cfg, const gl_train_un
                        const float* const* params, float* const* grads, float* eps_out, float* loss, gl_stream s) {
     NEED(ctx);
     if (!cfg || !in || !names || !params || !grads || !loss || n_params <= 0) return gl::set_error(GL_ERR_ARG, "gl_unet_train_step: null pointer");
-    if (cfg->grounding_kind != 0 || cfg->fuser_kind != 0 || cfg->inpaint_mode || cfg->extra_channels)
-        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_unet_train_step: the training step is built for the text tokenizer with gatedSA fusers (no inpainting / downsampler channels)");
+    if (cfg->grounding_kind < 0 || cfg->grounding_kind > 1 || cfg->fuser_kind != 0 || cfg->inpaint_mode || cfg->extra_channels)
+        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_unet_train_step: the training step is built for the text and text+image tokenizers with gatedSA fusers (no inpainting / downsampler channels)");
+    if (cfg->grounding_kind == 1 && (!in->text_masks || !in->image_masks || !in->image_embeddings))
+        return gl::set_error(GL_ERR_ARG, "gl_unet_train_step: the text+image tokenizer needs text_masks, image_masks and image_embeddings");
     if (!in->x || !in->timesteps || !in->context || !in->boxes || !in->masks || !in->positive_embeddings || !in->target)
         return gl::set_error(GL_ERR_ARG, "gl_unet_train_step: null input");
     if (cfg->gr_in_dim != cfg->gr_out_dim || cfg->gr_out_dim != cfg->context_dim)
@@ -606,10 +608,10 @@ int gl_unet_train_step(gl_ctx* ctx, const gl_unet_config* cfg, const gl_train_un
     eng.arena().reset();
     gl::TrainUNetCfg c{};
     c.in_channels = cfg->in_channels; c.out_channels = cfg->out_channels; c.model_channels = cfg->model_channels; c.num_res_blocks = cfg->num_res_blocks;
-    c.num_heads = cfg->num_heads; c.context_dim = cfg->context_dim; c.gr_dim = cfg->gr_in_dim; c.n_mult = cfg->n_mult; c.n_attn = cfg->n_attn;
+    c.num_heads = cfg->num_heads; c.context_dim = cfg->context_dim; c.gr_dim = cfg->gr_in_dim; c.grounding_kind = cfg->grounding_kind; c.n_mult = cfg->n_mult; c.n_attn = cfg->n_attn;
     for (int i = 0; i < 8; ++i) { c.channel_mult[i] = cfg->channel_mult[i]; c.attention_resolutions[i] = cfg->attention_resolutions[i]; }
-    gl::TrainUNetIn u{in->B, in->H, in->W, in->ctx_T, in->Ng, in->x, in->timesteps, in->context, in->boxes, in->masks, in->positive_embeddings, in->target,
-                      in->fuser_scale, in->checkpoint};
+    gl::TrainUNetIn u{in->B, in->H, in->W, in->ctx_T, cfg->grounding_kind == 1 ? 2 * in->Ng : in->Ng, in->Ng, in->x, in->timesteps, in->context, in->boxes,
+                      in->masks, in->positive_embeddings, in->text_masks, in->image_masks, in->image_embeddings, in->target, in->fuser_scale, in->checkpoint};
     int rc = gl::unet_train_step(eng.arena(), eng.splitk_ws(), eng.splitk_ws_bytes(), c, u, n_params, names, params, grads, k_train_block_names, eps_out, loss, S(s));
     if (rc != GL_OK) throw GlError(rc, gl::last_error());
     GL_API_END

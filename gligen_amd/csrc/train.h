@@ -57,16 +57,21 @@ int resample_train_step(Arena& ar, float* ws, size_t ws_bytes, int mode, int B, 
 // ---- the whole training iteration for a UNetModel with the text grounding tokenizer and gatedSA fusers (openaimodel.py:237-464)
 struct TrainUNetCfg {
     int in_channels, out_channels, model_channels, num_res_blocks, num_heads, context_dim, gr_dim;
+    int grounding_kind;                 // 0 text, 1 text+image (two MLPs, tokens concatenated)
     int n_mult, channel_mult[8], n_attn, attention_resolutions[8];
 };
 struct TrainUNetIn {
-    int B, H, W, ctx_T, Ng;
+    int B, H, W, ctx_T, Ng;             // Ng: grounding tokens per sample = Ng_boxes (text) or 2 * Ng_boxes (text+image)
+    int Ng_boxes;
     const float* x;                     // [B][H*W][in_channels] pixel rows: the noised latent
     const float* timesteps;             // [B]
     const float* context;               // [B][ctx_T][context_dim]
-    const float* boxes;                 // [B][Ng][4]
-    const float* masks;                 // [B][Ng]
-    const float* positive_embeddings;   // [B][Ng][gr_dim]
+    const float* boxes;                 // [B][Ng_boxes][4]
+    const float* masks;                 // [B][Ng_boxes]
+    const float* positive_embeddings;   // [B][Ng_boxes][gr_dim]: the text embeddings
+    const float* text_masks;            // text+image only: [B][Ng_boxes] each
+    const float* image_masks;
+    const float* image_embeddings;      // text+image only: [B][Ng_boxes][gr_dim]
     const float* target;                // [B][H*W][out_channels]: the noise
     float fuser_scale;
     int checkpoint;                     // 1: keep only every block's input and output; a block's backward recomputes its forward (same gradients, bit for bit)

@@ -923,12 +923,15 @@ __global__ void timestep_embedding_kernel(const float* __restrict__ t, int dim, 
 }
 // PositionNet input rows (text_grounding_net.py:33-48): [pe * m + (1 - m) * null_positive | fourier(boxes) * m + (1 - m) * null_position],
 // fourier = for k in 0..7: sin(f_k x) (4 values), cos(f_k x) (4 values), f_k = 100^(k / 8)   (util.py:12-26)
-__global__ void posnet_input_kernel_f32(const float* __restrict__ boxes, const float* __restrict__ masks, const float* __restrict__ pe,
-                                        const float* __restrict__ null_pos_feat, const float* __restrict__ null_xyxy, int D, float* __restrict__ out) {
+// (emb_masks: the mask of the embedding half -- `masks` itself for the text tokenizer, text_masks / image_masks for text+image,
+// text_image_grounding_net.py:57-59)
+__global__ void posnet_input_kernel_f32(const float* __restrict__ boxes, const float* __restrict__ masks, const float* __restrict__ emb_masks,
+                                        const float* __restrict__ pe, const float* __restrict__ null_pos_feat, const float* __restrict__ null_xyxy, int D,
+                                        float* __restrict__ out) {
     const int row = blockIdx.x, W = D + 64;
-    const float m = masks[row];
     for (int c = threadIdx.x; c < W; c += blockDim.x) {
         float v, nul;
+        const float m = c < D ? emb_masks[row] : masks[row];
         if (c < D) { v = pe[(size_t)row * D + c]; nul = null_pos_feat[c]; }
         else {
             const int j = c - D, k = j >> 3, r = j & 7;
@@ -940,12 +943,13 @@ __global__ void posnet_input_kernel_f32(const float* __restrict__ boxes, const f
     }
 }
 // out[c] = sum_rows (1 - m[row]) g[row][c0 + c]   (the gradient of a learnable null embedding)
-__global__ void null_grad_kernel(const float* __restrict__ g, const float* __restrict__ masks, int R, int ld, int c0, int n, float* __restrict__ out) {
+__global__ void null_grad_kernel(const float* __restrict__ g, const float* __restrict__ masks, int R, int ld, int c0, int n, float* __restrict__ out,
+                                 int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     float s = 0.f;
     for (int r = 0; r < R; ++r) s += (1.f - masks[r]) * g[(size_t)r * ld + c0 + c];
-    out[c] = s;
+    out[c] = accumulate ? out[c] + s : s;
 }
 __global__ void silu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, size_t n, float* __restrict__ dx) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1026,18 +1030,34 @@ int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& c
         if (mc % 64 || KD % 64 || cfg.gr_dim % 64 || B < 1) throw GlError(GL_ERR_ARG, "unet_train_step: model_channels / context_dim / grounding dim must be multiples of 64");
         auto in_attn = [&](int ds) { for (int i = 0; i < cfg.n_attn; ++i) if (cfg.attention_resolutions[i] == ds) return true; return false; };
 
-        // ---- grounding tokens (trainable)
-        const int MR = B * Ng, PW = cfg.gr_dim + 64;
-        float* pcat = c.f32((size_t)MR * PW);
-        hipLaunchKernelGGL(posnet_input_kernel_f32, dim3(MR), dim3(256), 0, s, in.boxes, in.masks, in.positive_embeddings,
-                           nm.w("position_net.null_positive_feature"), nm.w("position_net.null_position_feature"), cfg.gr_dim, pcat);
-        float* pl0 = c.lin_fwd(pcat, MR, PW, nm.w("position_net.linears.0.weight"), nm.w("position_net.linears.0.bias"), 512);
-        float* pa0 = c.f32((size_t)MR * 512);
-        hipLaunchKernelGGL(silu_kernel, Ctx::g1((size_t)MR * 512), dim3(256), 0, s, (const float*)pl0, (size_t)MR * 512, pa0);
-        float* pl1 = c.lin_fwd(pa0, MR, 512, nm.w("position_net.linears.2.weight"), nm.w("position_net.linears.2.bias"), 512);
-        float* pa1 = c.f32((size_t)MR * 512);
-        hipLaunchKernelGGL(silu_kernel, Ctx::g1((size_t)MR * 512), dim3(256), 0, s, (const float*)pl1, (size_t)MR * 512, pa1);
-        float* objs = c.lin_fwd(pa1, MR, 512, nm.w("position_net.linears.4.weight"), nm.w("position_net.linears.4.bias"), KD);
+        // ---- grounding tokens (trainable): one MLP over [embedding | fourier(boxes)] rows for the text tokenizer, two (text, image) whose
+        // tokens are concatenated along the token axis for text+image (text_grounding_net.py:30-52, text_image_grounding_net.py:41-70)
+        const int NB = in.Ng_boxes, MRB = B * NB, PW = cfg.gr_dim + 64, NBR = cfg.grounding_kind == 1 ? 2 : 1;
+        if (Ng != NB * NBR) throw GlError(GL_ERR_ARG, "unet_train_step: Ng must be the box count (text) or twice it (text+image)");
+        const int MR = B * Ng;
+        struct PosBranch { std::string lin, null_emb; const float* emb; const float* emb_mask; float *pcat, *l0, *a0, *l1, *a1, *out; };
+        PosBranch pb[2] = {{cfg.grounding_kind == 1 ? "position_net.linears_text" : "position_net.linears",
+                            cfg.grounding_kind == 1 ? "position_net.null_text_feature" : "position_net.null_positive_feature", in.positive_embeddings,
+                            cfg.grounding_kind == 1 ? in.text_masks : in.masks, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
+                           {"position_net.linears_image", "position_net.null_image_feature", in.image_embeddings, in.image_masks, nullptr, nullptr, nullptr, nullptr,
+                            nullptr, nullptr}};
+        float* objs = NBR == 1 ? nullptr : c.f32((size_t)MR * KD);
+        for (int r = 0; r < NBR; ++r) {
+            PosBranch& p = pb[r];
+            if (!p.emb || !p.emb_mask) throw GlError(GL_ERR_ARG, "unet_train_step: null grounding input");
+            p.pcat = c.f32((size_t)MRB * PW);
+            hipLaunchKernelGGL(posnet_input_kernel_f32, dim3(MRB), dim3(256), 0, s, in.boxes, in.masks, p.emb_mask, p.emb, nm.w(p.null_emb),
+                               nm.w("position_net.null_position_feature"), cfg.gr_dim, p.pcat);
+            p.l0 = c.lin_fwd(p.pcat, MRB, PW, nm.w(p.lin + ".0.weight"), nm.w(p.lin + ".0.bias"), 512);
+            p.a0 = c.f32((size_t)MRB * 512);
+            hipLaunchKernelGGL(silu_kernel, Ctx::g1((size_t)MRB * 512), dim3(256), 0, s, (const float*)p.l0, (size_t)MRB * 512, p.a0);
+            p.l1 = c.lin_fwd(p.a0, MRB, 512, nm.w(p.lin + ".2.weight"), nm.w(p.lin + ".2.bias"), 512);
+            p.a1 = c.f32((size_t)MRB * 512);
+            hipLaunchKernelGGL(silu_kernel, Ctx::g1((size_t)MRB * 512), dim3(256), 0, s, (const float*)p.l1, (size_t)MRB * 512, p.a1);
+            p.out = c.lin_fwd(p.a1, MRB, 512, nm.w(p.lin + ".4.weight"), nm.w(p.lin + ".4.bias"), KD);
+            if (NBR == 1) objs = p.out;
+            else c.put_rows(objs, B, Ng, r * NB, p.out, NB, KD);      // objs = cat([objs_text, objs_image], dim = 1)
+        }
         // ---- time embedding (frozen): silu(emb) is what every ResBlock's emb_layers starts with
         float* te = c.f32((size_t)B * mc);
         hipLaunchKernelGGL(timestep_embedding_kernel, dim3(B), dim3(256), 0, s, in.timesteps, mc, te);
@@ -1245,21 +1265,26 @@ int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& c
                 g = resample_backward(c, 1, B, l.H, l.W, l.Cin, l.P[0], g);
             }
         }
-        // ---- position_net backward (text_grounding_net.py:17-27: Linear, SiLU, Linear, SiLU, Linear; the two learnable null embeddings)
-        c.lin_wgrad(g_objs, pa1, MR, KD, 512, nm.g("position_net.linears.4.weight"), nm.g("position_net.linears.4.bias"));
-        float* g_a1 = c.lin_dgrad(g_objs, MR, KD, nm.w("position_net.linears.4.weight"), 512);
-        float* g_l1 = c.f32((size_t)MR * 512);
-        hipLaunchKernelGGL(silu_bwd_kernel, Ctx::g1((size_t)MR * 512), dim3(256), 0, s, (const float*)g_a1, (const float*)pl1, (size_t)MR * 512, g_l1);
-        c.lin_wgrad(g_l1, pa0, MR, 512, 512, nm.g("position_net.linears.2.weight"), nm.g("position_net.linears.2.bias"));
-        float* g_a0 = c.lin_dgrad(g_l1, MR, 512, nm.w("position_net.linears.2.weight"), 512);
-        float* g_l0 = c.f32((size_t)MR * 512);
-        hipLaunchKernelGGL(silu_bwd_kernel, Ctx::g1((size_t)MR * 512), dim3(256), 0, s, (const float*)g_a0, (const float*)pl0, (size_t)MR * 512, g_l0);
-        c.lin_wgrad(g_l0, pcat, MR, 512, PW, nm.g("position_net.linears.0.weight"), nm.g("position_net.linears.0.bias"));
-        float* g_cat = c.lin_dgrad(g_l0, MR, 512, nm.w("position_net.linears.0.weight"), PW);
-        if (float* gp = nm.g("position_net.null_positive_feature"))
-            hipLaunchKernelGGL(null_grad_kernel, Ctx::g1(cfg.gr_dim), dim3(256), 0, s, (const float*)g_cat, in.masks, MR, PW, 0, cfg.gr_dim, gp);
-        if (float* gp = nm.g("position_net.null_position_feature"))
-            hipLaunchKernelGGL(null_grad_kernel, Ctx::g1(64), dim3(256), 0, s, (const float*)g_cat, in.masks, MR, PW, cfg.gr_dim, 64, gp);
+        // ---- position_net backward (Linear, SiLU, Linear, SiLU, Linear per branch; the learnable null embeddings: the position one is
+        // shared by the branches)
+        for (int r = 0; r < NBR; ++r) {
+            const PosBranch& p = pb[r];
+            const float* go = NBR == 1 ? g_objs : c.slice_rows(g_objs, B, Ng, r * NB, NB, KD);
+            c.lin_wgrad(go, p.a1, MRB, KD, 512, nm.g(p.lin + ".4.weight"), nm.g(p.lin + ".4.bias"));
+            float* g_a1 = c.lin_dgrad(go, MRB, KD, nm.w(p.lin + ".4.weight"), 512);
+            float* g_l1 = c.f32((size_t)MRB * 512);
+            hipLaunchKernelGGL(silu_bwd_kernel, Ctx::g1((size_t)MRB * 512), dim3(256), 0, s, (const float*)g_a1, (const float*)p.l1, (size_t)MRB * 512, g_l1);
+            c.lin_wgrad(g_l1, p.a0, MRB, 512, 512, nm.g(p.lin + ".2.weight"), nm.g(p.lin + ".2.bias"));
+            float* g_a0 = c.lin_dgrad(g_l1, MRB, 512, nm.w(p.lin + ".2.weight"), 512);
+            float* g_l0 = c.f32((size_t)MRB * 512);
+            hipLaunchKernelGGL(silu_bwd_kernel, Ctx::g1((size_t)MRB * 512), dim3(256), 0, s, (const float*)g_a0, (const float*)p.l0, (size_t)MRB * 512, g_l0);
+            c.lin_wgrad(g_l0, p.pcat, MRB, 512, PW, nm.g(p.lin + ".0.weight"), nm.g(p.lin + ".0.bias"));
+            float* g_cat = c.lin_dgrad(g_l0, MRB, 512, nm.w(p.lin + ".0.weight"), PW);
+            if (float* gp = nm.g(p.null_emb))
+                hipLaunchKernelGGL(null_grad_kernel, Ctx::g1(cfg.gr_dim), dim3(256), 0, s, (const float*)g_cat, p.emb_mask, MRB, PW, 0, cfg.gr_dim, gp, 0);
+            if (float* gp = nm.g("position_net.null_position_feature"))
+                hipLaunchKernelGGL(null_grad_kernel, Ctx::g1(64), dim3(256), 0, s, (const float*)g_cat, in.masks, MRB, PW, cfg.gr_dim, 64, gp, r);
+        }
         c.hip(hipGetLastError(), "training step kernel launch");
     } catch (const GlError& e) {
         return set_error(e.code, "%s", e.what());

@@ -406,7 +406,7 @@ class Engine:
         """One training iteration of the reference (trainer.py:353-392: model(input), mse_loss(model_output, noise), backward) on the
         device (gl_unet_train_step). cfg: UNetModel kwargs (text tokenizer, gatedSA); state_dict: the model's parameters (fp32, on this
         device: they are used in place); batch: x [B, 4, H, W] (noised latent), timesteps [B], context [B, 77, 768], boxes, masks,
-        positive_embeddings, target [B, 4, H, W] (the noise). Returns (loss, eps [B, 4, H, W], grads) with grads over the reference's
+        positive_embeddings (or, for the text+image tokenizer, text_embeddings, image_embeddings, text_masks, image_masks), target [B, 4, H, W] (the noise). Returns (loss, eps [B, 4, H, W], grads) with grads over the reference's
         trainable set (trainer.py:217-245: '*.fuser.*' and 'position_net.*' keys) or the `trainable` names given; `grads`: buffers to
         write into instead of fresh ones (every entry is overwritten); `checkpoint`: keep only block inputs / outputs and recompute each block's
         forward in its backward (the same gradients bit for bit, a fraction of the arena)."""
@@ -420,7 +420,8 @@ class Engine:
         c.n_attn = len(cfg["attention_resolutions"])
         for i, v in enumerate(cfg["attention_resolutions"]):
             c.attention_resolutions[i] = int(v)
-        c.grounding_kind, c.fuser_kind = 0, 0
+        ti = "image_embeddings" in batch        # the text+image tokenizer (text_image_grounding_net.py); else the text tokenizer
+        c.grounding_kind, c.fuser_kind = (1 if ti else 0), 0
         c.gr_in_dim = c.gr_out_dim = 768
         names = [k for k in state_dict.keys()]
         params = [_f32(state_dict[k], dev) for k in names]
@@ -435,10 +436,13 @@ class Engine:
         B, Cx, H, W = x.shape
         rows = lambda t: _f32(t, dev).permute(0, 2, 3, 1).reshape(B, H * W, t.shape[1]).contiguous()
         keep = dict(x=rows(x), t=_f32(batch["timesteps"], dev), ctx=_f32(batch["context"], dev), boxes=_f32(batch["boxes"], dev),
-                    masks=_f32(batch["masks"], dev), pe=_f32(batch["positive_embeddings"], dev), target=rows(target))
+                    masks=_f32(batch["masks"], dev), pe=_f32(batch["text_embeddings" if ti else "positive_embeddings"], dev), target=rows(target))
+        if ti:
+            keep.update(tm=_f32(batch["text_masks"], dev), im=_f32(batch["image_masks"], dev), ie=_f32(batch["image_embeddings"], dev))
         u = _lib.TrainUNetIn(int(B), int(H), int(W), int(keep["ctx"].shape[1]), int(keep["boxes"].shape[1]), keep["x"].data_ptr(), keep["t"].data_ptr(),
                              keep["ctx"].data_ptr(), keep["boxes"].data_ptr(), keep["masks"].data_ptr(), keep["pe"].data_ptr(), keep["target"].data_ptr(),
-                             float(fuser_scale), int(bool(checkpoint)))
+                             float(fuser_scale), keep["tm"].data_ptr() if ti else None, keep["im"].data_ptr() if ti else None,
+                             keep["ie"].data_ptr() if ti else None, int(bool(checkpoint)))
         n = len(names)
         narr = (C.c_char_p * n)(*[k.encode() for k in names])
         parr = (C.c_void_p * n)(*[p.data_ptr() for p in params])

@@ -400,6 +400,34 @@ def c2_case(name="c2_end_to_end", S=50, hw=64):
     print(f"{name}: z std {z.std():.4f} img std {img.std():.4f} [{time.time() - t0:.1f}s]")
 
 
+def c2_b4_case(name="c2_end_to_end_b4", S=50, hw=64, B=4):
+    """BASELINE config C2 at the batch the metric is quoted on (B = 4 prompts with different boxes / embeddings / contexts / noise):
+    50 PLMS steps, CFG 7.5, gate on at every step, fp32 on the CPU through the reference's PLMSSampler + UNetModel +
+    AutoencoderKL.decode. Stored: the final latents and the decoded images average-pooled 4 x 4 (the full-resolution decode is
+    pinned by the B = 1 case)."""
+    t0 = time.time()
+    from functools import partial
+    diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000)
+    model = build_unet(syn.UNET_CFG, "text")
+    ae = AutoencoderKL(ddconfig=syn.VAE_DDCONFIG, embed_dim=4, scale_factor=0.18215).eval()
+    syn.fill_module_(ae, 4321)
+    batch = syn.make_batch("text", B, n_valid=8, seed=21)
+    g = model.grounding_tokenizer_input.prepare(batch)
+    x = syn.make_latent(B, 4, hw, hw, seed=26)
+    ctx, uc = syn.make_context(B, seed=21), syn.make_context(1, seed=9).expand(B, -1, -1).contiguous()
+    sampler = PLMSSampler(diffusion, model, alpha_generator_func=partial(ref_alpha_generator, type=None), set_alpha_scale=set_alpha_scale)
+    inp = dict(x=x.clone(), timesteps=None, context=ctx, grounding_input=g, inpainting_extra_input=None, grounding_extra_input=None)
+    with torch.no_grad():
+        z = sampler.sample(S=S, shape=tuple(x.shape), input=inp, uc=uc, guidance_scale=7.5)
+        t_s = time.time() - t0
+        img = torch.nn.functional.avg_pool2d(ae.decode(z), 4)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), z=z.numpy(), img_pool4=img.numpy().astype(np.float16),
+                        meta=json.dumps(dict(S=S, hw=hw, alpha_type=None, guidance_scale=7.5, B=B, n_valid=8, img_stored="float16, avg_pool2d(4)",
+                                             ref_cpu_seconds=round(time.time() - t0, 1), ref_sampler_seconds=round(t_s, 1),
+                                             cpu_threads=torch.get_num_threads())))
+    print(f"{name}: z std {z.std():.4f} img std {img.std():.4f} [{time.time() - t0:.1f}s]")
+
+
 def c1_case(name="c1_end_to_end", S=20, hw=32):
     """BASELINE config C1: box+text, 1 box, 256x256, 20 PLMS steps, CFG 7.5, B=1, fp32 on the CPU through the reference's
     PLMSSampler + UNetModel + AutoencoderKL.decode (gligen_inference.py:343-446 with steps / image_size overridden), the first
@@ -593,14 +621,17 @@ def _grad_sample(gq, n=4096):
     return (sub / sc).astype(np.float16), sc, float(np.sqrt((flat.astype(np.float64) ** 2).sum()))
 
 
-def unet_backward_case(name="unet_small_train_step", B=2, hw=16, n_valid=3, base_cfg=None):
+def unet_backward_case(name="unet_small_train_step", B=2, hw=16, n_valid=3, base_cfg=None, kind="text"):
     """One whole training iteration of the reference on the small UNet (trainer.py:353-392): model(input) on a noised latent,
     mse_loss(model_output, noise), loss.backward(), with requires_grad exactly as the trainer sets it (trainer.py:217-245: every
     fuser.* parameter and position_net). Stored: loss, eps, and per trainable tensor a strided sample of its gradient + its norm
     (34 M gradient values as a whole would be 70 MB)."""
     cfg = dict(base_cfg or syn.UNET_CFG_SMALL, use_checkpoint=False)
-    model = build_unet(cfg, "text")
-    batch = syn.make_batch("text", B, n_valid=n_valid, seed=5)
+    model = build_unet(cfg, kind)
+    batch = syn.make_batch(kind, B, n_valid=n_valid, seed=5)
+    if kind == "text_image":     # not every box has both modalities (text_image_grounding_net.py:57-58 masks them separately)
+        batch["text_masks"][:, 1] = 0
+        batch["image_masks"][:, 0] = 0
     g = model.grounding_tokenizer_input.prepare(batch)
     x = syn.make_latent(B, 4, hw, hw, seed=6)
     ctx = syn.make_context(B, seed=6)
@@ -622,7 +653,7 @@ def unet_backward_case(name="unet_small_train_step", B=2, hw=16, n_valid=3, base
             out["grad." + k] = sub
             out["scale." + k] = np.float64(sc)
             out["norm." + k] = np.float64(nrm)
-    meta = dict(cfg=cfg, B=B, hw=hw, n_valid=n_valid, weight_seed=1234, n_trainable=len(trainable), sample=4096)
+    meta = dict(cfg=cfg, B=B, hw=hw, n_valid=n_valid, weight_seed=1234, n_trainable=len(trainable), sample=4096, kind=kind)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), meta=json.dumps(meta), **out)
     print(f"{name}: loss {loss.item():.6f}, {len(trainable)} trainable tensors, {sum(p.numel() for k, p in model.named_parameters() if k in trainable) / 1e6:.1f} M gradient values")
     return {k: list(v.shape) for k, v in model.state_dict().items()}
@@ -696,6 +727,7 @@ CASES = {
     "unet_full_64_text_image": lambda: unet_pair_case("unet_full_64_text_image", "text_image", 1, 64),
     "unet_full_64_keypoint": lambda: unet_pair_case("unet_full_64_keypoint", "keypoint", 1, 64),
     "c1_end_to_end": c1_case,
+    "c2_end_to_end_b4": c2_b4_case,
     # spatial-map modalities
     "unet_small_canny": lambda: spatial_case("unet_small_canny", "canny"),
     "unet_small_hed": lambda: spatial_case("unet_small_hed", "hed", B=1, hw=64),  # the hed downsampler always resizes to 64 x 64
@@ -714,6 +746,7 @@ CASES = {
     "st_backward_gatedsa": st_backward_case,
     "unet_small_train_step": unet_backward_case,
     "unet_small_train_2steps": unet_train_2steps_case,
+    "unet_small_ti_train_step": lambda: unet_backward_case("unet_small_ti_train_step", kind="text_image"),
     # the shipped topology (4 levels, 16 fusers, head dims 40 / 80 / 160; 966 tensors) at a 16 x 16 latent
     "unet_full_train_step": lambda: unet_backward_case("unet_full_train_step", B=1, hw=16, base_cfg=syn.UNET_CFG),
     "resample_backward": resample_backward_case,

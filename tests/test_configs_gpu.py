@@ -174,6 +174,46 @@ def test_c2_end_to_end_vs_reference(full_models, monkeypatch):
     ae._drop_engine()
 
 
+def test_c2_end_to_end_b4_vs_reference(full_models, monkeypatch):
+    """BASELINE config C2 at the batch the metric is quoted on: 4 prompts (different boxes, embeddings, contexts and noise), 512x512,
+    50 PLMS steps, CFG 7.5, gate on at every step, decode -- against the reference's own sampler + UNet + decoder run on the CPU
+    (oracle/make_golden.py:c2_b4_case, ~1 h of reference CPU time). Per image: the final latent, and the decoded image average-pooled
+    4 x 4 (the golden stores it that way; the full-resolution decode is pinned by the B = 1 case above)."""
+    dev = _dev()
+    import gligen_inference as gi
+    from ldm.models.diffusion.ldm import LatentDiffusion
+    g = load_golden("c2_end_to_end_b4")
+    meta = g["meta"]
+    hw, S, B = meta["hw"], meta["S"], meta["B"]
+    monkeypatch.setattr(gi, "device", dev)
+    model = full_models("text")
+    ae = build_product_vae(syn.VAE_DDCONFIG, device=dev)
+    diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000).to(dev)
+    batch = _to(syn.make_batch("text", B, n_valid=meta["n_valid"], seed=21), dev)
+    ctx = syn.make_context(B, seed=21).to(dev)
+    uc = syn.make_context(1, seed=9).expand(B, -1, -1).contiguous().to(dev)
+    captured = {}
+    real_decode = type(ae).decode
+
+    def decode(self, z):
+        captured["z"] = z.clone()
+        return real_decode(self, z)
+    monkeypatch.setattr(type(ae), "decode", decode)
+    img = gi.generate(model, ae, diffusion, batch, ctx, uc, steps=S, guidance_scale=meta["guidance_scale"], alpha_type=meta["alpha_type"],
+                      starting_noise=syn.make_latent(B, 4, hw, hw, seed=26).to(dev))
+    z_ref, img_ref = g["z"], g["img_pool4"].astype(np.float32)
+    pooled = torch.nn.functional.avg_pool2d(img.float(), 4).cpu().numpy()
+    assert captured["z"].shape == tuple(z_ref.shape) == (B, 4, hw, hw) and pooled.shape == img_ref.shape
+    per = []
+    for i in range(B):
+        per.append(dict(z_rel_mse=mse(captured["z"][i], z_ref[i]) / float(z_ref[i].var()), img_rel_mse=mse(pooled[i], img_ref[i]) / float(img_ref[i].var())))
+    REPORT["c2_end_to_end_b4"] = dict(per_image=per, ref_cpu_seconds=meta["ref_cpu_seconds"])
+    assert all(p["z_rel_mse"] < 5e-3 and p["img_rel_mse"] < 1e-2 for p in per), per
+    # the four images are four different images (no cross-talk, nothing broadcast)
+    assert all(mse(z_ref[0], z_ref[i]) / float(z_ref[0].var()) > 0.5 for i in range(1, B))
+    ae._drop_engine()
+
+
 @pytest.mark.parametrize("name", ["plms_unet_small_canny", "ddim_unet_small_hed"])
 def test_spatial_sampler_vs_reference(name, tmp_path, monkeypatch):
     """The samplers on a spatial-map model (GroundingDownsampler -> 4 + k channel first conv, ConvNeXt tokens): CFG pairs share
