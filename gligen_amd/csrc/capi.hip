@@ -595,11 +595,11 @@ int gl_unet_train_step(gl_ctx* ctx, const gl_unet_config* cfg, const gl_train_un
                        const float* const* params, float* const* grads, float* eps_out, float* loss, gl_stream s) {
     NEED(ctx);
     if (!cfg || !in || !names || !params || !grads || !loss || n_params <= 0) return gl::set_error(GL_ERR_ARG, "gl_unet_train_step: null pointer");
-    if (cfg->grounding_kind < 0 || cfg->grounding_kind > 1 || cfg->fuser_kind != 0 || cfg->inpaint_mode || cfg->extra_channels)
-        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_unet_train_step: the training step is built for the text and text+image tokenizers with gatedSA fusers (no inpainting / downsampler channels)");
+    if (cfg->grounding_kind < 0 || cfg->grounding_kind > 2 || cfg->fuser_kind != 0 || cfg->inpaint_mode || cfg->extra_channels)
+        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_unet_train_step: the training step is built for the text, text+image and keypoint tokenizers with gatedSA fusers (no inpainting / downsampler channels)");
     if (cfg->grounding_kind == 1 && (!in->text_masks || !in->image_masks || !in->image_embeddings))
         return gl::set_error(GL_ERR_ARG, "gl_unet_train_step: the text+image tokenizer needs text_masks, image_masks and image_embeddings");
-    if (!in->x || !in->timesteps || !in->context || !in->boxes || !in->masks || !in->positive_embeddings || !in->target)
+    if (!in->x || !in->timesteps || !in->context || !in->boxes || !in->masks || (!in->positive_embeddings && cfg->grounding_kind != 2) || !in->target)
         return gl::set_error(GL_ERR_ARG, "gl_unet_train_step: null input");
     if (cfg->gr_in_dim != cfg->gr_out_dim || cfg->gr_out_dim != cfg->context_dim)
         return gl::set_error(GL_ERR_UNSUPPORTED, "gl_unet_train_step: grounding in / out dim and context_dim are expected to be equal (768 in every shipped config)");

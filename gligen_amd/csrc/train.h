@@ -57,7 +57,7 @@ int resample_train_step(Arena& ar, float* ws, size_t ws_bytes, int mode, int B, 
 // ---- the whole training iteration for a UNetModel with the text grounding tokenizer and gatedSA fusers (openaimodel.py:237-464)
 struct TrainUNetCfg {
     int in_channels, out_channels, model_channels, num_res_blocks, num_heads, context_dim, gr_dim;
-    int grounding_kind;                 // 0 text, 1 text+image (two MLPs, tokens concatenated)
+    int grounding_kind;                 // 0 text, 1 text+image (two MLPs, tokens concatenated), 2 keypoint (points in `boxes`, 17 tokens per person)
     int n_mult, channel_mult[8], n_attn, attention_resolutions[8];
 };
 struct TrainUNetIn {

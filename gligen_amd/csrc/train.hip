@@ -924,23 +924,45 @@ __global__ void timestep_embedding_kernel(const float* __restrict__ t, int dim, 
 // PositionNet input rows (text_grounding_net.py:33-48): [pe * m + (1 - m) * null_positive | fourier(boxes) * m + (1 - m) * null_position],
 // fourier = for k in 0..7: sin(f_k x) (4 values), cos(f_k x) (4 values), f_k = 100^(k / 8)   (util.py:12-26)
 // (emb_masks: the mask of the embedding half -- `masks` itself for the text tokenizer, text_masks / image_masks for text+image,
-// text_image_grounding_net.py:57-59)
-__global__ void posnet_input_kernel_f32(const float* __restrict__ boxes, const float* __restrict__ masks, const float* __restrict__ emb_masks,
-                                        const float* __restrict__ pe, const float* __restrict__ null_pos_feat, const float* __restrict__ null_xyxy, int D,
-                                        float* __restrict__ out) {
-    const int row = blockIdx.x, W = D + 64;
+// text_image_grounding_net.py:57-59). Keypoint tokenizer (keypoint_grounding_net.py:34-58): pe null, the embedding of token t of a sample
+// is person_emb[t / 17] + keypoint_emb[t % 17], coords = 2 (x, y). Columns [D + 16 ncoord, W) are zero padding up to the GEMM's K step.
+__global__ void posnet_input_kernel_f32(const float* __restrict__ coords, int ncoord, const float* __restrict__ masks, const float* __restrict__ emb_masks,
+                                        const float* __restrict__ pe, const float* __restrict__ person_emb, const float* __restrict__ keypoint_emb, int tokens,
+                                        const float* __restrict__ null_pos_feat, const float* __restrict__ null_xyxy, int D, int W, float* __restrict__ out) {
+    const int row = blockIdx.x, PD = 16 * ncoord;
+    const int t = row % tokens;
     for (int c = threadIdx.x; c < W; c += blockDim.x) {
         float v, nul;
+        if (c >= D + PD) { out[(size_t)row * W + c] = 0.f; continue; }
         const float m = c < D ? emb_masks[row] : masks[row];
-        if (c < D) { v = pe[(size_t)row * D + c]; nul = null_pos_feat[c]; }
-        else {
-            const int j = c - D, k = j >> 3, r = j & 7;
-            const float a = powf(100.f, (float)k / 8.f) * boxes[(size_t)row * 4 + (r & 3)];
-            v = r < 4 ? sinf(a) : cosf(a);
+        if (c < D) {
+            v = pe ? pe[(size_t)row * D + c] : person_emb[(size_t)(t / 17) * D + c] + keypoint_emb[(size_t)(t % 17) * D + c];
+            nul = null_pos_feat[c];
+        } else {
+            const int j = c - D, k = j / (2 * ncoord), r = j % (2 * ncoord);
+            const float a = powf(100.f, (float)k / 8.f) * coords[(size_t)row * ncoord + (r % ncoord)];
+            v = r < ncoord ? sinf(a) : cosf(a);
             nul = null_xyxy[j];
         }
         out[(size_t)row * W + c] = v * m + (1.f - m) * nul;
     }
+}
+// dst [N][Kp] = src [N][K] zero-padded on the right
+__global__ void pad_cols_kernel(const float* __restrict__ src, int K, int Kp, size_t n, float* __restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % Kp);
+    dst[i] = c < K ? src[(i / Kp) * K + c] : 0.f;
+}
+// keypoint tokenizer tables: d person_emb[p][c] = sum_{b, k} m g[b][17 p + k][c] (by = 17, inner = 17), d keypoint_emb[k][c] = sum_{b, p} m g[b][17 p + k][c]
+__global__ void table_grad_kernel(const float* __restrict__ g, const float* __restrict__ masks, int B, int tokens, int ld, int D, int person, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, e = blockIdx.y;
+    if (c >= D) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < tokens; ++t)
+            if ((person ? t / 17 : t % 17) == e) s += masks[b * tokens + t] * g[((size_t)b * tokens + t) * ld + c];
+    out[(size_t)e * D + c] = s;
 }
 // out[c] = sum_rows (1 - m[row]) g[row][c0 + c]   (the gradient of a learnable null embedding)
 __global__ void null_grad_kernel(const float* __restrict__ g, const float* __restrict__ masks, int R, int ld, int c0, int n, float* __restrict__ out,
@@ -1030,25 +1052,36 @@ int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& c
         if (mc % 64 || KD % 64 || cfg.gr_dim % 64 || B < 1) throw GlError(GL_ERR_ARG, "unet_train_step: model_channels / context_dim / grounding dim must be multiples of 64");
         auto in_attn = [&](int ds) { for (int i = 0; i < cfg.n_attn; ++i) if (cfg.attention_resolutions[i] == ds) return true; return false; };
 
-        // ---- grounding tokens (trainable): one MLP over [embedding | fourier(boxes)] rows for the text tokenizer, two (text, image) whose
-        // tokens are concatenated along the token axis for text+image (text_grounding_net.py:30-52, text_image_grounding_net.py:41-70)
-        const int NB = in.Ng_boxes, MRB = B * NB, PW = cfg.gr_dim + 64, NBR = cfg.grounding_kind == 1 ? 2 : 1;
-        if (Ng != NB * NBR) throw GlError(GL_ERR_ARG, "unet_train_step: Ng must be the box count (text) or twice it (text+image)");
+        // ---- grounding tokens (trainable): one MLP over [embedding | fourier(coords)] rows for the text tokenizer (boxes, 4 coords) and the
+        // keypoint tokenizer (points, 2 coords; the embedding is person + keypoint table rows), two MLPs (text, image) whose tokens are
+        // concatenated along the token axis for text+image (text_grounding_net.py:30-52, text_image_grounding_net.py:41-70,
+        // keypoint_grounding_net.py:34-58)
+        const int GK = cfg.grounding_kind, NB = in.Ng_boxes, MRB = B * NB, NC = GK == 2 ? 2 : 4, PWr = cfg.gr_dim + 16 * NC, PW = round_up(PWr, 64);
+        const int NBR = GK == 1 ? 2 : 1;
+        if (Ng != NB * NBR || (GK == 2 && NB % 17)) throw GlError(GL_ERR_ARG, "unet_train_step: Ng must be the box count (text), twice it (text+image), 17 per person (keypoint)");
         const int MR = B * Ng;
-        struct PosBranch { std::string lin, null_emb; const float* emb; const float* emb_mask; float *pcat, *l0, *a0, *l1, *a1, *out; };
-        PosBranch pb[2] = {{cfg.grounding_kind == 1 ? "position_net.linears_text" : "position_net.linears",
-                            cfg.grounding_kind == 1 ? "position_net.null_text_feature" : "position_net.null_positive_feature", in.positive_embeddings,
-                            cfg.grounding_kind == 1 ? in.text_masks : in.masks, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
+        const std::string null_pos = GK == 2 ? "position_net.null_xy_feature" : "position_net.null_position_feature";
+        struct PosBranch { std::string lin, null_emb; const float* emb; const float* emb_mask; float *pcat, *l0, *a0, *l1, *a1, *out, *w0p; };
+        PosBranch pb[2] = {{GK == 1 ? "position_net.linears_text" : "position_net.linears",
+                            GK == 1 ? "position_net.null_text_feature" : GK == 2 ? "position_net.null_person_feature" : "position_net.null_positive_feature",
+                            GK == 2 ? nullptr : in.positive_embeddings, GK == 1 ? in.text_masks : in.masks, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
                            {"position_net.linears_image", "position_net.null_image_feature", in.image_embeddings, in.image_masks, nullptr, nullptr, nullptr, nullptr,
-                            nullptr, nullptr}};
+                            nullptr, nullptr, nullptr}};
         float* objs = NBR == 1 ? nullptr : c.f32((size_t)MR * KD);
         for (int r = 0; r < NBR; ++r) {
             PosBranch& p = pb[r];
-            if (!p.emb || !p.emb_mask) throw GlError(GL_ERR_ARG, "unet_train_step: null grounding input");
+            if ((!p.emb && GK != 2) || !p.emb_mask) throw GlError(GL_ERR_ARG, "unet_train_step: null grounding input");
             p.pcat = c.f32((size_t)MRB * PW);
-            hipLaunchKernelGGL(posnet_input_kernel_f32, dim3(MRB), dim3(256), 0, s, in.boxes, in.masks, p.emb_mask, p.emb, nm.w(p.null_emb),
-                               nm.w("position_net.null_position_feature"), cfg.gr_dim, p.pcat);
-            p.l0 = c.lin_fwd(p.pcat, MRB, PW, nm.w(p.lin + ".0.weight"), nm.w(p.lin + ".0.bias"), 512);
+            hipLaunchKernelGGL(posnet_input_kernel_f32, dim3(MRB), dim3(256), 0, s, in.boxes, NC, in.masks, p.emb_mask, p.emb,
+                               GK == 2 ? nm.w("position_net.person_embeddings") : (const float*)nullptr,
+                               GK == 2 ? nm.w("position_net.keypoint_embeddings") : (const float*)nullptr, NB, nm.w(p.null_emb), nm.w(null_pos), cfg.gr_dim, PW, p.pcat);
+            const float* w0 = nm.w(p.lin + ".0.weight");
+            if (PW != PWr) {        // the first Linear's K (800 for the keypoint tokenizer) padded to the GEMM's 64-step with zero columns
+                p.w0p = c.f32((size_t)512 * PW);
+                hipLaunchKernelGGL(pad_cols_kernel, Ctx::g1((size_t)512 * PW), dim3(256), 0, s, w0, PWr, PW, (size_t)512 * PW, p.w0p);
+                w0 = p.w0p;
+            }
+            p.l0 = c.lin_fwd(p.pcat, MRB, PW, w0, nm.w(p.lin + ".0.bias"), 512);
             p.a0 = c.f32((size_t)MRB * 512);
             hipLaunchKernelGGL(silu_kernel, Ctx::g1((size_t)MRB * 512), dim3(256), 0, s, (const float*)p.l0, (size_t)MRB * 512, p.a0);
             p.l1 = c.lin_fwd(p.a0, MRB, 512, nm.w(p.lin + ".2.weight"), nm.w(p.lin + ".2.bias"), 512);
@@ -1266,7 +1299,7 @@ int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& c
             }
         }
         // ---- position_net backward (Linear, SiLU, Linear, SiLU, Linear per branch; the learnable null embeddings: the position one is
-        // shared by the branches)
+        // shared by the branches; the keypoint tokenizer's person / keypoint embedding tables)
         for (int r = 0; r < NBR; ++r) {
             const PosBranch& p = pb[r];
             const float* go = NBR == 1 ? g_objs : c.slice_rows(g_objs, B, Ng, r * NB, NB, KD);
@@ -1278,12 +1311,25 @@ int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& c
             float* g_a0 = c.lin_dgrad(g_l1, MRB, 512, nm.w(p.lin + ".2.weight"), 512);
             float* g_l0 = c.f32((size_t)MRB * 512);
             hipLaunchKernelGGL(silu_bwd_kernel, Ctx::g1((size_t)MRB * 512), dim3(256), 0, s, (const float*)g_a0, (const float*)p.l0, (size_t)MRB * 512, g_l0);
-            c.lin_wgrad(g_l0, p.pcat, MRB, 512, PW, nm.g(p.lin + ".0.weight"), nm.g(p.lin + ".0.bias"));
-            float* g_cat = c.lin_dgrad(g_l0, MRB, 512, nm.w(p.lin + ".0.weight"), PW);
+            float* gw0 = nm.g(p.lin + ".0.weight");
+            if (PW == PWr) {
+                c.lin_wgrad(g_l0, p.pcat, MRB, 512, PW, gw0, nm.g(p.lin + ".0.bias"));
+            } else {
+                float* gw0p = gw0 ? c.f32((size_t)512 * PW) : nullptr;
+                c.lin_wgrad(g_l0, p.pcat, MRB, 512, PW, gw0p, nm.g(p.lin + ".0.bias"));
+                if (gw0) hipLaunchKernelGGL(split_kernel, Ctx::g1((size_t)512 * PWr), dim3(256), 0, s, (const float*)gw0p, PW, 0, PWr, (size_t)512, gw0, 0);
+            }
+            float* g_cat = c.lin_dgrad(g_l0, MRB, 512, p.w0p ? p.w0p : nm.w(p.lin + ".0.weight"), PW);
             if (float* gp = nm.g(p.null_emb))
                 hipLaunchKernelGGL(null_grad_kernel, Ctx::g1(cfg.gr_dim), dim3(256), 0, s, (const float*)g_cat, p.emb_mask, MRB, PW, 0, cfg.gr_dim, gp, 0);
-            if (float* gp = nm.g("position_net.null_position_feature"))
-                hipLaunchKernelGGL(null_grad_kernel, Ctx::g1(64), dim3(256), 0, s, (const float*)g_cat, in.masks, MRB, PW, cfg.gr_dim, 64, gp, r);
+            if (float* gp = nm.g(null_pos))
+                hipLaunchKernelGGL(null_grad_kernel, Ctx::g1(16 * NC), dim3(256), 0, s, (const float*)g_cat, in.masks, MRB, PW, cfg.gr_dim, 16 * NC, gp, r);
+            if (GK == 2) {
+                if (float* gp = nm.g("position_net.person_embeddings"))
+                    hipLaunchKernelGGL(table_grad_kernel, dim3(cdiv(cfg.gr_dim, 256), NB / 17), dim3(256), 0, s, (const float*)g_cat, in.masks, B, NB, PW, cfg.gr_dim, 1, gp);
+                if (float* gp = nm.g("position_net.keypoint_embeddings"))
+                    hipLaunchKernelGGL(table_grad_kernel, dim3(cdiv(cfg.gr_dim, 256), 17), dim3(256), 0, s, (const float*)g_cat, in.masks, B, NB, PW, cfg.gr_dim, 0, gp);
+            }
         }
         c.hip(hipGetLastError(), "training step kernel launch");
     } catch (const GlError& e) {

@@ -420,8 +420,10 @@ class Engine:
         c.n_attn = len(cfg["attention_resolutions"])
         for i, v in enumerate(cfg["attention_resolutions"]):
             c.attention_resolutions[i] = int(v)
-        ti = "image_embeddings" in batch        # the text+image tokenizer (text_image_grounding_net.py); else the text tokenizer
-        c.grounding_kind, c.fuser_kind = (1 if ti else 0), 0
+        ti = "image_embeddings" in batch        # the text+image tokenizer (text_image_grounding_net.py)
+        kp = "points" in batch                  # the keypoint tokenizer (keypoint_grounding_net.py); else the text tokenizer
+        c.grounding_kind, c.fuser_kind = (1 if ti else 2 if kp else 0), 0
+        c.max_persons = int(batch["points"].shape[1]) // 17 if kp else 0
         c.gr_in_dim = c.gr_out_dim = 768
         names = [k for k in state_dict.keys()]
         params = [_f32(state_dict[k], dev) for k in names]
@@ -435,12 +437,12 @@ class Engine:
         x, target = batch["x"], batch["target"]
         B, Cx, H, W = x.shape
         rows = lambda t: _f32(t, dev).permute(0, 2, 3, 1).reshape(B, H * W, t.shape[1]).contiguous()
-        keep = dict(x=rows(x), t=_f32(batch["timesteps"], dev), ctx=_f32(batch["context"], dev), boxes=_f32(batch["boxes"], dev),
-                    masks=_f32(batch["masks"], dev), pe=_f32(batch["text_embeddings" if ti else "positive_embeddings"], dev), target=rows(target))
+        keep = dict(x=rows(x), t=_f32(batch["timesteps"], dev), ctx=_f32(batch["context"], dev), boxes=_f32(batch["points" if kp else "boxes"], dev),
+                    masks=_f32(batch["masks"], dev), pe=None if kp else _f32(batch["text_embeddings" if ti else "positive_embeddings"], dev), target=rows(target))
         if ti:
             keep.update(tm=_f32(batch["text_masks"], dev), im=_f32(batch["image_masks"], dev), ie=_f32(batch["image_embeddings"], dev))
         u = _lib.TrainUNetIn(int(B), int(H), int(W), int(keep["ctx"].shape[1]), int(keep["boxes"].shape[1]), keep["x"].data_ptr(), keep["t"].data_ptr(),
-                             keep["ctx"].data_ptr(), keep["boxes"].data_ptr(), keep["masks"].data_ptr(), keep["pe"].data_ptr(), keep["target"].data_ptr(),
+                             keep["ctx"].data_ptr(), keep["boxes"].data_ptr(), keep["masks"].data_ptr(), None if kp else keep["pe"].data_ptr(), keep["target"].data_ptr(),
                              float(fuser_scale), keep["tm"].data_ptr() if ti else None, keep["im"].data_ptr() if ti else None,
                              keep["ie"].data_ptr() if ti else None, int(bool(checkpoint)))
         n = len(names)

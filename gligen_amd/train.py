@@ -8,8 +8,9 @@ Everything numeric runs in the library: forward + backward in gl_unet_train_step
 the bookkeeping the reference leaves to torch.optim / DDP: the trainable parameters and their gradients are views into a few flat
 fp32 buffers (gligen_amd.dist.GradBuckets), so the backward writes the gradients where the collective reads them, one
 reduce-scatter + all-gather pair per bucket goes over RCCL, and AdamW is one launch per bucket over the flat range.
-The step is built for the text and text+image grounding tokenizers with gatedSA fusers (what the other modalities
-need); the batch dict carries positive_embeddings (text) or text_embeddings / image_embeddings / text_masks / image_masks (text+image)."""
+The step is built for the three discrete grounding tokenizers with gatedSA fusers (what the spatial-map modalities
+need); the batch dict carries boxes + masks + positive_embeddings (text), + text_embeddings / image_embeddings / text_masks / image_masks
+(text+image), or points + masks (keypoint)."""
 from __future__ import annotations
 
 from typing import Dict, Mapping, Optional

@@ -282,8 +282,8 @@ int gl_op_resample_train(gl_ctx* ctx, int mode, int B, int H, int W, int C, cons
                          const float* target, float* y, float* loss, float* dx, gl_stream s);
 
 /* ---- one whole training iteration (reference trainer.py:353-392: model(input), mse_loss(model_output, noise), loss.backward()) for a
- * UNetModel with the text or the text+image grounding tokenizer and gatedSA fusers (openaimodel.py:237-464; gl_unet_config with
- * grounding_kind 0 / 1, fuser_kind 0, no inpainting / extra channels). The model's parameters come as its state_dict: n_params names (the reference's
+ * UNetModel with the text, the text+image or the keypoint grounding tokenizer and gatedSA fusers (openaimodel.py:237-464; gl_unet_config with
+ * grounding_kind 0 / 1 / 2, fuser_kind 0, no inpainting / extra channels). The model's parameters come as its state_dict: n_params names (the reference's
  * keys, e.g. "input_blocks.1.1.transformer_blocks.0.fuser.linear.weight") with fp32 device pointers; grads[i] is a buffer shaped
  * like parameter i for every trainable parameter wanted -- the reference's trainable set is every "*.fuser.*" key and "position_net.*"
  * (trainer.py:217-245); any other non-NULL entry is rejected -- and NULL elsewhere. Tensors fp32 on the device, x / target / eps_out
@@ -293,9 +293,9 @@ typedef struct gl_train_unet_in {
     const float* x;                     /* [B][H*W][in_channels]: the noised latent */
     const float* timesteps;             /* [B], as float */
     const float* context;               /* [B][ctx_T][context_dim] */
-    const float* boxes;                 /* [B][Ng][4] */
+    const float* boxes;                 /* [B][Ng][4]; keypoint tokenizer (grounding_kind 2, keypoint_grounding_net.py:34): points [B][Ng][2], Ng = 17 per person */
     const float* masks;                 /* [B][Ng] */
-    const float* positive_embeddings;   /* [B][Ng][gr_in_dim]: positive_embeddings (text tokenizer) / text_embeddings (text+image) */
+    const float* positive_embeddings;   /* [B][Ng][gr_in_dim]: positive_embeddings (text tokenizer) / text_embeddings (text+image); NULL for keypoints */
     const float* target;                /* [B][H*W][out_channels]: the noise */
     float fuser_scale;
     /* text+image tokenizer (grounding_kind 1, text_image_grounding_net.py:41): NULL for the text tokenizer. The model then sees 2 * Ng

@@ -747,6 +747,7 @@ CASES = {
     "unet_small_train_step": unet_backward_case,
     "unet_small_train_2steps": unet_train_2steps_case,
     "unet_small_ti_train_step": lambda: unet_backward_case("unet_small_ti_train_step", kind="text_image"),
+    "unet_small_kp_train_step": lambda: unet_backward_case("unet_small_kp_train_step", kind="keypoint"),
     # the shipped topology (4 levels, 16 fusers, head dims 40 / 80 / 160; 966 tensors) at a 16 x 16 latent
     "unet_full_train_step": lambda: unet_backward_case("unet_full_train_step", B=1, hw=16, base_cfg=syn.UNET_CFG),
     "resample_backward": resample_backward_case,

@@ -401,7 +401,8 @@ def test_fuser_block_backward_vs_reference(engine):
                                                 *[C.c_void_p(t.data_ptr()) for t in outs], garr, None))
 
 
-@pytest.mark.parametrize("case,n_train,n_gates", [("unet_small_train_step", 127, 14), ("unet_full_train_step", 280, 32), ("unet_small_ti_train_step", 134, 14)])
+@pytest.mark.parametrize("case,n_train,n_gates", [("unet_small_train_step", 127, 14), ("unet_full_train_step", 280, 32), ("unet_small_ti_train_step", 134, 14),
+                                                  ("unet_small_kp_train_step", 129, 14)])
 def test_unet_train_step_vs_reference(engine, case, n_train, n_gates):
     """The whole training iteration (gl_unet_train_step): position_net, time embedding, every ResBlock / SpatialTransformer /
     Downsample / Upsample of the small UNet with its skip concatenations, mse_loss against the noise, and the backward pass -- against
@@ -426,11 +427,14 @@ def test_unet_train_step_vs_reference(engine, case, n_train, n_gates):
     kind = meta.get("kind", "text")
     b = syn.make_batch(kind, B, n_valid=meta["n_valid"], seed=5)
     batch = dict(x=syn.make_latent(B, 4, hw, hw, seed=6), timesteps=torch.tensor([981, 441][:B]).float(), context=syn.make_context(B, seed=6),
-                 boxes=b["boxes"], masks=b["masks"], target=syn.make_latent(B, 4, hw, hw, seed=7))
+                 boxes=b.get("boxes"), masks=b["masks"], target=syn.make_latent(B, 4, hw, hw, seed=7))
     if kind == "text_image":     # third case: the text+image tokenizer (two MLPs, 2 x 30 grounding tokens; the golden masks one modality per box)
         b["text_masks"][:, 1] = 0
         b["image_masks"][:, 0] = 0
         batch.update(text_embeddings=b["text_embeddings"], image_embeddings=b["image_embeddings"], text_masks=b["text_masks"], image_masks=b["image_masks"])
+    elif kind == "keypoint":     # fourth case: the keypoint tokenizer (person + keypoint embedding tables, 8 x 17 tokens, K = 800 padded to 832)
+        del batch["boxes"]
+        batch["points"] = b["points"]
     else:
         batch["positive_embeddings"] = b["text_embeddings"]
     loss, eps, grads = engine.unet_train_step(cfg, sd, batch)
