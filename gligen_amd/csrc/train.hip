@@ -78,13 +78,23 @@ __global__ void add3_kernel(float* __restrict__ dst, const float* __restrict__ a
     if (i < n) dst[i] += a[i] + b[i];
 }
 
-// out[c] = sum_r a[r][c] (* b[r][c])   -- one thread per column, rows in order: deterministic
-__global__ void colsum_kernel(const float* __restrict__ a, const float* __restrict__ b, int R, int Cc, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Cc) return;
+// out[c] = sum_r a[r][c] (* b[r][c]): 64 columns x 16 row lanes per workgroup, each row lane sums rows ry, ry + 16, ... in order and the
+// sixteen partial sums are combined in a fixed order -- deterministic, and 16 x the parallelism of one thread per column (which was
+// 8.5 % of a training iteration: profiles/r4_final/train_kernel_stats.csv is the profile before this change)
+__global__ void __launch_bounds__(1024) colsum_kernel(const float* __restrict__ a, const float* __restrict__ b, int R, int Cc, float* __restrict__ out) {
+    __shared__ float part[16][64];
+    const int tx = threadIdx.x & 63, ry = threadIdx.x >> 6, c = blockIdx.x * 64 + tx;
     float s = 0.f;
-    for (int r = 0; r < R; ++r) s += b ? a[(size_t)r * Cc + c] * b[(size_t)r * Cc + c] : a[(size_t)r * Cc + c];
-    out[c] = s;
+    if (c < Cc)
+        for (int r = ry; r < R; r += 16) s += b ? a[(size_t)r * Cc + c] * b[(size_t)r * Cc + c] : a[(size_t)r * Cc + c];
+    part[ry][tx] = s;
+    __syncthreads();
+    if (ry == 0 && c < Cc) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += part[i][tx];
+        out[c] = t;
+    }
 }
 
 // LayerNorm over C per row (eps 1e-5, nn.LayerNorm): one wave per row
@@ -122,88 +132,112 @@ __global__ void ln_bwd_kernel(const float* __restrict__ dy, const float* __restr
     }
 }
 
-// ---- attention on row-major q [B][Nq][H d], k / v [B][Nk][H d]: one thread per (batch, head, query) / (batch, head, key)
-template <int D>
+// ---- attention on row-major q [B][Nq][H d], k / v [B][Nk][H d]. A (batch, head, query) -- or key, in attn_bwd_kv -- is owned by LPQ
+// adjacent lanes, each holding a DC-wide chunk of the head dimension (d = DC * LPQ; DC <= 40 keeps a lane's q / accumulator chunks in
+// registers: with one lane per query d = 160 spilled 320 floats per lane and was 3 ms per launch). Dot products over d are chunk sums
+// combined across the LPQ lanes by xor shuffles.
+template <int LPQ>
+__device__ __forceinline__ float lpq_sum(float v) {
+    if constexpr (LPQ >= 2) v += __shfl_xor(v, 1, 64);
+    if constexpr (LPQ >= 4) v += __shfl_xor(v, 2, 64);
+    return v;
+}
+template <int DC, int LPQ>
 __global__ void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int H, int Nq, int Nk, float scale,
                                 float* __restrict__ o, float* __restrict__ lse) {
-    const int bh = blockIdx.y, b = bh / H, h = bh % H, i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Nq) return;
-    const int ld = H * D;
-    float qi[D], acc[D];
-    const float* qp = q + ((size_t)b * Nq + i) * ld + h * D;
+    constexpr int D = DC * LPQ;
+    const int bh = blockIdx.y, b = bh / H, h = bh % H, gi = blockIdx.x * blockDim.x + threadIdx.x, part = gi % LPQ;
+    const int i = min(gi / LPQ, Nq - 1);                  // (lanes past the end recompute the last query and do not store: the shuffles need them)
+    const bool live = gi / LPQ < Nq;
+    const int ld = H * D, c0 = h * D + part * DC;
+    float qi[DC], acc[DC];
+    const float* qp = q + ((size_t)b * Nq + i) * ld + c0;
 #pragma unroll
-    for (int c = 0; c < D; ++c) { qi[c] = qp[c] * scale; acc[c] = 0.f; }
+    for (int c = 0; c < DC; ++c) { qi[c] = qp[c] * scale; acc[c] = 0.f; }
     float m = -1e30f, l = 0.f;
     for (int j = 0; j < Nk; ++j) {
-        const float* kp = k + ((size_t)b * Nk + j) * ld + h * D;
-        const float* vp = v + ((size_t)b * Nk + j) * ld + h * D;
+        const float* kp = k + ((size_t)b * Nk + j) * ld + c0;
+        const float* vp = v + ((size_t)b * Nk + j) * ld + c0;
         float sc = 0.f;
 #pragma unroll
-        for (int c = 0; c < D; ++c) sc = fmaf(qi[c], kp[c], sc);
+        for (int c = 0; c < DC; ++c) sc = fmaf(qi[c], kp[c], sc);
+        sc = lpq_sum<LPQ>(sc);
         const float mn = fmaxf(m, sc), corr = __expf(m - mn), p = __expf(sc - mn);
         l = l * corr + p;
 #pragma unroll
-        for (int c = 0; c < D; ++c) acc[c] = fmaf(acc[c], corr, p * vp[c]);
+        for (int c = 0; c < DC; ++c) acc[c] = fmaf(acc[c], corr, p * vp[c]);
         m = mn;
     }
-    float* op = o + ((size_t)b * Nq + i) * ld + h * D;
+    if (!live) return;
+    float* op = o + ((size_t)b * Nq + i) * ld + c0;
     const float inv = 1.f / l;
 #pragma unroll
-    for (int c = 0; c < D; ++c) op[c] = acc[c] * inv;
-    lse[(size_t)bh * Nq + i] = m + __logf(l);
+    for (int c = 0; c < DC; ++c) op[c] = acc[c] * inv;
+    if (part == 0) lse[(size_t)bh * Nq + i] = m + __logf(l);
 }
 // dq and the row terms delta_i = do_i . o_i; the probabilities are recomputed from q, k and the saved log-sum-exp
-template <int D>
+template <int DC, int LPQ>
 __global__ void attn_bwd_q_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, const float* __restrict__ o,
                                   const float* __restrict__ dout, const float* __restrict__ lse, int H, int Nq, int Nk, float scale,
                                   float* __restrict__ dq, float* __restrict__ delta) {
-    const int bh = blockIdx.y, b = bh / H, h = bh % H, i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Nq) return;
+    constexpr int D = DC * LPQ;
+    const int bh = blockIdx.y, b = bh / H, h = bh % H, gi = blockIdx.x * blockDim.x + threadIdx.x, part = gi % LPQ;
+    const int i = min(gi / LPQ, Nq - 1);
+    const bool live = gi / LPQ < Nq;
     const int ld = H * D;
-    const size_t off = ((size_t)b * Nq + i) * ld + h * D;
-    float qi[D], di[D], acc[D];
+    const size_t off = ((size_t)b * Nq + i) * ld + h * D + part * DC;
+    float qi[DC], di[DC], acc[DC];
     float dl = 0.f;
 #pragma unroll
-    for (int c = 0; c < D; ++c) { qi[c] = q[off + c] * scale; di[c] = dout[off + c]; dl = fmaf(di[c], o[off + c], dl); acc[c] = 0.f; }
+    for (int c = 0; c < DC; ++c) { qi[c] = q[off + c] * scale; di[c] = dout[off + c]; dl = fmaf(di[c], o[off + c], dl); acc[c] = 0.f; }
+    dl = lpq_sum<LPQ>(dl);
     const float L = lse[(size_t)bh * Nq + i];
     for (int j = 0; j < Nk; ++j) {
-        const float* kp = k + ((size_t)b * Nk + j) * ld + h * D;
-        const float* vp = v + ((size_t)b * Nk + j) * ld + h * D;
+        const float* kp = k + ((size_t)b * Nk + j) * ld + h * D + part * DC;
+        const float* vp = v + ((size_t)b * Nk + j) * ld + h * D + part * DC;
         float sc = 0.f, dp = 0.f;
 #pragma unroll
-        for (int c = 0; c < D; ++c) { sc = fmaf(qi[c], kp[c], sc); dp = fmaf(di[c], vp[c], dp); }
+        for (int c = 0; c < DC; ++c) { sc = fmaf(qi[c], kp[c], sc); dp = fmaf(di[c], vp[c], dp); }
+        sc = lpq_sum<LPQ>(sc);
+        dp = lpq_sum<LPQ>(dp);
         const float ds = __expf(sc - L) * (dp - dl);
 #pragma unroll
-        for (int c = 0; c < D; ++c) acc[c] = fmaf(ds, kp[c], acc[c]);
+        for (int c = 0; c < DC; ++c) acc[c] = fmaf(ds, kp[c], acc[c]);
     }
+    if (!live) return;
 #pragma unroll
-    for (int c = 0; c < D; ++c) dq[off + c] = acc[c] * scale;
-    delta[(size_t)bh * Nq + i] = dl;
+    for (int c = 0; c < DC; ++c) dq[off + c] = acc[c] * scale;
+    if (part == 0) delta[(size_t)bh * Nq + i] = dl;
 }
-template <int D>
+template <int DC, int LPQ>
 __global__ void attn_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, const float* __restrict__ dout,
                                    const float* __restrict__ lse, const float* __restrict__ delta, int H, int Nq, int Nk, float scale,
                                    float* __restrict__ dk, float* __restrict__ dv) {
-    const int bh = blockIdx.y, b = bh / H, h = bh % H, j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= Nk) return;
+    constexpr int D = DC * LPQ;
+    const int bh = blockIdx.y, b = bh / H, h = bh % H, gj = blockIdx.x * blockDim.x + threadIdx.x, part = gj % LPQ;
+    const int j = min(gj / LPQ, Nk - 1);
+    const bool live = gj / LPQ < Nk;
     const int ld = H * D;
-    const size_t off = ((size_t)b * Nk + j) * ld + h * D;
-    float kj[D], vj[D], ak[D], av[D];
+    const size_t off = ((size_t)b * Nk + j) * ld + h * D + part * DC;
+    float kj[DC], vj[DC], ak[DC], av[DC];
 #pragma unroll
-    for (int c = 0; c < D; ++c) { kj[c] = k[off + c]; vj[c] = v[off + c]; ak[c] = 0.f; av[c] = 0.f; }
+    for (int c = 0; c < DC; ++c) { kj[c] = k[off + c]; vj[c] = v[off + c]; ak[c] = 0.f; av[c] = 0.f; }
     for (int i = 0; i < Nq; ++i) {
-        const float* qp = q + ((size_t)b * Nq + i) * ld + h * D;
-        const float* dp_ = dout + ((size_t)b * Nq + i) * ld + h * D;
+        const float* qp = q + ((size_t)b * Nq + i) * ld + h * D + part * DC;
+        const float* dp_ = dout + ((size_t)b * Nq + i) * ld + h * D + part * DC;
         float sc = 0.f, dp = 0.f;
 #pragma unroll
-        for (int c = 0; c < D; ++c) { sc = fmaf(qp[c], kj[c], sc); dp = fmaf(dp_[c], vj[c], dp); }
+        for (int c = 0; c < DC; ++c) { sc = fmaf(qp[c], kj[c], sc); dp = fmaf(dp_[c], vj[c], dp); }
+        sc = lpq_sum<LPQ>(sc);
+        dp = lpq_sum<LPQ>(dp);
         const float p = __expf(sc * scale - lse[(size_t)bh * Nq + i]);
         const float ds = p * (dp - delta[(size_t)bh * Nq + i]);
 #pragma unroll
-        for (int c = 0; c < D; ++c) { av[c] = fmaf(p, dp_[c], av[c]); ak[c] = fmaf(ds, qp[c], ak[c]); }
+        for (int c = 0; c < DC; ++c) { av[c] = fmaf(p, dp_[c], av[c]); ak[c] = fmaf(ds, qp[c], ak[c]); }
     }
+    if (!live) return;
 #pragma unroll
-    for (int c = 0; c < D; ++c) { dk[off + c] = ak[c] * scale; dv[off + c] = av[c]; }
+    for (int c = 0; c < DC; ++c) { dk[off + c] = ak[c] * scale; dv[off + c] = av[c]; }
 }
 
 // GEGLU (attention.py:37-44): h = val * gelu(gate), u = [val | gate] of width 2 I (erf GELU, F.gelu default)
@@ -444,7 +478,7 @@ struct Ctx {
     void lin_wgrad(const float* dy, const float* x, int M, int N, int K, float* dW, float* db) const {
         const int Mp = round_up(M, 64);
         if (dW) mm(transposed(dy, M, N, Mp), transposed(x, M, K, Mp), N, K, Mp, nullptr, dW);
-        if (db) hipLaunchKernelGGL(colsum_kernel, g1(N), dim3(256), 0, s, dy, (const float*)nullptr, M, N, db);
+        if (db) hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64)), dim3(1024), 0, s, dy, (const float*)nullptr, M, N, db);
     }
     struct LN { float* y; float* xhat; float* rstd; };
     LN ln_fwd(const float* x, int R, int Cc, const float* g, const float* b) const {
@@ -454,49 +488,50 @@ struct Ctx {
     }
     void ln_bwd(const float* dy, const LN& f, const float* g, int R, int Cc, float* dx, bool accumulate, float* dgamma, float* dbeta) const {
         hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, dy, f.xhat, f.rstd, g, R, Cc, dx, accumulate ? 1 : 0);
-        if (dgamma) hipLaunchKernelGGL(colsum_kernel, g1(Cc), dim3(256), 0, s, dy, (const float*)f.xhat, R, Cc, dgamma);
-        if (dbeta) hipLaunchKernelGGL(colsum_kernel, g1(Cc), dim3(256), 0, s, dy, (const float*)nullptr, R, Cc, dbeta);
+        if (dgamma) hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(Cc, 64)), dim3(1024), 0, s, dy, (const float*)f.xhat, R, Cc, dgamma);
+        if (dbeta) hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(Cc, 64)), dim3(1024), 0, s, dy, (const float*)nullptr, R, Cc, dbeta);
     }
     struct Attn { float* o; float* lse; };
-    template <int D>
+    template <int DC, int LPQ>
     Attn attn_fwd_d(const float* q, const float* k, const float* v, int B, int H, int Nq, int Nk) const {
+        constexpr int D = DC * LPQ;
         Attn a{f32((size_t)B * Nq * H * D), f32((size_t)B * H * Nq)};
-        hipLaunchKernelGGL(attn_fwd_kernel<D>, dim3(cdiv(Nq, 64), B * H), dim3(64), 0, s, q, k, v, H, Nq, Nk, 1.f / sqrtf((float)D), a.o, a.lse);
+        hipLaunchKernelGGL((attn_fwd_kernel<DC, LPQ>), dim3(cdiv(Nq * LPQ, 64), B * H), dim3(64), 0, s, q, k, v, H, Nq, Nk, 1.f / sqrtf((float)D), a.o, a.lse);
         return a;
     }
-    template <int D>
+    template <int DC, int LPQ>
     void attn_bwd_d(const float* q, const float* k, const float* v, const Attn& f, const float* dout, int B, int H, int Nq, int Nk, float* dq,
                     float* dk, float* dv) const {
+        constexpr int D = DC * LPQ;
         float* delta = f32((size_t)B * H * Nq);
         const float sc = 1.f / sqrtf((float)D);
-        hipLaunchKernelGGL(attn_bwd_q_kernel<D>, dim3(cdiv(Nq, 64), B * H), dim3(64), 0, s, q, k, v, (const float*)f.o, dout, (const float*)f.lse, H, Nq, Nk, sc,
-                           dq, delta);
+        hipLaunchKernelGGL((attn_bwd_q_kernel<DC, LPQ>), dim3(cdiv(Nq * LPQ, 64), B * H), dim3(64), 0, s, q, k, v, (const float*)f.o, dout, (const float*)f.lse, H, Nq,
+                           Nk, sc, dq, delta);
         if (dk && dv)
-            hipLaunchKernelGGL(attn_bwd_kv_kernel<D>, dim3(cdiv(Nk, 64), B * H), dim3(64), 0, s, q, k, v, dout, (const float*)f.lse, (const float*)delta, H, Nq,
-                               Nk, sc, dk, dv);
+            hipLaunchKernelGGL((attn_bwd_kv_kernel<DC, LPQ>), dim3(cdiv(Nk * LPQ, 64), B * H), dim3(64), 0, s, q, k, v, dout, (const float*)f.lse,
+                               (const float*)delta, H, Nq, Nk, sc, dk, dv);
     }
     Attn attn_fwd(int D, const float* q, const float* k, const float* v, int B, int H, int Nq, int Nk) const {
         switch (D) {
-            case 32: return attn_fwd_d<32>(q, k, v, B, H, Nq, Nk);
-            case 40: return attn_fwd_d<40>(q, k, v, B, H, Nq, Nk);
-            case 64: return attn_fwd_d<64>(q, k, v, B, H, Nq, Nk);
-            case 80: return attn_fwd_d<80>(q, k, v, B, H, Nq, Nk);
-            case 160: return attn_fwd_d<160>(q, k, v, B, H, Nq, Nk);
+            case 32: return attn_fwd_d<32, 1>(q, k, v, B, H, Nq, Nk);
+            case 40: return attn_fwd_d<40, 1>(q, k, v, B, H, Nq, Nk);
+            case 64: return attn_fwd_d<32, 2>(q, k, v, B, H, Nq, Nk);
+            case 80: return attn_fwd_d<40, 2>(q, k, v, B, H, Nq, Nk);
+            case 160: return attn_fwd_d<40, 4>(q, k, v, B, H, Nq, Nk);
             default: throw GlError(GL_ERR_UNSUPPORTED, fmt("training slice: head dim %d (32, 40, 64, 80, 160 are built)", D));
         }
     }
     void attn_bwd(int D, const float* q, const float* k, const float* v, const Attn& f, const float* dout, int B, int H, int Nq, int Nk, float* dq,
                   float* dk, float* dv) const {
         switch (D) {
-            case 32: return attn_bwd_d<32>(q, k, v, f, dout, B, H, Nq, Nk, dq, dk, dv);
-            case 40: return attn_bwd_d<40>(q, k, v, f, dout, B, H, Nq, Nk, dq, dk, dv);
-            case 64: return attn_bwd_d<64>(q, k, v, f, dout, B, H, Nq, Nk, dq, dk, dv);
-            case 80: return attn_bwd_d<80>(q, k, v, f, dout, B, H, Nq, Nk, dq, dk, dv);
-            case 160: return attn_bwd_d<160>(q, k, v, f, dout, B, H, Nq, Nk, dq, dk, dv);
+            case 32: return attn_bwd_d<32, 1>(q, k, v, f, dout, B, H, Nq, Nk, dq, dk, dv);
+            case 40: return attn_bwd_d<40, 1>(q, k, v, f, dout, B, H, Nq, Nk, dq, dk, dv);
+            case 64: return attn_bwd_d<32, 2>(q, k, v, f, dout, B, H, Nq, Nk, dq, dk, dv);
+            case 80: return attn_bwd_d<40, 2>(q, k, v, f, dout, B, H, Nq, Nk, dq, dk, dv);
+            case 160: return attn_bwd_d<40, 4>(q, k, v, f, dout, B, H, Nq, Nk, dq, dk, dv);
             default: throw GlError(GL_ERR_UNSUPPORTED, "training slice: head dim");
         }
     }
-
     // 3x3 conv, stride 1, pad 1, over pixel rows a [B][H*W][Cin] (fp32; cast to bf16 for the implicit-GEMM kernel of gemm.hip) with
     // an OIHW fp32 weight -> [B][H*W][Cout] fp32 (+ bias). dgrad = true: the data gradient of that conv, a [..][Cout] -> [..][Cin].
     // stride 2 (Downsample: output (H/2) x (W/2)) and ups = 1 (Upsample: nearest 2x in the loader, output 2H x 2W) for the forward only
