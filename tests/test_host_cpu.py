@@ -672,3 +672,24 @@ def test_train_step_bookkeeping_on_flat_buckets():
     assert {c[0] for c in eng.adamw_calls} == {b.data_ptr() for b in ts.pbuf.buckets}
     out = ts.state_dict()
     assert torch.all(out["position_net.linears.0.bias"] == 0.0) and torch.all(out["out.2.weight"] == 1.0)      # 1 - 2 * 0.5; frozen untouched
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """Every struct that crosses the C ABI has the same size in include/gligen_amd.h (compiled by gcc as C99) and in the ctypes
+    mirror of gligen_amd/_lib.py / engine.py -- a field added on one side only would otherwise be read as garbage, not rejected."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from gligen_amd import _lib, engine
+    pairs = {"gl_unet_config": _lib.UNetConfig, "gl_vae_config": _lib.VaeConfig, "gl_grounding": _lib.Grounding, "gl_plms_args": _lib.PlmsArgs,
+             "gl_train_unet_in": _lib.TrainUNetIn, "gl_train_block_dims": engine.TrainBlockDims, "gl_train_resblock_dims": engine.TrainResDims}
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "gligen_amd.h"\nint main(void) {\n' +
+                   "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in pairs) + "  return 0;\n}\n")
+    exe = tmp_path / "sz"
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for name, ct in pairs.items():
+        assert int(out[name]) == C.sizeof(ct), (name, out[name], C.sizeof(ct))
