@@ -347,3 +347,29 @@ def test_ffn_dma_statements_declare_what_they_clobber():
     stmts = re.findall(r'asm volatile\("(?:s_nop 4\\n\\t)?s_mov_b32 m0.*?;', src, re.S)
     assert len(stmts) == 2
     assert all('"scc"' in st for st in stmts)
+
+
+def test_training_attention_kernels_keep_their_chunks_in_registers(tmp_path):
+    """train.hip's fp32 attention kernels split a head dimension over 1 / 2 / 4 lanes in chunks of <= 40 so that a lane's q /
+    accumulator chunks stay in registers (one lane per query at d = 160 spilled 320 floats and ran 3 ms per launch): the forward
+    kernels use no scratch at all, the backward ones at most a few dozen dwords (they sit at the 128-register default bound)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = tmp_path / "train.s"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", str(ROOT / "include"), "--offload-device-only", "-S",
+                        str(ROOT / "gligen_amd" / "csrc" / "train.hip"), "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    asm = out.read_text()
+    seen = 0
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)", asm):
+        blk = asm[m.start():asm.index(".end_amdhsa_kernel", m.start())]
+        name = m.group(1)
+        scratch = int(re.search(r"private_segment_fixed_size (\d+)", blk).group(1))
+        if "attn_fwd_kernel" in name:
+            assert scratch == 0, (name, scratch)
+            seen += 1
+        elif "attn_bwd" in name:
+            assert scratch <= 256, (name, scratch)
+            seen += 1
+        elif "colsum_kernel" in name or "gn_silu" in name:
+            assert scratch == 0, (name, scratch)
+    assert seen == 15       # 5 head dims x (forward, backward-q, backward-kv)
