@@ -293,22 +293,26 @@ def test_resblock_backward_golden(name):
     assert float(((x.grad - ref) ** 2).mean() / (ref ** 2).mean()) < 1e-8
 
 
-def test_unet_train_step_golden_through_the_oracle():
-    """The whole-iteration golden (the reference's loss.backward() on the small UNet): torch autograd THROUGH the oracle's
-    unet_forward reproduces the loss and the sampled gradients of all 127 trainable tensors -- the oracle is a pinned checker for the
-    training path too (smoke() uses it that way)."""
-    g = load_golden("unet_small_train_step")
+@pytest.mark.parametrize("case", ["unet_small_train_step", "unet_small_ti_train_step", "unet_small_kp_train_step"])
+def test_unet_train_step_golden_through_the_oracle(case):
+    """The whole-iteration goldens (the reference's loss.backward() on the small UNet, for the text, text+image and keypoint
+    tokenizers): torch autograd THROUGH the oracle's unet_forward reproduces the loss and the sampled gradients of every trainable
+    tensor -- the oracle is a pinned checker for the training path too (smoke() uses it that way)."""
+    g = load_golden(case)
     meta = g["meta"]
-    B, hw = meta["B"], meta["hw"]
-    sd = syn.seeded_state_dict(golden_shapes("unet_small_train_step"), meta["weight_seed"])
+    B, hw, kind = meta["B"], meta["hw"], meta.get("kind", "text")
+    sd = syn.seeded_state_dict(golden_shapes(case), meta["weight_seed"])
     train = [k for k in sd if ".fuser." in k or k.startswith("position_net.")]
     assert len(train) == meta["n_trainable"]
     for k in train:
         sd[k].requires_grad_(True)
-    b = syn.make_batch("text", B, n_valid=meta["n_valid"], seed=5)
+    b = syn.make_batch(kind, B, n_valid=meta["n_valid"], seed=5)
+    if kind == "text_image":
+        b["text_masks"][:, 1] = 0
+        b["image_masks"][:, 0] = 0
     inp = dict(x=syn.make_latent(B, 4, hw, hw, seed=6), timesteps=torch.tensor([981, 441][:B]), context=syn.make_context(B, seed=6),
-               grounding_input=grounding_kwargs("text", b))
-    eps = orc.unet_forward(sd, oracle_cfg(meta["cfg"], "text"), inp)
+               grounding_input=grounding_kwargs(kind, b))
+    eps = orc.unet_forward(sd, oracle_cfg(meta["cfg"], kind), inp)
     loss = torch.nn.functional.mse_loss(eps, syn.make_latent(B, 4, hw, hw, seed=7))
     loss.backward()
     assert abs(float(loss) - float(g["loss"])) < 1e-6
