@@ -17,6 +17,13 @@ AutoencoderKL.decode -> B images. --config picks the BASELINE.json configuration
 Inputs (x_T, CLIP-shaped context, grounding features, seeded random weights of the SD-1.4 GLIGEN architecture) are
 resident in HBM before the timed region. N > 1: every rank runs the same batch size on its own GPU (weak scaling, no
 data-path collective); value = all images / max-over-ranks time.
+
+Beside the contract's keys the line carries what makes a number comparable across boxes and rounds:
+    box_calibration   float4-copy GB/s, global->LDS DMA TB/s, sustained bf16 MFMA TFLOP/s of THIS box (gl_box_calibrate)
+    ff_rows_ab        one-lane UNet evaluation ms with the row-local feed-forward kernel off / forced on / chosen by the engine's
+                      on-device timing (the default), and the timed table itself: the same-box A/B of that kernel
+    train_step        one iteration of the reference's trainer step (forward + loss + backward + nothing else) of the shipped
+                      topology at the same batch and latent, outside the timed region (rank 0, text / text+image / keypoint models)
 """
 import argparse
 import glob
@@ -129,6 +136,51 @@ def pmc_traffic(kernel):
     return fetch + write, (f"{os.path.relpath(files[-1], ROOT)}: mean over the run's launches of this symbol, "
                            f"2 x FETCH_SIZE ({fetch / 1e6:.1f} MB) + WRITE_SIZE ({write / 1e6:.1f} MB); L2-to-fabric requests, "
                            "Infinity-Cache hits included, so an upper bound on HBM bytes; per-problem rows: pmc_traffic_per_problem.csv beside it")
+
+
+def train_step_line(model, kind, B, dev):
+    """One training iteration (gl_unet_train_step: forward + mse loss + backward for the reference's trainable set, activation
+    checkpointing on, trainer.py:353-392) of the benchmark's own model at the benchmark's batch and latent, after one untimed
+    warm-up iteration (tile tuning). tflops: 3.2 x the forward's algorithmic FLOPs (forward + recomputed forward + input-gradient
+    backward of the frozen layers + weight gradients of the fusers only) / time, against the same bf16 roof."""
+    import time as _t
+    from gligen_amd import synthetic as syn
+    from gligen_amd.engine import Engine
+    try:
+        sd = {k: v.detach() for k, v in model.state_dict().items()}
+        if any(v.dtype != torch.float32 or not v.is_cuda for v in sd.values()):
+            sd = {k: v.float().to(dev).contiguous() for k, v in sd.items()}
+        b = syn.make_batch(kind, B, n_valid=8, seed=5)
+        if kind == "keypoint":
+            b["boxes"] = None
+        ts = torch.tensor([981, 441, 300, 77, 650, 12, 850, 505][:B] if B <= 8 else list(range(1, 1000, 1000 // B))[:B]).float()
+        batch = dict(x=syn.make_latent(B, 4, 64, 64, seed=6), timesteps=ts, context=syn.make_context(B, seed=6), masks=b["masks"],
+                     target=syn.make_latent(B, 4, 64, 64, seed=7))
+        if kind != "keypoint":
+            batch["boxes"] = b["boxes"]
+        if kind == "keypoint":
+            batch["points"] = b["points"]
+        elif kind == "text_image":
+            batch.update(text_embeddings=b["text_embeddings"], text_masks=b["text_masks"], image_masks=b["image_masks"], image_embeddings=b["image_embeddings"])
+        else:
+            batch["positive_embeddings"] = b["text_embeddings"]
+        grads = {k: torch.zeros_like(v) for k, v in sd.items() if ".fuser." in k or k.startswith("position_net.")}
+        cfg = dict(syn.UNET_CFG, grounding_tokenizer=syn.GROUNDING_TOKENIZERS[kind])
+        eng = Engine(dev, arena_gb=24.0)
+        eng.unet_train_step(cfg, sd, batch, grads=grads, checkpoint=True)
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        loss, _, _ = eng.unet_train_step(cfg, sd, batch, grads=grads, checkpoint=True)
+        torch.cuda.synchronize()
+        dt = _t.perf_counter() - t0
+        ng = {"text": 30, "text_image": 60, "keypoint": 136}[kind]
+        tf = 3.2 * B * F_UNET[ng] / dt / 1e12
+        return {"ms": round(dt * 1e3, 1), "B": B, "latent": 64, "checkpoint": True, "loss": float(loss), "tflops": round(tf, 1), "frac": round(tf * 1e12 / PEAK_BF16, 4),
+                "trainable_values": sum(int(g.numel()) for g in grads.values()), "arena_high_water_gb": round(eng.arena_high_water() / 2 ** 30, 2),
+                "desc": "gl_unet_train_step of the shipped topology: forward + mse_loss + backward (fuser + position_net gradients), fp32 activations, "
+                        "three-pass bf16 MFMA products; gradient exchange and AdamW not included (1 GPU)"}
+    except Exception as e:   # a measurement aid must not take the bench line down
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
 class ClockSampler(threading.Thread):
@@ -247,6 +299,8 @@ def main():
                          "gaps and memory-bound kernels overlap the other's MFMA work. 1 = strictly one batch at a time; the line "
                          "carries that number too (value_one_lane)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the training-iteration line (train_step)")
+    ap.add_argument("--no-ff-ab", action="store_true", help="skip the same-box A/B of the row-local feed-forward kernel (ff_rows_ab)")
     ap.add_argument("--alpha-type", default=None,
                     help="gate schedule 'on,decay,off' (fractions of the steps), e.g. 0.3,0,0.7 as in the reference's demo prompts; default: "
                          "None = fusers on at every step, the configuration the metric is quoted on (and the one with the most work)")
@@ -316,10 +370,28 @@ def main():
         for lane in range(L):
             one_pass(lane)
             torch.cuda.synchronize()
+    # same-box A/B of the row-local feed-forward kernel, one lane, untimed passes: never / wherever it exists / the engine's own
+    # on-device timing (the default, restored last; a policy change drops the captured graphs, so every lane re-captures below)
+    eng0 = lanes[0][0].engine
+    ff_ab = None
+    if not args.no_ff_ab:
+        ff_ab = {}
+        for name, mode in (("off", 0), ("forced", 1)):
+            eng0.set_ff_rows_policy(mode)
+            one_pass(0)
+            torch.cuda.synchronize()
+            ff_ab["unet_step_ms_" + name] = round(eng0.sampler_timing()[0], 4)
+        eng0.set_ff_rows_policy(-1)
+        for lane in range(L):
+            one_pass(lane)
+            torch.cuda.synchronize()
     # UNet evaluation time with the GPU to itself: one more untimed pass on lane 0 alone
     one_pass(0)
     torch.cuda.synchronize()
-    unet_ms, first_ms, n_evals = lanes[0][0].engine.sampler_timing()
+    unet_ms, first_ms, n_evals = eng0.sampler_timing()
+    if ff_ab is not None:
+        ff_ab["unet_step_ms_timed_choice"] = round(unet_ms, 4)
+        ff_ab["timed_table"] = eng0.ff_rows_policy_report()
 
     clocks = ClockSampler(local_rank)
     gdist.barrier(); torch.cuda.synchronize()
@@ -363,6 +435,21 @@ def main():
     dec_ms = (time.perf_counter() - t0) * 1e3
     del d
 
+    mem_line = {"arena_high_water_gb": round(lanes[0][0].engine.arena_high_water() / 2 ** 30, 3),   # activation arena of one execution context (gl_arena_high_water)
+                # footprint of this rank: packed weights + slabs of every context (forks share the weights: theirs are slabs only) and the
+                # device memory committed behind the arenas (UNet + VAE contexts of every lane)
+                "per_gpu_weight_bytes": sum(e.memory()["own_bytes"] for ln in lanes for e in (ln[0].engine, ln[1].engine)),
+                "arena_reserved_bytes": sum(e.memory()["arena_bytes"] for ln in lanes for e in (ln[0].engine, ln[1].engine))}
+    box = None
+    train = None
+    if rank == 0:
+        try:
+            box = eng0.box_calibrate()     # (after the memory numbers above: it borrows 1 GiB of lane 0's arena)
+        except Exception as e:
+            box = {"error": str(e)[:200]}
+        if not args.no_train_step and not cfg["inpaint"] and alpha_type is None:
+            train = train_step_line(lanes[0][0], kind, B, dev)
+
     if rank == 0:
         n_images = B * world * args.steps
         value = n_images / elapsed
@@ -402,11 +489,10 @@ def main():
                                                        f"measured in an untimed pass with one batch in flight)",
             "vae_decode_ms": dec_ms,
             "launches_per_unet_eval": launches_per_eval,
-            "arena_high_water_gb": round(lanes[0][0].engine.arena_high_water() / 2 ** 30, 3),   # activation arena of one execution context (gl_arena_high_water)
-            # footprint of this rank: packed weights + slabs of every context (forks share the weights: theirs are slabs only) and the
-            # device memory committed behind the arenas (UNet + VAE contexts of every lane)
-            "per_gpu_weight_bytes": sum(e.memory()["own_bytes"] for ln in lanes for e in (ln[0].engine, ln[1].engine)),
-            "arena_reserved_bytes": sum(e.memory()["arena_bytes"] for ln in lanes for e in (ln[0].engine, ln[1].engine)),
+            **mem_line,
+            "box_calibration": box,
+            "ff_rows_ab": ff_ab,
+            "train_step": train,
             "value_one_lane": (B * world * args.steps / elapsed_one) if elapsed_one else value,
             "collective_world_size": dist_world, "collective_backend": dist_backend,   # the RCCL world the barrier / max-over-ranks ran in
             "gpu_clocks": clk,

@@ -61,6 +61,10 @@ class TrainUNetIn(C.Structure):   # = gl_train_unet_in
                [("fuser_scale", C.c_float)] + [(n, C.c_void_p) for n in ("text_masks", "image_masks", "image_embeddings")] + [("checkpoint", C.c_int)]
 
 
+class BoxCalibration(C.Structure):   # = gl_box_calibration
+    _fields_ = [("hbm_copy_gbs", C.c_float), ("lds_dma_tbs", C.c_float), ("mfma_bf16_tflops", C.c_float)]
+
+
 class ProfRec(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("calls", C.c_int), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
 
@@ -94,6 +98,9 @@ SYMBOLS = {
     "gl_to_uint8": (_I, [_P, _P, _I, _I, _I, _P]),
     "gl_arena_high_water": (_I, [_P, C.POINTER(C.c_size_t)]),
     "gl_launch_count": (_I, [_P, C.POINTER(C.c_int64)]),
+    "gl_set_ff_rows_policy": (_I, [_I]),
+    "gl_ff_rows_policy_report": (_I, [C.c_char_p, C.c_size_t]),
+    "gl_box_calibrate": (_I, [_P, C.POINTER(BoxCalibration), _P]),
     "gl_op_linear": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "gl_op_geglu": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "gl_op_ln_linear": (_I, [_P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, C.POINTER(_I), _P]),
@@ -106,7 +113,7 @@ SYMBOLS = {
     "gl_op_resblock_train": (_I, [_P, _P, C.POINTER(_P), _P, _P, _P, _P, _P, _P, _P]),
     "gl_op_resample_train": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gl_unet_train_step": (_I, [_P, C.POINTER(UNetConfig), C.POINTER(TrainUNetIn), _I, C.POINTER(C.c_char_p), C.POINTER(_P), C.POINTER(_P), _P, _P, _P]),
-    "gl_op_adamw_step": (_I, [_P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I, _P]),
+    "gl_op_adamw_step": (_I, [_P, _P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _I, _P]),
     "gl_op_ff_chain": (_I, [_P, _P, _I, _I] + [_P] * 16),
     "gl_op_conv3x3": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "gl_op_groupnorm": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, C.c_float, _I, _P, _P]),

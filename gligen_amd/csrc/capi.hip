@@ -296,6 +296,29 @@ int gl_launch_count(gl_ctx* ctx, int64_t* n) {
     return GL_OK;
 }
 
+int gl_set_ff_rows_policy(int mode) { return gl::ff_rows_policy_set(mode); }
+
+int gl_ff_rows_policy_report(char* buf, size_t cap) { return gl::ff_rows_policy_report(buf, cap); }
+
+int gl_box_calibrate(gl_ctx* ctx, gl_box_calibration* out, gl_stream s) {
+    NEED(ctx);
+    if (!out) return gl::set_error(GL_ERR_ARG, "gl_box_calibrate: null out pointer");
+    GL_API_BEGIN
+    Arena& ar = ctx->eng->arena();
+    const size_t mk = ar.mark();
+    const size_t bytes = size_t(1) << 30;   // 512 MiB -> 512 MiB: twice the Infinity Cache in each direction
+    void* scratch = ar.alloc(bytes);
+    HIPCK_API(hipMemsetAsync(scratch, 1, bytes, S(s)));
+    float v[3] = {0.f, 0.f, 0.f};
+    int rc = box_calibrate_launch(scratch, bytes, v, S(s));
+    ar.release(mk);
+    if (rc != GL_OK) throw GlError(rc, gl::last_error());
+    out->hbm_copy_gbs = v[0];
+    out->lds_dma_tbs = v[1];
+    out->mfma_bf16_tflops = v[2];
+    GL_API_END
+}
+
 // ------------------------------------------------------------------ single operators
 int gl_op_linear(gl_ctx* ctx, const void* x, const void* w, const float* bias, const void* res, void* y,
                  int M, int N, int K, int act, int out_f32, gl_stream s) {
@@ -421,6 +444,9 @@ int gl_op_feedforward(gl_ctx* ctx, const void* x, int M, int C, const float* gam
     }
     const bool rows = ff_rows_supported(M, C) && !(gl::dev_env("GL_FF_ROWS") && atoi(gl::dev_env("GL_FF_ROWS")) == 0);
     *used_rows = rows ? 1 : 0;
+    // the per-row (sum, sum of squares) come out of the row-local kernel's epilogue; the two-GEMM form writes per-column-block partials
+    // in the consumer's own layout (gemm.h Epilogue::stats_out), not this one: refuse rather than hand back zeros
+    if (stats && !rows) throw GlError(GL_ERR_UNSUPPORTED, "gl_op_feedforward: row statistics are produced only by the row-local kernel (C = 320, M % 128 == 0)");
     if (rows) {
         void* st = ar.alloc(ff_stream_bytes(C));
         ck(ff_pack_launch(w1e, b1e, w2, st, C, S(s)));
@@ -457,7 +483,6 @@ int gl_op_feedforward(gl_ctx* ctx, const void* x, int M, int C, const float* gam
         epilogue_defaults(E2);
         E2.out = y; E2.ldo = C; E2.bias = b2; E2.res = (const bf16*)res; E2.ldres = C; E2.gate = gate;
         ck(gemm_launch(A2, w2b, M, C, 4 * C, E2, eng.splitk_ws(), eng.splitk_ws_bytes(), S(s)));
-        if (stats) HIPCK_API(hipMemsetAsync(stats, 0, (size_t)M * sizeof(float2), S(s)));
     }
     GL_API_END
 }
@@ -488,8 +513,8 @@ int gl_op_ff_chain(gl_ctx* ctx, const void* x, int M, int C, const float* pre_w,
     GL_API_END
 }
 
-int gl_op_adamw_step(gl_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                     float weight_decay, int step, gl_stream s) {
+int gl_op_adamw_step(gl_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                     double weight_decay, int step, gl_stream s) {
     NEED(ctx);
     if (!p || !g || !m || !v || n < 0) return gl::set_error(GL_ERR_ARG, "gl_op_adamw_step: null pointer");
     return gl::adamw_step(p, g, m, v, (size_t)n, lr, beta1, beta2, eps, weight_decay, step, S(s));

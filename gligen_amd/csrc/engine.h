@@ -137,6 +137,10 @@ struct AttnBufs {  // persistent, zero-initialised head-layout buffers for one a
 // channel-concat view of up to two NHWC bf16 tensors
 struct TRef { const bf16* p0 = nullptr; int C0 = 0; const bf16* p1 = nullptr; int C1 = 0; int C() const { return C0 + C1; } };
 
+// row-local feed-forward kernel or two GEMMs (engine.hip ff_policy): -1 = by on-device timing (default), 0 = never, 1 = wherever it exists
+int ff_rows_policy_set(int mode);
+int ff_rows_policy_report(char* buf, size_t cap);
+
 class Engine {
    public:
     explicit Engine(int device);
@@ -238,9 +242,20 @@ class Engine {
     bf16* transformer(const STW& t, const bf16* x, int B, int H, int W, hipStream_t s);
     // in_stats: `ln` holds RAW rows whose statistics are in_stats (folded LayerNorm applied by the GEMM); out_stats: statistics of the result
     // raw_rows: with a folded LayerNorm, `ln` may be the RAW rows (no in_stats needed) when ff_rows(f, M) says the row-local kernel runs
+    // use_rows: run the row-local kernel (the caller asked ff_rows_for)
     bf16* feedforward(const FFW& f, const bf16* ln, int M, const bf16* res, const float* gate, hipStream_t s, const RowStats* in_stats = nullptr,
-                      RowStats* out_stats = nullptr, bool raw_rows = false);
-    bool ff_rows(const FFW& f, int M) const;
+                      RowStats* out_stats = nullptr, bool raw_rows = false, bool use_rows = false);
+    // Row-local kernel or LayerNorm + two GEMMs (+ the separate projections) for the feed-forward `which` (1 = fuser.ff, 2 = ff) of
+    // block t at B x HW rows: decided once per (shape, chain form) by TIMING both forms on this device at the first eager launch
+    // (ff_policy.* below, gl_set_ff_rows_policy); under a stream capture an undecided shape takes the static rule
+    bool ff_rows_for(const STW& t, int which, int B, int HW, hipStream_t s);
+    // fuser.attn.to_out (+ gated residual) -> LayerNorm -> fuser.ff (+ gated residual)  [gatedSA, attention.py:236-244]
+    bf16* fuser_ff_tail(const STW& t, const bf16* o, const bf16* t1, int B, int HW, bool rows, hipStream_t s, RowStats* st3);
+    // attn2.to_out (+ residual) -> LayerNorm -> ff (+ residual) -> proj_out + x_in  [attention.py:337-338, 374-376]
+    void block_ff_tail(const STW& t, const bf16* o, const bf16* t3, const bf16* x, bf16* out, int B, int HW, bool rows, hipStream_t s);
+    bf16* ff_behind(const FFW& f, const NormW& nw, const bf16* rows_in, RowStats& st_in, int B, int HW, const float* gate, bool rows, hipStream_t s,
+                    RowStats* out_stats);
+    bool can_fold(const RowStats& st, int M, int C, int Nc, int mode, int act, bool aligned);
     // the chained launch: t = pre_res + pre_gate (x Wpre^T + pre_b); y = t + gate ff(LN(t)); out = y, or post_res + y Wpost^T + post_b
     bf16* feedforward_chain(const FFW& f, const bf16* x, int M, const LinW& pre, const bf16* pre_res, const float* pre_gate, const float* gate,
                             const LinW* post, const bf16* post_res, bf16* out, hipStream_t s, RowStats* out_stats);
@@ -346,6 +361,8 @@ class Engine {
         int n_evals = 0;
         bool has_extra = false;
         const float* extra = nullptr;
+        bool warm[2] = {false, false};   // this variant has run eagerly on this context (arena mapped, shapes tuned): it may be captured
+        unsigned policy_epoch = 0;       // ff_policy epoch the graphs were captured under
     } smp_;
     void sampler_release_graph();
 };

@@ -3,10 +3,13 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 namespace gl {
 
@@ -1207,12 +1210,158 @@ bf16* Engine::feedforward_chain(const FFW& f, const bf16* x, int M, const LinW& 
     return out;
 }
 
-bool Engine::ff_rows(const FFW& f, int M) const { return f.rows_stream && ff_rows_supported(M, f.C); }
+// ---------------------------------------------------------------- row-local kernel or two GEMMs: decided by timing
+// The row-local kernel (ffn.hip) wins where a launch fills the chip (one 128-row workgroup per CU: M = 32768) on a box whose
+// fabric keeps up with its exposed row loads / stores, and loses elsewhere (M = 8192: 68 against 42 us for LayerNorm + two GEMMs;
+// 1.65x slower on a slow-fabric box). So the engine does not dispatch on shape: at the first EAGER launch of a
+// (feed-forward, chain form, M) it runs both forms on scratch rows with the block's real weights, times them with HIP events on the
+// launch stream and keeps the faster for the life of the process (all contexts of a device share the table, so forks agree).
+namespace ff_policy {
+static std::mutex mu;
+struct Entry { int rows; float us_rows, us_gemm; };
+static std::map<uint64_t, Entry> table;
+static std::atomic<int> mode{-1};          // -1 timed (default), 0 never the row-local kernel, 1 wherever it exists
+static std::atomic<unsigned> epoch{1};     // bumped when the mode changes: captured graphs of another epoch are dropped
+static uint64_t key(int dev, int which, int form, int C, int M) {
+    return ((uint64_t)dev << 56) | ((uint64_t)which << 52) | ((uint64_t)form << 48) | ((uint64_t)C << 32) | (uint64_t)(unsigned)M;
+}
+// the rule for shapes that cannot be timed (first seen inside a stream capture): a launch of at least 7/8 of the chip's CUs
+static bool static_rule(int M) { return M / 128 >= 224; }
+}  // namespace ff_policy
+
+int ff_rows_policy_set(int mode) {
+    if (mode < -1 || mode > 1) return set_error(GL_ERR_ARG, "ff_rows policy %d (expected -1 timed, 0 off, 1 wherever supported)", mode);
+    if (ff_policy::mode.exchange(mode) != mode) ff_policy::epoch.fetch_add(1);
+    return GL_OK;
+}
+int ff_rows_policy_report(char* buf, size_t cap) {
+    if (!buf || !cap) return set_error(GL_ERR_ARG, "ff_rows_policy_report: no buffer");
+    std::lock_guard<std::mutex> lk(ff_policy::mu);
+    size_t n = (size_t)snprintf(buf, cap, "mode=%d", ff_policy::mode.load());
+    for (const auto& kv : ff_policy::table) {
+        if (n + 96 >= cap) break;
+        const uint64_t k = kv.first;
+        n += (size_t)snprintf(buf + n, cap - n, ";dev%d %s form%d C%d M%d -> %s (rows %.1f us, gemm %.1f us)", (int)(k >> 56),
+                              ((k >> 52) & 15) == 1 ? "fuser.ff" : "ff", (int)((k >> 48) & 15), (int)((k >> 32) & 0xffff), (int)(k & 0xffffffffu),
+                              kv.second.rows ? "rows" : "gemm", kv.second.us_rows, kv.second.us_gemm);
+    }
+    return GL_OK;
+}
+
+bool Engine::can_fold(const RowStats& st, int M, int C, int Nc, int mode, int act, bool aligned) {
+    if (!st.nb || !aligned) return false;
+    AOperand A;
+    aoperand_rows(A, nullptr, C, C);
+    Epilogue E;
+    epilogue_defaults(E);
+    E.mode = mode; E.act = act; E.geglu16 = gemm_geglu_layout();
+    return gemm_ln_fold_supported(A, M, Nc, C, E);
+}
+
+// LayerNorm + feed-forward (+ gated residual) behind a projection that produced rows_in (statistics st_in, if it wrote any)
+bf16* Engine::ff_behind(const FFW& f, const NormW& nw, const bf16* rows_in, RowStats& st_in, int B, int HW, const float* gate, bool rows, hipStream_t s,
+                        RowStats* out_stats) {
+    const int M = B * HW, C = f.C;
+    const bool fold = rows || (f.folded && can_fold(st_in, M, C, 8 * C, EPI_ROWMAJOR, ACT_GEGLU, round_up(HW, 64) == HW));
+    const bf16* ln = fold ? rows_in : (f.folded ? layernorm_plain(rows_in, B, HW, C, false, s) : layernorm(rows_in, B, HW, C, nw, false, s));
+    return feedforward(f, ln, M, rows_in, gate, s, (fold && !rows) ? &st_in : nullptr, out_stats, rows, rows);
+}
+
+bf16* Engine::fuser_ff_tail(const STW& t, const bf16* o, const bf16* t1, int B, int HW, bool rows, hipStream_t s, RowStats* st3) {
+    const int M = B * HW;
+    const float* g_attn = gates_ + 2 * t.idx;
+    if (rows && t.fff.chain_stream && !t.fff.chain_post)   // one row-local launch for the three
+        return feedforward_chain(t.fff, o, M, t.fa.out, t1, g_attn, g_attn + 1, nullptr, nullptr, nullptr, s, st3);
+    RowStats st2;
+    bf16* t2 = linear_rows(o, M, t.fa.out, ACT_NONE, t1, g_attn, s, rows ? nullptr : &st2);
+    return ff_behind(t.fff, t.fn2, t2, st2, B, HW, g_attn + 1, rows, s, st3);
+}
+
+void Engine::block_ff_tail(const STW& t, const bf16* o, const bf16* t3, const bf16* x, bf16* out, int B, int HW, bool rows, hipStream_t s) {
+    const int M = B * HW, C = t.C;
+    if (rows && t.ff.chain_stream && t.ff.chain_post) {   // attn2.to_out + residual, LayerNorm, ff + residual, proj_out + x_in: one row-local launch
+        feedforward_chain(t.ff, o, M, t.a2.out, t3, nullptr, nullptr, &t.proj_out, x, out, s, nullptr);
+        return;
+    }
+    RowStats st4;
+    bf16* t4 = linear_rows(o, M, t.a2.out, ACT_NONE, t3, nullptr, s, rows ? nullptr : &st4);
+    bf16* t5 = ff_behind(t.ff, t.ln3, t4, st4, B, HW, nullptr, rows, s, nullptr);
+    AOperand A;
+    aoperand_rows(A, t5, C, C);
+    Epilogue E;
+    epilogue_defaults(E);
+    E.out = out; E.ldo = C; E.bias = t.proj_out.b; E.res = x; E.ldres = C;
+    gemm(A, t.proj_out.w, M, C, C, E, s);
+}
+
+bool Engine::ff_rows_for(const STW& t, int which, int B, int HW, hipStream_t s) {
+    if (which == 1 && ucfg_.fuser_kind != 0) which = 2;   // (gatedSA2 / gatedCA produce the fuser's rows differently: they follow the block's ff)
+    const FFW& f = which == 1 ? t.fff : t.ff;
+    const int M = B * HW, C = t.C;
+    if (!f.folded || !f.rows_stream || !ff_rows_supported(M, C)) return false;
+    const int mode = ff_policy::mode.load();
+    if (mode == 0) return false;
+    if (mode == 1) return true;
+    const int form = f.chain_stream ? (f.chain_post ? 2 : 1) : 0;
+    const uint64_t key = ff_policy::key(device_, which, form, C, M);
+    std::unique_lock<std::mutex> lk(ff_policy::mu);   // held across the timing pass: two contexts timing at once would time each other
+    auto it = ff_policy::table.find(key);
+    if (it != ff_policy::table.end()) return it->second.rows != 0;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    if (cap != hipStreamCaptureStatusNone) return ff_policy::static_rule(M);
+
+    // ---- time both forms of this tail on scratch rows (zeros: no kernel on the path is data dependent), real weights
+    const size_t mk = arena_.mark();
+    const int64_t launches0 = n_launches;
+    const bool prof0 = profiling_;
+    profiling_ = false;
+    bf16* zo = arena_.get<bf16>((size_t)M * C);
+    bf16* zr = arena_.get<bf16>((size_t)M * C);
+    bf16* zx = arena_.get<bf16>((size_t)M * C);
+    bf16* zout = arena_.get<bf16>((size_t)M * C);
+    HIPCK(hipMemsetAsync(zo, 0, (size_t)M * C * sizeof(bf16), s));
+    HIPCK(hipMemsetAsync(zr, 0, (size_t)M * C * sizeof(bf16), s));
+    HIPCK(hipMemsetAsync(zx, 0, (size_t)M * C * sizeof(bf16), s));
+    auto run = [&](bool rows) {
+        const size_t m2 = arena_.mark();
+        RowStats st;
+        if (which == 1) fuser_ff_tail(t, zo, zr, B, HW, rows, s, &st);
+        else block_ff_tail(t, zo, zr, zx, zout, B, HW, rows, s);
+        arena_.release(m2);
+    };
+    hipEvent_t ev[2];
+    HIPCK(hipEventCreate(&ev[0]));
+    HIPCK(hipEventCreate(&ev[1]));
+    struct EvGuard { hipEvent_t* e; ~EvGuard() { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); } } guard{ev};
+    float best[2] = {1e30f, 1e30f};
+    constexpr int REPS = 4, ROUNDS = 3;
+    for (int form_i = 0; form_i < 2; ++form_i) run(form_i == 1);    // warm-up: GEMM tile tuning, kernel attributes
+    for (int r = 0; r < ROUNDS; ++r)
+        for (int form_i = 0; form_i < 2; ++form_i) {                // alternate the two forms: a clock ramp hits both
+            HIPCK(hipEventRecord(ev[0], s));
+            for (int i = 0; i < REPS; ++i) run(form_i == 1);
+            HIPCK(hipEventRecord(ev[1], s));
+            HIPCK(hipEventSynchronize(ev[1]));
+            float ms = 0.f;
+            HIPCK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+            best[form_i] = std::min(best[form_i], ms * 1e3f / REPS);
+        }
+    arena_.release(mk);
+    n_launches = launches0;
+    profiling_ = prof0;
+    const ff_policy::Entry e{best[1] < best[0] ? 1 : 0, best[1], best[0]};
+    ff_policy::table[key] = e;
+    static const bool log = dev_env("GL_FF_POLICY_LOG") != nullptr;
+    if (log) fprintf(stderr, "[ff policy] %s form %d C %d M %d: rows %.1f us, gemm %.1f us -> %s\n", which == 1 ? "fuser.ff" : "ff", form, C, M, e.us_rows, e.us_gemm, e.rows ? "rows" : "gemm");
+    return e.rows != 0;
+}
 
 bf16* Engine::feedforward(const FFW& f, const bf16* ln, int M, const bf16* res, const float* gate, hipStream_t s, const RowStats* in_stats,
-                          RowStats* out_stats, bool raw_rows) {
+                          RowStats* out_stats, bool raw_rows, bool use_rows) {
     const int C = f.C;
-    if (ff_rows(f, M)) {
+    if (use_rows) {
+        if (!f.rows_stream || !ff_rows_supported(M, C)) throw GlError(GL_ERR_STATE, "feedforward: no row-local stream of this shape");
         // one launch: LayerNorm (where folded and the rows are raw) + GEGLU projection + FF-out + (gated) residual + row statistics
         bf16* out = arena_.get<bf16>((size_t)M * C);
         FFRowsParams P{};
@@ -1267,62 +1416,28 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
     // Where no statistics exist (split-K producer, the [x ; objs] concatenation, an epilogue without the fold) the rows go
     // through ln_kernel without affine -- gamma / beta live in the folded weights either way.
     const int Tp = round_up(HW, 64);
-    auto can_fold = [&](const RowStats& st, int Nc, int mode, int act) {
-        if (!st.nb || Tp != HW) return false;
-        AOperand A;
-        aoperand_rows(A, x, C, C);
-        Epilogue E;
-        epilogue_defaults(E);
-        E.mode = mode; E.act = act; E.geglu16 = gemm_geglu_layout();
-        return gemm_ln_fold_supported(A, M, Nc, C, E);
-    };
+    const bool aligned = Tp == HW;
     auto normed = [&](const bf16* rows, const NormW& nw, bool folded, bool fuse, bool pad64) -> const bf16* {
         if (fuse) return rows;
         return folded ? layernorm_plain(rows, B, HW, C, pad64, s) : layernorm(rows, B, HW, C, nw, pad64, s);
     };
-    RowStats st0, st1, st2, st3, st4;
+    RowStats st0, st1, st2, st3;
     // the row-local feed-forward kernel normalises its raw input rows itself: their producers need not write statistics
-    const bool r2 = t.fff.folded && ff_rows(t.fff, M), r4 = t.ff.folded && ff_rows(t.ff, M);
+    const bool r2 = !fuser_off_ && ff_rows_for(t, 1, B, HW, s), r4 = ff_rows_for(t, 2, B, HW, s);
     bf16* t0 = linear_rows(n, M, t.proj_in, ACT_NONE, nullptr, nullptr, s, &st0);
 
     // x = attn1(norm1(x)) + x
-    const bool f1 = t.a1.folded && can_fold(st0, 3 * C, EPI_QKV_HEADS, ACT_NONE);
+    const bool f1 = t.a1.folded && can_fold(st0, M, C, 3 * C, EPI_QKV_HEADS, ACT_NONE, aligned);
     const bf16* ln = normed(t0, t.ln1, t.a1.folded, f1, true);
     bf16* o = arena_.get<bf16>((size_t)M * C);
     self_attention(t.a1, ln, B, Tp, HW, HW, C, d, o, s, f1 ? &st0 : nullptr);
     bf16* t1 = linear_rows(o, M, t.a1.out, ACT_NONE, t0, nullptr, s, &st1);
 
     const int Ng = cond_.Ng;
-    bf16* t2 = nullptr;
     bf16* t3;
-    bool fuser_chained = false;
     if (fuser_off_) {
         t3 = t1;
         st3 = st1;
-    } else {
-    if (ucfg_.fuser_kind == 1) {
-        // fuser (gatedSA2, attention.py:271-297): the attention outputs AT the grounding tokens (an sg x sg grid) are
-        // projected, resized bicubically to the visual grid and added as the gated residual
-        int sg = 0;
-        while (sg * sg < Ng) ++sg;
-        if (sg * sg != Ng || H != W) throw GlError(GL_ERR_ARG, fmt("gatedSA2 needs square token grids (visual %dx%d, %d grounding tokens)", H, W, Ng));
-        const int Ta = HW + Ng;
-        const int Tf = round_up(Ta, 64);
-        bf16* lnc = arena_.get<bf16>((size_t)B * Tf * C);
-        {
-            LNParams P{};
-            P.x = t1; P.x2 = cond_.objs[t.idx]; P.B = B; P.N1 = HW; P.N2 = Ng; P.Tpad = Tf; P.C = C; P.eps = 1e-5f;
-            P.gamma = t.fa.folded ? nullptr : t.fn1.g; P.beta = t.fa.folded ? nullptr : t.fn1.b; P.y = lnc;
-            ProfScope ps(this, s, "ln_kernel", 0.0, 2.0 * B * Ta * (double)C * 2);
-            CK(layernorm_launch(P, s));
-            ++n_launches;
-        }
-        bf16* oa = arena_.get<bf16>((size_t)B * Ta * C);
-        self_attention(t.fa, lnc, B, Tf, Ta, Ta, C, d, oa, s);                 // every token is a query here
-        bf16* pr = linear_rows(oa, B * Ta, t.fa.out, ACT_NONE, nullptr, nullptr, s);  // [B][HW + Ng][C]
-        t2 = arena_.get<bf16>((size_t)M * C);
-        CK(fuser_resize_launch(pr, t1, gates_ + 2 * t.idx, t2, B, Ta, HW, sg, H, C, s));
-        ++n_launches;
     } else if (ucfg_.fuser_kind == 0) {
         // fuser (gatedSA): x = x + scale*tanh(alpha_attn) * attn(norm1([x ; linear(objs)]))[:, :N]
         const int Tf = round_up(HW + Ng, 64);
@@ -1336,49 +1451,65 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
             ++n_launches;
         }
         self_attention(t.fa, lnc, B, Tf, HW, HW + Ng, C, d, o, s);
-        if (r2 && t.fff.chain_stream && !t.fff.chain_post) {
-            // fuser.attn.to_out + gated residual, LayerNorm, fuser.ff + gated residual: one row-local launch
-            t3 = feedforward_chain(t.fff, o, M, t.fa.out, t1, gates_ + 2 * t.idx, gates_ + 2 * t.idx + 1, nullptr, nullptr, nullptr, s, &st3);
-            fuser_chained = true;
-        } else {
-            t2 = linear_rows(o, M, t.fa.out, ACT_NONE, t1, gates_ + 2 * t.idx, s, r2 ? nullptr : &st2);
-        }
+        //    x = x + scale*tanh(alpha_dense) * ff(norm2(x))
+        t3 = fuser_ff_tail(t, o, t1, B, HW, r2, s, &st3);
     } else {
-        // fuser (gatedCA, attention.py:207-212): x = x + scale*tanh(alpha_attn) * attn(norm1(x), objs, objs)
-        ln = layernorm(t1, B, HW, C, t.fn1, true, s);
-        int dp, dpv;
-        CK(attn_dims(d, &dp, &dpv));
-        AttnBufs& bufs = attn_bufs(B, heads, d, Tp, cond_.obj_Tpad);
-        AOperand A;
-        aoperand_rows(A, ln, C, C);
-        Epilogue E;
-        epilogue_defaults(E);
-        E.mode = EPI_QK_HEADS;
-        E.q = bufs.q; E.k = nullptr; E.C = C; E.H = heads; E.d = d; E.DP = dp; E.T = Tp; E.Tpad_q = bufs.Tq_pad; E.Tpad_k = 0;
-        gemm(A, t.fca.q.w, B * Tp, C, C, E, s);
-        AttnParams P{};
-        P.q = bufs.q; P.k = cond_.obj_k[t.idx]; P.vt = cond_.obj_vt[t.idx]; P.o = o;
-        P.H = heads; P.d = d; P.Nq = HW; P.Nk = Ng; P.Tq_pad = bufs.Tq_pad; P.Tk_pad = cond_.obj_Tpad;
-        P.ldo = C; P.o_rows_per_b = HW;
-        P.scale_log2e = (float)(1.4426950408889634 / std::sqrt((double)d));
-        {
-            ProfScope ps(this, s, attn_kernel_name(d, Ng), 4.0 * B * heads * (double)HW * Ng * d, 0.0);
-            CK(attn_launch(P, B, s));
-            log_attention(attn_kernel_name(d, Ng), B, heads, HW, Ng, d);
+        bf16* t2;
+        if (ucfg_.fuser_kind == 1) {
+            // fuser (gatedSA2, attention.py:271-297): the attention outputs AT the grounding tokens (an sg x sg grid) are
+            // projected, resized bicubically to the visual grid and added as the gated residual
+            int sg = 0;
+            while (sg * sg < Ng) ++sg;
+            if (sg * sg != Ng || H != W) throw GlError(GL_ERR_ARG, fmt("gatedSA2 needs square token grids (visual %dx%d, %d grounding tokens)", H, W, Ng));
+            const int Ta = HW + Ng;
+            const int Tf = round_up(Ta, 64);
+            bf16* lnc = arena_.get<bf16>((size_t)B * Tf * C);
+            {
+                LNParams P{};
+                P.x = t1; P.x2 = cond_.objs[t.idx]; P.B = B; P.N1 = HW; P.N2 = Ng; P.Tpad = Tf; P.C = C; P.eps = 1e-5f;
+                P.gamma = t.fa.folded ? nullptr : t.fn1.g; P.beta = t.fa.folded ? nullptr : t.fn1.b; P.y = lnc;
+                ProfScope ps(this, s, "ln_kernel", 0.0, 2.0 * B * Ta * (double)C * 2);
+                CK(layernorm_launch(P, s));
+                ++n_launches;
+            }
+            bf16* oa = arena_.get<bf16>((size_t)B * Ta * C);
+            self_attention(t.fa, lnc, B, Tf, Ta, Ta, C, d, oa, s);                 // every token is a query here
+            bf16* pr = linear_rows(oa, B * Ta, t.fa.out, ACT_NONE, nullptr, nullptr, s);  // [B][HW + Ng][C]
+            t2 = arena_.get<bf16>((size_t)M * C);
+            CK(fuser_resize_launch(pr, t1, gates_ + 2 * t.idx, t2, B, Ta, HW, sg, H, C, s));
+            ++n_launches;
+        } else {
+            // fuser (gatedCA, attention.py:207-212): x = x + scale*tanh(alpha_attn) * attn(norm1(x), objs, objs)
+            ln = layernorm(t1, B, HW, C, t.fn1, true, s);
+            int dp, dpv;
+            CK(attn_dims(d, &dp, &dpv));
+            AttnBufs& bufs = attn_bufs(B, heads, d, Tp, cond_.obj_Tpad);
+            AOperand A;
+            aoperand_rows(A, ln, C, C);
+            Epilogue E;
+            epilogue_defaults(E);
+            E.mode = EPI_QK_HEADS;
+            E.q = bufs.q; E.k = nullptr; E.C = C; E.H = heads; E.d = d; E.DP = dp; E.T = Tp; E.Tpad_q = bufs.Tq_pad; E.Tpad_k = 0;
+            gemm(A, t.fca.q.w, B * Tp, C, C, E, s);
+            AttnParams P{};
+            P.q = bufs.q; P.k = cond_.obj_k[t.idx]; P.vt = cond_.obj_vt[t.idx]; P.o = o;
+            P.H = heads; P.d = d; P.Nq = HW; P.Nk = Ng; P.Tq_pad = bufs.Tq_pad; P.Tk_pad = cond_.obj_Tpad;
+            P.ldo = C; P.o_rows_per_b = HW;
+            P.scale_log2e = (float)(1.4426950408889634 / std::sqrt((double)d));
+            {
+                ProfScope ps(this, s, attn_kernel_name(d, Ng), 4.0 * B * heads * (double)HW * Ng * d, 0.0);
+                CK(attn_launch(P, B, s));
+                log_attention(attn_kernel_name(d, Ng), B, heads, HW, Ng, d);
+            }
+            ++n_launches;
+            t2 = linear_rows(o, M, t.fca.out, ACT_NONE, t1, gates_ + 2 * t.idx, s, r2 ? nullptr : &st2);
         }
-        ++n_launches;
-        t2 = linear_rows(o, M, t.fca.out, ACT_NONE, t1, gates_ + 2 * t.idx, s, r2 ? nullptr : &st2);
-    }
-    //        x = x + scale*tanh(alpha_dense) * ff(norm2(x))
-    if (!fuser_chained) {
-    const bool f2 = r2 || (t.fff.folded && can_fold(st2, 8 * C, EPI_ROWMAJOR, ACT_GEGLU));
-    ln = normed(t2, t.fn2, t.fff.folded, f2, false);
-    t3 = feedforward(t.fff, ln, M, t2, gates_ + 2 * t.idx + 1, s, (f2 && !r2) ? &st2 : nullptr, &st3, r2);
-    }
+        //        x = x + scale*tanh(alpha_dense) * ff(norm2(x))
+        t3 = ff_behind(t.fff, t.fn2, t2, st2, B, HW, gates_ + 2 * t.idx + 1, r2, s, &st3);
     }
 
     // x = attn2(norm2(x), context) + x
-    const bool f3 = t.a2.folded && can_fold(st3, C, EPI_QK_HEADS, ACT_NONE);
+    const bool f3 = t.a2.folded && can_fold(st3, M, C, C, EPI_QK_HEADS, ACT_NONE, aligned);
     ln = normed(t3, t.ln2, t.a2.folded, f3, true);
     {
         int dp, dpv;
@@ -1408,28 +1539,8 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
         }
         ++n_launches;
     }
-    if (r4 && t.ff.chain_stream && t.ff.chain_post) {
-        // attn2.to_out + residual, LayerNorm, ff + residual, proj_out + x_in: one row-local launch (attention.py:337-338, 374-376)
-        feedforward_chain(t.ff, o, M, t.a2.out, t3, nullptr, nullptr, &t.proj_out, x, out, s, nullptr);
-        arena_.release(mk);
-        return out;
-    }
-    bf16* t4 = linear_rows(o, M, t.a2.out, ACT_NONE, t3, nullptr, s, r4 ? nullptr : &st4);
-
-    // x = ff(norm3(x)) + x
-    const bool f4 = r4 || (t.ff.folded && can_fold(st4, 8 * C, EPI_ROWMAJOR, ACT_GEGLU));
-    ln = normed(t4, t.ln3, t.ff.folded, f4, false);
-    bf16* t5 = feedforward(t.ff, ln, M, t4, nullptr, s, (f4 && !r4) ? &st4 : nullptr, nullptr, r4);
-
-    // proj_out + x_in
-    {
-        AOperand A;
-        aoperand_rows(A, t5, C, C);
-        Epilogue E;
-        epilogue_defaults(E);
-        E.out = out; E.ldo = C; E.bias = t.proj_out.b; E.res = x; E.ldres = C;
-        gemm(A, t.proj_out.w, M, C, C, E, s);
-    }
+    // x = attn2.to_out(.) + x;  x = ff(norm3(x)) + x;  proj_out + x_in
+    block_ff_tail(t, o, t3, x, out, B, HW, r4, s);
     arena_.release(mk);
     return out;
 }
@@ -1939,6 +2050,7 @@ void Engine::sampler_release_graph() {
         if (smp_.graph[i]) (void)hipGraphDestroy(smp_.graph[i]);
         smp_.exec[i] = nullptr;
         smp_.graph[i] = nullptr;
+        smp_.warm[i] = false;
     }
 }
 
@@ -1965,9 +2077,10 @@ void Engine::sample_plms(const gl_plms_args& a, hipStream_t caller) {
     if (cond_.Beff != Beff) throw GlError(GL_ERR_STATE, fmt("sample_plms: conditioning batch is %d, need %d", cond_.Beff, Beff));
     const int Cl = c.in_channels;
     const int64_t n = (int64_t)a.B * Cl * a.h * a.w;
-    if (smp_.B != a.B || smp_.h != a.h || smp_.w != a.w || smp_.extra != a.inpaint_extra) {
+    if (smp_.B != a.B || smp_.h != a.h || smp_.w != a.w || smp_.extra != a.inpaint_extra || smp_.policy_epoch != ff_policy::epoch.load()) {
         HIPCK(hipStreamSynchronize(s));
         sampler_release_graph();
+        smp_.policy_epoch = ff_policy::epoch.load();
         if (smp_.B != a.B || smp_.h != a.h || smp_.w != a.w) {
             smp_.x2 = reinterpret_cast<float*>(persist(n * sizeof(float), false));
             smp_.eps_pair = reinterpret_cast<float*>(persist(2 * n * sizeof(float), false));
@@ -1989,7 +2102,9 @@ void Engine::sample_plms(const gl_plms_args& a, hipStream_t caller) {
         }
         HIPCK(hipEventRecord(smp_.tev[2 * evals], s));
         const int gi = fuser_off_ ? 1 : 0;
-        if (a.use_graph && evals >= 1) {
+        // A variant is captured only after it has run EAGERLY once on this context with these shapes: that pass commits the arena up to
+        // the variant's high-water mark (no hipMemMap inside a capture), tunes GEMM tiles and times the row-local / two-GEMM choice
+        if (a.use_graph && evals >= 1 && smp_.warm[gi]) {
             if (!smp_.exec[gi]) {
                 HIPCK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
                 try {
@@ -2008,6 +2123,7 @@ void Engine::sample_plms(const gl_plms_args& a, hipStream_t caller) {
             HIPCK(hipGraphLaunch(smp_.exec[gi], s));
         } else {
             unet_forward(Beff, a.h, a.w, smp_.x2, a.B, smp_.t_dev, a.inpaint_extra, a.B, smp_.eps_pair, s);
+            smp_.warm[gi] = true;
         }
         HIPCK(hipEventRecord(smp_.tev[2 * evals + 1], s));
         ++evals;

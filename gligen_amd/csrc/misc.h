@@ -100,6 +100,8 @@ int vae_posterior_launch(const float* h, const float* wq, const float* bq, const
                          float scale, hipStream_t stream);
 
 int fill_i64_launch(int64_t* dst, int64_t v, int n, hipStream_t stream);
+// box calibration (gl_box_calibrate): out3 = {float4-copy GB/s (read + write), LDS-DMA TB/s from L2 (chip), sustained bf16 MFMA TFLOP/s}
+int box_calibrate_launch(void* scratch, size_t scratch_bytes, float* out3, hipStream_t stream);
 int zero_launch(void* dst, size_t bytes, hipStream_t stream);
 
 }  // namespace gl

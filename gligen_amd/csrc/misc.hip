@@ -566,4 +566,102 @@ int conv4x4s2_f32_launch(const float* x, const float* w, const float* bias, floa
     return GL_OK;
 }
 
+// ---------------------------------------------------------------- box calibration (gl_box_calibrate)
+// Three numbers that say what THIS box delivers, next to the bench line (same commit: +-10 % images/s between boxes):
+//   hbm_copy_gbs     float4 copy of `bytes` (read + written bytes / time), far beyond the 256 MB Infinity Cache
+//   lds_dma_tbs      every CU streams a private, L2-resident 1-KiB-per-instruction window into LDS (buffer-less global_load_lds: the
+//                    operand-delivery path of every GEMM / conv / attention / row-local kernel here), chip total
+//   mfma_bf16_tflops all SIMDs issue independent v_mfma_f32_32x32x16_bf16 back to back (two waves per SIMD): the dense bf16 rate
+//                    the chip sustains under load (the 2.5 PFLOP/s roof is 2.4 GHz x 256 CUs; a power-limited clock shows up here)
+__global__ void __launch_bounds__(256) calib_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(256) calib_dma_kernel(const char* __restrict__ src, size_t region, int iters, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    size_t base = ((size_t)blockIdx.x * 7919 * 8192) % (region - 65536);
+    base &= ~(size_t)1023;
+    for (int it = 0; it < iters; ++it) {
+        const char* p = src + base + (size_t)wave * 8192 + lane * 16;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + (size_t)j * 1024),
+                                             (__attribute__((address_space(3))) void*)(smem + ((wave * 8 + j) & 31) * 1024), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        base += 32768;
+        if (base + 65536 > region) base = 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (smem[threadIdx.x] == 77 && iters < 0) sink[0] = 1;
+}
+__global__ void __launch_bounds__(256, 2) calib_mfma_kernel(int iters, float* sink) {
+    bf16x8 a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = f2bf(0.001f * (threadIdx.x + e)); b[e] = f2bf(0.002f * (threadIdx.x - e)); }
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 12345.678f) sink[0] = s;
+}
+int box_calibrate_launch(void* scratch, size_t scratch_bytes, float* out3, hipStream_t stream) {
+    if (!scratch || scratch_bytes < (size_t(64) << 20) || !out3) return set_error(GL_ERR_ARG, "box_calibrate: needs >= 64 MiB of scratch");
+    int dev = 0, cus = 256;
+    GL_HIP(hipGetDevice(&dev));
+    GL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    hipEvent_t e0, e1;
+    GL_HIP(hipEventCreate(&e0));
+    GL_HIP(hipEventCreate(&e1));
+    struct Guard { hipEvent_t a, b; ~Guard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } guard{e0, e1};
+    auto timed = [&](auto&& launch, int reps, float* best_ms) -> int {
+        *best_ms = 1e30f;
+        launch();   // warm-up
+        for (int r = 0; r < reps; ++r) {
+            GL_HIP(hipEventRecord(e0, stream));
+            launch();
+            GL_HIP(hipEventRecord(e1, stream));
+            GL_HIP(hipEventSynchronize(e1));
+            float ms = 0.f;
+            GL_HIP(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < *best_ms) *best_ms = ms;
+        }
+        GL_LAUNCH_CHECK();
+        return GL_OK;
+    };
+    float ms = 0.f;
+    // 1. copy: half of the scratch to the other half
+    const size_t half = (scratch_bytes / 2) & ~(size_t)4095;
+    GL_TRY(timed([&] { hipLaunchKernelGGL(calib_copy_kernel, dim3(cus * 8), dim3(256), 0, stream, (const uint4*)scratch, (uint4*)((char*)scratch + half), half / 16); }, 3, &ms));
+    out3[0] = (float)(2.0 * (double)half / (ms * 1e-3) / 1e9);
+    // 2. LDS-DMA from an L2-resident window
+    const size_t region = size_t(24) << 20;
+    const int it_dma = 1000;
+    GL_TRY(timed([&] { hipLaunchKernelGGL(calib_dma_kernel, dim3(cus), dim3(256), 32 * 1024, stream, (const char*)scratch, region, it_dma, (unsigned*)((char*)scratch + half)); }, 3, &ms));
+    out3[1] = (float)((double)cus * 4 * 8 * 1024.0 * it_dma / (ms * 1e-3) / 1e12);
+    // 3. MFMA issue rate
+    const int it_mfma = 2000;
+    GL_TRY(timed([&] { hipLaunchKernelGGL(calib_mfma_kernel, dim3(cus * 2), dim3(256), 0, stream, it_mfma, (float*)((char*)scratch + half)); }, 3, &ms));
+    out3[2] = (float)((double)cus * 2 * 4 * 16.0 * it_mfma * (2.0 * 32 * 32 * 16) / (ms * 1e-3) / 1e12);
+    return GL_OK;
+}
+
 }  // namespace gl

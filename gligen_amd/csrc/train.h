@@ -82,6 +82,6 @@ int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& c
                     const float* const* params, float* const* grads, const char* const* block_names, float* eps_out, float* loss, hipStream_t s);
 
 // One AdamW update of a flat fp32 parameter range, in place (torch.optim.AdamW semantics: trainer.py:245, :384 opt.step()); step = 1, 2, ...
-int adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd, int step, hipStream_t s);
+int adamw_step(float* p, const float* g, float* m, float* v, size_t n, double lr, double b1, double b2, double eps, double wd, int step, hipStream_t s);
 
 }  // namespace gl

@@ -302,16 +302,19 @@ __global__ void mse_grad_kernel(const float* __restrict__ y, const float* __rest
 
 // torch.optim.AdamW (trainer.py:245, one step of opt.step()): decoupled weight decay, bias-corrected moments, in place
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
-                             float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+                             float b1, float omb1, float b2, float omb2, float eps, float decay, float step_size, float bc2_sqrt) {
+    // torch.optim.AdamW (_single_tensor_adamw): every scalar below is formed in double on the host, as torch forms them from Python
+    // floats, and rounded to fp32 once: decay = 1 - lr wd, omb = 1 - beta, step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    (void)lr;
     const float gi = g[i];
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float mi = b1 * m[i] + omb1 * gi;
+    const float vi = b2 * v[i] + omb2 * gi * gi;
     m[i] = mi;
     v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = p[i] * (1.f - lr * wd) - (lr / bc1) * (mi / denom);
+    p[i] = p[i] * decay - step_size * (mi / denom);
 }
 
 
@@ -465,19 +468,25 @@ struct Ctx {
     // y = x W^T + b
     float* lin_fwd(const float* x, int M, int K, const float* W, const float* b, int N) const {
         float* y = f32((size_t)M * N);
+        const size_t mk = ar.mark();       // the bf16 operand copies live for this product only (stream order keeps their reuse safe)
         mm(to_bf16(x, (size_t)M * K), to_bf16(W, (size_t)N * K), M, N, K, b, y);
+        ar.release(mk);
         return y;
     }
     // dgrad: dx [M][K] = dy [M][N] W [N][K]   (the GEMM's "weight" operand is W^T, contraction over N)
     float* lin_dgrad(const float* dy, int M, int N, const float* W, int K) const {
         float* dx = f32((size_t)M * K);
+        const size_t mk = ar.mark();
         mm(to_bf16(dy, (size_t)M * N), transposed(W, N, K, N), M, K, N, nullptr, dx);
+        ar.release(mk);
         return dx;
     }
     // wgrad: dW [N][K] = dy^T x (contraction over the M rows, zero-padded to a multiple of 64), db [N] = column sums of dy
     void lin_wgrad(const float* dy, const float* x, int M, int N, int K, float* dW, float* db) const {
         const int Mp = round_up(M, 64);
+        const size_t mk = ar.mark();
         if (dW) mm(transposed(dy, M, N, Mp), transposed(x, M, K, Mp), N, K, Mp, nullptr, dW);
+        ar.release(mk);
         if (db) hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64)), dim3(1024), 0, s, dy, (const float*)nullptr, M, N, db);
     }
     struct LN { float* y; float* xhat; float* rstd; };
@@ -538,6 +547,8 @@ struct Ctx {
     float* conv3(const float* a, int B, int H, int W, const float* w_oihw, const float* bias, int Cin, int Cout, bool dgrad, int stride = 1, int ups = 0) const {
         const int Ho = stride == 2 ? H / 2 : H << ups, Wo = stride == 2 ? W / 2 : W << ups;
         const int Ci = dgrad ? Cout : Cin, Co = dgrad ? Cin : Cout, M = B * Ho * Wo;
+        float* out = f32((size_t)M * Co);
+        const size_t mk_ops = ar.mark();   // packed weights / bf16 activation copies: this product's, released behind it
         const float* wsrc = w_oihw;
         if (dgrad) {
             float* wt = f32((size_t)Cin * Cout * 9);
@@ -554,7 +565,6 @@ struct Ctx {
             wp_lo = ar.get<bf16>(nw);
             ck(pack_conv_weight_launch(wres, wp_lo, Co, Ci, 3, 3, Co, s));
         }
-        float* out = f32((size_t)M * Co);
         const Split av = to_bf16(a, (size_t)B * H * W * Ci);
         auto one = [&](const bf16* ap, const bf16* wq, const float* bb, float* o) {
             AOperand A{};
@@ -575,6 +585,7 @@ struct Ctx {
             hipLaunchKernelGGL(add3_kernel, g1((size_t)M * Co), dim3(256), 0, s, out, (const float*)t1, (const float*)t2, (size_t)M * Co);
             ar.release(mk);
         }
+        ar.release(mk_ops);
         return out;
     }
     struct GN { float* a; float* xhat; float* rstd; };
@@ -603,10 +614,11 @@ struct Ctx {
 
 }  // namespace
 
-int adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd, int step, hipStream_t s) {
+int adamw_step(float* p, const float* g, float* m, float* v, size_t n, double lr, double b1, double b2, double eps, double wd, int step, hipStream_t s) {
     if (step < 1) return set_error(GL_ERR_ARG, "adamw_step: step counts from 1");
-    const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
-    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, sqrtf(bc2));
+    const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, (float)lr, (float)b1, (float)(1.0 - b1), (float)b2,
+                       (float)(1.0 - b2), (float)eps, (float)(1.0 - lr * wd), (float)(lr / bc1), (float)sqrt(bc2));
     GL_LAUNCH_CHECK();
     return GL_OK;
 }

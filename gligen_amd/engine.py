@@ -343,6 +343,25 @@ class Engine:
         check(self.lib.gl_launch_count(self._ctx, C.byref(v)))
         return int(v.value)
 
+    def box_calibrate(self) -> dict:
+        """What this box delivers (gl_box_calibrate): float4-copy GB/s beyond the Infinity Cache, global->LDS DMA TB/s from L2, sustained
+        dense bf16 MFMA TFLOP/s with every SIMD issuing."""
+        from ._lib import BoxCalibration
+        c = BoxCalibration()
+        check(self.lib.gl_box_calibrate(self._ctx, C.byref(c), _stream(self.device)))
+        return {"hbm_copy_GBps": round(float(c.hbm_copy_gbs), 1), "lds_dma_TBps": round(float(c.lds_dma_tbs), 2),
+                "mfma_bf16_TFLOPs": round(float(c.mfma_bf16_tflops), 1)}
+
+    def set_ff_rows_policy(self, mode: int) -> None:
+        """Row-local feed-forward kernel or two GEMMs at C = 320 (gl_set_ff_rows_policy): -1 = decided by on-device timing (default),
+        0 = never, 1 = wherever the kernel exists. Process-wide."""
+        check(self.lib.gl_set_ff_rows_policy(int(mode)))
+
+    def ff_rows_policy_report(self) -> str:
+        buf = C.create_string_buffer(4096)
+        check(self.lib.gl_ff_rows_policy_report(buf, 4096))
+        return buf.value.decode()
+
     # ---- single operators (parity tests / per-kernel profiling) -------------------
     def op_linear(self, x, w, bias=None, res=None, act=0, out_f32=False):
         M, K = x.shape

@@ -13,11 +13,36 @@ need); the batch dict carries boxes + masks + positive_embeddings (text), + text
 (text+image), or points + masks (keypoint)."""
 from __future__ import annotations
 
-from typing import Dict, Mapping, Optional
+import math
+import random
+from typing import Callable, Dict, Mapping, Optional, Union
 
 import torch
+import torch.distributed as tdist
 
 from .dist import GradBuckets
+
+GROUNDING_KEYS = ("boxes", "masks", "positive_embeddings", "text_embeddings", "image_embeddings", "text_masks", "image_masks", "points")
+
+
+def warmup_schedule(base_lr: float, warmup_steps: int, total_iters: Optional[int] = None) -> Callable[[int], float]:
+    """The reference's LR schedules (trainer.py:262-267, transformers' get_constant_ / get_cosine_schedule_with_warmup):
+    linear warm-up over `warmup_steps`, then constant -- or, with total_iters, half a cosine down to 0. step counts from 1
+    (the optimiser step about to be taken), i.e. LambdaLR's epoch + 1 at the time opt.step() uses the rate."""
+    def lr(step: int) -> float:
+        k = step - 1                     # LambdaLR's epoch when this step's update is computed
+        if k < warmup_steps:
+            return base_lr * k / max(1, warmup_steps)
+        if total_iters is None:
+            return base_lr
+        prog = (k - warmup_steps) / max(1, total_iters - warmup_steps)
+        return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
+    return lr
+
+
+def null_grounding(batch: Mapping[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """GroundingNetInput.get_null_input (grounding_input/*_tokinzer_input.py:30-45): every grounding tensor zeroed."""
+    return {k: (torch.zeros_like(v) if k in GROUNDING_KEYS else v) for k, v in batch.items()}
 
 
 def trainable_names(state_dict: Mapping[str, torch.Tensor]):
@@ -26,11 +51,21 @@ def trainable_names(state_dict: Mapping[str, torch.Tensor]):
 
 
 class TrainStep:
-    def __init__(self, engine, cfg: Mapping, state_dict: Mapping[str, torch.Tensor], lr: float = 5e-5, weight_decay: float = 0.0,
-                 betas=(0.9, 0.999), eps: float = 1e-8, bucket_mb: float = 128.0, world: Optional[int] = None, checkpoint: bool = True):
+    """lr: a float, or a callable step -> rate (warmup_schedule: the reference's warm-up schedulers). drop_prob: the probability with
+    which an iteration trains on the null grounding input (UNetModel.forward, openaimodel.py:428: 0.1 while training; 0 here by
+    default so that a step is a pure function of its batch) -- drawn from `rng` (random.Random; seed it identically on every rank
+    or not at all, as the reference does). With torch.distributed initialised, rank 0's trainable parameters are broadcast once at
+    construction, as DistributedDataParallel does (trainer.py:321-322): replicas that start from different state_dicts would
+    otherwise drift apart silently."""
+
+    def __init__(self, engine, cfg: Mapping, state_dict: Mapping[str, torch.Tensor], lr: Union[float, Callable[[int], float]] = 5e-5,
+                 weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8, bucket_mb: float = 128.0, world: Optional[int] = None,
+                 checkpoint: bool = True, drop_prob: float = 0.0, rng: Optional[random.Random] = None, broadcast: bool = True):
         self.engine, self.cfg = engine, dict(cfg)
         dev = engine.device
-        self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), tuple(betas), float(eps)
+        self.lr = lr if callable(lr) else float(lr)
+        self.wd, self.betas, self.eps = float(weight_decay), tuple(betas), float(eps)
+        self.drop_prob, self.rng = float(drop_prob), rng or random.Random()
         self.checkpoint = bool(checkpoint)       # activation checkpointing per block (the reference: use_checkpoint=True in every shipped config)
         names = trainable_names(state_dict)
         shapes = {k: tuple(state_dict[k].shape) for k in names}
@@ -47,15 +82,24 @@ class TrainStep:
                 self.params[k] = self.pbuf.views[k]          # the model's trainable tensors ARE the flat buffers
             else:
                 self.params[k] = t
+        if broadcast and tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+            for b in self.pbuf.buckets:            # the views alias the buckets: one collective per bucket moves every trainable tensor
+                tdist.broadcast(b, src=0)
         self.steps = 0
+
+    def lr_at(self, step: int) -> float:
+        return float(self.lr(step)) if callable(self.lr) else self.lr
 
     def step(self, batch: Mapping[str, torch.Tensor], fuser_scale: float = 1.0):
         """One iteration: forward, loss, backward, gradient average over the ranks, AdamW. Returns (loss of this rank, eps)."""
+        if self.drop_prob > 0.0 and self.rng.random() < self.drop_prob:      # random drop for guidance (openaimodel.py:428)
+            batch = null_grounding(batch)
         loss, eps, _ = self.engine.unet_train_step(self.cfg, self.params, batch, fuser_scale=fuser_scale, grads=self.gbuf.views, checkpoint=self.checkpoint)
         self.gbuf.all_reduce(average=True)
         self.steps += 1
+        lr = self.lr_at(self.steps)
         for p, g, m, v in zip(self.pbuf.buckets, self.gbuf.buckets, self.m, self.v):
-            self.engine.op_adamw_step(p, g, m, v, self.steps, lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.wd)
+            self.engine.op_adamw_step(p, g, m, v, self.steps, lr=lr, betas=self.betas, eps=self.eps, weight_decay=self.wd)
         return loss, eps
 
     def state_dict(self) -> Dict[str, torch.Tensor]:

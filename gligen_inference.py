@@ -16,6 +16,7 @@ Differences that follow from running offline / on the native engine:
 import argparse
 import os
 import pickle
+import time
 from functools import partial
 
 import numpy as np
@@ -446,6 +447,36 @@ def generate_lanes(model, autoencoder, diffusion, batch, context, uc, *, lanes=2
     return torch.cat(outs, dim=0)
 
 
+@torch.no_grad()
+def generate_stream(model, autoencoder, diffusion, batch, context, uc, noises, *, lanes=2, **kw):
+    """Several WHOLE batches of the same prompt (one starting noise each), issued round-robin to `lanes` execution contexts -- what
+    bench.py times: while one batch's evaluation is in its kernel tails and memory-bound kernels, the other's matrix work fills the
+    chip. Each batch keeps the benchmark's shape (the tile table, the captured graph and the timed row-local / two-GEMM choice are
+    per shape), unlike generate_lanes, which splits ONE batch into halves. Returns the list of decoded batches in issue order."""
+    import copy
+    lanes = max(1, min(int(lanes), len(noises)))
+    model.engine, autoencoder.engine
+    dev = context.device
+    main = torch.cuda.current_stream(dev)
+    ctxs = [(model, autoencoder, main)] + [c[:3] for c in _lanes_of(model, autoencoder, lanes, dev)[:lanes - 1]]
+    tokenizer = model.grounding_tokenizer_input
+    outs = []
+    try:
+        for i, x_T in enumerate(noises):
+            m, ae, stream = ctxs[i % lanes]
+            if m is not model:
+                m.grounding_tokenizer_input = copy.copy(tokenizer)
+                m.first_conv_type = model.first_conv_type
+                stream.wait_stream(main)
+            with torch.cuda.stream(stream):
+                outs.append(generate(m, ae, diffusion, batch, context, uc, starting_noise=x_T, **kw))
+    finally:
+        model.grounding_tokenizer_input = tokenizer
+    for c in ctxs[1:]:
+        main.wait_stream(c[2])
+    return outs
+
+
 def save_images(samples, output_folder, first_id=None):
     os.makedirs(output_folder, exist_ok=True)
     start = len(os.listdir(output_folder)) if first_id is None else first_id
@@ -534,10 +565,40 @@ def run(meta, config, starting_noise=None, models=None):
         lanes = 1
     if lanes > 1 and starting_noise is None:   # x_T as the sampler would draw it (plms.py:71), before the batch is split
         starting_noise = torch.randn((hi - lo, model.in_channels, model.image_size, model.image_size), device=device)
-    samples = generate_lanes(model, autoencoder, diffusion, batch, context, uc, lanes=lanes, steps=steps,
-                             guidance_scale=args["guidance_scale"], alpha_type=meta.get("alpha_type"), starting_noise=starting_noise,
-                             inpainting_mask=mask, z0=z0, no_plms=no_plms, grounding_extra_input=grounding_extra_input,
-                             grounding_input=grounding_input)
+    repeat = max(1, int(args.get("repeat") or 1))
+    n_lanes_req = 2 if args.get("lanes") is None else max(1, int(args.get("lanes")))
+    if repeat > 1 and mask is None and meta.get("alpha_type") in (None, [1, 0, 0], [1.0, 0.0, 0.0]):
+        # `repeat` batches of this prompt (seed, seed + 1, ...): whole batches in flight on the lanes, as bench.py runs them
+        gkw = dict(steps=steps, guidance_scale=args["guidance_scale"], alpha_type=meta.get("alpha_type"), no_plms=no_plms,
+                   grounding_extra_input=grounding_extra_input, grounding_input=grounding_input)
+        shape = (hi - lo, model.in_channels, model.image_size, model.image_size)
+        seed0 = int(args.get("seed") or 0)
+        def noise(r):
+            if r == 0 and starting_noise is not None:
+                return starting_noise
+            return torch.randn((B,) + shape[1:], generator=torch.Generator().manual_seed(seed0 + r))[lo:hi].to(device)
+        for _ in range(max(0, int(args.get("warmup") or 0))):
+            generate_stream(model, autoencoder, diffusion, batch, context, uc, [noise(0)] * n_lanes_req, lanes=n_lanes_req, **gkw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs = generate_stream(model, autoencoder, diffusion, batch, context, uc, [noise(r) for r in range(repeat)], lanes=n_lanes_req, **gkw)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        samples = torch.cat(outs, dim=0)
+        print(f"[gligen_amd] {samples.shape[0]} images in {dt:.3f} s = {samples.shape[0] / dt:.3f} images/s on this GPU "
+              f"(sampling + decode of {repeat} batches of {hi - lo}, {min(n_lanes_req, repeat)} in flight)", flush=True)
+    else:
+        torch.cuda.synchronize() if torch.cuda.is_available() else None
+        t0 = time.perf_counter()
+        samples = generate_lanes(model, autoencoder, diffusion, batch, context, uc, lanes=lanes, steps=steps,
+                                 guidance_scale=args["guidance_scale"], alpha_type=meta.get("alpha_type"), starting_noise=starting_noise,
+                                 inpainting_mask=mask, z0=z0, no_plms=no_plms, grounding_extra_input=grounding_extra_input,
+                                 grounding_input=grounding_input)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            print(f"[gligen_amd] {samples.shape[0]} images in {dt:.3f} s = {samples.shape[0] / dt:.3f} images/s on this GPU "
+                  f"(sampling + decode, first call of a shape includes tile tuning and graph capture; {lanes} sub-batch(es) in flight)", flush=True)
     if world > 1:
         os.makedirs(folder, exist_ok=True)
         gdist.barrier()
@@ -617,6 +678,8 @@ def main(argv=None):
     parser.add_argument("--seed", type=int, default=None, help="seed of x_T (one draw for the whole batch, sliced across ranks)")
     parser.add_argument("--lanes", type=int, default=2, help="per-GPU batches of 8 and more run as this many sub-batches in flight (1 = off)")
     parser.add_argument("--steps", type=int, default=None, help="override the sampler's step count (reference: 50 PLMS / 250 DDIM)")
+    parser.add_argument("--repeat", type=int, default=1, help="batches of --batch_size per prompt (seed, seed + 1, ...): whole batches run --lanes at a time, as bench.py times them")
+    parser.add_argument("--warmup", type=int, default=0, help="with --repeat: untimed rounds first (tile tuning, graph capture), so the printed images/s is the steady state")
     args = parser.parse_args(argv)
 
     # one process per GPU: `python -m torch.distributed.run --nproc-per-node N gligen_inference.py ...` shards --batch_size

@@ -179,6 +179,27 @@ int gl_unet_profile(gl_ctx* ctx, int Beff, int h, int w, const float* x, int xB,
 int gl_arena_high_water(gl_ctx* ctx, size_t* bytes);
 int gl_launch_count(gl_ctx* ctx, int64_t* n);
 
+/* FeedForward + the LayerNorm in front of it (+ the C x C projections either side: attention.py:37-64, 236-244, 333-338, 374-376) exist
+ * in two forms at C = 320: ONE row-local launch (ffn.hip) or LayerNorm + GEGLU GEMM + FF-out GEMM (+ separate projections). Which is
+ * faster depends on the row count and on the box (the row-local form ran 1.65x slower on a slow-fabric box), so the
+ * engine TIMES both on the device at the first eager launch of each (block form, row count) and keeps the faster for the process.
+ * mode: -1 = that (default), 0 = never the row-local kernel, 1 = the row-local kernel wherever it exists. Process-wide; contexts drop
+ * their captured graphs when it changes. gl_ff_rows_policy_report: "mode=..;<form> C M -> rows|gemm (rows us, gemm us);.." of what
+ * has been timed so far. Measurement aids (bench.py's same-box A/B); the reference has no counterpart. */
+int gl_set_ff_rows_policy(int mode);
+int gl_ff_rows_policy_report(char* buf, size_t cap);
+
+/* What this box delivers, measured in ~50 ms on ctx's device (uses 1 GiB of the arena): a float4 copy far beyond the Infinity Cache
+ * (read + written GB/s), the global->LDS DMA path from an L2-resident window (TB/s over all CUs: the operand-delivery path of the
+ * GEMM / conv / attention kernels) and the sustained dense bf16 MFMA rate with every SIMD issuing (TFLOP/s). bench.py prints them
+ * beside images/s so that box-to-box spread of one commit is evidence, not a sentence. */
+typedef struct gl_box_calibration {
+    float hbm_copy_gbs;
+    float lds_dma_tbs;
+    float mfma_bf16_tflops;
+} gl_box_calibration;
+int gl_box_calibrate(gl_ctx* ctx, gl_box_calibration* out, gl_stream s);
+
 /* PositionNet.forward of the spatial-map modalities (reference canny_/hed_/depth_/normal_/sem_grounding_net.py:38-62):
  * image fp32 [B][C][H][W] (the map as RGB in [-1,1], or in_dim one-hot planes), mask fp32 [B] -> nearest resize to
  * resize_input -> (sem: Conv2d(in_dim,3,3,1,1)) -> ConvNeXt-tiny (convnext.py) -> null-feature mixing, + pos_embedding,
@@ -216,7 +237,8 @@ int gl_op_ln_linear(gl_ctx* ctx, const void* a, int M, int K0, const float* w0, 
  * :333-338 x = ff(norm3(x)) + x, :236-244 x = x + scale*tanh(alpha_dense) * ff(norm2(x))):
  *   y = res + gate * ( GEGLU( LN(x) W1^T + b1 ) W2^T + b2 ),  LN over C with gamma / beta (NULL: x is multiplied as it is)
  * x / res / y [M][C] bf16 (res may be NULL), W1 [8C][C] fp32 (value rows, then gate rows), b1 [8C], W2 [C][4C] fp32, b2 [C],
- * gate: device scalar or NULL (1). stats: optional [M] float2 (sum, sum of squares) of each output row.
+ * gate: device scalar or NULL (1). stats: optional [M] float2 (sum, sum of squares) of each output row -- written by the row-local
+ * kernel only: with stats != NULL a shape that kernel does not cover is refused (GL_ERR_UNSUPPORTED), not answered with zeros.
  * *used_rows = 1: the row-local kernel ran (one launch, hidden activation on chip: C = 320, M % 128 == 0); 0: LayerNorm kernel +
  * GEGLU GEMM + FF-out GEMM (both are product paths). */
 int gl_op_feedforward(gl_ctx* ctx, const void* x, int M, int C, const float* gamma, const float* beta, const float* w1, const float* b1,
@@ -310,9 +332,11 @@ int gl_unet_train_step(gl_ctx* ctx, const gl_unet_config* cfg, const gl_train_un
                        const float* const* params, float* const* grads, float* eps_out, float* loss, gl_stream s);
 
 /* One AdamW step over a flat fp32 range, in place: p, exp_avg m, exp_avg_sq v [n]; g the (all-reduced) gradient; step counts from 1.
- * torch.optim.AdamW semantics -- the reference's optimizer over the trainable set (trainer.py:245, opt.step() at :384). */
-int gl_op_adamw_step(gl_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                     float weight_decay, int step, gl_stream s);
+ * torch.optim.AdamW semantics -- the reference's optimizer over the trainable set (trainer.py:245, opt.step() at :384) -- down to where
+ * the scalars are formed: lr, the betas, eps and weight_decay arrive as doubles (Python floats), 1 - beta^step, lr / (1 - beta1^step),
+ * sqrt(1 - beta2^step) and 1 - lr weight_decay are computed in double and rounded to fp32 once, as torch does. */
+int gl_op_adamw_step(gl_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                     double weight_decay, int step, gl_stream s);
 
 /* 3x3 conv over NHWC bf16 (channel-concat of x0,x1), weight OIHW fp32, stride 1|2, optional
  * nearest 2x upsample of the input, pad_lo 1 (symmetric) or 0 (VAE-encoder style). y NHWC bf16. */

@@ -182,7 +182,9 @@ TRAIN_WORKER = textwrap.dedent("""
     sd = {{"input_blocks.1.1.transformer_blocks.0.fuser.linear.weight": torch.randn(16, 8, generator=gw),
           "input_blocks.1.1.transformer_blocks.0.fuser.alpha_attn": torch.randn((), generator=gw),
           "position_net.linears.0.weight": torch.randn(12, 5, generator=gw), "out.2.weight": torch.randn(4, 4, generator=gw)}}
-    ts = TrainStep(Eng(), {{}}, sd, lr=0.1, weight_decay=0.01, bucket_mb=4e-4, world=world)
+    # rank 1 starts from OTHER trainable values: the constructor broadcasts rank 0's (as DistributedDataParallel does, trainer.py:321-322)
+    sd_mine = {{k: (v + 1.0 if (rank == 1 and (".fuser." in k or k.startswith("position_net."))) else v.clone()) for k, v in sd.items()}}
+    ts = TrainStep(Eng(), {{}}, sd_mine, lr=0.1, weight_decay=0.01, bucket_mb=4e-4, world=world)
     for it in range(3):
         ts.step(dict(it=it))
     # the same three steps in one process on the MEAN gradient of the two ranks
@@ -206,7 +208,8 @@ TRAIN_WORKER = textwrap.dedent("""
 
 
 def test_two_rank_gloo_train_step(tmp_path):
-    """Two ranks with different gradients end every step with the same parameters: those of AdamW on the mean gradient
+    """Two ranks with different gradients -- and different initial trainable values, which the constructor's broadcast from rank 0
+    levels -- end every step with the same parameters: those of AdamW on the mean gradient
     (the reference's DDP + torch.optim.AdamW, trainer.py:245, 321-322, 384), over several flat buckets."""
     import json
     port = _free_port()

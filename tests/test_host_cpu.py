@@ -674,6 +674,53 @@ def test_train_step_bookkeeping_on_flat_buckets():
     assert torch.all(out["position_net.linears.0.bias"] == 0.0) and torch.all(out["out.2.weight"] == 1.0)      # 1 - 2 * 0.5; frozen untouched
 
 
+def test_train_step_lr_schedule_and_guidance_drop():
+    """TrainStep's learning-rate hook against the reference's schedulers (trainer.py:262-267: transformers'
+    get_constant_schedule_with_warmup / get_cosine_schedule_with_warmup on an AdamW) and its random drop to the null grounding input
+    (UNetModel.forward while training, openaimodel.py:428; get_null_input: every grounding tensor zero)."""
+    import random
+    import torch
+    from transformers import get_constant_schedule_with_warmup, get_cosine_schedule_with_warmup
+    from gligen_amd.train import TrainStep, warmup_schedule
+    for total in (None, 40):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.AdamW([p], lr=5e-5)
+        sched = get_constant_schedule_with_warmup(opt, 10) if total is None else get_cosine_schedule_with_warmup(opt, 10, total)
+        mine = warmup_schedule(5e-5, 10, total)
+        for step in range(1, 31):
+            assert abs(opt.param_groups[0]["lr"] - mine(step)) < 1e-12, (total, step)     # the rate opt.step() number `step` uses
+            opt.step()
+            sched.step()
+
+    class Eng:
+        device = torch.device("cpu")
+
+        def __init__(self):
+            self.seen, self.lrs = [], []
+
+        def unet_train_step(self, cfg, params, batch, fuser_scale=1.0, trainable=None, grads=None, checkpoint=False):
+            self.seen.append({k: float(v.abs().sum()) for k, v in batch.items()})
+            return torch.tensor([0.0]), torch.zeros(1), grads
+
+        def op_adamw_step(self, p, g, m, v, step, lr, betas, eps, weight_decay):
+            self.lrs.append(lr)
+
+    sd = {"input_blocks.1.1.transformer_blocks.0.fuser.linear.weight": torch.ones(4, 4), "out.2.weight": torch.ones(2, 2)}
+    batch = dict(x=torch.ones(2, 4, 8, 8), boxes=torch.ones(2, 30, 4), masks=torch.ones(2, 30), positive_embeddings=torch.ones(2, 30, 768), target=torch.ones(2, 4, 8, 8))
+    eng = Eng()
+    ts = TrainStep(eng, {}, sd, lr=warmup_schedule(1e-3, 4), world=1, drop_prob=0.5, rng=random.Random(0))
+    for _ in range(40):
+        ts.step(batch)
+    assert eng.lrs[:6] == [0.0, 0.00025, 0.0005, 0.00075, 0.001, 0.001]
+    dropped = [s for s in eng.seen if s["masks"] == 0.0]
+    assert 8 <= len(dropped) <= 32 and all(s["boxes"] == 0.0 and s["positive_embeddings"] == 0.0 and s["x"] > 0 and s["target"] > 0 for s in dropped)
+    assert all(s["boxes"] > 0 for s in eng.seen if s["masks"] > 0) and float(batch["masks"].sum()) == 60.0      # the caller's batch is untouched
+    eng2 = Eng()
+    ts2 = TrainStep(eng2, {}, sd, lr=1e-3, world=1)        # defaults: constant rate, no drop
+    ts2.step(batch)
+    assert eng2.lrs == [1e-3] and eng2.seen[0]["masks"] > 0
+
+
 def test_ctypes_structs_match_the_c_header(tmp_path):
     """Every struct that crosses the C ABI has the same size in include/gligen_amd.h (compiled by gcc as C99) and in the ctypes
     mirror of gligen_amd/_lib.py / engine.py -- a field added on one side only would otherwise be read as garbage, not rejected."""
@@ -682,7 +729,7 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     import subprocess
     from gligen_amd import _lib, engine
     pairs = {"gl_unet_config": _lib.UNetConfig, "gl_vae_config": _lib.VaeConfig, "gl_grounding": _lib.Grounding, "gl_plms_args": _lib.PlmsArgs,
-             "gl_train_unet_in": _lib.TrainUNetIn, "gl_train_block_dims": engine.TrainBlockDims, "gl_train_resblock_dims": engine.TrainResDims}
+             "gl_train_unet_in": _lib.TrainUNetIn, "gl_box_calibration": _lib.BoxCalibration, "gl_prof_rec": _lib.ProfRec, "gl_train_block_dims": engine.TrainBlockDims, "gl_train_resblock_dims": engine.TrainResDims}
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "gligen_amd.h"\nint main(void) {\n' +
                    "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in pairs) + "  return 0;\n}\n")

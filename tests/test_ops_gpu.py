@@ -311,8 +311,12 @@ def test_feedforward_rows(engine, M, C, ln, gated):
     gamma, beta = (1.0 + 0.3 * rnd(C, seed=6), 0.2 * rnd(C, seed=7)) if ln else (None, None)
     res = bf(rnd(M, C, seed=8))
     gate = torch.tensor([0.37], device=x.device) if gated else None
-    y, stats, used = engine.op_feedforward(x, w1, b1, w2, b2, gamma, beta, res, gate, want_stats=True)
-    assert used == (1 if (C == 320 and M % 128 == 0) else 0)
+    rows = C == 320 and M % 128 == 0
+    if not rows:   # row statistics come from the row-local kernel only: asking the two-GEMM form for them is refused, not answered with zeros
+        with pytest.raises(Exception, match="row statistics"):
+            engine.op_feedforward(x, w1, b1, w2, b2, gamma, beta, res, gate, want_stats=True)
+    y, stats, used = engine.op_feedforward(x, w1, b1, w2, b2, gamma, beta, res, gate, want_stats=rows)
+    assert used == (1 if rows else 0)
     xs = x.float()
     h = (F.layer_norm(xs, (C,), gamma, beta, 1e-5) if ln else xs) @ w1.t() + b1
     val, g = h.chunk(2, dim=-1)

@@ -35,6 +35,9 @@ def run(name, cfg, B, hw, reps, eng, checkpoint=False):
 
 if __name__ == "__main__":
     eng = Engine(0, arena_gb=160.0)
+    if "--b4only" in sys.argv:          # the profiled line (tools/gpu_run.sh train with TRAIN_PROF=1): the bench line's train_step shape
+        run("shipped topology", syn.UNET_CFG, 4, 64, 1, eng, checkpoint=True)
+        sys.exit(0)
     run("small UNet", syn.UNET_CFG_SMALL, 2, 16, 3, eng)
     run("shipped topology", syn.UNET_CFG, 1, 16, 2, eng)
     if "--full64" in sys.argv:
