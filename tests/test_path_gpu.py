@@ -258,3 +258,35 @@ def test_plms_vs_reference(name, tmp_path, monkeypatch):
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_ff_rows_policy_modes_and_box_calibration():
+    """The engine's choice between the row-local feed-forward kernel and LayerNorm + two GEMMs (gl_set_ff_rows_policy): never / wherever it
+    exists / decided by on-device timing (the default) all reproduce the reference's eps of the small UNet (its C = 320 level at
+    B x 16 x 16 = 512 rows satisfies the kernel's M % 128 == 0), the timed mode records what it measured, and gl_box_calibrate returns
+    the three box numbers in physically possible ranges."""
+    dev = _dev()
+    g = load_golden("unet_small_text")
+    meta = g["meta"]
+    model = build_product_unet(meta["cfg"], meta["kind"], meta["inpaint"], device=dev)
+    batch, x, ctx, t, extra = unet_inputs(meta)
+    gin = model.grounding_tokenizer_input.prepare(_to(batch, dev))
+    inp = dict(x=x.to(dev), timesteps=t.to(dev), context=ctx.to(dev), grounding_input=gin, inpainting_extra_input=None, grounding_extra_input=None)
+    eng = model.engine
+    out = {}
+    try:
+        for mode in (0, 1, -1):
+            eng.set_ff_rows_policy(mode)
+            out[mode] = model(inp)
+            assert mse(out[mode], g["eps"]) < EPS_MSE_TOL, (mode, mse(out[mode], g["eps"]))
+            assert torch.equal(out[mode], model(inp))        # a decided shape stays decided: same kernels, same bits
+    finally:
+        eng.set_ff_rows_policy(-1)
+    assert not torch.equal(out[0], out[1])                   # the two forms are different kernels (bf16 summation order)
+    rep = eng.ff_rows_policy_report()
+    assert rep.startswith("mode=-1") and "C320 M512" in rep and ("-> rows" in rep or "-> gemm" in rep), rep
+    assert torch.equal(out[-1], out[1]) or torch.equal(out[-1], out[0])
+    REPORT["ff_rows_policy"] = rep
+    cal = eng.box_calibrate()
+    REPORT["box_calibration"] = cal
+    assert 500 < cal["hbm_copy_GBps"] < 8000 and 1 < cal["lds_dma_TBps"] < 60 and 300 < cal["mfma_bf16_TFLOPs"] < 2600, cal

@@ -13,7 +13,8 @@
 #   prof             rocprofv3 --kernel-trace --stats of the bench command -> bench_kernel_stats.csv
 #   traffic          FETCH_SIZE / WRITE_SIZE PMC passes per symbol and per problem (tools/gpu_traffic.sh)
 #   mfma             MFMA-busy / LDS-conflict PMC passes per symbol (tools/gpu_mfma_util.sh)
-#   train            tools/train_bench.py --full64 (+ rocprofv3 stats of one iteration with TRAIN_PROF=1)
+#   train            tools/train_bench.py $TRAIN_ARGS (default --b4only: the bench line's train_step shape; --full64: every configuration)
+#                    + rocprofv3 stats of one B = 4 iteration with TRAIN_PROF=1
 #   ab VAR A B [N]   same-box A/B of a developer switch: bench.py alternated N times (default 2) with VAR=A / VAR=B
 #   lib DIR          swap in the variant library built by tools/build_variant.sh for the tasks that follow
 export TMPDIR=/tmp
@@ -45,10 +46,10 @@ while [ $# -gt 0 ]; do
            cp $(find gpurun_out/prof -name "*kernel_stats*" | head -1) $O/bench_kernel_stats.csv; head -8 $O/bench_kernel_stats.csv | cut -c1-160 ;;
     traffic) bash tools/gpu_traffic.sh > $O/traffic.log 2>&1; cp gpurun_out/pmc_traffic.csv gpurun_out/pmc_traffic_per_problem.csv $O/; tail -12 $O/traffic.log | cut -c1-200 ;;
     mfma) bash tools/gpu_mfma_util.sh > $O/mfma.log 2>&1; cp gpurun_out/pmc_mfma.csv gpurun_out/pmc_mfma_report.txt $O/; head -12 $O/pmc_mfma_report.txt | cut -c1-150 ;;
-    train) dev; ( PYTHONPATH=. timeout 900 python tools/train_bench.py --full64 ) > $O/train_bench.txt 2> $O/train_bench.err; cat $O/train_bench.txt | cut -c1-260
+    train) dev; ( PYTHONPATH=. timeout 900 python tools/train_bench.py ${TRAIN_ARGS:---b4only} ) > $O/train_bench.txt 2> $O/train_bench.err; cat $O/train_bench.txt | cut -c1-260
            if [ -n "$TRAIN_PROF" ]; then rm -rf gpurun_out/tprof
              ( cd /tmp && PYTHONPATH=$R timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/tprof -- python $R/tools/train_bench.py --b4only ) > $O/train_prof.log 2>&1
-             find gpurun_out/tprof -name "*kernel_trace*" -delete; cp $(find gpurun_out/tprof -name "*kernel_stats*" | head -1) $O/train_kernel_stats.csv; head -14 $O/train_kernel_stats.csv | cut -c1-170; fi ;;
+             find gpurun_out/tprof -name "*kernel_trace*" -delete; cp $(find gpurun_out/tprof -name "*kernel_stats*" | head -1) $O/train_kernel_stats.csv; head -16 $O/train_kernel_stats.csv | cut -c1-170; fi ;;
     ab) dev; var=$1; a=$2; b=$3; shift 3; n=2; case "$1" in ''|*[!0-9]*) ;; *) n=$1; shift ;; esac
            : > $O/ab_$var.txt
            for i in $(seq $n); do for v in $a $b; do
