@@ -635,6 +635,358 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn2_kernel(AttnPar
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// v3 (round 5), d = 40: attn2_kernel with O^T += V^T P^T on v_mfma_f32_16x16x32_bf16.
+//
+// The 32x32x16 shape makes O^T a [64 x 32 queries] product for 40 real rows (+ the ones row): 37 % of the P V work multiplies padding,
+// a V^T tile is 8 KB of DMA and LDS reads where 5.1 KB carry data, and O^T takes 32 accumulator registers. With 16-row MFMAs O^T is
+// [48 x 16] per query half: 12 MFMAs of 16 clocks per 64-key tile instead of 8 of 32 (-25 % of the P V issue time, -14 % of the
+// tile's), 6 KB per V^T tile (K + V^T stage 12 KB instead of 14), 6 fragment reads instead of 8, 24 accumulator registers.
+// S^T = K Q^T stays on 32x32x16 (its k dimension is the head dim: 48 padded columns in three k-steps; a 32-wide k-step would pad
+// 40 -> 64). The price is the operand hand-over: a 32x32 accumulator holds query q in lane q (keys 8 j + e) and lane q + 32 (keys
+// 8 j + 4 + e), the 16x16x32 B operand wants query q & 15 of ONE 16-query half in all four 16-lane rows, each row with its own 8
+// keys. v_permlane16_swap_b32 does exactly that exchange: with X = the packed exps of accumulator registers 0..7 and Y = those of
+// registers 8..15, swapping the odd rows of X with the even rows of Y leaves X = the operand of queries 0..15 and Y = that of
+// queries 16..31, k-slot groups (lane >> 4 = 0..3) = keys {0-3, 8-11}, {16-19, 24-27}, {4-7, 12-15}, {20-23, 28-31} of the 32-key
+// sub-tile. The q,k,v^T projection stores V^T's tokens in that order (Epilogue::vt_perm32), so an A fragment (16 rows x 32 keys)
+// is one ds_read_b128 per lane: row 16 i + (lane & 15), 16-byte chunk 4 u + (lane >> 4) of the tile's 128-byte row. 8 swaps per
+// lane and tile buy 4 fewer MFMA issue slots' worth of matrix time -- what the kernel is short of is issue time under the MFMAs,
+// so the ledger is: -64 MFMA clocks, +4 MFMA issues, +8 VALU, -2 ds_read, -1 DMA per wave and tile.
+// Everything else is attn2_kernel's: pipeline (S(j) || exp2 of S(j-1) || P V (j-1)), LDS-DMA ring, lazy stabiliser in Q column 40,
+// denominator from the ones row (row 40 of V^T = accumulator register 0 of row block 2 in lanes 32..47).
+__device__ __forceinline__ void swap16(bf16x8& x, bf16x8& y) {
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t a = __builtin_bit_cast(u32x4_t, x), b = __builtin_bit_cast(u32x4_t, y);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const auto r = __builtin_amdgcn_permlane16_swap(a[w], b[w], false, false);   // odd 16-lane rows of a <-> even rows of b
+        a[w] = r[0];
+        b[w] = r[1];
+    }
+    x = __builtin_bit_cast(bf16x8, a);
+    y = __builtin_bit_cast(bf16x8, b);
+}
+template <int N, int I = 0>
+__device__ __forceinline__ void lds_rd_v16(bf16x8 (&d)[N], unsigned a) {
+    if constexpr (I < N) {
+        lds_rd16<I * 2048>(d[I], a);      // row block i: 16 rows of 128 bytes on
+        lds_rd_v16<N, I + 1>(d, a);
+    }
+}
+// DP / DPV: padded head dims of the q,k / v^T buffers (48 / 48 at d = 40, 80 / 96 at d = 80); BIAS: the stabiliser rides in the free Q column
+// (d = 40), else it is subtracted in front of the exps. The ones row of V^T is row d (P.d) in both.
+template <int DP, int DPV, bool BIAS, int NW>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn3_kernel(AttnParams P) {
+    static_assert(DP % 16 == 0 && DPV % 16 == 0 && DPV > DP - 8, "tile geometry");
+    constexpr int KS = DP / 16;            // k-steps of S^T = K Q^T
+    constexpr int DB = DPV / 16;           // 16-row blocks of O^T
+    constexpr int KP = DP / 8, VP = DPV / 8;   // 1-KiB DMA pieces per K / V^T tile
+    constexpr int KBYTES = KP * 1024, VBYTES = VP * 1024, STAGE = KBYTES + VBYTES;
+    constexpr int KR = (KP + NW - 1) / NW, VR = (VP + NW - 1) / NW;
+    // LATE_V (d = 80): a sub-tile's V^T fragments are read when the registers of what ran before them are free (the K fragments behind
+    // S(j)'s MFMAs, sub-tile 0's behind the first half of P V) instead of a region ahead: 48 fewer live registers, which is what lets
+    // the pipelined form run at two waves per SIMD there (the early form spills 84); the read's latency then hides behind the
+    // operand swaps and the SIMD's other wave only
+    constexpr bool LATE_V = DPV > 64;
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lrow = lane & 31;
+    const int half = lane >> 5;
+    const int l15 = lane & 15;
+    const int g4 = lane >> 4;
+    int lin = blockIdx.x;
+    {   // XCD-aware block order, as above
+        const int total = gridDim.x;
+        if ((total & 7) == 0) lin = (lin & 7) * (total >> 3) + (lin >> 3);
+    }
+    const int qblk = lin % P.nqb;
+    const int bhi = lin / P.nqb;
+    const int h = bhi % P.H;
+    const int b = bhi / P.H;
+    const size_t bh = (size_t)bhi;
+
+    const bf16* __restrict__ Qg = P.q + bh * P.Tq_pad * DP;
+    const bf16* __restrict__ Kg = P.k + bh * P.Tk_pad * DP;
+    const bf16* __restrict__ Vg = P.vt + bh * DPV * P.Tk_pad;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kg, 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vg, 0, 0x80000000u, 0x00020000);
+
+    const int nt = (P.Nk + 63) >> 6;
+    const int q0 = qblk * (NW * 32) + wave * 32;
+    const int myq = q0 + lrow;
+    const int myq_ld = myq < P.Tq_pad ? myq : P.Tq_pad - 1;
+
+    const lds_ptr lbase = (lds_ptr)smem;
+    const int w1k = wave * 1024;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    unsigned vvoff[VR];
+#pragma unroll
+    for (int i = 0; i < VR; ++i) {
+        const int r = 8 * (wave + NW * i) + (lane >> 3);          // (pieces >= VP of the short last round are never issued)
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        vvoff[i] = (unsigned)(r * P.Tk_pad) * 2u + (unsigned)c * 16u;
+    }
+    auto issue_k = [&](int jj, int slot) {
+        const lds_ptr st = lbase + slot * STAGE + w1k;
+        const int so = jj * KBYTES + w1k;
+#pragma unroll
+        for (int i = 0; i < KR; ++i) {
+            if ((i + 1) * NW <= KP) GL_BLDS16(rk, st + i * NW * 1024, lane16, so + i * NW * 1024);
+            else if (wave < KP - i * NW) GL_BLDS16(rk, st + i * NW * 1024, lane16, so + i * NW * 1024);
+        }
+    };
+    auto issue_v = [&](int jj, int slot) {
+        const lds_ptr st = lbase + slot * STAGE + KBYTES + w1k;
+        const int so = (jj - 1) * 128;
+#pragma unroll
+        for (int i = 0; i < VR; ++i) {
+            if ((i + 1) * NW <= VP) GL_BLDS16(rv, st + i * NW * 1024, vvoff[i], so);
+            else if (wave < VP - i * NW) GL_BLDS16(rv, st + i * NW * 1024, vvoff[i], so);
+        }
+    };
+    issue_k(0, 0);
+
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)myq_ld * DP + 16 * s + 8 * half);
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[s][e] = f2bf((float)qf[s][e] * P.scale_log2e);
+    if constexpr (BIAS) {
+        if (half == 1) qf[2][0] = f2bf(0.f);   // column 40 = -m, m = 0 until the first tile has been seen
+    }
+
+    f32x4_t ot[2][DB];                     // [query half][row block]: lane holds query 16 qh + (lane & 15), rows 16 i + 4 (lane >> 4) + r
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh)
+#pragma unroll
+        for (int i = 0; i < DB; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ot[qh][i][r] = 0.f;
+    float m_run = BIAS ? 0.f : -1e30f;   // BIAS: the stabiliser baked into Q column 40; else subtracted in front of the exps
+
+    const unsigned k_lane = (unsigned)(lrow * 16 + half * 1024);
+    const unsigned v_lane = KBYTES + (unsigned)(l15 * 128) + (unsigned)((g4 ^ ((l15 >> 1) & 7)) << 4);
+
+    auto iter = [&](int j, f32x16 (&sc)[2], f32x16 (&sn)[2], auto slot_c, auto issue_c, auto sm_c, auto qk_c, auto tail_c, auto first_c) {
+        constexpr int SLOT = decltype(slot_c)::value, ISSUE = decltype(issue_c)::value;
+        constexpr bool SM = decltype(sm_c)::value, QK = decltype(qk_c)::value, TAILCK = decltype(tail_c)::value, FIRSTMOVE = decltype(first_c)::value;
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): stage j has landed (this wave's pieces; the barrier covers the others')
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int slot = SLOT >= 0 ? SLOT : (j & 1);
+        if constexpr (ISSUE != 0) {
+            if constexpr (ISSUE == 1) issue_k(j + 1, slot ^ 1);
+            if constexpr (ISSUE == 3) { if (j + 1 < nt) issue_k(j + 1, slot ^ 1); }
+            issue_v(j + 1, slot ^ 1);
+        }
+        const unsigned sb = (unsigned)(slot * STAGE);
+        const unsigned ak = k_lane + sb;
+        const unsigned av0 = v_lane + sb, av1 = av0 ^ 64u;     // key sub-tile 1: chunk index + 4
+
+        bf16x8 kf[2 * KS], vfa[DB], vfb[LATE_V ? 1 : DB];
+        if constexpr (QK) lds_rd_k(kf, ak);
+        if constexpr (SM && !LATE_V) lds_rd_v16(vfa, av0);
+        // ---- region 1: S(j) on the matrix core  ||  exp2 of the first 32 keys of tile j-1
+        if constexpr (QK) {
+            if constexpr (SM && !LATE_V) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(DB));
+            else asm volatile("s_waitcnt lgkmcnt(0)");
+            pin_regs(kf);
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            sn[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], zero, 0, 0, 0);
+            sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[0], zero, 0, 0, 0);
+#pragma unroll
+            for (int s = 1; s < KS; ++s) {
+                sn[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2 * s], qf[s], sn[0], 0, 0, 0);
+                sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2 * s + 1], qf[s], sn[1], 0, 0, 0);
+            }
+        }
+        if constexpr (SM) {
+            bf16x8 px, py;     // after swap16: px = P^T operand of queries 0..15, py = of queries 16..31
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                px[e] = f2bf(__builtin_amdgcn_exp2f(BIAS ? sc[0][e] : sc[0][e] - m_run));
+                py[e] = f2bf(__builtin_amdgcn_exp2f(BIAS ? sc[0][8 + e] : sc[0][8 + e] - m_run));
+            }
+            if constexpr (!LATE_V) {
+                swap16(px, py);
+                __builtin_amdgcn_sched_barrier(0);
+                lds_rd_v16(vfb, av1);                                   // the second sub-tile's V^T fragments
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(DB));      // vfa has arrived
+            } else {
+                __builtin_amdgcn_sched_barrier(0);
+                lds_rd_v16(vfa, av0);                                   // (into the registers S(j)'s MFMAs have released)
+                swap16(px, py);
+                asm volatile("s_waitcnt lgkmcnt(0)");
+            }
+            pin_regs(vfa);
+            // ---- region 2: first half of O^T += V^T P^T  ||  exp2 of the other 32 keys
+#pragma unroll
+            for (int i = 0; i < DB; ++i) {
+                ot[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfa[i], px, ot[0][i], 0, 0, 0);
+                ot[1][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfa[i], py, ot[1][i], 0, 0, 0);
+            }
+            bf16x8 pz, pw;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pz[e] = f2bf(__builtin_amdgcn_exp2f(BIAS ? sc[1][e] : sc[1][e] - m_run));
+                pw[e] = f2bf(__builtin_amdgcn_exp2f(BIAS ? sc[1][8 + e] : sc[1][8 + e] - m_run));
+            }
+            if constexpr (!LATE_V) {
+                swap16(pz, pw);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)");
+                pin_regs(vfb);
+            } else {
+                __builtin_amdgcn_sched_barrier(0);
+                lds_rd_v16(vfa, av1);                                   // (the first half's MFMAs are issued: their operands are free)
+                swap16(pz, pw);
+                asm volatile("s_waitcnt lgkmcnt(0)");
+                pin_regs(vfa);
+            }
+            // ---- region 3: second half of PV  ||  row maximum of S(j)
+            bf16x8 (&vf2)[DB] = *reinterpret_cast<bf16x8 (*)[DB]>(LATE_V ? &vfa[0] : &vfb[0]);
+#pragma unroll
+            for (int i = 0; i < DB; ++i) {
+                ot[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf2[i], pz, ot[0][i], 0, 0, 0);
+                ot[1][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf2[i], pw, ot[1][i], 0, 0, 0);
+            }
+        }
+        if constexpr (QK) {
+            if constexpr (TAILCK) {
+                const int kv0 = j << 6;
+                if (kv0 + 64 > P.Nk) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int kv = kv0 + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            if (kv >= P.Nk) sn[u][r] = -1e30f;
+                        }
+                }
+            }
+            float mx = sn[0][0];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sn[u][r]);
+            mx = max_xor32(mx);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- stabiliser move (rare after the first tiles). O^T holds query 16 qh + (lane & 15) in every 16-lane row: the factor of
+            // this lane's query (lane & 31) goes to the rows that hold it -- one swap gives both halves' (the two lanes of a query agree:
+            // mx went through max_xor32)
+            auto rescale_o = [&](float alpha) {
+                const auto ar = __builtin_amdgcn_permlane16_swap(__float_as_uint(alpha), __float_as_uint(alpha), false, false);
+                const float a0 = __uint_as_float(ar[0]), a1 = __uint_as_float(ar[1]);
+#pragma unroll
+                for (int i = 0; i < DB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { ot[0][i][r] *= a0; ot[1][i][r] *= a1; }
+            };
+            if constexpr (BIAS) {
+                // sn is s * c - m_run (the stabiliser rode through the MFMA in Q column 40)
+                const bool move = FIRSTMOVE || mx > 6.f;
+                if (__builtin_amdgcn_ballot_w64(move) != 0) {
+                    const bf16 mb = f2bf(m_run + mx);
+                    const float m_upd = move ? (float)mb : m_run;
+                    const float delta = m_upd - m_run;   // exact: both are bf16 values
+                    if constexpr (!FIRSTMOVE) rescale_o(__builtin_amdgcn_exp2f(-delta));
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sn[u][r] -= delta;
+                    m_run = m_upd;
+                    const bf16 nb = f2bf(-m_upd);
+                    if (half == 1) qf[2][0] = nb;
+                }
+            } else {
+                // sn is s * c; the exps subtract m_run
+                const bool move = FIRSTMOVE || mx - m_run > 6.f;
+                if (__builtin_amdgcn_ballot_w64(move) != 0) {
+                    const float m_upd = move ? mx : m_run;
+                    if constexpr (!FIRSTMOVE) rescale_o(__builtin_amdgcn_exp2f(m_run - m_upd));
+                    m_run = m_upd;
+                }
+            }
+        }
+    };
+
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    f32x16 sa[2], sb2[2];
+    iter(0, sb2, sa, S0{}, I3{}, F_{}, T_{}, T_{}, T_{});                      // S(0) -> sa
+    if (nt == 1) {
+        iter(1, sa, sb2, S1{}, I0{}, T_{}, F_{}, F_{}, F_{});                  // drain
+    } else {
+        int j = 1;
+        for (; j + 1 <= nt - 2; j += 2) {
+            iter(j, sa, sb2, S1{}, I1{}, T_{}, T_{}, F_{}, F_{});
+            iter(j + 1, sb2, sa, S0{}, I1{}, T_{}, T_{}, F_{}, F_{});
+        }
+        if (j <= nt - 2) {
+            iter(j, sa, sb2, S1{}, I1{}, T_{}, T_{}, F_{}, F_{});
+            ++j;
+            iter(j, sb2, sa, S0{}, I2{}, T_{}, T_{}, T_{}, F_{});
+            iter(j + 1, sa, sb2, S1{}, I0{}, T_{}, F_{}, F_{}, F_{});
+        } else {
+            iter(j, sa, sb2, S1{}, I2{}, T_{}, T_{}, T_{}, F_{});
+            iter(j + 1, sb2, sa, S0{}, I0{}, T_{}, F_{}, F_{}, F_{});
+        }
+    }
+
+    // softmax denominator = O^T row d (the ones row of V^T): row block d / 16, local row d % 16 = register (d % 4) of the 16-lane row
+    // (d % 16) / 4   (d = 40: block 2, lanes 32..47, register 0; d = 80: block 5, lanes 0..15, register 0)
+    const int ob = P.d >> 4, og = (P.d & 15) >> 2, orr = P.d & 3;
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh) {
+        float cand = 0.f;
+#pragma unroll
+        for (int i = 0; i < DB; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (i == ob && r == orr) cand = ot[qh][i][r];
+        const float l_tot = __shfl(cand, 16 * og + l15, 64);
+        const float inv = 1.f / l_tot;
+        const int q = q0 + 16 * qh + l15;
+        if (q < P.Nq) {
+            bf16* orow = P.o + ((size_t)b * P.o_rows_per_b + q) * P.ldo + h * P.d;
+#pragma unroll
+            for (int i = 0; i < DB; ++i) {
+                const int dd0 = 16 * i + 4 * g4;
+                if (dd0 < P.d) {
+                    U2BF4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o.e[e] = f2bf(ot[qh][i][e] * inv);
+                    *reinterpret_cast<uint2*>(orow + dd0) = o.u;
+                }
+            }
+        }
+    }
+}
+
+template <int DP, int DPV, bool BIAS, int NW>
+static int launch_attn3(const AttnParams& P, int B, hipStream_t stream) {
+    const size_t lds = 2 * ((DP / 8) * 1024 + (DPV / 8) * 1024);
+    AttnParams Q = P;
+    Q.nqb = cdiv(P.Nq, NW * 32);
+    dim3 grid(Q.nqb * P.H * B);
+    hipLaunchKernelGGL((attn3_kernel<DP, DPV, BIAS, NW>), grid, dim3(NW * 64), lds, stream, Q);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
 template <int DP, int DPV, bool BIAS, int NW>
 static int launch_attn2(const AttnParams& P, int B, hipStream_t stream) {
     const size_t lds = 2 * ((DP / 8) * 1024 + (DPV / 8) * 1024);
@@ -685,30 +1037,42 @@ __global__ void vt_ones_kernel(bf16* vt, int DPV, int Tk_pad, int d) {
     bf16* row = vt + ((size_t)blockIdx.x * DPV + d) * Tk_pad;
     for (int i = threadIdx.x; i < Tk_pad; i += blockDim.x) row[i] = (bf16)1.0f;
 }
-int attn_vt_ones_launch(bf16* vt, int BH, int d, int Tk_pad, hipStream_t stream) {
+int attn_vt_ones_launch(bf16* vt, int BH, int d, int Tk_pad, hipStream_t stream, int DPV) {
     int dp, dpv;
     GL_TRY(attn_dims(d, &dp, &dpv));
+    if (DPV) dpv = DPV;
     if (dpv == d) return GL_OK;
     hipLaunchKernelGGL(vt_ones_kernel, dim3(BH), dim3(256), 0, stream, vt, dpv, Tk_pad, d);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }
 
-// GL_ATTN_V2 (developer A/B): 0 = the unpipelined kernel for every head dim, 1 (default) = attn2_kernel with 4 waves (two
-// workgroups per CU) for d = 40, 2 = attn2_kernel with 8 waves (one workgroup per CU: half the K / V^T DMA per query row)
+// GL_ATTN_V2 (developer A/B): 0 = the unpipelined kernel for every head dim, 1 = attn2_kernel with 4 waves (two workgroups per CU)
+// for d = 40, 2 = attn2_kernel with 8 waves (one workgroup per CU: half the K / V^T DMA per query row), 3 (default) = attn3_kernel:
+// attn2's pipeline with P V on 16x16x32 MFMAs (V^T buffers in the attn_vt_layout == 1 form) at d = 40 AND d = 80 (48 O^T registers
+// instead of 96: the pipelined form fits two waves per SIMD there too), 4 = attn3_kernel at d = 40 only
 static int attn_v2_mode() {
-    static const int m = dev_env("GL_ATTN_V2") ? atoi(dev_env("GL_ATTN_V2")) : 1;
+    static const int m = dev_env("GL_ATTN_V2") ? atoi(dev_env("GL_ATTN_V2")) : 3;
     return m;
 }
 
 // (short key sequences -- the 77 text tokens of the cross-attention: two tiles -- stay on the unpipelined kernel: nothing to
 // pipeline, and its four workgroups per CU start and drain faster; 19.5 against 22.8 us at 4096 x 77, profiles/r3)
-static bool attn_use_v2(int d, int Nk) { return d == 40 && attn_v2_mode() != 0 && Nk > 128; }
+static bool attn_use_v2(int d, int Nk) { return Nk > 128 && ((d == 40 && attn_v2_mode() != 0) || (d == 80 && attn_v2_mode() == 3)); }
 
-const char* attn_kernel_name(int d, int Nk) {
-    const int v2 = attn_use_v2(d, Nk) ? attn_v2_mode() : 0;
-    if (d == 40) return v2 == 0 ? "attn_kernel<48, 64, true>" : v2 == 1 ? "attn2_kernel<48, 64, true, 4>" : "attn2_kernel<48, 64, true, 8>";
-    if (d == 80) return "attn_kernel<80, 96, true>";
+int attn_vt_layout(int d, int Nk, int* DPV) {
+    int dp, dpv = 0;
+    (void)attn_dims(d, &dp, &dpv);
+    const int layout = (attn_use_v2(d, Nk) && attn_v2_mode() >= 3) ? 1 : 0;
+    if (DPV) *DPV = (layout && d == 40) ? 48 : dpv;
+    return layout;
+}
+
+const char* attn_kernel_name(int d, int Nk, int vt_layout) {
+    int v2 = attn_use_v2(d, Nk) ? attn_v2_mode() : 0;
+    if (vt_layout == 0 && v2 >= 3) v2 = 1;     // a caller whose V^T buffer is in the 16-token form gets the kernel that reads it
+    if (d == 40) return v2 == 0 ? "attn_kernel<48, 64, true>" : v2 == 1 ? "attn2_kernel<48, 64, true, 4>" : v2 == 2 ? "attn2_kernel<48, 64, true, 8>" : "attn3_kernel<48, 48, true, 4>";
+    if (d == 80) return (v2 >= 3 && vt_layout != 0) ? "attn3_kernel<80, 96, false, 4>" : "attn_kernel<80, 96, true>";
     return "attn_kernel<160, 160, false>";
 }
 
@@ -729,7 +1093,15 @@ int attn_launch(const AttnParams& P, int B, hipStream_t stream) {
     if (P.Nq <= 0 || P.Nk <= 0) return set_error(GL_ERR_ARG, "attention: empty Nq=%d Nk=%d", P.Nq, P.Nk);
     if (P.Tq_pad % 128 != 0 || P.Tk_pad % 64 != 0 || P.Tq_pad < P.Nq || P.Tk_pad < P.Nk)
         return set_error(GL_ERR_ARG, "attention: bad padding Tq_pad=%d Tk_pad=%d (Nq=%d Nk=%d)", P.Tq_pad, P.Tk_pad, P.Nq, P.Nk);
-    const int v2 = attn_use_v2(P.d, P.Nk) ? attn_v2_mode() : 0;
+    int v2 = attn_use_v2(P.d, P.Nk) ? attn_v2_mode() : 0;
+    // The V^T buffer's form decides between the two pipelined d = 40 kernels: a caller that laid it out per attn_vt_layout() == 1 gets
+    // attn3_kernel, one that kept the 16-token form (the hoisted grounding-token K / V of gatedCA, older callers) gets attn2_kernel
+    if (P.vt_layout == 1) {
+        if (P.d == 40) return launch_attn3<48, 48, true, 4>(P, B, stream);
+        if (P.d == 80) return launch_attn3<80, 96, false, 4>(P, B, stream);
+        return set_error(GL_ERR_ARG, "attention: vt_layout 1 exists for head dims 40 and 80 (d = %d)", P.d);
+    }
+    if (v2 >= 3) v2 = 1;
     switch (P.d) {
         case 40:
             if (v2 == 1) return launch_attn2<48, 64, true, 4>(P, B, stream);

@@ -707,7 +707,8 @@ int gl_op_attention(gl_ctx* ctx, const void* xq, const void* xkv, int B, int Nq,
     int r = attn_dims(d, &dp, &dpv);
     if (r != GL_OK) throw GlError(r, gl::last_error());
     const int Tq = round_up(Nq, 64), Tk = round_up(Nk, 64);
-    AttnBufs& bufs = eng.attn_bufs(B, H, d, Tq, Tk);
+    const int vt_layout = attn_vt_layout(d, Nk, &dpv);
+    AttnBufs& bufs = eng.attn_bufs(B, H, d, Tq, Tk, dpv);
     bf16* wqb = ar.get<bf16>((size_t)C * C);
     bf16* wkb = ar.get<bf16>((size_t)C * Ck);
     bf16* wvb = ar.get<bf16>((size_t)C * Ck);
@@ -731,7 +732,7 @@ int gl_op_attention(gl_ctx* ctx, const void* xq, const void* xkv, int B, int Nq,
         aoperand_rows(A, xqp, C, C);
         Epilogue E;
         epilogue_defaults(E);
-        E.mode = EPI_QKV_HEADS; E.q = bufs.q; E.k = bufs.k; E.vt = bufs.vt; E.C = C; E.H = H; E.d = d; E.DP = dp; E.DPV = dpv; E.T = Tq;
+        E.mode = EPI_QKV_HEADS; E.q = bufs.q; E.k = bufs.k; E.vt = bufs.vt; E.C = C; E.H = H; E.d = d; E.DP = dp; E.DPV = dpv; E.T = Tq; E.vt_perm32 = vt_layout;
         E.Tpad_q = bufs.Tq_pad; E.Tpad_k = bufs.Tk_pad;
         ck(gemm_launch(A, wqkv, B * Tq, 3 * C, C, E, nullptr, 0, S(s)));
     } else {
@@ -754,13 +755,13 @@ int gl_op_attention(gl_ctx* ctx, const void* xq, const void* xkv, int B, int Nq,
         {
             Epilogue E;
             epilogue_defaults(E);
-            E.mode = EPI_VT_HEADS; E.out = bufs.vt; E.H = H; E.d = d; E.DPV = dpv; E.T = Tk; E.Tpad_k = bufs.Tk_pad;
+            E.mode = EPI_VT_HEADS; E.out = bufs.vt; E.H = H; E.d = d; E.DPV = dpv; E.T = Tk; E.Tpad_k = bufs.Tk_pad; E.vt_perm32 = vt_layout;
             ck(gemm_launch_t(wvb, C, xkp, B * Tk, Ck, E, S(s)));
         }
     }
     AttnParams P{};
     P.q = bufs.q; P.k = bufs.k; P.vt = bufs.vt; P.o = (bf16*)o; P.H = H; P.d = d; P.Nq = Nq; P.Nk = Nk;
-    P.Tq_pad = bufs.Tq_pad; P.Tk_pad = bufs.Tk_pad; P.ldo = C; P.o_rows_per_b = Nq;
+    P.Tq_pad = bufs.Tq_pad; P.Tk_pad = bufs.Tk_pad; P.ldo = C; P.o_rows_per_b = Nq; P.vt_layout = vt_layout;
     P.scale_log2e = (float)(1.4426950408889634 / std::sqrt((double)d));
     ck(attn_launch(P, B, S(s)));
     GL_API_END

@@ -182,7 +182,7 @@ class Engine {
     size_t splitk_ws_bytes() const { return ws_bytes_; }
     void* persist(size_t bytes, bool zero);
     void init_workspace();
-    AttnBufs& attn_bufs(int B, int H, int d, int Tq, int Tk);
+    AttnBufs& attn_bufs(int B, int H, int d, int Tq, int Tk, int dpv_layout = 0);   // dpv_layout: V^T rows when not attn_dims' (attn_vt_layout)
 
     int device() const { return device_; }
     int64_t n_launches = 0;

@@ -1102,22 +1102,21 @@ bf16* Engine::resblock(const ResW& r, const TRef& x, int B, int H, int W, const 
     return out;
 }
 
-AttnBufs& Engine::attn_bufs(int B, int H, int d, int Tq, int Tk) {
+AttnBufs& Engine::attn_bufs(int B, int H, int d, int Tq, int Tk, int dpv_layout) {
     const int Tq_pad = round_up(Tq, 128), Tk_pad = round_up(Tk, 64);
-    const uint64_t key = ((uint64_t)B << 52) ^ ((uint64_t)H << 44) ^ ((uint64_t)d << 34) ^ ((uint64_t)Tq_pad << 17) ^ (uint64_t)Tk_pad;
-    auto it = attn_bufs_.find(key);
-    if (it != attn_bufs_.end()) return it->second;
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     int dp, dpv;
     CK(attn_dims(d, &dp, &dpv));
+    if (dpv_layout) dpv = dpv_layout;      // (attn_vt_layout: the 16x16x32 P V kernel reads a 48-row V^T at d = 40)
+    const uint64_t key = ((uint64_t)B << 52) ^ ((uint64_t)H << 44) ^ ((uint64_t)d << 34) ^ ((uint64_t)Tq_pad << 17) ^ (uint64_t)Tk_pad ^ ((uint64_t)dpv << 58);
+    auto it = attn_bufs_.find(key);
+    if (it != attn_bufs_.end()) return it->second;
     AttnBufs b;
     b.Tq_pad = Tq_pad;
     b.Tk_pad = Tk_pad;
-    (void)st;
     b.q = reinterpret_cast<bf16*>(persist((size_t)B * H * Tq_pad * dp * sizeof(bf16), true));
     b.k = reinterpret_cast<bf16*>(persist((size_t)B * H * Tk_pad * dp * sizeof(bf16), true));
     b.vt = reinterpret_cast<bf16*>(persist((size_t)B * H * dpv * Tk_pad * sizeof(bf16), true));
-    CK(attn_vt_ones_launch(b.vt, B * H, d, Tk_pad, 0));  // denominator row (attention.hip), once per buffer
+    CK(attn_vt_ones_launch(b.vt, B * H, d, Tk_pad, 0, dpv));  // denominator row (attention.hip), once per buffer
     CK(attn_k_init_launch(b.k, B * H, d, Tk_pad, 0));     // d = 40: the stabiliser's multiplier column
     HIPCK(hipStreamSynchronize(0));
     return attn_bufs_.emplace(key, b).first->second;
@@ -1130,7 +1129,8 @@ void Engine::self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, in
     const int H = C / d;
     int dp, dpv;
     CK(attn_dims(d, &dp, &dpv));
-    AttnBufs& bufs = attn_bufs(B, H, d, T, T);
+    const int vt_layout = attn_vt_layout(d, Nk, &dpv);    // which V^T form the attention kernel for this (d, Nk) reads
+    AttnBufs& bufs = attn_bufs(B, H, d, T, T, dpv);
     if (in_stats && !(a.fused && a.folded)) throw GlError(GL_ERR_STATE, "self_attention: row statistics given to an unfolded projection");
     if (a.fused) {
         AOperand A;
@@ -1138,7 +1138,7 @@ void Engine::self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, in
         Epilogue E;
         epilogue_defaults(E);
         E.mode = EPI_QKV_HEADS;
-        E.q = bufs.q; E.k = bufs.k; E.vt = bufs.vt; E.C = C; E.H = H; E.d = d; E.DP = dp; E.DPV = dpv; E.T = T;
+        E.q = bufs.q; E.k = bufs.k; E.vt = bufs.vt; E.C = C; E.H = H; E.d = d; E.DP = dp; E.DPV = dpv; E.T = T; E.vt_perm32 = vt_layout;
         E.Tpad_q = bufs.Tq_pad; E.Tpad_k = bufs.Tk_pad;
         if (a.folded) E.bias = a.b;      // W beta of the folded LayerNorm (to_q / to_k / to_v have no bias of their own)
         if (in_stats) {                  // `ln` holds the raw rows: (x - mean) * rstd happens in the epilogue
@@ -1160,7 +1160,7 @@ void Engine::self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, in
         Epilogue E;
         epilogue_defaults(E);
         E.mode = EPI_VT_HEADS;
-        E.out = bufs.vt; E.H = H; E.d = d; E.DPV = dpv; E.T = T; E.Tpad_k = bufs.Tk_pad;
+        E.out = bufs.vt; E.H = H; E.d = d; E.DPV = dpv; E.T = T; E.Tpad_k = bufs.Tk_pad; E.vt_perm32 = vt_layout;
         ProfScope ps(this, s, "gemm", 2.0 * C * (double)B * T * C, 0.0);
         CK(gemm_launch_t(a.wv, C, ln, B * T, C, E, s));
         if (profiling_) ps.rename(gemm_last_kernel_name());
@@ -1169,12 +1169,12 @@ void Engine::self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, in
     AttnParams P{};
     P.q = bufs.q; P.k = bufs.k; P.vt = bufs.vt; P.o = o;
     P.H = H; P.d = d; P.Nq = Nq; P.Nk = Nk; P.Tq_pad = bufs.Tq_pad; P.Tk_pad = bufs.Tk_pad;
-    P.ldo = C; P.o_rows_per_b = Nq;
+    P.ldo = C; P.o_rows_per_b = Nq; P.vt_layout = vt_layout;
     P.scale_log2e = (float)(1.4426950408889634 / std::sqrt((double)d));
     {
-        ProfScope ps(this, s, attn_kernel_name(d, Nk), 4.0 * B * H * (double)Nq * Nk * d, 0.0);
+        ProfScope ps(this, s, attn_kernel_name(d, Nk, vt_layout), 4.0 * B * H * (double)Nq * Nk * d, 0.0);
         CK(attn_launch(P, B, s));
-        log_attention(attn_kernel_name(d, Nk), B, H, Nq, Nk, d);
+        log_attention(attn_kernel_name(d, Nk, vt_layout), B, H, Nq, Nk, d);
     }
     ++n_launches;
 }
@@ -1497,9 +1497,9 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
             P.ldo = C; P.o_rows_per_b = HW;
             P.scale_log2e = (float)(1.4426950408889634 / std::sqrt((double)d));
             {
-                ProfScope ps(this, s, attn_kernel_name(d, Ng), 4.0 * B * heads * (double)HW * Ng * d, 0.0);
+                ProfScope ps(this, s, attn_kernel_name(d, Ng, 0), 4.0 * B * heads * (double)HW * Ng * d, 0.0);
                 CK(attn_launch(P, B, s));
-                log_attention(attn_kernel_name(d, Ng), B, heads, HW, Ng, d);
+                log_attention(attn_kernel_name(d, Ng, 0), B, heads, HW, Ng, d);
             }
             ++n_launches;
             t2 = linear_rows(o, M, t.fca.out, ACT_NONE, t1, gates_ + 2 * t.idx, s, r2 ? nullptr : &st2);
@@ -1533,9 +1533,9 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
         P.ldo = C; P.o_rows_per_b = HW;
         P.scale_log2e = (float)(1.4426950408889634 / std::sqrt((double)d));
         {
-            ProfScope ps(this, s, attn_kernel_name(d, cond_.ctx_T), 4.0 * B * heads * (double)HW * cond_.ctx_T * d, 0.0);
+            ProfScope ps(this, s, attn_kernel_name(d, cond_.ctx_T, 0), 4.0 * B * heads * (double)HW * cond_.ctx_T * d, 0.0);
             CK(attn_launch(P, B, s));
-            log_attention(attn_kernel_name(d, cond_.ctx_T), B, heads, HW, cond_.ctx_T, d);
+            log_attention(attn_kernel_name(d, cond_.ctx_T, 0), B, heads, HW, cond_.ctx_T, d);
         }
         ++n_launches;
     }

@@ -51,7 +51,13 @@ void aoperand_rows(AOperand& A, const bf16* p, int K, int ld) {
 
 // tokens are permuted inside groups of 16 so that the attention kernel's P^T fragment (taken
 // straight from MFMA accumulators) lines up with one ds_read_b128 of V^T: [0-3,8-11,4-7,12-15].
-__device__ __forceinline__ int perm_tok4(int t0) {
+// p32 (Epilogue::vt_perm32, attn3_kernel): groups of 32, quads in the order [0,2,4,6,1,3,5,7] -- the four 8-key k-slot groups of a
+// v_mfma_f32_16x16x32 B operand assembled from a 32x32 S^T accumulator by v_permlane16_swap (attention.hip).
+__device__ __forceinline__ int perm_tok4(int t0, int p32 = 0) {
+    if (p32) {
+        const int g = (t0 >> 2) & 7;
+        return (t0 & ~31) | ((((g & 1) << 2) | (g >> 1)) << 2);
+    }
     int g = (t0 >> 2) & 3;
     int gp = ((g & 1) << 1) | (g >> 1);
     return (t0 & ~15) | (gp << 2);
@@ -127,7 +133,7 @@ __device__ __forceinline__ void epi_finish4(const Epilogue& E, int m, int n0, fl
             int b = n0 / E.T;
             int t0 = n0 - b * E.T;
             bf16* base = reinterpret_cast<bf16*>(E.out);
-            store_bf16x4(base + ((size_t)(b * E.H + h) * E.DPV + dd) * E.Tpad_k + perm_tok4(t0), v);
+            store_bf16x4(base + ((size_t)(b * E.H + h) * E.DPV + dd) * E.Tpad_k + perm_tok4(t0, E.vt_perm32), v);
             break;
         }
         case EPI_NCHW_F32: {
@@ -187,7 +193,7 @@ __device__ __forceinline__ void epi_store4(const Epilogue& E, int m, int n0, flo
             int b = n0 / E.T;
             int t0 = n0 - b * E.T;
             bf16* base = reinterpret_cast<bf16*>(E.out);
-            store_bf16x4(base + ((size_t)(b * E.H + h) * E.DPV + dd) * E.Tpad_k + perm_tok4(t0), v);
+            store_bf16x4(base + ((size_t)(b * E.H + h) * E.DPV + dd) * E.Tpad_k + perm_tok4(t0, E.vt_perm32), v);
             break;
         }
         case EPI_NCHW_F32: {
@@ -1110,7 +1116,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
                 const int t0 = m0 - b * E.T;
                 float v[4] = {s01[i].y * (acc[i][j][0] - s01[i].x * cs) + bn, s01[i].w * (acc[i][j][1] - s01[i].z * cs) + bn,
                               s23[i].y * (acc[i][j][2] - s23[i].x * cs) + bn, s23[i].w * (acc[i][j][3] - s23[i].z * cs) + bn};
-                store_bf16x4(E.vt + ((size_t)(b * E.H + h) * E.DPV + dd) * E.Tpad_k + perm_tok4(t0), v);
+                store_bf16x4(E.vt + ((size_t)(b * E.H + h) * E.DPV + dd) * E.Tpad_k + perm_tok4(t0, E.vt_perm32), v);
             }
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -448,13 +448,14 @@ int main(int argc, char** argv) {
             int dp, dpv;
             GC(attn_dims(d, &dp, &dpv));
             AttnParams P{};
+            P.vt_layout = attn_vt_layout(d, Nk, &dpv);
             P.q = a0; P.k = a1; P.vt = a2;
             bf16* o = a2 + ((size_t)200 << 20);
             P.o = o;
             P.H = H; P.d = d; P.Nq = Nq; P.Nk = Nk; P.Tq_pad = round_up(Nq, 128); P.Tk_pad = round_up(Nk, 64);
             P.ldo = H * d; P.o_rows_per_b = Nq;
             P.scale_log2e = 1.4426950408889634f / sqrtf((float)d);
-            GC(attn_vt_ones_launch(a2, B * H, d, P.Tk_pad, s));
+            GC(attn_vt_ones_launch(a2, B * H, d, P.Tk_pad, s, dpv));
             GC(attn_k_init_launch(a1, B * H, d, P.Tk_pad, s));
             relaunch = [=] { GC(attn_launch(P, B, cur_s)); };
             us = time_us(relaunch, reps, s);

@@ -674,6 +674,96 @@ def test_train_step_bookkeeping_on_flat_buckets():
     assert torch.all(out["position_net.linears.0.bias"] == 0.0) and torch.all(out["out.2.weight"] == 1.0)      # 1 - 2 * 0.5; frozen untouched
 
 
+def test_attn3_operand_handover_model():
+    """The index arithmetic of attn3_kernel (attention.hip, round 5), modelled lane by lane: 32x32x16 S^T accumulators -> packed exps ->
+    v_permlane16_swap (odd 16-lane rows of the first operand <-> even rows of the second) -> B operands of two 16-query halves of
+    v_mfma_f32_16x16x32; V^T stored by the projection epilogue with tokens permuted in groups of 32 (gemm.hip perm_tok4, p32), copied to
+    LDS by the source-swizzled DMA, read back as A fragments (row 16 i + (lane & 15), chunk 4 u + (lane >> 4)): the product must be
+    V^T P^T, and every 16-lane group of a ds_read_b128 must touch 16 distinct 16-byte slots (no bank conflict)."""
+    import numpy as np
+    rng=np.random.default_rng(0)
+    NK=64; NQ=32; DPV=48; d=40
+    # ---- P^T values for one 64-key tile: p[key, query]
+    p = rng.random((NK, NQ)).astype(np.float32)
+    vt = rng.standard_normal((DPV, NK)).astype(np.float32)      # V^T rows x keys (logical token order)
+    ref = vt @ p                                                  # O^T [DPV x NQ]
+
+    def perm_tok4(t0, p32):
+        if p32:
+            g=(t0>>2)&7
+            return (t0 & ~31) | ((((g&1)<<2) | (g>>1))<<2)
+        g=(t0>>2)&3
+        gp=((g&1)<<1)|(g>>1)
+        return (t0&~15)|(gp<<2)
+    # ---- global V^T buffer as the projection epilogue stores it (tokens permuted in 32s), one 64-key tile = 128 B per row (bf16)
+    vt_g = np.zeros((DPV, NK), np.float32)
+    for t0 in range(0, NK, 4):
+        pos = perm_tok4(t0, 1)
+        vt_g[:, pos:pos+4] = vt[:, t0:t0+4]
+    # ---- DMA into LDS: piece pc (8 rows), lane -> row r = 8 pc + (lane >> 3), LDS chunk position (lane & 7) receives SOURCE chunk (lane & 7) ^ ((r >> 1) & 7)
+    lds = np.zeros((DPV*128//2,), np.float32)    # element-addressed (2 B per element): index = byte/2
+    for pc in range(DPV//8):
+        for lane in range(64):
+            r = 8*pc + (lane>>3)
+            c_src = (lane & 7) ^ ((r>>1)&7)
+            dst_byte = pc*1024 + lane*16
+            lds[dst_byte//2: dst_byte//2+8] = vt_g[r, c_src*8:(c_src+1)*8]
+    # ---- S^T accumulators of the two 32-key sub-tiles (32x32x16 D layout): lane L holds column (query) L & 31, reg 4 j + e = key 8 j + 4 (L >> 5) + e
+    def sc(u, L, reg):
+        j, e = reg>>2, reg&3
+        key = 32*u + 8*j + 4*(L>>5) + e
+        return p[key, L&31]
+    def swap16(x, y):
+        # x, y: [64 lanes][4 dwords] ; odd 16-lane rows of x <-> even rows of y
+        x=x.copy(); y=y.copy()
+        for row in (1,3):
+            a = x[16*row:16*row+16].copy()
+            x[16*row:16*row+16] = y[16*(row-1):16*(row-1)+16]
+            y[16*(row-1):16*(row-1)+16] = a
+        return x, y
+    ot = np.zeros((2, 3, 64, 4), np.float32)    # [query half][row block][lane][reg]
+    conflicts = 0
+    for u in range(2):
+        # packed exps: px = regs 0..7, py = regs 8..15 (8 values = 4 dwords of 2; keep as 8 floats)
+        px = np.array([[sc(u, L, e) for e in range(8)] for L in range(64)])
+        py = np.array([[sc(u, L, 8+e) for e in range(8)] for L in range(64)])
+        # dword w = values 2w, 2w+1
+        X = px.reshape(64,4,2); Y = py.reshape(64,4,2)
+        X, Y = swap16(X, Y)
+        bop = [X.reshape(64,8), Y.reshape(64,8)]       # B operands of query halves 0 / 1: lane L -> column L & 15, k-slots 8 (L >> 4) + e
+        # V^T fragment reads
+        for i in range(3):
+            afrag = np.zeros((64,8), np.float32)
+            slots = {}
+            for L in range(64):
+                l15, g4 = L&15, L>>4
+                v_lane = l15*128 + ((g4 ^ ((l15>>1)&7))<<4)
+                addr = (v_lane ^ (64 if u else 0)) + i*2048
+                afrag[L] = lds[addr//2: addr//2+8]
+                slots.setdefault(g4, []).append((addr//16) % 16)
+            for g in slots:
+                conflicts += len(slots[g]) - len(set(slots[g]))
+            for qh in range(2):
+                # D[row 4 (L>>4) + r][col L & 15] += sum_k A[row][k] B[k][col];  A lane (row = L & 15, k = 8 (L >> 4) + e)
+                A = np.zeros((16,32), np.float32); B = np.zeros((32,16), np.float32)
+                for L in range(64):
+                    A[L&15, 8*(L>>4):8*(L>>4)+8] = afrag[L]
+                    B[8*(L>>4):8*(L>>4)+8, L&15] = bop[qh][L]
+                D = A @ B
+                for L in range(64):
+                    for r in range(4):
+                        ot[qh, i, L, r] += D[4*(L>>4)+r, L&15]
+    # ---- read back: query 16 qh + (L & 15), row 16 i + 4 (L >> 4) + r
+    got = np.zeros_like(ref)
+    for qh in range(2):
+        for i in range(3):
+            for L in range(64):
+                for r in range(4):
+                    got[16*i + 4*(L>>4) + r, 16*qh + (L&15)] = ot[qh,i,L,r]
+    assert np.abs(got - ref).max() < 1e-4 and conflicts == 0, (np.abs(got - ref).max(), conflicts)
+
+
+
 def test_train_step_lr_schedule_and_guidance_drop():
     """TrainStep's learning-rate hook against the reference's schedulers (trainer.py:262-267: transformers'
     get_constant_schedule_with_warmup / get_cosine_schedule_with_warmup on an AdamW) and its random drop to the null grounding input

@@ -185,6 +185,41 @@ def test_attn2_loop_is_pipelined_and_lean(attn_asm):
     assert worst_v <= 10 and worst_m <= 3, (worst_v, worst_m)
 
 
+def test_attn3_loop_puts_pv_on_16x16x32(attn_asm):
+    """attn3_kernel (d = 40, round 5): attn2's pipeline with O^T += V^T P^T on v_mfma_f32_16x16x32_bf16. Per iteration of the
+    steady-state loop (two per trip, the score sets swap roles): 6 MFMAs 32x32x16 for S^T, 12 MFMAs 16x16x32 for P V, the 8
+    v_permlane16_swap that turn the 32x32 accumulators into the 16-query B operands, 6 + 6 fragment reads, K / V^T by LDS-DMA
+    (at most 4 pieces per wave), one vmcnt wait + one barrier; no scratch, fewer registers than attn2 (O^T is 24, not 32)."""
+    name = re.search(r"^(_ZN2gl12attn3_kernelILi4EE[^:\s]*):", attn_asm, re.M).group(1)
+    a = attn_asm.index(name + ":")
+    body = attn_asm[a:attn_asm.index(".Lfunc_end", a)].split("\n")
+    meta = attn_asm[attn_asm.index(".name:           " + name):]
+    assert int(re.search(r"\.vgpr_spill_count:\s*(\d+)", meta).group(1)) == 0
+    assert int(re.search(r"\.private_segment_fixed_size:\s*(\d+)", meta).group(1)) == 0
+    assert int(re.search(r"\.vgpr_count:\s*(\d+)", meta).group(1)) <= 256
+    head = next(i for i, l in enumerate(body) if "Inner Loop Header" in l)
+    label = body[head].split(":")[0].strip()
+    back = max(i for i, l in enumerate(body) if re.search(r"s_(c?branch\w*)\s+" + re.escape(label) + r"\s*$", l))
+    loop = [l.strip() for l in body[head:back + 1] if l.strip() and not l.strip().startswith((";", "."))]
+    ops = [l.split()[0] for l in loop]
+    count = lambda op: sum(1 for o in ops if o.startswith(op))
+    assert count("v_mfma_f32_32x32x16_bf16") == 12 and count("v_mfma_f32_16x16x32_bf16") == 24 and count("s_barrier") == 2
+    assert count("v_permlane16_swap") >= 16 and count("v_exp_f32") >= 64
+    assert count("ds_read_b128") == 24 and count("buffer_load_dwordx4") <= 16
+    assert count("global_load") == 0 and count("ds_write") == 0 and count("scratch_") == 0
+    assert [l for l in loop if l.startswith("s_waitcnt") and "vmcnt" in l] == ["s_waitcnt vmcnt(0)"] * 2
+    # the interleave of the first iteration: VALU work sits between the MFMAs
+    mf = [i for i, o in enumerate(ops) if o.startswith("v_mfma")]
+    run_v = run_m = worst_v = worst_m = 0
+    for o in ops[mf[0]:mf[17] + 1]:
+        if o.startswith("v_mfma"):
+            run_m += 1; run_v = 0
+        elif o.startswith("v_"):
+            run_v += 1; run_m = 0
+        worst_v, worst_m = max(worst_v, run_v), max(worst_m, run_m)
+    assert worst_v <= 22 and worst_m <= 4, (worst_v, worst_m)
+
+
 @pytest.fixture(scope="module")
 def norm_asm(tmp_path_factory):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

@@ -237,9 +237,11 @@ def test_splitk_is_deterministic(engine):
             assert torch.equal(engine.op_linear(x, wb, b, res), y0)
 
 
-def test_attention_spike(engine):
-    """Force the online-softmax rescale: one key dominates a late tile (§ rule: data-dependent branch needs its own test)."""
-    B, N, C, H = 1, 512, 320, 8
+@pytest.mark.parametrize("C", [320, 640])
+def test_attention_spike(engine, C):
+    """Force the online-softmax rescale: one key dominates a late tile (§ rule: data-dependent branch needs its own test). d = 40: the
+    stabiliser rides in Q column 40; d = 80: it is subtracted in front of the exps -- both rescale O^T across 16-lane rows in attn3_kernel."""
+    B, N, H = 1, 512, 8
     xq = bf(rnd(B, N, C, seed=1))
     xkv = xq.clone()
     xkv[0, 400] = xq[0, 7] * 6  # key 400 (tile 6) spikes against query 7
