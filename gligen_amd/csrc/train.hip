@@ -73,6 +73,67 @@ __global__ void bf16_residual_kernel(const float* __restrict__ src, size_t n, fl
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) res[i] = src[i] - bf2f(f2bf(src[i]));
 }
+// The three passes of a split-precision product as ONE contraction (round 5): x = hi + lo in bf16, and
+//     a w^T  ~  a_hi w_hi^T + a_lo w_hi^T + a_hi w_lo^T  =  [a_hi | a_lo | a_hi] [w_hi | w_hi | w_lo]^T
+// -- the k dimension tripled, one GEMM launch with one fp32 accumulator instead of three launches, two fp32 temporaries and an add
+// pass. side 0 (activation): segments (hi, lo, hi); side 1 (weight): (hi, hi, lo). Rows [R][3 K], columns K' = seg * K + c.
+__global__ void cat3_rows_kernel(const float* __restrict__ src, size_t n, int K, int side, bf16* __restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t r = i / K;
+    const int c = (int)(i - r * K);
+    const float v = src[i];
+    const bf16 h = f2bf(v), l = f2bf(v - bf2f(h));
+    bf16* row = dst + r * 3 * (size_t)K;
+    row[c] = h;
+    row[K + c] = side ? h : l;
+    row[2 * (size_t)K + c] = side ? l : h;
+}
+// [R][Cc] fp32 -> [Cc][3 Rpad] (the transposed operand of dgrad / wgrad), zero behind row R
+__global__ void cat3_transposed_kernel(const float* __restrict__ src, int R, int Cc, int ld, int side, bf16* __restrict__ dst, int Rpad) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + threadIdx.x;
+        tile[i][threadIdx.x] = (r < R && c < Cc) ? src[(size_t)r * ld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + threadIdx.x;
+        if (c < Cc && r < Rpad) {
+            const float v = tile[threadIdx.x][i];
+            const bf16 h = f2bf(v), l = f2bf(v - bf2f(h));
+            bf16* row = dst + (size_t)c * 3 * Rpad;
+            row[r] = h;
+            row[Rpad + r] = side ? h : l;
+            row[2 * (size_t)Rpad + r] = side ? l : h;
+        }
+    }
+}
+// conv activations [rows][C] fp32 -> [rows][2 C] = (hi | lo): the implicit-GEMM loader reads channels (hi | lo | hi) as a two-source
+// concat of this buffer with its own first half
+__global__ void cat2_rows_kernel(const float* __restrict__ src, size_t n, int C, bf16* __restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t r = i / C;
+    const int c = (int)(i - r * C);
+    const float v = src[i];
+    const bf16 h = f2bf(v);
+    dst[r * 2 * (size_t)C + c] = h;
+    dst[r * 2 * (size_t)C + C + c] = f2bf(v - bf2f(h));
+}
+// conv weight OIHW fp32 [O][I][9] -> [O][3 I][9] fp32 = (w | w | w - bf16(w)) along I: packed to bf16 it is (hi | hi | lo)
+__global__ void conv_w_cat3_kernel(const float* __restrict__ w, int O, int I, float* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)O * I * 9) return;
+    const int t = (int)(idx % 9), i = (int)((idx / 9) % I);
+    const size_t o = idx / ((size_t)9 * I);
+    const float v = w[idx];
+    float* row = out + o * 3 * (size_t)I * 9;
+    row[(size_t)i * 9 + t] = v;
+    row[((size_t)I + i) * 9 + t] = v;
+    row[((size_t)2 * I + i) * 9 + t] = v - bf2f(f2bf(v));
+}
 __global__ void add3_kernel(float* __restrict__ dst, const float* __restrict__ a, const float* __restrict__ b, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] += a[i] + b[i];
@@ -240,6 +301,299 @@ __global__ void attn_bwd_kv_kernel(const float* __restrict__ q, const float* __r
     for (int c = 0; c < DC; ++c) { dk[off + c] = ak[c] * scale; dv[off + c] = av[c]; }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same three attention passes on the matrix cores (round 5): flash-style, one wave per 32 queries (forward, dq) or 32 keys (dk, dv),
+// every product as THREE bf16 MFMA passes over (hi, lo) splits of its fp32 operands (x = hi + lo; hi.hi + lo.hi + hi.lo with fp32
+// accumulation, the same scheme as the training GEMMs: 2^-16 relative), softmax arithmetic in fp32 registers. A prep pass writes every
+// operand once per call in the two forms the MFMA fragments read straight from memory (no LDS in these kernels: a wave's fragment is
+// one 16-byte load per lane):
+//   R  [bh][N_pad][DP]   token-major rows, head dim zero-padded to a multiple of 16        (operand with k-slots over the head dim)
+//   T  [bh][DPO][N_pad]  transposed, tokens permuted inside groups of 16 as [0-3, 8-11, 4-7, 12-15] (k-slots over tokens: the B
+//                        operand of those products comes straight out of 32x32 accumulator registers, attention.hip's S^T -> P^T trick)
+// each as hi and lo bf16. v_mfma_f32_32x32x16_bf16 layouts: A lane L = row L & 31, k-slots 8 (L >> 5) .. + 7; B lane L = column L & 31,
+// same k-slots; D lane L = column L & 31, register 4 j + e = row 8 j + 4 (L >> 5) + e.
+// Head dims 32 / 40 / 64 / 80 (d = 160 -- the 16 x 16 level, 256 tokens -- stays on the VALU kernels above: 5 % of the attention time).
+struct APrep {
+    const bf16* r_hi; const bf16* r_lo; const bf16* t_hi; const bf16* t_lo;
+    int Npad;
+};
+__device__ __forceinline__ int perm16_tok(int t) {
+    const int g = (t >> 2) & 3;
+    return (t & ~15) | ((((g & 1) << 1) | (g >> 1)) << 2) | (t & 3);
+}
+// x [B][N][H d] fp32 (times mul) -> R / T hi / lo for every (b, h); one thread per (bh, token, column)
+__global__ void attn_prep_kernel(const float* __restrict__ x, int N, int H, int d, float mul, int Npad, int DP, int DPO, bf16* __restrict__ r_hi,
+                                 bf16* __restrict__ r_lo, bf16* __restrict__ t_hi, bf16* __restrict__ t_lo, size_t total) {
+    const int CW = DP > DPO ? DP : DPO;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % CW);
+        const int t = (int)((idx / CW) % Npad);
+        const int bh = (int)(idx / ((size_t)CW * Npad));
+        const int b = bh / H, h = bh - b * H;
+        const float v = (t < N && c < d) ? x[(((size_t)b * N + t) * H + h) * d + c] * mul : 0.f;
+        const bf16 hi = f2bf(v);
+        const bf16 lo = f2bf(v - bf2f(hi));
+        if (c < DP) {
+            const size_t o = ((size_t)bh * Npad + t) * DP + c;
+            r_hi[o] = hi; r_lo[o] = lo;
+        }
+        if (c < DPO) {
+            const size_t o = ((size_t)bh * DPO + c) * Npad + perm16_tok(t);
+            t_hi[o] = hi; t_lo[o] = lo;
+        }
+    }
+}
+// lse_pad [bh][Npad] (+1e30 behind the last query: its probabilities vanish), delta_pad [bh][Npad] = do_i . o_i (0 behind the last query)
+__global__ void attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ dout, const float* __restrict__ lse, int N, int H, int d, int Npad,
+                                  float* __restrict__ lse_pad, float* __restrict__ delta_pad, size_t total) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(idx % Npad);
+        const int bh = (int)(idx / Npad);
+        const int b = bh / H, h = bh - b * H;
+        float dl = 0.f, L = 1e30f;
+        if (t < N) {
+            const size_t off = (((size_t)b * N + t) * H + h) * d;
+            for (int c = 0; c < d; ++c) dl = fmaf(dout[off + c], o[off + c], dl);
+            L = lse[(size_t)bh * N + t];
+        }
+        lse_pad[idx] = L;
+        delta_pad[idx] = dl;
+    }
+}
+__device__ __forceinline__ float tr_max_xor32(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ bf16x8 ld8(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+// acc += (ah + al) (bh + bl) without the lo.lo term
+__device__ __forceinline__ void mfma3(f32x16& acc, const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+}
+// accumulator registers 8 kk .. 8 kk + 7 of a 32 x 32 tile -> (hi, lo) B operands of k-step kk (k-slots = the tile's rows, in the
+// permuted order of the T layouts)
+__device__ __forceinline__ void split8(const f32x16& v, int kk, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = kk ? v[8 + e] : v[e];
+        hi[e] = f2bf(x);
+        lo[e] = f2bf(x - bf2f(hi[e]));
+    }
+}
+
+// forward: o = softmax(q' k^T) v (q' = q scale, folded by the prep pass), lse = log sum exp. grid (Nq_pad / 32, B H), one wave
+template <int DP, int DPO>
+__global__ void __launch_bounds__(64) attn_mfma_fwd_kernel(APrep Q, APrep K, APrep V, int H, int d, int Nq, int Nk, float* __restrict__ o, float* __restrict__ lse) {
+    constexpr int KS = DP / 16, DT = DPO / 32;
+    const int lane = threadIdx.x, lrow = lane & 31, half = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H, q0 = blockIdx.x * 32;
+    bf16x8 qh[KS], ql[KS];
+    {
+        const size_t off = ((size_t)bh * Q.Npad + q0 + lrow) * DP + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { qh[ks] = ld8(Q.r_hi + off + 16 * ks); ql[ks] = ld8(Q.r_lo + off + 16 * ks); }
+    }
+    f32x16 ot[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
+    float m = -1e30f, l = 0.f;
+    const bf16* krh = K.r_hi + ((size_t)bh * K.Npad + lrow) * DP + 8 * half;
+    const bf16* krl = K.r_lo + ((size_t)bh * K.Npad + lrow) * DP + 8 * half;
+    const bf16* vth = V.t_hi + ((size_t)bh * DPO + lrow) * V.Npad + 8 * half;
+    const bf16* vtl = V.t_lo + ((size_t)bh * DPO + lrow) * V.Npad + 8 * half;
+    for (int k0 = 0; k0 < Nk; k0 += 32) {
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) mfma3(s, ld8(krh + (size_t)k0 * DP + 16 * ks), ld8(krl + (size_t)k0 * DP + 16 * ks), qh[ks], ql[ks]);
+        float mx = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (k0 + 8 * (r >> 2) + 4 * half + (r & 3) >= Nk) s[r] = -1e30f;
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = tr_max_xor32(mx);
+        const float mn = fmaxf(m, mx), alpha = __expf(m - mn);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - mn); ps += s[r]; }
+        l = l * alpha + ps;
+        m = mn;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 ph, pl;
+            split8(s, kk, ph, pl);
+#pragma unroll
+            for (int i = 0; i < DT; ++i) {
+                const size_t off = (size_t)32 * i * V.Npad + k0 + 16 * kk;
+                mfma3(ot[i], ld8(vth + off), ld8(vtl + off), ph, pl);
+            }
+        }
+    }
+    const float lt = l + __shfl_xor(l, 32, 64);
+    const int q = q0 + lrow;
+    if (q >= Nq) return;
+    const float inv = 1.f / lt;
+    float* op = o + (((size_t)b * Nq + q) * H + h) * d;
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int dd = 32 * i + 8 * j + 4 * half;
+            if (dd < d) *reinterpret_cast<float4*>(op + dd) = make_float4(ot[i][4 * j] * inv, ot[i][4 * j + 1] * inv, ot[i][4 * j + 2] * inv, ot[i][4 * j + 3] * inv);
+        }
+    if (half == 0) lse[(size_t)bh * Nq + q] = m + __logf(lt);
+}
+
+// dq = scale (dS K), dS = P (dP - delta), P = exp(q' k^T - lse), dP = do v^T. grid (Nq_pad / 32, B H), one wave
+template <int DP, int DPO>
+__global__ void __launch_bounds__(64) attn_mfma_bwd_q_kernel(APrep Q, APrep K, APrep V, APrep DO, const float* __restrict__ lse_pad,
+                                                              const float* __restrict__ delta_pad, int H, int d, int Nq, int Nk, float scale,
+                                                              float* __restrict__ dq) {
+    constexpr int KS = DP / 16, DT = DPO / 32;
+    const int lane = threadIdx.x, lrow = lane & 31, half = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H, q0 = blockIdx.x * 32;
+    bf16x8 qh[KS], ql[KS], gh[KS], gl_[KS];
+    {
+        const size_t off = ((size_t)bh * Q.Npad + q0 + lrow) * DP + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qh[ks] = ld8(Q.r_hi + off + 16 * ks); ql[ks] = ld8(Q.r_lo + off + 16 * ks);
+            gh[ks] = ld8(DO.r_hi + off + 16 * ks); gl_[ks] = ld8(DO.r_lo + off + 16 * ks);
+        }
+    }
+    const float L = lse_pad[(size_t)bh * Q.Npad + q0 + lrow], dl = delta_pad[(size_t)bh * Q.Npad + q0 + lrow];
+    f32x16 acc[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const size_t rbase = ((size_t)bh * K.Npad + lrow) * DP + 8 * half;
+    const size_t tbase = ((size_t)bh * DPO + lrow) * K.Npad + 8 * half;
+    for (int k0 = 0; k0 < Nk; k0 += 32) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const size_t off = rbase + (size_t)k0 * DP + 16 * ks;
+            mfma3(s, ld8(K.r_hi + off), ld8(K.r_lo + off), qh[ks], ql[ks]);
+            mfma3(dp, ld8(V.r_hi + off), ld8(V.r_lo + off), gh[ks], gl_[ks]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = k0 + 8 * (r >> 2) + 4 * half + (r & 3) < Nk;
+            s[r] = ok ? __expf(s[r] - L) * (dp[r] - dl) : 0.f;       // dS
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 dh, dlo;
+            split8(s, kk, dh, dlo);
+#pragma unroll
+            for (int i = 0; i < DT; ++i) {
+                const size_t off = tbase + (size_t)32 * i * K.Npad + k0 + 16 * kk;
+                mfma3(acc[i], ld8(K.t_hi + off), ld8(K.t_lo + off), dh, dlo);
+            }
+        }
+    }
+    const int q = q0 + lrow;
+    if (q >= Nq) return;
+    float* op = dq + (((size_t)b * Nq + q) * H + h) * d;
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int dd = 32 * i + 8 * j + 4 * half;
+            if (dd < d) *reinterpret_cast<float4*>(op + dd) = make_float4(acc[i][4 * j] * scale, acc[i][4 * j + 1] * scale, acc[i][4 * j + 2] * scale, acc[i][4 * j + 3] * scale);
+        }
+}
+
+// dk = dS^T q' (= scale dS^T q), dv = P^T do. grid (Nk_pad / 32, B H), one wave owns 32 keys and walks the queries
+template <int DP, int DPO>
+__global__ void __launch_bounds__(64) attn_mfma_bwd_kv_kernel(APrep Q, APrep K, APrep V, APrep DO, const float* __restrict__ lse_pad,
+                                                               const float* __restrict__ delta_pad, int H, int d, int Nq, int Nk, float* __restrict__ dk,
+                                                               float* __restrict__ dv) {
+    constexpr int KS = DP / 16, DT = DPO / 32;
+    const int lane = threadIdx.x, lrow = lane & 31, half = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H, kb0 = blockIdx.x * 32;
+    bf16x8 kh[KS], kl[KS], vh[KS], vl[KS];
+    {
+        const size_t off = ((size_t)bh * K.Npad + kb0 + lrow) * DP + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kh[ks] = ld8(K.r_hi + off + 16 * ks); kl[ks] = ld8(K.r_lo + off + 16 * ks);
+            vh[ks] = ld8(V.r_hi + off + 16 * ks); vl[ks] = ld8(V.r_lo + off + 16 * ks);
+        }
+    }
+    f32x16 ak[DT], av[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ak[i][r] = 0.f; av[i][r] = 0.f; }
+    const size_t rbase = ((size_t)bh * Q.Npad + lrow) * DP + 8 * half;
+    const size_t tbase = ((size_t)bh * DPO + lrow) * Q.Npad + 8 * half;
+    const float* Lp = lse_pad + (size_t)bh * Q.Npad + 4 * half;
+    const float* Dp = delta_pad + (size_t)bh * Q.Npad + 4 * half;
+    const int nq_pad32 = (Nq + 31) & ~31;
+    for (int q0 = 0; q0 < nq_pad32; q0 += 32) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const size_t off = rbase + (size_t)q0 * DP + 16 * ks;
+            mfma3(s, ld8(Q.r_hi + off), ld8(Q.r_lo + off), kh[ks], kl[ks]);      // rows = queries, columns = this wave's keys
+            mfma3(dp, ld8(DO.r_hi + off), ld8(DO.r_lo + off), vh[ks], vl[ks]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 L4 = *reinterpret_cast<const float4*>(Lp + q0 + 8 * j);
+            const float4 D4 = *reinterpret_cast<const float4*>(Dp + q0 + 8 * j);
+            const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float p = __expf(s[4 * j + e] - Lr[e]);        // (queries behind the last one carry lse = 1e30: p = 0)
+                s[4 * j + e] = p;
+                dp[4 * j + e] = p * (dp[4 * j + e] - Dr[e]);          // dS
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 ph, pl, dh, dlo;
+            split8(s, kk, ph, pl);
+            split8(dp, kk, dh, dlo);
+#pragma unroll
+            for (int i = 0; i < DT; ++i) {
+                const size_t off = tbase + (size_t)32 * i * Q.Npad + q0 + 16 * kk;
+                mfma3(av[i], ld8(DO.t_hi + off), ld8(DO.t_lo + off), ph, pl);
+                mfma3(ak[i], ld8(Q.t_hi + off), ld8(Q.t_lo + off), dh, dlo);
+            }
+        }
+    }
+    const int key = kb0 + lrow;
+    if (key >= Nk) return;
+    const size_t ob = (((size_t)b * Nk + key) * H + h) * d;
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int dd = 32 * i + 8 * j + 4 * half;
+            if (dd < d) {
+                *reinterpret_cast<float4*>(dk + ob + dd) = make_float4(ak[i][4 * j], ak[i][4 * j + 1], ak[i][4 * j + 2], ak[i][4 * j + 3]);
+                *reinterpret_cast<float4*>(dv + ob + dd) = make_float4(av[i][4 * j], av[i][4 * j + 1], av[i][4 * j + 2], av[i][4 * j + 3]);
+            }
+        }
+}
+
 // GEGLU (attention.py:37-44): h = val * gelu(gate), u = [val | gate] of width 2 I (erf GELU, F.gelu default)
 __global__ void geglu_fwd_kernel(const float* __restrict__ u, int R, int I, float* __restrict__ h) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -293,6 +647,30 @@ __global__ void __launch_bounds__(1024) dot_reduce_kernel(const float* __restric
         if (mode) out[0] = t / (float)n;
         else { const float th = tanhf(*alpha); out[0] = scale * (1.f - th * th) * t; }
     }
+}
+// the same reduction for long vectors (the tanh-gate gradients and the loss at the 64 x 64 level are 10^7-element dots: one block took
+// 1.2 ms each, 4 % of an iteration): fixed chunks -> partial sums (one block per chunk) -> one wave adds the partials in order
+__global__ void __launch_bounds__(1024) dot_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, size_t chunk, int mode,
+                                                           float* __restrict__ partial) {
+    __shared__ float red[16];
+    const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    float s = 0.f;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 1024) s += mode ? (a[i] - b[i]) * (a[i] - b[i]) : a[i] * b[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        partial[blockIdx.x] = t;
+    }
+}
+__global__ void dot_final_kernel(const float* __restrict__ partial, int nb, size_t n, const float* __restrict__ alpha, float scale, int mode, float* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    float t = 0.f;
+    for (int i = 0; i < nb; ++i) t += partial[i];
+    if (mode) out[0] = t / (float)n;
+    else { const float th = tanhf(*alpha); out[0] = scale * (1.f - th * th) * t; }
 }
 // dy = 2 (y - t) / n   (d mse_loss / dy)
 __global__ void mse_grad_kernel(const float* __restrict__ y, const float* __restrict__ t, size_t n, float* __restrict__ dy) {
@@ -465,11 +843,27 @@ struct Ctx {
             ar.release(mk);
         }
     }
+    // ---- one-launch split-precision products (cat3_* above); GL_TRAIN_3LAUNCH=1 (developer A/B) keeps the three-launch form
+    static bool one_launch() {
+        static const bool three = dev_env("GL_TRAIN_3LAUNCH") && atoi(dev_env("GL_TRAIN_3LAUNCH")) != 0;
+        return split_precision() && !three;
+    }
+    bf16* cat3_rows(const float* src, size_t R, int K, int side) const {
+        bf16* d = ar.get<bf16>(R * 3 * (size_t)K);
+        hipLaunchKernelGGL(cat3_rows_kernel, g1(R * (size_t)K), dim3(256), 0, s, src, R * (size_t)K, K, side, d);
+        return d;
+    }
+    bf16* cat3_transposed(const float* src, int R, int Cc, int Rpad, int side) const {
+        bf16* d = ar.get<bf16>((size_t)Cc * 3 * Rpad);
+        hipLaunchKernelGGL(cat3_transposed_kernel, dim3(cdiv(Cc, 32), cdiv(Rpad, 32)), dim3(32, 8), 0, s, src, R, Cc, Cc, side, d, Rpad);
+        return d;
+    }
     // y = x W^T + b
     float* lin_fwd(const float* x, int M, int K, const float* W, const float* b, int N) const {
         float* y = f32((size_t)M * N);
         const size_t mk = ar.mark();       // the bf16 operand copies live for this product only (stream order keeps their reuse safe)
-        mm(to_bf16(x, (size_t)M * K), to_bf16(W, (size_t)N * K), M, N, K, b, y);
+        if (one_launch()) mm1(cat3_rows(x, M, K, 0), cat3_rows(W, N, K, 1), M, N, 3 * K, b, y);
+        else mm(to_bf16(x, (size_t)M * K), to_bf16(W, (size_t)N * K), M, N, K, b, y);
         ar.release(mk);
         return y;
     }
@@ -477,7 +871,8 @@ struct Ctx {
     float* lin_dgrad(const float* dy, int M, int N, const float* W, int K) const {
         float* dx = f32((size_t)M * K);
         const size_t mk = ar.mark();
-        mm(to_bf16(dy, (size_t)M * N), transposed(W, N, K, N), M, K, N, nullptr, dx);
+        if (one_launch()) mm1(cat3_rows(dy, M, N, 0), cat3_transposed(W, N, K, N, 1), M, K, 3 * N, nullptr, dx);
+        else mm(to_bf16(dy, (size_t)M * N), transposed(W, N, K, N), M, K, N, nullptr, dx);
         ar.release(mk);
         return dx;
     }
@@ -485,9 +880,26 @@ struct Ctx {
     void lin_wgrad(const float* dy, const float* x, int M, int N, int K, float* dW, float* db) const {
         const int Mp = round_up(M, 64);
         const size_t mk = ar.mark();
-        if (dW) mm(transposed(dy, M, N, Mp), transposed(x, M, K, Mp), N, K, Mp, nullptr, dW);
+        if (dW) {
+            if (one_launch()) mm1(cat3_transposed(dy, M, N, Mp, 0), cat3_transposed(x, M, K, Mp, 1), N, K, 3 * Mp, nullptr, dW);
+            else mm(transposed(dy, M, N, Mp), transposed(x, M, K, Mp), N, K, Mp, nullptr, dW);
+        }
         ar.release(mk);
         if (db) hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64)), dim3(1024), 0, s, dy, (const float*)nullptr, M, N, db);
+    }
+    // out[0] = coef * sum a b (mode 0: the tanh gate's derivative) / mean (a - b)^2 (mode 1: the loss); fixed summation order
+    void dot_reduce(const float* a, const float* b, size_t n, const float* alpha, float scale, int mode, float* out) const {
+        if (n <= ((size_t)1 << 18)) {
+            hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(1024), 0, s, a, b, n, alpha, scale, mode, out);
+            return;
+        }
+        const size_t chunk = (size_t)1 << 16;
+        const int nb = (int)((n + chunk - 1) / chunk);
+        const size_t mk = ar.mark();
+        float* partial = f32(nb);
+        hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(1024), 0, s, a, b, n, chunk, mode, partial);
+        hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(64), 0, s, (const float*)partial, nb, n, alpha, scale, mode, out);
+        ar.release(mk);
     }
     struct LN { float* y; float* xhat; float* rstd; };
     LN ln_fwd(const float* x, int R, int Cc, const float* g, const float* b) const {
@@ -520,7 +932,63 @@ struct Ctx {
             hipLaunchKernelGGL((attn_bwd_kv_kernel<DC, LPQ>), dim3(cdiv(Nk * LPQ, 64), B * H), dim3(64), 0, s, q, k, v, dout, (const float*)f.lse,
                                (const float*)delta, H, Nq, Nk, sc, dk, dv);
     }
+    // ---- MFMA attention (head dims 32 / 40 / 64 / 80): prep passes + the three kernels above
+    static bool attn_on_mfma(int D) {
+        static const bool valu = dev_env("GL_TRAIN_ATTN_VALU") && atoi(dev_env("GL_TRAIN_ATTN_VALU")) != 0;
+        return !valu && (D == 32 || D == 40 || D == 64 || D == 80);
+    }
+    APrep attn_prep(const float* x, int B, int N, int H, int D, float mul) const {
+        const int Npad = round_up(N, 64), DP = round_up(D, 16), DPO = round_up(D, 32);
+        const size_t nr = (size_t)B * H * Npad * DP, nt = (size_t)B * H * DPO * Npad;
+        bf16* rh = ar.get<bf16>(nr); bf16* rl = ar.get<bf16>(nr); bf16* th = ar.get<bf16>(nt); bf16* tl = ar.get<bf16>(nt);
+        const size_t total = (size_t)B * H * Npad * std::max(DP, DPO);
+        hipLaunchKernelGGL(attn_prep_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65535 * 16)), dim3(256), 0, s, x, N, H, D, mul, Npad, DP, DPO, rh, rl, th, tl,
+                           total);
+        return APrep{rh, rl, th, tl, Npad};
+    }
+    template <int DP, int DPO>
+    void attn_mfma_fwd_d(const APrep& Q, const APrep& K, const APrep& V, int B, int H, int D, int Nq, int Nk, float* o, float* lse) const {
+        hipLaunchKernelGGL((attn_mfma_fwd_kernel<DP, DPO>), dim3(Q.Npad / 32, B * H), dim3(64), 0, s, Q, K, V, H, D, Nq, Nk, o, lse);
+    }
+    template <int DP, int DPO>
+    void attn_mfma_bwd_d(const APrep& Q, const APrep& K, const APrep& V, const APrep& G, const float* lp, const float* dp, int B, int H, int D, int Nq, int Nk,
+                         float sc, float* dq, float* dk, float* dv) const {
+        hipLaunchKernelGGL((attn_mfma_bwd_q_kernel<DP, DPO>), dim3(Q.Npad / 32, B * H), dim3(64), 0, s, Q, K, V, G, lp, dp, H, D, Nq, Nk, sc, dq);
+        if (dk && dv) hipLaunchKernelGGL((attn_mfma_bwd_kv_kernel<DP, DPO>), dim3(K.Npad / 32, B * H), dim3(64), 0, s, Q, K, V, G, lp, dp, H, D, Nq, Nk, dk, dv);
+    }
+    Attn attn_fwd_mfma(int D, const float* q, const float* k, const float* v, int B, int H, int Nq, int Nk) const {
+        Attn a{f32((size_t)B * Nq * H * D), f32((size_t)B * H * Nq)};
+        const size_t mk = ar.mark();
+        const float sc = 1.f / sqrtf((float)D);
+        const APrep Q = attn_prep(q, B, Nq, H, D, sc), K = attn_prep(k, B, Nk, H, D, 1.f), V = attn_prep(v, B, Nk, H, D, 1.f);
+        switch (D) {
+            case 32: attn_mfma_fwd_d<32, 32>(Q, K, V, B, H, D, Nq, Nk, a.o, a.lse); break;
+            case 40: attn_mfma_fwd_d<48, 64>(Q, K, V, B, H, D, Nq, Nk, a.o, a.lse); break;
+            case 64: attn_mfma_fwd_d<64, 64>(Q, K, V, B, H, D, Nq, Nk, a.o, a.lse); break;
+            default: attn_mfma_fwd_d<80, 96>(Q, K, V, B, H, D, Nq, Nk, a.o, a.lse); break;
+        }
+        ar.release(mk);
+        return a;
+    }
+    void attn_bwd_mfma(int D, const float* q, const float* k, const float* v, const Attn& f, const float* dout, int B, int H, int Nq, int Nk, float* dq,
+                       float* dk, float* dv) const {
+        const size_t mk = ar.mark();
+        const float sc = 1.f / sqrtf((float)D);
+        const APrep Q = attn_prep(q, B, Nq, H, D, sc), K = attn_prep(k, B, Nk, H, D, 1.f), V = attn_prep(v, B, Nk, H, D, 1.f), G = attn_prep(dout, B, Nq, H, D, 1.f);
+        float* lp = f32((size_t)B * H * Q.Npad);
+        float* dp = f32((size_t)B * H * Q.Npad);
+        const size_t total = (size_t)B * H * Q.Npad;
+        hipLaunchKernelGGL(attn_delta_kernel, g1(total), dim3(256), 0, s, (const float*)f.o, dout, (const float*)f.lse, Nq, H, D, Q.Npad, lp, dp, total);
+        switch (D) {
+            case 32: attn_mfma_bwd_d<32, 32>(Q, K, V, G, lp, dp, B, H, D, Nq, Nk, sc, dq, dk, dv); break;
+            case 40: attn_mfma_bwd_d<48, 64>(Q, K, V, G, lp, dp, B, H, D, Nq, Nk, sc, dq, dk, dv); break;
+            case 64: attn_mfma_bwd_d<64, 64>(Q, K, V, G, lp, dp, B, H, D, Nq, Nk, sc, dq, dk, dv); break;
+            default: attn_mfma_bwd_d<80, 96>(Q, K, V, G, lp, dp, B, H, D, Nq, Nk, sc, dq, dk, dv); break;
+        }
+        ar.release(mk);
+    }
     Attn attn_fwd(int D, const float* q, const float* k, const float* v, int B, int H, int Nq, int Nk) const {
+        if (attn_on_mfma(D)) return attn_fwd_mfma(D, q, k, v, B, H, Nq, Nk);
         switch (D) {
             case 32: return attn_fwd_d<32, 1>(q, k, v, B, H, Nq, Nk);
             case 40: return attn_fwd_d<40, 1>(q, k, v, B, H, Nq, Nk);
@@ -532,6 +1000,7 @@ struct Ctx {
     }
     void attn_bwd(int D, const float* q, const float* k, const float* v, const Attn& f, const float* dout, int B, int H, int Nq, int Nk, float* dq,
                   float* dk, float* dv) const {
+        if (attn_on_mfma(D)) return attn_bwd_mfma(D, q, k, v, f, dout, B, H, Nq, Nk, dq, dk, dv);
         switch (D) {
             case 32: return attn_bwd_d<32, 1>(q, k, v, f, dout, B, H, Nq, Nk, dq, dk, dv);
             case 40: return attn_bwd_d<40, 1>(q, k, v, f, dout, B, H, Nq, Nk, dq, dk, dv);
@@ -554,6 +1023,27 @@ struct Ctx {
             float* wt = f32((size_t)Cin * Cout * 9);
             hipLaunchKernelGGL(conv_dgrad_weight_kernel, g1((size_t)Cin * Cout * 9), dim3(256), 0, s, w_oihw, Cout, Cin, wt);
             wsrc = wt;
+        }
+        if (one_launch() && Ci % 64 == 0) {
+            // one implicit-GEMM launch over 3 Ci input channels: activations (hi | lo | hi) as a two-source concat of the (hi | lo) buffer
+            // with its own first half, weights (hi | hi | lo) along I
+            const size_t nw = (size_t)Co * 9 * Ci;
+            float* w3 = f32(3 * nw);
+            hipLaunchKernelGGL(conv_w_cat3_kernel, g1(nw), dim3(256), 0, s, wsrc, Co, Ci, w3);
+            bf16* wp3 = ar.get<bf16>(3 * nw);
+            ck(pack_conv_weight_launch(w3, wp3, Co, 3 * Ci, 3, 3, Co, s));
+            const size_t na = (size_t)B * H * W * Ci;
+            bf16* a2 = ar.get<bf16>(2 * na);
+            hipLaunchKernelGGL(cat2_rows_kernel, g1(na), dim3(256), 0, s, a, na, Ci, a2);
+            AOperand A{};
+            A.p0 = a2; A.C0 = 2 * Ci; A.ld0 = 2 * Ci; A.p1 = a2; A.C1 = Ci; A.ld1 = 2 * Ci; A.mode = A_CONV3;
+            A.Hin = H; A.Win = W; A.Ho = Ho; A.Wo = Wo; A.stride = stride; A.ups = ups; A.pad_lo = 1;
+            Epilogue E;
+            epilogue_defaults(E);
+            E.out = out; E.ldo = Co; E.out_f32 = 1; E.bias = bias; E.rows_per_b = Ho * Wo;
+            ck(gemm_launch(A, wp3, M, Co, 27 * Ci, E, ws, ws_bytes, s));
+            ar.release(mk_ops);
+            return out;
         }
         bf16* wp = ar.get<bf16>((size_t)Co * 9 * Ci);
         ck(pack_conv_weight_launch(wsrc, wp, Co, Ci, 3, 3, Co, s));
@@ -709,7 +1199,7 @@ static void block_backward(const Ctx& c, const TrainBlockDims& d, const float* c
     }
     {   // x3 = x2 + g_d ff(norm2(x2)), g_d = scale tanh(alpha_dense): the fuser's feed-forward, TRAINABLE
         if (G[TP_F_ALPHA_DENSE])
-            hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)g, (const float*)S.ff_f, nx, P[TP_F_ALPHA_DENSE], d.fuser_scale, 0,
+            c.dot_reduce((const float*)g, (const float*)S.ff_f, nx, P[TP_F_ALPHA_DENSE], d.fuser_scale, 0,
                                G[TP_F_ALPHA_DENSE]);
         float* g_ff = c.f32(nx);
         hipLaunchKernelGGL(gated_scale_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)g, P[TP_F_ALPHA_DENSE], d.fuser_scale, nx, g_ff);
@@ -723,7 +1213,7 @@ static void block_backward(const Ctx& c, const TrainBlockDims& d, const float* c
     }
     {   // x2 = x1 + g_a attn(norm1([x1 ; linear(objs)]))[:, :N]: the fuser's attention, TRAINABLE
         if (G[TP_F_ALPHA_ATTN])
-            hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)g, (const float*)S.of, nx, P[TP_F_ALPHA_ATTN], d.fuser_scale, 0,
+            c.dot_reduce((const float*)g, (const float*)S.of, nx, P[TP_F_ALPHA_ATTN], d.fuser_scale, 0,
                                G[TP_F_ALPHA_ATTN]);
         float* g_of = c.f32(nx);
         hipLaunchKernelGGL(gated_scale_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)g, P[TP_F_ALPHA_ATTN], d.fuser_scale, nx, g_of);
@@ -777,7 +1267,7 @@ int block_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainBlockDims
         const size_t nx = (size_t)d.B * d.N * d.C;
         const BlockSaved S = block_forward(c, d, P, x, objs, context, y);
         // loss (trainer.py:366) and its gradient
-        hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)y, target, nx, (const float*)nullptr, 1.f, 1, loss);
+        c.dot_reduce((const float*)y, target, nx, (const float*)nullptr, 1.f, 1, loss);
         float* g = c.f32(nx);
         hipLaunchKernelGGL(mse_grad_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)y, target, nx, g);
         block_backward(c, d, P, S, objs, g, dobjs, G);
@@ -831,7 +1321,7 @@ int st_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainBlockDims& d
         Ctx c{ar, ws, ws_bytes, s};
         const size_t nx = (size_t)d.B * d.N * d.C;
         const STSaved S = st_forward(c, d, P, x, objs, context, y);
-        hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)y, target, nx, (const float*)nullptr, 1.f, 1, loss);
+        c.dot_reduce((const float*)y, target, nx, (const float*)nullptr, 1.f, 1, loss);
         float* g = c.f32(nx);
         hipLaunchKernelGGL(mse_grad_kernel, Ctx::g1(nx), dim3(256), 0, s, (const float*)y, target, nx, g);
         st_backward(c, d, P, S, objs, g, dobjs, G);
@@ -897,7 +1387,7 @@ int resblock_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainResDim
         float* se = c.f32((size_t)d.B * d.emb_dim);
         hipLaunchKernelGGL(silu_kernel, Ctx::g1((size_t)d.B * d.emb_dim), dim3(256), 0, s, emb, (size_t)d.B * d.emb_dim, se);
         const ResSaved S = res_forward(c, d, P, x, se, y);
-        hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)y, target, ny, (const float*)nullptr, 1.f, 1, loss);
+        c.dot_reduce((const float*)y, target, ny, (const float*)nullptr, 1.f, 1, loss);
         float* g = c.f32(ny);
         hipLaunchKernelGGL(mse_grad_kernel, Ctx::g1(ny), dim3(256), 0, s, (const float*)y, target, ny, g);
         float* g_x = res_backward(c, d, P, S, g);
@@ -937,7 +1427,7 @@ int resample_train_step(Arena& ar, float* ws, size_t ws_bytes, int mode, int B, 
         const size_t ny = (size_t)B * Ho * Wo * C, nx = (size_t)B * H * W * C;
         float* yv = resample_forward(c, mode, B, H, W, C, w_oihw, bias, x);
         c.hip(hipMemcpyAsync(y, yv, ny * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
-        hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)y, target, ny, (const float*)nullptr, 1.f, 1, loss);
+        c.dot_reduce((const float*)y, target, ny, (const float*)nullptr, 1.f, 1, loss);
         float* g = c.f32(ny);
         hipLaunchKernelGGL(mse_grad_kernel, Ctx::g1(ny), dim3(256), 0, s, (const float*)y, target, ny, g);
         float* gx = resample_backward(c, mode, B, H, W, C, w_oihw, g);
@@ -1284,7 +1774,7 @@ int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& c
         float* y = c.f32(ny);
         hipLaunchKernelGGL(conv3x3_direct_kernel, Ctx::g1(ny), dim3(256), 0, s, (const float*)on.a, nm.w("out.2.weight"), nm.w("out.2.bias"), H0, W0, mc, Co, ny, y);
         if (eps_out) c.hip(hipMemcpyAsync(eps_out, y, ny * 4, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
-        hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)y, in.target, ny, (const float*)nullptr, 1.f, 1, loss);
+        c.dot_reduce((const float*)y, in.target, ny, (const float*)nullptr, 1.f, 1, loss);
 
         // ---- backward
         float* gy = c.f32(ny);

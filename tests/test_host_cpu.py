@@ -764,6 +764,132 @@ def test_attn3_operand_handover_model():
 
 
 
+def test_training_attention_mfma_index_model():
+    """The three MFMA attention kernels of the training path (train.hip, round 5: forward, dq, dk / dv) modelled lane by lane in
+    float64: the prep pass's R / T layouts (tokens of T permuted in 16s), the 32x32x16 operand / accumulator layouts, accumulator
+    registers re-used as B operands, key / query padding masks, the per-lane softmax bookkeeping. Ragged sizes (70 queries, 75 keys,
+    d = 40 padded to 48 / 64). The hi / lo splits of the real kernels only add passes over the same indices."""
+    import numpy as np
+    rng=np.random.default_rng(1)
+    def perm16(t):
+        g=(t>>2)&3
+        return (t&~15)|((((g&1)<<1)|(g>>1))<<2)|(t&3)
+    def prep(x, N, d, mul, Npad, DP, DPO):      # x [N][d] for one (b,h)
+        R=np.zeros((Npad,DP)); T=np.zeros((DPO,Npad))
+        for t in range(N):
+            R[t,:d]=x[t]*mul
+            T[:d,perm16(t)]=x[t]*mul
+        return R,T
+    def mfma(acc, A, B):   # A[64][8], B[64][8] lane fragments; acc [64][16]
+        Am=np.zeros((32,16)); Bm=np.zeros((16,32))
+        for L in range(64):
+            Am[L&31, 8*(L>>5):8*(L>>5)+8]=A[L]
+            Bm[8*(L>>5):8*(L>>5)+8, L&31]=B[L]
+        D=Am@Bm
+        for L in range(64):
+            for j in range(4):
+                for e in range(4):
+                    acc[L,4*j+e]+=D[8*j+4*(L>>5)+e, L&31]
+    def rfrag(R, row0, ks):    # lane L: row row0 + (L&31), cols 16ks + 8(L>>5)..+7
+        return np.array([R[row0+(L&31), 16*ks+8*(L>>5):16*ks+8*(L>>5)+8] for L in range(64)])
+    def tfrag(T, i, tok0):     # lane L: row 32i + (L&31), positions tok0 + 8(L>>5)..+7
+        return np.array([T[32*i+(L&31), tok0+8*(L>>5):tok0+8*(L>>5)+8] for L in range(64)])
+    def split8(v, kk): return v[:, 8*kk:8*kk+8].copy()
+
+    Nq, Nk, d = 70, 75, 40
+    DP, DPO = 48, 64; KS, DT = DP//16, DPO//32
+    q=rng.standard_normal((Nq,d)); k=rng.standard_normal((Nk,d)); v=rng.standard_normal((Nk,d)); do=rng.standard_normal((Nq,d))
+    sc=d**-0.5
+    S=(q*sc)@k.T; P=np.exp(S-S.max(1,keepdims=True)); P/=P.sum(1,keepdims=True); O=P@v
+    lse=np.log(np.exp(S).sum(1))
+    dP=do@v.T; delta=(do*O).sum(1); dS=P*(dP-delta[:,None]); dQ=sc*dS@k; dK=dS.T@(q*sc); dV=P.T@do
+    Nqp, Nkp = 128, 128
+    QR,QT=prep(q,Nq,d,sc,Nqp,DP,DPO); KR,KT=prep(k,Nk,d,1,Nkp,DP,DPO); VR,VT=prep(v,Nk,d,1,Nkp,DP,DPO); GR,GT=prep(do,Nq,d,1,Nqp,DP,DPO)
+    lse_pad=np.full(Nqp,1e30); lse_pad[:Nq]=lse; delta_pad=np.zeros(Nqp); delta_pad[:Nq]=delta
+    # ---- forward
+    o=np.zeros((Nq,d)); lse_o=np.zeros(Nq)
+    for q0 in range(0,Nqp,32):
+        qf=[rfrag(QR,q0,ks) for ks in range(KS)]
+        ot=[np.zeros((64,16)) for _ in range(DT)]; m=np.full(64,-1e30); l=np.zeros(64)
+        for k0 in range(0,Nk,32):
+            s=np.zeros((64,16))
+            for ks in range(KS): mfma(s, rfrag(KR,k0,ks), qf[ks])
+            for L in range(64):
+                for r in range(16):
+                    if k0+8*(r>>2)+4*(L>>5)+(r&3)>=Nk: s[L,r]=-1e30
+            mx=s.max(1); mx=np.maximum(mx, np.roll(mx,32))
+            mn=np.maximum(m,mx); alpha=np.exp(m-mn)
+            s=np.exp(s-mn[:,None]); l=l*alpha+s.sum(1); m=mn
+            for i in range(DT): ot[i]*=alpha[:,None]
+            for kk in range(2):
+                ph=split8(s,kk)
+                for i in range(DT): mfma(ot[i], tfrag(VT,i,k0+16*kk), ph)
+        lt=l+np.roll(l,32)
+        for L in range(64):
+            qq=q0+(L&31)
+            if qq>=Nq: continue
+            for i in range(DT):
+                for j in range(4):
+                    dd=32*i+8*j+4*(L>>5)
+                    if dd<d: o[qq,dd:dd+4]=ot[i][L,4*j:4*j+4]/lt[L]
+            lse_o[qq]=m[L]+np.log(lt[L])
+    assert np.abs(o - O).max() < 1e-12 and np.abs(lse_o - lse).max() < 1e-12
+    # ---- bwd_q
+    dq=np.zeros((Nq,d))
+    for q0 in range(0,Nqp,32):
+        qf=[rfrag(QR,q0,ks) for ks in range(KS)]; gf=[rfrag(GR,q0,ks) for ks in range(KS)]
+        Lq=np.array([lse_pad[q0+(L&31)] for L in range(64)]); dl=np.array([delta_pad[q0+(L&31)] for L in range(64)])
+        acc=[np.zeros((64,16)) for _ in range(DT)]
+        for k0 in range(0,Nk,32):
+            s=np.zeros((64,16)); dp=np.zeros((64,16))
+            for ks in range(KS):
+                mfma(s, rfrag(KR,k0,ks), qf[ks]); mfma(dp, rfrag(VR,k0,ks), gf[ks])
+            for L in range(64):
+                for r in range(16):
+                    ok=k0+8*(r>>2)+4*(L>>5)+(r&3)<Nk
+                    s[L,r]=np.exp(s[L,r]-Lq[L])*(dp[L,r]-dl[L]) if ok else 0.0
+            for kk in range(2):
+                dh=split8(s,kk)
+                for i in range(DT): mfma(acc[i], tfrag(KT,i,k0+16*kk), dh)
+        for L in range(64):
+            qq=q0+(L&31)
+            if qq>=Nq: continue
+            for i in range(DT):
+                for j in range(4):
+                    dd=32*i+8*j+4*(L>>5)
+                    if dd<d: dq[qq,dd:dd+4]=acc[i][L,4*j:4*j+4]*sc
+    assert np.abs(dq - dQ).max() < 1e-12
+    # ---- bwd_kv
+    dk=np.zeros((Nk,d)); dv=np.zeros((Nk,d))
+    for kb0 in range(0,Nkp,32):
+        kf=[rfrag(KR,kb0,ks) for ks in range(KS)]; vf=[rfrag(VR,kb0,ks) for ks in range(KS)]
+        ak=[np.zeros((64,16)) for _ in range(DT)]; av=[np.zeros((64,16)) for _ in range(DT)]
+        for q0 in range(0,(Nq+31)&~31,32):
+            s=np.zeros((64,16)); dp=np.zeros((64,16))
+            for ks in range(KS):
+                mfma(s, rfrag(QR,q0,ks), kf[ks]); mfma(dp, rfrag(GR,q0,ks), vf[ks])
+            for L in range(64):
+                for j in range(4):
+                    for e in range(4):
+                        qi=q0+8*j+4*(L>>5)+e
+                        p=np.exp(min(s[L,4*j+e]-lse_pad[qi], 80.0)) if lse_pad[qi]<1e29 else 0.0
+                        s[L,4*j+e]=p; dp[L,4*j+e]=p*(dp[L,4*j+e]-delta_pad[qi])
+            for kk in range(2):
+                ph=split8(s,kk); dh=split8(dp,kk)
+                for i in range(DT):
+                    mfma(av[i], tfrag(GT,i,q0+16*kk), ph); mfma(ak[i], tfrag(QT,i,q0+16*kk), dh)
+        for L in range(64):
+            key=kb0+(L&31)
+            if key>=Nk: continue
+            for i in range(DT):
+                for j in range(4):
+                    dd=32*i+8*j+4*(L>>5)
+                    if dd<d:
+                        dk[key,dd:dd+4]=ak[i][L,4*j:4*j+4]; dv[key,dd:dd+4]=av[i][L,4*j:4*j+4]
+    assert np.abs(dk - dK).max() < 1e-12 and np.abs(dv - dV).max() < 1e-12
+
+
+
 def test_train_step_lr_schedule_and_guidance_drop():
     """TrainStep's learning-rate hook against the reference's schedulers (trainer.py:262-267: transformers'
     get_constant_schedule_with_warmup / get_cosine_schedule_with_warmup on an AdamW) and its random drop to the null grounding input
