@@ -190,7 +190,7 @@ def test_attn3_loop_puts_pv_on_16x16x32(attn_asm):
     steady-state loop (two per trip, the score sets swap roles): 6 MFMAs 32x32x16 for S^T, 12 MFMAs 16x16x32 for P V, the 8
     v_permlane16_swap that turn the 32x32 accumulators into the 16-query B operands, 6 + 6 fragment reads, K / V^T by LDS-DMA
     (at most 4 pieces per wave), one vmcnt wait + one barrier; no scratch, fewer registers than attn2 (O^T is 24, not 32)."""
-    name = re.search(r"^(_ZN2gl12attn3_kernelILi4EE[^:\s]*):", attn_asm, re.M).group(1)
+    name = re.search(r"^(_ZN2gl12attn3_kernelILi48ELi48ELb1ELi4EE[^:\s]*):", attn_asm, re.M).group(1)
     a = attn_asm.index(name + ":")
     body = attn_asm[a:attn_asm.index(".Lfunc_end", a)].split("\n")
     meta = attn_asm[attn_asm.index(".name:           " + name):]
@@ -218,6 +218,19 @@ def test_attn3_loop_puts_pv_on_16x16x32(attn_asm):
             run_v += 1; run_m = 0
         worst_v, worst_m = max(worst_v, run_v), max(worst_m, run_m)
     assert worst_v <= 22 and worst_m <= 4, (worst_v, worst_m)
+    # d = 80 (attn3_kernel<80, 96, false, 4>, the LATE_V form): the steady-state loop fits 256 registers without scratch traffic
+    # (the once-only first / last iterations may spill a few accumulator tuples across their merges: bounded here)
+    name80 = re.search(r"^(_ZN2gl12attn3_kernelILi80ELi96ELb0ELi4EE[^:\s]*):", attn_asm, re.M).group(1)
+    a = attn_asm.index(name80 + ":")
+    body = attn_asm[a:attn_asm.index(".Lfunc_end", a)].split("\n")
+    meta = attn_asm[attn_asm.index(".name:           " + name80):]
+    assert int(re.search(r"\.private_segment_fixed_size:\s*(\d+)", meta).group(1)) <= 256
+    head = next(i for i, l in enumerate(body) if "Inner Loop Header" in l)
+    label = body[head].split(":")[0].strip()
+    back = max(i for i, l in enumerate(body) if re.search(r"s_(c?branch\w*)\s+" + re.escape(label) + r"\s*$", l))
+    ops = [l.strip().split()[0] for l in body[head:back + 1] if l.strip() and not l.strip().startswith((";", "."))]
+    count = lambda op: sum(1 for o in ops if o.startswith(op))
+    assert count("scratch_") == 0 and count("v_mfma_f32_32x32x16_bf16") == 20 and count("v_mfma_f32_16x16x32_bf16") == 48
 
 
 @pytest.fixture(scope="module")
