@@ -400,6 +400,51 @@ def c2_case(name="c2_end_to_end", S=50, hw=64):
     print(f"{name}: z std {z.std():.4f} img std {img.std():.4f} [{time.time() - t0:.1f}s]")
 
 
+def c4_case(name="c4_end_to_end", S=50, hw=64):
+    """BASELINE config C4 for ONE image at its real size: inpainting box+text -- AutoencoderKL.encode of a 512x512 input image,
+    mask from the boxes, 9-channel first conv on [x ; z0 * mask ; mask], per-step q_sample blend (plms.py:96-100), 50 PLMS steps
+    (102 UNet forwards), CFG 7.5, decode (gligen_inference.py:396-446). fp32 on the CPU through the reference's own modules. The S
+    q_sample draws are torch.randn(S, 1, 4, hw, hw) from generator seed 77 (the test regenerates them; their sum is stored as a
+    check), the encoder's posterior draw from seed 5."""
+    t0 = time.time()
+    from functools import partial
+    diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000)
+    model = build_unet(syn.UNET_CFG, "text", inpaint=True)
+    ae = AutoencoderKL(ddconfig=syn.VAE_DDCONFIG, embed_dim=4, scale_factor=0.18215).eval()
+    syn.fill_module_(ae, 4321)
+    batch = syn.make_batch("text", 1, n_valid=8, seed=1)
+    g = model.grounding_tokenizer_input.prepare(batch)
+    x = syn.make_latent(1, 4, hw, hw, seed=6)
+    ctx, uc = syn.make_context(1, seed=1), syn.make_context(1, seed=9)
+    image = torch.rand(1, 3, 8 * hw, 8 * hw, generator=torch.Generator().manual_seed(8)) * 2 - 1
+    post_noise = torch.randn(1, 4, hw, hw, generator=torch.Generator().manual_seed(5))
+    real_randn = torch.randn
+    torch.randn = lambda *a, **k: post_noise.clone()          # the posterior's torch.randn(mean.shape) (distributions.py:35)
+    try:
+        with torch.no_grad():
+            z0 = ae.encode(image)
+    finally:
+        torch.randn = real_randn
+    mask = ref_draw_masks(batch["boxes"], hw)
+    extra = torch.cat([z0 * mask, mask], dim=1)
+    noise = torch.randn(S, 1, 4, hw, hw, generator=torch.Generator().manual_seed(77))
+    draws = iter(noise)
+    diffusion_q = diffusion.q_sample
+    diffusion.q_sample = lambda x_start, t, noise=None: diffusion_q(x_start, t, noise=next(draws))
+    sampler = PLMSSampler(diffusion, model, alpha_generator_func=partial(ref_alpha_generator, type=None), set_alpha_scale=set_alpha_scale)
+    inp = dict(x=x.clone(), timesteps=None, context=ctx, grounding_input=g, inpainting_extra_input=extra, grounding_extra_input=None)
+    with torch.no_grad():
+        z = sampler.sample(S=S, shape=tuple(x.shape), input=inp, uc=uc, guidance_scale=7.5, mask=mask, x0=z0)
+        t_s = time.time() - t0
+        img = ae.decode(z)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), z=z.numpy(), z0=z0.numpy(), img=img.numpy().astype(np.float16),
+                        meta=json.dumps(dict(S=S, hw=hw, alpha_type=None, guidance_scale=7.5, B=1, n_valid=8, img_stored="float16", inpaint=True,
+                                             noise_seed=77, noise_sum=float(noise.double().sum()), posterior_seed=5, image_seed=8,
+                                             ref_cpu_seconds=round(time.time() - t0, 1), ref_sampler_seconds=round(t_s, 1),
+                                             cpu_threads=torch.get_num_threads())))
+    print(f"{name}: z std {z.std():.4f} img std {img.std():.4f} [{time.time() - t0:.1f}s]")
+
+
 def c2_b4_case(name="c2_end_to_end_b4", S=50, hw=64, B=4):
     """BASELINE config C2 at the batch the metric is quoted on (B = 4 prompts with different boxes / embeddings / contexts / noise):
     50 PLMS steps, CFG 7.5, gate on at every step, fp32 on the CPU through the reference's PLMSSampler + UNetModel +
@@ -741,6 +786,7 @@ CASES = {
     "unet_full_64_text_image_b4": lambda: unet_pair_case("unet_full_64_text_image_b4", "text_image", 4, 64),
     "unet_full_64_keypoint_b4": lambda: unet_pair_case("unet_full_64_keypoint_b4", "keypoint", 4, 64),
     "c2_end_to_end": c2_case,
+    "c4_end_to_end": c4_case,
     # ---- round 4: the training slice (gradients through one transformer block, from the reference's autograd)
     "block_backward_gatedsa": block_backward_case,
     "st_backward_gatedsa": st_backward_case,

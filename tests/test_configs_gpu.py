@@ -174,6 +174,57 @@ def test_c2_end_to_end_vs_reference(full_models, monkeypatch):
     ae._drop_engine()
 
 
+def test_c4_end_to_end_vs_reference(full_models, monkeypatch):
+    """BASELINE config C4 for one image at its real size: inpainting box+text -- AutoencoderKL.encode of the 512x512 input image,
+    mask from the boxes, the 9-channel first conv on [x ; z0 * mask ; mask], the per-step q_sample blend, 50 PLMS steps (51 CFG
+    evaluations of the shipped inpainting UNet at the 64x64 latent), decode -- gligen_inference.generate against the reference's own
+    encoder + PLMSSampler + UNetModel + decoder run on the CPU (oracle/make_golden.py:c4_case). The q_sample draws are regenerated from
+    the generator seed the golden names (their sum is checked), the encoder's posterior draw likewise."""
+    dev = _dev()
+    import gligen_inference as gi
+    from ldm.models.diffusion.ldm import LatentDiffusion
+    from oracle.gligen_oracle import draw_masks_from_boxes
+    from helpers import scripted_randn_like
+    g = load_golden("c4_end_to_end")
+    meta = g["meta"]
+    hw, S = meta["hw"], meta["S"]
+    monkeypatch.setattr(gi, "device", dev)
+    model = full_models("text", True)
+    ae = build_product_vae(syn.VAE_DDCONFIG, device=dev)
+    diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000).to(dev)
+    batch = syn.make_batch("text", 1, n_valid=meta["n_valid"], seed=1)
+    ctx, uc = syn.make_context(1, seed=1).to(dev), syn.make_context(1, seed=9).to(dev)
+    image = torch.rand(1, 3, 8 * hw, 8 * hw, generator=torch.Generator().manual_seed(meta["image_seed"])) * 2 - 1
+    post_noise = torch.randn(1, 4, hw, hw, generator=torch.Generator().manual_seed(meta["posterior_seed"]))
+    noise = torch.randn(S, 1, 4, hw, hw, generator=torch.Generator().manual_seed(meta["noise_seed"]))
+    assert abs(float(noise.double().sum()) - meta["noise_sum"]) < 1e-6, "torch.randn no longer reproduces the golden's q_sample draws"
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: post_noise.clone())      # the one posterior draw (distributions.py:35)
+    z0 = ae.encode(image.to(dev))
+    monkeypatch.undo()
+    monkeypatch.setattr(gi, "device", dev)
+    z0_rel = mse(z0, g["z0"]) / float(g["z0"].var())
+    mask = draw_masks_from_boxes(batch["boxes"], hw).to(dev)
+    captured = {}
+    real_decode = type(ae).decode
+
+    def decode(self, z):
+        captured["z"] = z.clone()
+        return real_decode(self, z)
+    monkeypatch.setattr(type(ae), "decode", decode)
+    monkeypatch.setattr(torch, "randn_like", scripted_randn_like(noise.to(dev)))
+    img = gi.generate(model, ae, diffusion, _to(batch, dev), ctx, uc, steps=S, guidance_scale=meta["guidance_scale"], alpha_type=meta["alpha_type"],
+                      starting_noise=syn.make_latent(1, 4, hw, hw, seed=6).to(dev), inpainting_mask=mask, z0=z0)
+    monkeypatch.undo()
+    z_ref, img_ref = g["z"], g["img"].astype(np.float32)
+    r = dict(z0_rel_mse=z0_rel, z_rel_mse=mse(captured["z"], z_ref) / float(z_ref.var()), z_std=float(z_ref.std()),
+             img_mse=mse(img, img_ref), img_var=float(img_ref.var()), ref_cpu_seconds=meta["ref_cpu_seconds"])
+    r["img_rel_mse"] = r["img_mse"] / r["img_var"]
+    REPORT["c4_end_to_end"] = r
+    assert img.shape == tuple(img_ref.shape) == (1, 3, 8 * hw, 8 * hw)
+    assert r["z0_rel_mse"] < 5e-3 and r["z_rel_mse"] < 5e-3 and r["img_rel_mse"] < 1e-2, r
+    ae._drop_engine()
+
+
 def test_c2_end_to_end_b4_vs_reference(full_models, monkeypatch):
     """BASELINE config C2 at the batch the metric is quoted on: 4 prompts (different boxes, embeddings, contexts and noise), 512x512,
     50 PLMS steps, CFG 7.5, gate on at every step, decode -- against the reference's own sampler + UNet + decoder run on the CPU

@@ -475,6 +475,23 @@ def test_unet_train_step_vs_reference(engine, case, n_train, n_gates):
     bad = {k: v for k, v in report.items() if v >= 1e-5}
     assert not bad, bad
     assert all(abs(v - 1) < 1e-3 for v in norms.values()), {k: v for k, v in norms.items() if abs(v - 1) >= 1e-3}
+    if case == "unet_small_train_step":
+        # every gradient tensor IN FULL (the golden holds 4096-element strided samples + norms: a wrong value off the stride would only
+        # move a norm): autograd through the CPU oracle, itself held to the reference's loss.backward() on these goldens by
+        # tests/test_oracle_golden.py, gives all 35 M values
+        from oracle import gligen_oracle as orc
+        from helpers import grounding_kwargs, oracle_cfg
+        sdo = {k: v.detach().cpu().clone() for k, v in sd.items()}
+        for k in grads:
+            sdo[k].requires_grad_(True)
+        eps_o = orc.unet_forward(sdo, oracle_cfg(cfg, kind), dict(x=batch["x"], timesteps=batch["timesteps"].long(), context=batch["context"],
+                                                                    grounding_input=grounding_kwargs(kind, b)))
+        torch.nn.functional.mse_loss(eps_o, batch["target"]).backward()
+        full = {k: rel_mse(grads[k], sdo[k].grad) for k in grads if k not in gates}
+        full["<the gates>"] = rel_mse(torch.stack([grads[k].reshape(()) for k in gates]), torch.stack([sdo[k].grad.reshape(()) for k in gates]))
+        worst_full = max(full, key=full.get)
+        print("unet training step: every gradient tensor in full vs oracle autograd: worst", worst_full, full[worst_full])
+        assert full[worst_full] < 1e-5, {k: v for k, v in full.items() if v >= 1e-5}
     # activation checkpointing (every block's forward recomputed in its backward): the same numbers, bit for bit, in a fraction of the arena
     hw_full = engine.arena_high_water()
     loss_c, eps_c, grads_c = engine.unet_train_step(cfg, sd, batch, checkpoint=True)
