@@ -113,6 +113,7 @@ SYMBOLS = {
     "gl_op_resblock_train": (_I, [_P, _P, C.POINTER(_P), _P, _P, _P, _P, _P, _P, _P]),
     "gl_op_resample_train": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gl_unet_train_step": (_I, [_P, C.POINTER(UNetConfig), C.POINTER(TrainUNetIn), _I, C.POINTER(C.c_char_p), C.POINTER(_P), C.POINTER(_P), _P, _P, _P]),
+    "gl_train_wait_grads": (_I, [_P, _I, _P]),
     "gl_op_adamw_step": (_I, [_P, _P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _I, _P]),
     "gl_op_ff_chain": (_I, [_P, _P, _I, _I] + [_P] * 16),
     "gl_op_conv3x3": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),

@@ -637,8 +637,20 @@ int gl_unet_train_step(gl_ctx* ctx, const gl_unet_config* cfg, const gl_train_un
     for (int i = 0; i < 8; ++i) { c.channel_mult[i] = cfg->channel_mult[i]; c.attention_resolutions[i] = cfg->attention_resolutions[i]; }
     gl::TrainUNetIn u{in->B, in->H, in->W, in->ctx_T, cfg->grounding_kind == 1 ? 2 * in->Ng : in->Ng, in->Ng, in->x, in->timesteps, in->context, in->boxes,
                       in->masks, in->positive_embeddings, in->text_masks, in->image_masks, in->image_embeddings, in->target, in->fuser_scale, in->checkpoint};
-    int rc = gl::unet_train_step(eng.arena(), eng.splitk_ws(), eng.splitk_ws_bytes(), c, u, n_params, names, params, grads, k_train_block_names, eps_out, loss, S(s));
+    int rc = gl::unet_train_step(eng.arena(), eng.splitk_ws(), eng.splitk_ws_bytes(), c, u, n_params, names, params, grads, k_train_block_names, eps_out, loss, S(s),
+                                 eng.train_events(), Engine::kTrainEvents);
     if (rc != GL_OK) throw GlError(rc, gl::last_error());
+    eng.train_events_recorded = true;
+    GL_API_END
+}
+
+int gl_train_wait_grads(gl_ctx* ctx, int index, gl_stream s) {
+    NEED(ctx);
+    GL_API_BEGIN
+    Engine& eng = *ctx->eng;
+    if (index < 0 || index >= Engine::kTrainEvents) throw GlError(GL_ERR_ARG, "gl_train_wait_grads: milestone index out of range");
+    if (!eng.train_events_recorded) throw GlError(GL_ERR_STATE, "gl_train_wait_grads: no gl_unet_train_step has run on this context");
+    HIPCK_API(hipStreamWaitEvent(S(s), eng.train_events()[index], 0));
     GL_API_END
 }
 

@@ -186,6 +186,10 @@ class Engine {
 
     int device() const { return device_; }
     int64_t n_launches = 0;
+    // events of the training step's gradient milestones (train.h unet_train_step: grad_events), created on first use
+    static constexpr int kTrainEvents = 64;
+    hipEvent_t* train_events();
+    bool train_events_recorded = false;
 
     // ---- per-kernel profile of one eager UNetModel.forward: HIP events around every GEMM / conv / attention /
     // norm launch on the stream it is launched on, aggregated by kernel symbol (bench.py's roofline block)
@@ -316,6 +320,7 @@ class Engine {
     } cond_;
 
     std::unordered_map<uint64_t, AttnBufs> attn_bufs_;
+    std::vector<hipEvent_t> train_events_;
 
     // ---- VAE decoder
     bool has_vae_ = false;

@@ -141,6 +141,8 @@ Engine::~Engine() {
     if (smp_.ev_in) (void)hipEventDestroy(smp_.ev_in);
     if (smp_.ev_out) (void)hipEventDestroy(smp_.ev_out);
     if (smp_.stream) (void)hipStreamDestroy(smp_.stream);
+    for (hipEvent_t e : train_events_)
+        if (e) (void)hipEventDestroy(e);
     if (!parent_)
         for (auto& kv : raw_)
             if (kv.second.p) (void)hipFree(kv.second.p);
@@ -166,6 +168,14 @@ Engine::ProfScope::ProfScope(Engine* eng, hipStream_t st, const std::string& nam
 Engine::ProfScope::~ProfScope() {
     if (e->profiling_) (void)hipEventRecord(e->prof_[idx].e1, s);
 }
+hipEvent_t* Engine::train_events() {
+    if (train_events_.empty()) {
+        train_events_.resize(kTrainEvents, nullptr);
+        for (auto& e : train_events_) HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    return train_events_.data();
+}
+
 void Engine::profile_begin() {
     prof_.clear();
     profiling_ = true;
@@ -219,6 +229,8 @@ std::shared_ptr<Engine> Engine::fork(const std::shared_ptr<Engine>& parent, size
     e.cond_ = Cond{};
     e.attn_bufs_.clear();
     e.smp_ = Sampler{};
+    e.train_events_.clear();
+    e.train_events_recorded = false;
     e.profiling_ = false;
     e.prof_.clear();
     e.prof_pool_.clear();

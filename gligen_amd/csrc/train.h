@@ -79,7 +79,11 @@ struct TrainUNetIn {
 // names / params / grads: the model's state_dict (fp32 device pointers; grads[i] non-null only for fuser.* and position_net.* entries:
 // the reference's trainable set, trainer.py:217-245). block_names: the TP_* state_dict keys. eps_out (optional) [B][H*W][out_channels].
 int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& cfg, const TrainUNetIn& in, int n_params, const char* const* names,
-                    const float* const* params, float* const* grads, const char* const* block_names, float* eps_out, float* loss, hipStream_t s);
+                    const float* const* params, float* const* grads, const char* const* block_names, float* eps_out, float* loss, hipStream_t s,
+                    hipEvent_t* grad_events = nullptr, int n_grad_events = 0);
+// grad_events (optional): event j is recorded on `s` when the backward of the j-th SpatialTransformer (module order) has written its
+// fuser gradients -- the backward runs from the last block to the first, so high j come early --, event [number of SpatialTransformers]
+// when position_net's (the last gradients of the step) are written
 
 // One AdamW update of a flat fp32 parameter range, in place (torch.optim.AdamW semantics: trainer.py:245, :384 opt.step()); step = 1, 2, ...
 int adamw_step(float* p, const float* g, float* m, float* v, size_t n, double lr, double b1, double b2, double eps, double wd, int step, hipStream_t s);

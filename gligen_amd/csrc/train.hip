@@ -1575,7 +1575,7 @@ struct Names {
 }  // namespace
 
 int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& cfg, const TrainUNetIn& in, int n_params, const char* const* names,
-                    const float* const* params, float* const* grads, const char* const* block_names, float* eps_out, float* loss, hipStream_t s) {
+                    const float* const* params, float* const* grads, const char* const* block_names, float* eps_out, float* loss, hipStream_t s, hipEvent_t* grad_events, int n_grad_events) {
     try {
         Names nm;
         nm.params = params;
@@ -1792,6 +1792,10 @@ int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& c
         int first_st = -1;
         for (size_t i = 0; i < L.size(); ++i)
             if (L[i].kind == K_ST) { first_st = (int)i; break; }
+        std::vector<int> st_ordinal(L.size(), -1);            // SpatialTransformer number in module order (input_blocks .. middle .. output_blocks)
+        int n_st_layers = 0;
+        for (size_t i = 0; i < L.size(); ++i)
+            if (L[i].kind == K_ST) st_ordinal[i] = n_st_layers++;
         for (int i = (int)L.size() - 1; i >= 0 && i >= first_st; --i) {
             Layer& l = L[i];
             const size_t rows = (size_t)B * l.H * l.W;
@@ -1829,6 +1833,9 @@ int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& c
                 st_backward(c, bd, l.P.data(), l.ss, objs, g, d_o, l.G.data());      // g in place
                 c.add(g_objs, d_o, (size_t)MR * KD);
                 if (in.checkpoint) ar.release(mk);
+                // this block's fuser gradients are final: the caller's communication stream may pick them up (gl_train_wait_grads)
+                // while the blocks in front of it are still in backward
+                if (grad_events && st_ordinal[i] < n_grad_events) c.hip(hipEventRecord(grad_events[st_ordinal[i]], s), "hipEventRecord");
             } else if (l.kind == K_DOWN) {
                 g = resample_backward(c, 0, B, l.H, l.W, l.Cin, l.P[0], g);
             } else if (l.kind == K_UP) {
@@ -1868,6 +1875,8 @@ int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& c
                     hipLaunchKernelGGL(table_grad_kernel, dim3(cdiv(cfg.gr_dim, 256), 17), dim3(256), 0, s, (const float*)g_cat, in.masks, B, NB, PW, cfg.gr_dim, 0, gp);
             }
         }
+        // position_net's gradients -- the last ones of the step -- are final
+        if (grad_events && n_st_layers < n_grad_events) c.hip(hipEventRecord(grad_events[n_st_layers], s), "hipEventRecord");
         c.hip(hipGetLastError(), "training step kernel launch");
     } catch (const GlError& e) {
         return set_error(e.code, "%s", e.what());

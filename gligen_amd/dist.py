@@ -104,24 +104,24 @@ class GradBuckets:
         for b in self.buckets:
             b.zero_()
 
-    def all_reduce(self, average: bool = True):
-        """Sum (or mean) of every bucket over the ranks, in place. Returns the number of collectives issued."""
+    def all_reduce_bucket(self, i: int, average: bool = True) -> int:
+        """Sum (or mean) of bucket i over the ranks, in place, on the current stream. Returns the number of collectives issued."""
         if not dist.is_initialized() or self.world == 1:
             return 0
-        n = 0
-        nccl = dist.get_backend() == "nccl"
-        for buf in self.buckets:
-            if nccl:
-                shard = buf.numel() // self.world
-                mine = torch.empty(shard, dtype=buf.dtype, device=buf.device)
-                dist.reduce_scatter_tensor(mine, buf, op=dist.ReduceOp.SUM)
-                if average:
-                    mine.div_(self.world)
-                dist.all_gather_into_tensor(buf, mine)
-                n += 2
-            else:
-                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-                if average:
-                    buf.div_(self.world)
-                n += 1
-        return n
+        buf = self.buckets[i]
+        if dist.get_backend() == "nccl":
+            shard = buf.numel() // self.world
+            mine = torch.empty(shard, dtype=buf.dtype, device=buf.device)
+            dist.reduce_scatter_tensor(mine, buf, op=dist.ReduceOp.SUM)
+            if average:
+                mine.div_(self.world)
+            dist.all_gather_into_tensor(buf, mine)
+            return 2
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        if average:
+            buf.div_(self.world)
+        return 1
+
+    def all_reduce(self, average: bool = True):
+        """Sum (or mean) of every bucket over the ranks, in place. Returns the number of collectives issued."""
+        return sum(self.all_reduce_bucket(i, average) for i in range(len(self.buckets)))

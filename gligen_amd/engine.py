@@ -473,6 +473,12 @@ class Engine:
         check(self.lib.gl_unet_train_step(self._ctx, C.byref(c), C.byref(u), n, narr, parr, garr, _ptr(eps), _ptr(loss), _stream(dev)))
         return loss, eps.reshape(B, H, W, c.out_channels).permute(0, 3, 1, 2).contiguous(), grads
 
+    def train_wait_grads(self, index: int, stream=None) -> None:
+        """Make `stream` (a torch.cuda.Stream; None: the current one) wait until the gradients of the index-th SpatialTransformer of the
+        last unet_train_step -- or, index = number of SpatialTransformers, position_net's -- are written (gl_train_wait_grads)."""
+        h = C.c_void_p(stream.cuda_stream) if stream is not None else _stream(self.device)
+        check(self.lib.gl_train_wait_grads(self._ctx, int(index), h))
+
     def st_train_param_names(self):
         names = self.lib.gl_train_st_param_names()
         return [names[i].decode() for i in range(43)]

@@ -50,17 +50,38 @@ def trainable_names(state_dict: Mapping[str, torch.Tensor]):
     return [k for k in state_dict if ".fuser." in k or k.startswith("position_net.")]
 
 
+def gradient_milestones(names):
+    """For every trainable tensor the milestone of gl_unet_train_step behind which its gradient is final (gl_train_wait_grads): a fuser
+    tensor's is the number of its SpatialTransformer in module order (= state_dict order: input_blocks .., middle_block,
+    output_blocks ..), position_net's is the number of SpatialTransformers -- the end of the backward. The backward walks the blocks
+    from the last to the first, so milestone j is reached before milestone j - 1."""
+    blocks = []
+    for k in names:
+        if ".fuser." in k:
+            b = k.split(".transformer_blocks.")[0]
+            if b not in blocks:
+                blocks.append(b)
+    return {k: (blocks.index(k.split(".transformer_blocks.")[0]) if ".fuser." in k else len(blocks)) for k in names}
+
+
 class TrainStep:
     """lr: a float, or a callable step -> rate (warmup_schedule: the reference's warm-up schedulers). drop_prob: the probability with
     which an iteration trains on the null grounding input (UNetModel.forward, openaimodel.py:428: 0.1 while training; 0 here by
     default so that a step is a pure function of its batch) -- drawn from `rng` (random.Random; seed it identically on every rank
     or not at all, as the reference does). With torch.distributed initialised, rank 0's trainable parameters are broadcast once at
     construction, as DistributedDataParallel does (trainer.py:321-322): replicas that start from different state_dicts would
-    otherwise drift apart silently."""
+    otherwise drift apart silently.
+
+    overlap (default): the gradient exchange runs UNDER the backward, as DDP's does. The buckets are laid out in the order the
+    gradients become final (last SpatialTransformer first, position_net last); after the training step has been enqueued, each
+    bucket's reduce-scatter + all-gather and its AdamW update go to a communication stream that waits only for that bucket's
+    milestone (gl_train_wait_grads), so bucket 0 is on the wire while the encoder blocks are still in backward; the compute stream
+    joins the communication stream at the end of the step. overlap=False: backward, then every collective, then every update, on
+    one stream (the round-4 schedule) -- the same numbers bit for bit (same kernels per bucket, same order inside a bucket)."""
 
     def __init__(self, engine, cfg: Mapping, state_dict: Mapping[str, torch.Tensor], lr: Union[float, Callable[[int], float]] = 5e-5,
                  weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8, bucket_mb: float = 128.0, world: Optional[int] = None,
-                 checkpoint: bool = True, drop_prob: float = 0.0, rng: Optional[random.Random] = None, broadcast: bool = True):
+                 checkpoint: bool = True, drop_prob: float = 0.0, rng: Optional[random.Random] = None, broadcast: bool = True, overlap: bool = True):
         self.engine, self.cfg = engine, dict(cfg)
         dev = engine.device
         self.lr = lr if callable(lr) else float(lr)
@@ -68,6 +89,10 @@ class TrainStep:
         self.drop_prob, self.rng = float(drop_prob), rng or random.Random()
         self.checkpoint = bool(checkpoint)       # activation checkpointing per block (the reference: use_checkpoint=True in every shipped config)
         names = trainable_names(state_dict)
+        self.milestone = gradient_milestones(names)
+        n_blocks = max(self.milestone.values(), default=0)
+        # bucket order = the order in which gradients become final: blocks from the last to the first, position_net at the end
+        names = sorted(names, key=lambda k: (self.milestone[k] == n_blocks, -self.milestone[k]))
         shapes = {k: tuple(state_dict[k].shape) for k in names}
         # parameters, gradients and the two AdamW moments share one bucket layout
         self.pbuf = GradBuckets(shapes, bucket_mb, world, device=dev)
@@ -85,6 +110,13 @@ class TrainStep:
         if broadcast and tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
             for b in self.pbuf.buckets:            # the views alias the buckets: one collective per bucket moves every trainable tensor
                 tdist.broadcast(b, src=0)
+        # a bucket may go out once the LAST of its gradients is written: its lowest block number -- or the end of the backward
+        self.bucket_ready = []
+        for items in self.gbuf.layout:
+            ms = [self.milestone[n] for n, *_ in items]
+            self.bucket_ready.append(n_blocks if n_blocks in ms else min(ms))
+        self.overlap = bool(overlap) and hasattr(engine, "train_wait_grads")
+        self._comm = torch.cuda.Stream(device=dev) if (self.overlap and torch.device(dev).type == "cuda") else None
         self.steps = 0
 
     def lr_at(self, step: int) -> float:
@@ -95,11 +127,28 @@ class TrainStep:
         if self.drop_prob > 0.0 and self.rng.random() < self.drop_prob:      # random drop for guidance (openaimodel.py:428)
             batch = null_grounding(batch)
         loss, eps, _ = self.engine.unet_train_step(self.cfg, self.params, batch, fuser_scale=fuser_scale, grads=self.gbuf.views, checkpoint=self.checkpoint)
-        self.gbuf.all_reduce(average=True)
         self.steps += 1
         lr = self.lr_at(self.steps)
-        for p, g, m, v in zip(self.pbuf.buckets, self.gbuf.buckets, self.m, self.v):
-            self.engine.op_adamw_step(p, g, m, v, self.steps, lr=lr, betas=self.betas, eps=self.eps, weight_decay=self.wd)
+        upd = lambda i: self.engine.op_adamw_step(self.pbuf.buckets[i], self.gbuf.buckets[i], self.m[i], self.v[i], self.steps, lr=lr, betas=self.betas,
+                                                  eps=self.eps, weight_decay=self.wd)
+        nb = len(self.gbuf.buckets)
+        if not self.overlap:                        # backward, every collective, every update: one stream
+            self.gbuf.all_reduce(average=True)
+            for i in range(nb):
+                upd(i)
+        elif self._comm is None:                    # (a host-side engine: the same per-bucket order without streams)
+            for i in range(nb):
+                self.engine.train_wait_grads(self.bucket_ready[i], None)
+                self.gbuf.all_reduce_bucket(i, average=True)
+                upd(i)
+        else:
+            main = torch.cuda.current_stream(self.engine.device)
+            for i in range(nb):                     # bucket i: wait for its last gradient only, exchange, update -- all behind the backward
+                self.engine.train_wait_grads(self.bucket_ready[i], self._comm)
+                with torch.cuda.stream(self._comm):
+                    self.gbuf.all_reduce_bucket(i, average=True)
+                    upd(i)
+            main.wait_stream(self._comm)            # the next forward reads the updated parameters
         return loss, eps
 
     def state_dict(self) -> Dict[str, torch.Tensor]:

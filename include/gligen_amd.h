@@ -331,6 +331,14 @@ typedef struct gl_train_unet_in {
 int gl_unet_train_step(gl_ctx* ctx, const gl_unet_config* cfg, const gl_train_unet_in* in, int n_params, const char* const* names,
                        const float* const* params, float* const* grads, float* eps_out, float* loss, gl_stream s);
 
+/* Gradient milestones of the last gl_unet_train_step on this context: make stream `s` wait until the fuser gradients of the
+ * index-th SpatialTransformer (module order: input_blocks .., middle_block, output_blocks ..) are written -- the backward runs from the
+ * last block to the first, so the last blocks' gradients are final long before the step ends -- or, with index = the number of
+ * SpatialTransformers, until position_net's (the step's last) are. The training step itself is enqueued on its own stream and
+ * returns at once; a communication stream that waits here can start a bucket's reduce-scatter while the rest of the backward still
+ * runs, which is what DistributedDataParallel's bucket hooks do under loss.backward() (reference trainer.py:321-322, 366-384). */
+int gl_train_wait_grads(gl_ctx* ctx, int index, gl_stream s);
+
 /* One AdamW step over a flat fp32 range, in place: p, exp_avg m, exp_avg_sq v [n]; g the (all-reduced) gradient; step counts from 1.
  * torch.optim.AdamW semantics -- the reference's optimizer over the trainable set (trainer.py:245, opt.step() at :384) -- down to where
  * the scalars are formed: lr, the betas, eps and weight_decay arrive as doubles (Python floats), 1 - beta^step, lr / (1 - beta1^step),

@@ -174,6 +174,9 @@ TRAIN_WORKER = textwrap.dedent("""
             for k in sorted(grads):
                 grads[k].copy_(torch.randn(grads[k].shape, generator=g))
             return torch.tensor([float(rank)]), torch.zeros(1), grads
+        waits = []
+        def train_wait_grads(self, index, stream=None):      # the overlapped schedule: per bucket wait -> exchange -> update
+            self.waits.append(index)
         def op_adamw_step(self, p, g, m, v, step, lr, betas, eps, weight_decay):
             m.mul_(betas[0]).add_(g, alpha=1 - betas[0]); v.mul_(betas[1]).addcmul_(g, g, value=1 - betas[1])
             p.mul_(1 - lr * weight_decay).addcdiv_(m / (1 - betas[0] ** step), (v / (1 - betas[1] ** step)).sqrt() + eps, value=-lr)
@@ -185,8 +188,10 @@ TRAIN_WORKER = textwrap.dedent("""
     # rank 1 starts from OTHER trainable values: the constructor broadcasts rank 0's (as DistributedDataParallel does, trainer.py:321-322)
     sd_mine = {{k: (v + 1.0 if (rank == 1 and (".fuser." in k or k.startswith("position_net."))) else v.clone()) for k, v in sd.items()}}
     ts = TrainStep(Eng(), {{}}, sd_mine, lr=0.1, weight_decay=0.01, bucket_mb=4e-4, world=world)
+    assert ts.overlap and len(ts.bucket_ready) == len(ts.gbuf.buckets)
     for it in range(3):
         ts.step(dict(it=it))
+    assert Eng.waits == ts.bucket_ready * 3      # every bucket waited for its own milestone, in bucket order, every step
     # the same three steps in one process on the MEAN gradient of the two ranks
     names = trainable_names(sd)
     ref = {{k: sd[k].clone() for k in names}}

@@ -637,41 +637,63 @@ def test_row_local_kernel_gelu_constants():
 def test_train_step_bookkeeping_on_flat_buckets():
     """gligen_amd.train.TrainStep without a device: a stand-in engine records what it is given. The trainable tensors are the
     reference's set (trainer.py:217-245), they and their gradients are views into flat buckets (what the library writes is what the
-    collective reads and what AdamW updates), and one AdamW launch is issued per bucket with a step count from 1."""
+    collective reads and what AdamW updates), the buckets are laid out in the order the backward finishes the gradients (last
+    SpatialTransformer first, position_net last), and per bucket the step waits for that bucket's gradient milestone only, then
+    exchanges, then updates -- one AdamW launch per bucket with a step count from 1."""
     import torch
-    from gligen_amd.train import TrainStep, trainable_names
+    from gligen_amd.train import TrainStep, gradient_milestones, trainable_names
 
     class FakeEngine:
         device = torch.device("cpu")
 
         def __init__(self):
-            self.adamw_calls = []
+            self.calls = []
 
         def unet_train_step(self, cfg, params, batch, fuser_scale=1.0, trainable=None, grads=None, checkpoint=False):
             assert set(grads) == set(trainable_names(params))
             for i, (k, gt) in enumerate(sorted(grads.items())):
                 gt.fill_(float(i + 1))
+            self.calls.append(("step",))
             return torch.tensor([1.0]), torch.zeros(1), grads
 
+        def train_wait_grads(self, index, stream=None):
+            self.calls.append(("wait", index))
+
         def op_adamw_step(self, p, g, m, v, step, lr, betas, eps, weight_decay):
-            self.adamw_calls.append((p.data_ptr(), g.data_ptr(), step, p.numel()))
+            self.calls.append(("adamw", p.data_ptr(), g.data_ptr(), step, p.numel()))
             p.sub_(lr * torch.sign(g))
 
     sd = {"input_blocks.1.1.transformer_blocks.0.fuser.linear.weight": torch.ones(8, 4), "position_net.linears.0.bias": torch.ones(6),
           "input_blocks.1.1.transformer_blocks.0.attn1.to_q.weight": torch.ones(4, 4), "out.2.weight": torch.ones(2, 2),
-          "middle_block.1.transformer_blocks.0.fuser.alpha_attn": torch.ones(())}
+          "middle_block.1.transformer_blocks.0.fuser.alpha_attn": torch.ones(()), "output_blocks.3.1.transformer_blocks.0.fuser.linear.bias": torch.ones(4)}
+    assert gradient_milestones(trainable_names(sd)) == {"input_blocks.1.1.transformer_blocks.0.fuser.linear.weight": 0, "position_net.linears.0.bias": 3,
+                                                        "middle_block.1.transformer_blocks.0.fuser.alpha_attn": 1,
+                                                        "output_blocks.3.1.transformer_blocks.0.fuser.linear.bias": 2}
     eng = FakeEngine()
-    ts = TrainStep(eng, {}, sd, lr=0.5, bucket_mb=1e-4, world=1)      # 26 floats per bucket: the three trainable tensors need two buckets
+    ts = TrainStep(eng, {}, sd, lr=0.5, bucket_mb=1e-4, world=1)      # 26 floats per bucket
     assert sorted(ts.gbuf.views) == sorted(k for k in sd if ".fuser." in k or k.startswith("position_net."))
-    assert len(ts.pbuf.buckets) == 2 and [len(x) for x in ts.pbuf.layout] == [len(x) for x in ts.gbuf.layout]
+    # completion order: output block (2), middle (1), input block (0), position_net (3 = the end of the backward)
+    order = [n for items in ts.gbuf.layout for (n, *_r) in items]
+    assert order == ["output_blocks.3.1.transformer_blocks.0.fuser.linear.bias", "middle_block.1.transformer_blocks.0.fuser.alpha_attn",
+                     "input_blocks.1.1.transformer_blocks.0.fuser.linear.weight", "position_net.linears.0.bias"]
+    assert [len(x) for x in ts.pbuf.layout] == [len(x) for x in ts.gbuf.layout] == [2, 1, 1] and ts.bucket_ready == [1, 0, 3]
     for k in ts.gbuf.views:         # the model's trainable tensors ARE the flat buffers
         assert ts.params[k].data_ptr() == ts.pbuf.views[k].data_ptr()
     ts.step({})
     ts.step({})
-    assert [c[2] for c in eng.adamw_calls] == [1, 1, 2, 2]
-    assert {c[0] for c in eng.adamw_calls} == {b.data_ptr() for b in ts.pbuf.buckets}
+    kinds = [c[0] if c[0] != "wait" else c for c in eng.calls]
+    assert kinds == ["step", ("wait", 1), "adamw", ("wait", 0), "adamw", ("wait", 3), "adamw"] * 2     # per bucket: its milestone, then its update
+    ad = [c for c in eng.calls if c[0] == "adamw"]
+    assert [c[3] for c in ad] == [1, 1, 1, 2, 2, 2]
+    assert [c[1] for c in ad[:3]] == [b.data_ptr() for b in ts.pbuf.buckets] and [c[2] for c in ad[:3]] == [b.data_ptr() for b in ts.gbuf.buckets]
     out = ts.state_dict()
     assert torch.all(out["position_net.linears.0.bias"] == 0.0) and torch.all(out["out.2.weight"] == 1.0)      # 1 - 2 * 0.5; frozen untouched
+    # overlap=False: the round-4 schedule (everything after the backward), the same parameters
+    eng2 = FakeEngine()
+    ts2 = TrainStep(eng2, {}, sd, lr=0.5, bucket_mb=1e-4, world=1, overlap=False)
+    ts2.step({})
+    ts2.step({})
+    assert not any(c[0] == "wait" for c in eng2.calls) and all(torch.equal(ts2.state_dict()[k], out[k]) for k in out)
 
 
 def test_attn3_operand_handover_model():

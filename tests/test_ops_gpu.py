@@ -539,6 +539,14 @@ def test_train_two_optimizer_steps_vs_reference(engine):
         print("train steps:", key, "update rel-MSE", rel)
         assert rel < 1e-3, (key, rel)
     assert not torch.equal(after2["position_net.linears.4.weight"], p2["position_net.linears.4.weight"])
+    # the overlapped schedule (default: per bucket, a communication stream waits for that bucket's gradient milestone, exchanges, updates,
+    # while the backward of the earlier blocks still runs) against everything-after-the-backward on one stream: the same bits
+    assert ts2.overlap and ts2._comm is not None and ts2.bucket_ready[-1] == max(ts2.milestone.values())
+    ts3 = TrainStep(engine, meta["cfg"], sd, lr=meta["lr"], weight_decay=0.0, world=1, overlap=False)
+    ts3.step(batch); ts3.step(batch)
+    torch.cuda.synchronize()
+    p3 = ts3.state_dict()
+    assert all(torch.equal(p2[k], p3[k]) for k in p2), [k for k in p2 if not torch.equal(p2[k], p3[k])][:5]
 
 
 def test_spatial_transformer_backward_vs_reference(engine):
