@@ -182,7 +182,7 @@ class Engine {
     size_t splitk_ws_bytes() const { return ws_bytes_; }
     void* persist(size_t bytes, bool zero);
     void init_workspace();
-    AttnBufs& attn_bufs(int B, int H, int d, int Tq, int Tk, int dpv_layout = 0);   // dpv_layout: V^T rows when not attn_dims' (attn_vt_layout)
+    AttnBufs& attn_bufs(int B, int H, int d, int Tq, int Tk, int dpv_layout = 0, int slot = 0);   // dpv_layout: V^T rows when not attn_dims' (attn_vt_layout)
 
     int device() const { return device_; }
     int64_t n_launches = 0;
@@ -263,8 +263,18 @@ class Engine {
     // the chained launch: t = pre_res + pre_gate (x Wpre^T + pre_b); y = t + gate ff(LN(t)); out = y, or post_res + y Wpost^T + post_b
     bf16* feedforward_chain(const FFW& f, const bf16* x, int M, const LinW& pre, const bf16* pre_res, const float* pre_gate, const float* gate,
                             const LinW* post, const bf16* post_res, bf16* out, hipStream_t s, RowStats* out_stats);
+    // Tbuf / slot: the head-layout buffers are sized for Tbuf tokens per sample (0: T) and private to attention number `slot`
+    // (0: shared by every attention of this shape) -- the fuser's attention with hoisted grounding-token keys (fuser_kv_fill)
     void self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, int Nq, int Nk, int C, int d, bf16* o, hipStream_t s,
-                        const RowStats* in_stats = nullptr);
+                        const RowStats* in_stats = nullptr, int Tbuf = 0, int slot = 0);
+    // GatedSelfAttentionDense (attention.py:236-244): the K / V rows of the grounding tokens linear(objs) do not depend on the step.
+    // They are projected ONCE per prompt into the tail (tokens HW .. HW + Ng - 1) of this block's own K / V^T buffers; per step only
+    // the HW visual rows go through the (LayerNorm-folded) q,k,v^T projection -- no [x ; objs] concat LayerNorm pass.
+    void fuser_kv_fill(const STW& t, int B, int HW, hipStream_t s);
+    struct FuserKV { uint64_t epoch = 0; int B = 0, HW = 0; };
+    std::vector<FuserKV> fuser_kv_;
+    uint64_t cond_epoch_ = 0;
+    bool fuser_hoist_ = true;    // GL_FUSER_KV_HOIST=0 (developer A/B): the [x ; objs] concat LayerNorm + projection over all rows every step
     bf16* vae_attn(const VaeAttnW& a, const bf16* x, int B, int HW, hipStream_t s);
 
     Engine(const Engine&) = default;       // (fork() copies the weight descriptors member by member, then resets the per-context state)

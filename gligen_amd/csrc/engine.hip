@@ -230,6 +230,7 @@ std::shared_ptr<Engine> Engine::fork(const std::shared_ptr<Engine>& parent, size
     e.attn_bufs_.clear();
     e.smp_ = Sampler{};
     e.train_events_.clear();
+    e.fuser_kv_.clear();
     e.train_events_recorded = false;
     e.profiling_ = false;
     e.prof_.clear();
@@ -507,6 +508,7 @@ void Engine::build_unet() {
         ln_fold_ = fold;
         ff_rows_ = !(dev_env("GL_FF_ROWS") && atoi(dev_env("GL_FF_ROWS")) == 0);   // row-local feed-forward kernel (ffn.hip) where it exists
         ff_chain_ = dev_env("GL_FF_CHAIN") ? atoi(dev_env("GL_FF_CHAIN")) : 2;
+        fuser_hoist_ = !(dev_env("GL_FUSER_KV_HOIST") && atoi(dev_env("GL_FUSER_KV_HOIST")) == 0);
         auto self_attn_w = [&](const std::string& a, const NormW* ln) {
             SelfAttnW w;
             w.fused = fuse_qkv;
@@ -1114,12 +1116,13 @@ bf16* Engine::resblock(const ResW& r, const TRef& x, int B, int H, int W, const 
     return out;
 }
 
-AttnBufs& Engine::attn_bufs(int B, int H, int d, int Tq, int Tk, int dpv_layout) {
+AttnBufs& Engine::attn_bufs(int B, int H, int d, int Tq, int Tk, int dpv_layout, int slot) {
     const int Tq_pad = round_up(Tq, 128), Tk_pad = round_up(Tk, 64);
     int dp, dpv;
     CK(attn_dims(d, &dp, &dpv));
     if (dpv_layout) dpv = dpv_layout;      // (attn_vt_layout: the 16x16x32 P V kernel reads a 48-row V^T at d = 40)
-    const uint64_t key = ((uint64_t)B << 52) ^ ((uint64_t)H << 44) ^ ((uint64_t)d << 34) ^ ((uint64_t)Tq_pad << 17) ^ (uint64_t)Tk_pad ^ ((uint64_t)dpv << 58);
+    const uint64_t key = (((uint64_t)B << 52) ^ ((uint64_t)H << 44) ^ ((uint64_t)d << 34) ^ ((uint64_t)Tq_pad << 17) ^ (uint64_t)Tk_pad ^ ((uint64_t)dpv << 58)) +
+                         (uint64_t)slot * 0x9E3779B97F4A7C15ull;
     auto it = attn_bufs_.find(key);
     if (it != attn_bufs_.end()) return it->second;
     AttnBufs b;
@@ -1136,13 +1139,43 @@ AttnBufs& Engine::attn_bufs(int B, int H, int d, int Tq, int Tk, int dpv_layout)
 
 // SelfAttention.forward (attention.py:167-186) on LayerNorm'ed rows ln [B][T][C] (T % 64 == 0,
 // rows >= Nk are zero), queries = first Nq rows, keys/values = first Nk rows.
+void Engine::fuser_kv_fill(const STW& t, int B, int HW, hipStream_t s) {
+    const int Ng = cond_.Ng, C = t.C, d = t.d, H = C / d;
+    const int Ng64 = round_up(Ng, 64), Tf = HW + Ng64;
+    int dp, dpv;
+    CK(attn_dims(d, &dp, &dpv));
+    const int vt_layout = attn_vt_layout(d, HW + Ng, &dpv);
+    AttnBufs& bufs = attn_bufs(B, H, d, Tf, Tf, dpv, t.idx + 1);
+    const size_t mk = arena_.mark();
+    // LayerNorm of the grounding-token rows alone (per row: what the [x ; objs] pass computed for them), no affine: gamma / beta live in
+    // the folded q,k,v weights; rows Ng .. Ng64 - 1 of every sample are zero and land behind the last key
+    bf16* lno = arena_.get<bf16>((size_t)B * Ng64 * C);
+    {
+        LNParams P{};
+        P.x = cond_.objs[t.idx]; P.B = B; P.N1 = Ng; P.N2 = 0; P.Tpad = Ng64; P.C = C; P.eps = 1e-5f; P.y = lno;
+        CK(layernorm_launch(P, s));
+    }
+    AOperand A;
+    aoperand_rows(A, lno, C, C);
+    Epilogue E;
+    epilogue_defaults(E);
+    E.mode = EPI_QKV_HEADS;
+    E.q = bufs.q; E.k = bufs.k; E.vt = bufs.vt; E.C = C; E.H = H; E.d = d; E.DP = dp; E.DPV = dpv; E.T = Ng64; E.tok_off = HW; E.vt_perm32 = vt_layout;
+    E.Tpad_q = bufs.Tq_pad; E.Tpad_k = bufs.Tk_pad;
+    E.bias = t.fa.b;          // W beta of the folded LayerNorm
+    CK(gemm_launch(A, t.fa.wqk, B * Ng64, 3 * C, C, E, ws_, ws_bytes_, s));   // (its q rows land behind the last query: never read)
+    arena_.release(mk);
+    if (fuser_kv_.size() < st_.size()) fuser_kv_.resize(st_.size());
+    fuser_kv_[t.idx] = FuserKV{cond_epoch_, B, HW};
+}
+
 void Engine::self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, int Nq, int Nk, int C, int d, bf16* o, hipStream_t s,
-                            const RowStats* in_stats) {
+                            const RowStats* in_stats, int Tbuf, int slot) {
     const int H = C / d;
     int dp, dpv;
     CK(attn_dims(d, &dp, &dpv));
     const int vt_layout = attn_vt_layout(d, Nk, &dpv);    // which V^T form the attention kernel for this (d, Nk) reads
-    AttnBufs& bufs = attn_bufs(B, H, d, T, T, dpv);
+    AttnBufs& bufs = attn_bufs(B, H, d, Tbuf ? Tbuf : T, Tbuf ? Tbuf : T, dpv, slot);
     if (in_stats && !(a.fused && a.folded)) throw GlError(GL_ERR_STATE, "self_attention: row statistics given to an unfolded projection");
     if (a.fused) {
         AOperand A;
@@ -1453,6 +1486,22 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
     } else if (ucfg_.fuser_kind == 0) {
         // fuser (gatedSA): x = x + scale*tanh(alpha_attn) * attn(norm1([x ; linear(objs)]))[:, :N]
         const int Tf = round_up(HW + Ng, 64);
+        if (fuser_hoist_ && t.fa.fused && t.fa.folded && aligned) {
+            // the grounding tokens' keys / values are in this block's buffers since the prompt was set (fuser_kv_fill); only the visual
+            // rows are projected, raw, with the statistics attn1.to_out wrote (or through the plain LayerNorm where it wrote none)
+            if (fuser_kv_.size() < st_.size()) fuser_kv_.resize(st_.size());
+            const FuserKV& kv = fuser_kv_[t.idx];
+            if (kv.epoch != cond_epoch_ || kv.B != B || kv.HW != HW) {
+                hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+                (void)hipStreamIsCapturing(s, &cap);
+                if (cap != hipStreamCaptureStatusNone) throw GlError(GL_ERR_STATE, "fuser keys of this prompt / shape were not projected before the graph capture");
+                fuser_kv_fill(t, B, HW, s);
+                n_launches += 2;
+            }
+            const bool ff = can_fold(st1, M, C, 3 * C, EPI_QKV_HEADS, ACT_NONE, aligned);
+            const bf16* rows = ff ? t1 : layernorm_plain(t1, B, HW, C, false, s);
+            self_attention(t.fa, rows, B, HW, HW, HW + Ng, C, d, o, s, ff ? &st1 : nullptr, Tf, t.idx + 1);
+        } else {
         bf16* lnc = arena_.get<bf16>((size_t)B * Tf * C);
         {
             LNParams P{};
@@ -1463,6 +1512,7 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
             ++n_launches;
         }
         self_attention(t.fa, lnc, B, Tf, HW, HW + Ng, C, d, o, s);
+        }
         //    x = x + scale*tanh(alpha_dense) * ff(norm2(x))
         t3 = fuser_ff_tail(t, o, t1, B, HW, r2, s, &st3);
     } else {
@@ -1684,6 +1734,7 @@ void Engine::set_cond(int Beff, const float* context, int n_ctx, const gl_ground
         mlp(0, pin, 0);
     }
 
+    ++cond_epoch_;
     cond_.obj_stride = obj_stride;
     HIPCK(hipMemcpyAsync(cond_.tokens, objs, (size_t)Beff * obj_stride * out_dim * sizeof(bf16), hipMemcpyDeviceToDevice, s));  // gl_unet_grounding_tokens
 
@@ -1735,6 +1786,11 @@ void Engine::set_cond(int Beff, const float* context, int n_ctx, const gl_ground
             CK(gemm_launch_t(t.a2.wv, t.C, ctxb, Beff * ctx_Tpad, t.a2.ctx_dim, E, s));
         }
     }
+    // A captured graph of these shapes may be replayed for this prompt without another eager pass: the blocks whose shape is known
+    // from the previous prompt get the new grounding-token keys / values now
+    if (!ca && fuser_hoist_ && c.fuser_kind == 0)
+        for (const STW& t : st_)
+            if ((size_t)t.idx < fuser_kv_.size() && fuser_kv_[t.idx].HW && fuser_kv_[t.idx].B == Beff && t.fa.fused && t.fa.folded) fuser_kv_fill(t, Beff, fuser_kv_[t.idx].HW, s);
 }
 
 // the `scale` attributes of the fuser modules, one per transformer block in module order (they are plain Python attributes in

@@ -49,6 +49,8 @@ struct Epilogue {
     int Tpad_q, Tpad_k;
     bf16* vt;           // EPI_QKV_HEADS: v^T destination (EPI_VT_HEADS passes it in `out`)
     int DPV;            // EPI_VT_HEADS / EPI_QKV_HEADS: vt [B*H][DPV][Tpad_k], tokens permuted within groups of 16
+    int tok_off;        // head-layout epilogues: token index = (row % T) + tok_off (rows of a SECOND token range of the same sequence: the
+                        // grounding tokens behind the visual ones in the fuser's [x ; objs] attention, written once per prompt)
     int vt_perm32;      // 1: tokens permuted within groups of 32 instead (attention.h attn_vt_layout == 1: the 16x16x32 P V kernel)
     int n_real;         // EPI_NCHW_F32: number of real output channels (<= N)
     // EPI_ROWMAJOR optional row remap: out row = (m / remap_in) * remap_out + m % remap_in + remap_off

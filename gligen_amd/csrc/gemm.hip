@@ -120,7 +120,7 @@ __device__ __forceinline__ void epi_finish4(const Epilogue& E, int m, int n0, fl
             int h = c / E.d;
             int dd = c - h * E.d;
             int b = m / E.T;
-            int t = m - b * E.T;
+            int t = m - b * E.T + E.tok_off;
             int tp = which ? E.Tpad_k : E.Tpad_q;
             bf16* base = which ? E.k : E.q;
             const size_t off = (which || E.q_tiled) ? ktile_off((size_t)(b * E.H + h), tp, t, dd, E.DP) : ((size_t)(b * E.H + h) * tp + t) * E.DP + dd;
@@ -131,7 +131,7 @@ __device__ __forceinline__ void epi_finish4(const Epilogue& E, int m, int n0, fl
             int h = m / E.d;
             int dd = m - h * E.d;
             int b = n0 / E.T;
-            int t0 = n0 - b * E.T;
+            int t0 = n0 - b * E.T + E.tok_off;
             bf16* base = reinterpret_cast<bf16*>(E.out);
             store_bf16x4(base + ((size_t)(b * E.H + h) * E.DPV + dd) * E.Tpad_k + perm_tok4(t0, E.vt_perm32), v);
             break;
@@ -180,7 +180,7 @@ __device__ __forceinline__ void epi_store4(const Epilogue& E, int m, int n0, flo
             int h = c / E.d;
             int dd = c - h * E.d;
             int b = m / E.T;
-            int t = m - b * E.T;
+            int t = m - b * E.T + E.tok_off;
             int tp = which ? E.Tpad_k : E.Tpad_q;
             bf16* base = which ? E.k : E.q;
             const size_t off = (which || E.q_tiled) ? ktile_off((size_t)(b * E.H + h), tp, t, dd, E.DP) : ((size_t)(b * E.H + h) * tp + t) * E.DP + dd;
@@ -191,7 +191,7 @@ __device__ __forceinline__ void epi_store4(const Epilogue& E, int m, int n0, flo
             int h = m / E.d;
             int dd = m - h * E.d;
             int b = n0 / E.T;
-            int t0 = n0 - b * E.T;
+            int t0 = n0 - b * E.T + E.tok_off;
             bf16* base = reinterpret_cast<bf16*>(E.out);
             store_bf16x4(base + ((size_t)(b * E.H + h) * E.DPV + dd) * E.Tpad_k + perm_tok4(t0, E.vt_perm32), v);
             break;
@@ -1035,7 +1035,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
             st[i] = lst ? lst[wm * TM * 16 + i * 16 + l15] : make_float2(0.f, 1.f);
             const int m = mrow + i * 16;
             rb[i] = m / E.T;
-            rt[i] = m - rb[i] * E.T;
+            rt[i] = m - rb[i] * E.T + E.tok_off;
         }
         float4 cs[TN], bj[TN];
 #pragma unroll
@@ -1113,7 +1113,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
                 const int m0 = mtok + i * 16;
                 if (m0 >= M) continue;
                 const int b = m0 / E.T;
-                const int t0 = m0 - b * E.T;
+                const int t0 = m0 - b * E.T + E.tok_off;
                 float v[4] = {s01[i].y * (acc[i][j][0] - s01[i].x * cs) + bn, s01[i].w * (acc[i][j][1] - s01[i].z * cs) + bn,
                               s23[i].y * (acc[i][j][2] - s23[i].x * cs) + bn, s23[i].w * (acc[i][j][3] - s23[i].z * cs) + bn};
                 store_bf16x4(E.vt + ((size_t)(b * E.H + h) * E.DPV + dd) * E.Tpad_k + perm_tok4(t0, E.vt_perm32), v);
