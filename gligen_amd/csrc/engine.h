@@ -168,8 +168,10 @@ class Engine {
     void spatial_tokens(int B, const float* image, int C, int H, int W, const float* mask, float* out, hipStream_t s);
     int spatial_token_count() const { return cnx_.tokens; }  // [Beff][Ng][gr_out_dim] fp32: objs of openaimodel.py:433 for the current conditioning
     void restore_first_conv(const float* w, const float* b, hipStream_t s);
+    // emb_row (the sampler): the step's emb_layers outputs [sum Cout] fp32, the same for every sample -- the time-embedding MLP and
+    // the concatenated emb_layers GEMM are then not launched (emb_table_build computed them for the whole schedule)
     void unet_forward(int Beff, int h, int w, const float* x, int xB, const int64_t* t, const float* extra,
-                      int extraB, float* eps, hipStream_t s);
+                      int extraB, float* eps, hipStream_t s, const float* emb_row = nullptr);
     void vae_decode(int B, int h, int w, const float* z, float* out, hipStream_t s);
     void vae_encode(int B, int H, int W, const float* img, const float* noise, float* z, hipStream_t s);
     bool has_vae_encoder() const { return has_venc_; }
@@ -380,6 +382,14 @@ class Engine {
         unsigned policy_epoch = 0;       // ff_policy epoch the graphs were captured under
     } smp_;
     void sampler_release_graph();
+    // time_embed + every ResBlock's emb_layers (openaimodel.py:436-437, 220-221) depend on the timestep alone, and a sampling run knows
+    // its timesteps: one batched pass over the whole schedule at the start of gl_sample_plms instead of 4 tiny GEMM chains per evaluation
+    void emb_table_build(const int64_t* t_host, int R, hipStream_t s);
+    float* emb_table_ = nullptr;     // [rows][embcat_.N]
+    float* emb_cur_ = nullptr;       // [embcat_.N]: the row of the evaluation in flight (what the captured graph reads)
+    int64_t* emb_t_dev_ = nullptr;
+    int emb_table_cap_ = 0;
+    std::vector<int64_t> emb_t_cache_;
 };
 
 }  // namespace gl

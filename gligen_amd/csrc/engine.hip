@@ -231,6 +231,7 @@ std::shared_ptr<Engine> Engine::fork(const std::shared_ptr<Engine>& parent, size
     e.smp_ = Sampler{};
     e.train_events_.clear();
     e.fuser_kv_.clear();
+    e.emb_table_ = nullptr; e.emb_cur_ = nullptr; e.emb_t_dev_ = nullptr; e.emb_table_cap_ = 0; e.emb_t_cache_.clear();
     e.train_events_recorded = false;
     e.profiling_ = false;
     e.prof_.clear();
@@ -1344,6 +1345,11 @@ bool Engine::ff_rows_for(const STW& t, int which, int B, int HW, hipStream_t s) 
     const FFW& f = which == 1 ? t.fff : t.ff;
     const int M = B * HW, C = t.C;
     if (!f.folded || !f.rows_stream || !ff_rows_supported(M, C)) return false;
+    static const bool env_once = [] {      // developer switch: GL_FF_POLICY=-1|0|1 presets the mode (PMC passes: no timing launches)
+        if (const char* e = dev_env("GL_FF_POLICY")) ff_policy::mode.store(atoi(e));
+        return true;
+    }();
+    (void)env_once;
     const int mode = ff_policy::mode.load();
     if (mode == 0) return false;
     if (mode == 1) return true;
@@ -1811,8 +1817,34 @@ void Engine::grounding_tokens(float* out, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------- UNetModel.forward (openaimodel.py:420-464)
+void Engine::emb_table_build(const int64_t* t_host, int R, hipStream_t s) {
+    const int mc = ucfg_.model_channels;
+    if ((int)emb_t_cache_.size() == R && std::equal(t_host, t_host + R, emb_t_cache_.begin())) return;   // the schedule of the last run
+    if (R > emb_table_cap_) {
+        const int cap = std::max(R, 64);
+        emb_table_ = reinterpret_cast<float*>(persist((size_t)cap * embcat_.N * sizeof(float), false));
+        emb_t_dev_ = reinterpret_cast<int64_t*>(persist((size_t)cap * sizeof(int64_t), false));
+        if (!emb_cur_) emb_cur_ = reinterpret_cast<float*>(persist((size_t)embcat_.N * sizeof(float), true));
+        emb_table_cap_ = cap;
+    }
+    HIPCK(hipMemcpyAsync(emb_t_dev_, t_host, (size_t)R * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    const size_t mk = arena_.mark();
+    bf16* temb = arena_.get<bf16>((size_t)R * mc);
+    CK(timestep_embed_launch(emb_t_dev_, temb, R, mc, s));
+    bf16* e1 = linear_rows(temb, R, te0_, ACT_SILU, nullptr, nullptr, s);
+    bf16* semb = linear_rows(e1, R, te2_, ACT_SILU, nullptr, nullptr, s);
+    AOperand A;
+    aoperand_rows(A, semb, embcat_.K, embcat_.K);
+    Epilogue E;
+    epilogue_defaults(E);
+    E.out = emb_table_; E.ldo = embcat_.N; E.out_f32 = 1; E.bias = embcat_.b;
+    gemm(A, embcat_.w, R, embcat_.N, embcat_.K, E, s);
+    arena_.release(mk);
+    emb_t_cache_.assign(t_host, t_host + R);
+}
+
 void Engine::unet_forward(int Beff, int h, int w, const float* x, int xB, const int64_t* t, const float* extra,
-                          int extraB, float* eps, hipStream_t s) {
+                          int extraB, float* eps, hipStream_t s, const float* emb_row) {
     if (!has_unet_ || !finalized_) throw GlError(GL_ERR_STATE, "unet not finalized");
     if (cond_.Beff != Beff) throw GlError(GL_ERR_STATE, fmt("unet_forward batch %d but conditioning was set for %d", Beff, cond_.Beff));
     const gl_unet_config& c = ucfg_;
@@ -1824,21 +1856,26 @@ void Engine::unet_forward(int Beff, int h, int w, const float* x, int xB, const 
     arena_.reset();
 
     // time embedding: emb = time_embed(timestep_embedding(t)); every ResBlock consumes SiLU(emb)
-    bf16* temb = arena_.get<bf16>((size_t)Beff * mc);
-    CK(timestep_embed_launch(t, temb, Beff, mc, s));
-    bf16* e1 = linear_rows(temb, Beff, te0_, ACT_SILU, nullptr, nullptr, s);
-    bf16* semb = linear_rows(e1, Beff, te2_, ACT_SILU, nullptr, nullptr, s);
-    float* embout = arena_.get<float>((size_t)Beff * embcat_.N);
-    {
+    const float* embout = emb_row;
+    int emb_ld = 0;                   // (a precomputed row is every sample's)
+    if (!emb_row) {
+        bf16* temb = arena_.get<bf16>((size_t)Beff * mc);
+        CK(timestep_embed_launch(t, temb, Beff, mc, s));
+        bf16* e1 = linear_rows(temb, Beff, te0_, ACT_SILU, nullptr, nullptr, s);
+        bf16* semb = linear_rows(e1, Beff, te2_, ACT_SILU, nullptr, nullptr, s);
+        float* eo = arena_.get<float>((size_t)Beff * embcat_.N);
         AOperand A;
         aoperand_rows(A, semb, embcat_.K, embcat_.K);
         Epilogue E;
         epilogue_defaults(E);
-        E.out = embout; E.ldo = embcat_.N; E.out_f32 = 1; E.bias = embcat_.b;
+        E.out = eo; E.ldo = embcat_.N; E.out_f32 = 1; E.bias = embcat_.b;
         gemm(A, embcat_.w, Beff, embcat_.N, embcat_.K, E, s);
+        embout = eo;
+        emb_ld = embcat_.N;
+        ++n_launches;
     }
     CK(gates_launch(alpha_ptrs_, fuser_scale_, gates_, 2 * (int)st_.size(), s));
-    n_launches += 2;
+    ++n_launches;
 
     struct Act { bf16* p; int C, H, W; };
     std::vector<Act> hs;
@@ -1873,7 +1910,7 @@ void Engine::unet_forward(int Beff, int h, int w, const float* x, int xB, const 
             }
             case L_RES: {
                 const ResW& r = res_[L.idx];
-                cur.p = resblock(r, in, Beff, cur.H, cur.W, embout, embcat_.N, 1e-5f, s);
+                cur.p = resblock(r, in, Beff, cur.H, cur.W, embout, emb_ld, 1e-5f, s);
                 cur.C = r.Cout;
                 break;
             }
@@ -2159,10 +2196,15 @@ void Engine::sample_plms(const gl_plms_args& a, hipStream_t caller) {
         smp_.B = a.B; smp_.h = a.h; smp_.w = a.w; smp_.extra = a.inpaint_extra;
     }
 
+    // every evaluation of the run shares one timestep over its samples, and the schedule is known: the time-embedding MLP and the
+    // emb_layers GEMM of all steps in one batched pass; an evaluation copies its row (80 KB) instead of launching four tiny GEMM chains
+    static const bool emb_table_on = !(dev_env("GL_EMB_TABLE") && atoi(dev_env("GL_EMB_TABLE")) == 0);    // developer A/B: 0 = per-evaluation time MLP
+    if (emb_table_on) emb_table_build(a.timesteps, a.n_steps, s);
     int evals = 0;
-    auto eval = [&](const float* xin, int64_t t) {
+    auto eval = [&](const float* xin, int64_t t, int row) {
         HIPCK(hipMemcpyAsync(smp_.x2, xin, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-        CK(fill_i64_launch(smp_.t_dev, t, Beff, s));
+        if (emb_table_on) HIPCK(hipMemcpyAsync(emb_cur_, emb_table_ + (size_t)row * embcat_.N, (size_t)embcat_.N * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (!emb_table_on) CK(fill_i64_launch(smp_.t_dev, t, Beff, s));      // (with the table nothing on the device reads the timestep)
         while ((int)smp_.tev.size() < 2 * (evals + 1)) {
             hipEvent_t e;
             HIPCK(hipEventCreate(&e));
@@ -2176,7 +2218,7 @@ void Engine::sample_plms(const gl_plms_args& a, hipStream_t caller) {
             if (!smp_.exec[gi]) {
                 HIPCK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
                 try {
-                    unet_forward(Beff, a.h, a.w, smp_.x2, a.B, smp_.t_dev, a.inpaint_extra, a.B, smp_.eps_pair, s);
+                    unet_forward(Beff, a.h, a.w, smp_.x2, a.B, smp_.t_dev, a.inpaint_extra, a.B, smp_.eps_pair, s, emb_table_on ? emb_cur_ : nullptr);
                 } catch (...) {
                     hipGraph_t g = nullptr;
                     (void)hipStreamEndCapture(s, &g);
@@ -2190,7 +2232,7 @@ void Engine::sample_plms(const gl_plms_args& a, hipStream_t caller) {
         } else if (a.use_graph && smp_.exec[gi]) {
             HIPCK(hipGraphLaunch(smp_.exec[gi], s));
         } else {
-            unet_forward(Beff, a.h, a.w, smp_.x2, a.B, smp_.t_dev, a.inpaint_extra, a.B, smp_.eps_pair, s);
+            unet_forward(Beff, a.h, a.w, smp_.x2, a.B, smp_.t_dev, a.inpaint_extra, a.B, smp_.eps_pair, s, emb_table_on ? emb_cur_ : nullptr);
             smp_.warm[gi] = true;
         }
         HIPCK(hipEventRecord(smp_.tev[2 * evals + 1], s));
@@ -2222,7 +2264,7 @@ void Engine::sample_plms(const gl_plms_args& a, hipStream_t caller) {
         if (a.mask)
             CK(inpaint_blend_launch(a.x, a.x0, a.noise + (size_t)i * (n / a.B) * noiseB, a.mask, a.sqrt_ac[i], a.sqrt_1mac[i], a.B, Cl, a.h * a.w,
                                     x0B, noiseB, maskB, s));
-        eval(a.x, a.timesteps[i]);
+        eval(a.x, a.timesteps[i], i);
         PlmsParams P{};
         P.eps_pair = smp_.eps_pair; P.has_uncond = cfg ? 1 : 0; P.guidance = a.guidance_scale;
         P.a_t = a.a_t[i]; P.a_prev = a.a_prev[i]; P.n = n;
@@ -2235,7 +2277,7 @@ void Engine::sample_plms(const gl_plms_args& a, hipStream_t caller) {
             // pseudo improved Euler (plms.py:143-149): x_prev from e_t, evaluate at t_next, average
             P.e_t_out = slot; P.c0 = 1.f; P.x = a.x; P.x_out = smp_.x_tmp;
             CK(plms_update_launch(P, s));
-            eval(smp_.x_tmp, a.timesteps[std::min(1, a.n_steps - 1)]);
+            eval(smp_.x_tmp, a.timesteps[std::min(1, a.n_steps - 1)], std::min(1, a.n_steps - 1));
             P.e_t_out = smp_.hist[1]; P.c0 = 0.5f; P.o1 = slot; P.c1 = 0.5f; P.x = a.x; P.x_out = a.x;
             CK(plms_update_launch(P, s));
         } else {

@@ -458,7 +458,15 @@ def generate_stream(model, autoencoder, diffusion, batch, context, uc, noises, *
     model.engine, autoencoder.engine
     dev = context.device
     main = torch.cuda.current_stream(dev)
-    ctxs = [(model, autoencoder, main)] + [c[:3] for c in _lanes_of(model, autoencoder, lanes, dev)[:lanes - 1]]
+    # every lane -- the first too -- runs on a stream of its own that waits ONCE for what the caller's stream had produced when this
+    # call began (the inputs); a lane that waited on the caller's stream per batch would queue behind the other lane's whole batch
+    s0 = model.__dict__.get("_lane0_stream")
+    if s0 is None or s0.device != torch.device(dev):
+        s0 = model.__dict__["_lane0_stream"] = torch.cuda.Stream(device=dev)
+    ctxs = [(model, autoencoder, s0)] + [c[:3] for c in _lanes_of(model, autoencoder, lanes, dev)[:lanes - 1]]
+    start = main.record_event()
+    for c in ctxs:
+        c[2].wait_event(start)
     tokenizer = model.grounding_tokenizer_input
     outs = []
     try:
@@ -467,12 +475,11 @@ def generate_stream(model, autoencoder, diffusion, batch, context, uc, noises, *
             if m is not model:
                 m.grounding_tokenizer_input = copy.copy(tokenizer)
                 m.first_conv_type = model.first_conv_type
-                stream.wait_stream(main)
             with torch.cuda.stream(stream):
                 outs.append(generate(m, ae, diffusion, batch, context, uc, starting_noise=x_T, **kw))
     finally:
         model.grounding_tokenizer_input = tokenizer
-    for c in ctxs[1:]:
+    for c in ctxs:
         main.wait_stream(c[2])
     return outs
 

@@ -11,8 +11,8 @@ rm -rf gpurun_out/pmc_m1 gpurun_out/pmc_m2
 i=0
 for ctrs in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_WAVES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU"; do
   i=$((i+1))
-  ( cd /tmp && GL_GEMM_AUTOTUNE=0 timeout 700 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $R/gpurun_out/pmc_m$i -- \
-      python $R/bench.py --steps 1 --warmup 0 --lanes 1 --no-graph --plms-steps 2 --no-cpu-baseline ) > gpurun_out/pmc_m$i.log 2>&1
+  ( cd /tmp && GL_GEMM_AUTOTUNE=0 GL_FF_POLICY=1 timeout 700 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $R/gpurun_out/pmc_m$i -- \
+      python $R/bench.py --steps 1 --warmup 0 --lanes 1 --no-graph --plms-steps 2 --no-cpu-baseline --no-train-step --no-ff-ab ) > gpurun_out/pmc_m$i.log 2>&1
   tail -1 gpurun_out/pmc_m$i.log | cut -c1-200
 done
 python tools/pmc_summarize.py gpurun_out/pmc_mfma.csv gpurun_out/pmc_m1 gpurun_out/pmc_m2

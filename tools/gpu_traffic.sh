@@ -10,8 +10,8 @@ mkdir -p gpurun_out
 rm -rf gpurun_out/pmc_f gpurun_out/pmc_w
 for c in f:FETCH_SIZE w:WRITE_SIZE; do
   n=${c%%:*}; ctr=${c#*:}
-  ( cd /tmp && GL_GEMM_AUTOTUNE=0 GL_LAUNCH_LOG=$R/gpurun_out/launch_$n.log timeout 700 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$n -- \
-      python $R/bench.py --steps 1 --warmup 0 --lanes 1 --no-graph --plms-steps 2 --no-cpu-baseline ) > gpurun_out/pmc_$n.log 2>&1
+  ( cd /tmp && GL_GEMM_AUTOTUNE=0 GL_FF_POLICY=1 GL_LAUNCH_LOG=$R/gpurun_out/launch_$n.log timeout 700 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$n -- \
+      python $R/bench.py --steps 1 --warmup 0 --lanes 1 --no-graph --plms-steps 2 --no-cpu-baseline --no-train-step --no-ff-ab ) > gpurun_out/pmc_$n.log 2>&1
   tail -1 gpurun_out/pmc_$n.log | cut -c1-300
 done
 python tools/pmc_summarize.py gpurun_out/pmc_traffic.csv gpurun_out/pmc_f gpurun_out/pmc_w --launch-log gpurun_out/launch_f.log --per-problem gpurun_out/pmc_traffic_per_problem.csv
