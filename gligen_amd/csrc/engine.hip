@@ -1362,7 +1362,10 @@ bool Engine::ff_rows_for(const STW& t, int which, int B, int HW, hipStream_t s) 
     (void)hipStreamIsCapturing(s, &cap);
     if (cap != hipStreamCaptureStatusNone) return ff_policy::static_rule(M);
 
-    // ---- time both forms of this tail on scratch rows (zeros: no kernel on the path is data dependent), real weights
+    // ---- time both forms of this tail on scratch rows (zeros: no kernel on the path is data dependent), real weights. The device is
+    // drained first: another lane's batch in flight on its own stream (gligen_inference.generate_stream starts lanes back to back) would
+    // otherwise share the chip with the timed launches and decide the table
+    HIPCK(hipDeviceSynchronize());
     const size_t mk = arena_.mark();
     const int64_t launches0 = n_launches;
     const bool prof0 = profiling_;

@@ -2746,6 +2746,7 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
 
     // timing events live on the device that is current for this call (the context's device), for this tuning pass only;
     // the lock is held across the pass: two threads tuning at once would time each other's launches
+    GL_HIP(hipDeviceSynchronize());     // a quiet chip: work another execution context has in flight on its own stream must not share the timed launches
     hipEvent_t g_tune_ev[2];
     GL_HIP(hipEventCreate(&g_tune_ev[0]));
     GL_HIP(hipEventCreate(&g_tune_ev[1]));

@@ -448,13 +448,14 @@ def generate_lanes(model, autoencoder, diffusion, batch, context, uc, *, lanes=2
 
 
 @torch.no_grad()
-def generate_stream(model, autoencoder, diffusion, batch, context, uc, noises, *, lanes=2, **kw):
+def generate_stream(model, autoencoder, diffusion, batch, context, uc, noises, *, lanes=2, first_lane=0, **kw):
     """Several WHOLE batches of the same prompt (one starting noise each), issued round-robin to `lanes` execution contexts -- what
     bench.py times: while one batch's evaluation is in its kernel tails and memory-bound kernels, the other's matrix work fills the
     chip. Each batch keeps the benchmark's shape (the tile table, the captured graph and the timed row-local / two-GEMM choice are
-    per shape), unlike generate_lanes, which splits ONE batch into halves. Returns the list of decoded batches in issue order."""
+    per shape), unlike generate_lanes, which splits ONE batch into halves. Returns the list of decoded batches in issue order.
+    Batch i goes to lane (first_lane + i) % lanes."""
     import copy
-    lanes = max(1, min(int(lanes), len(noises)))
+    lanes = max(1, int(lanes))
     model.engine, autoencoder.engine
     dev = context.device
     main = torch.cuda.current_stream(dev)
@@ -471,7 +472,7 @@ def generate_stream(model, autoencoder, diffusion, batch, context, uc, noises, *
     outs = []
     try:
         for i, x_T in enumerate(noises):
-            m, ae, stream = ctxs[i % lanes]
+            m, ae, stream = ctxs[(first_lane + i) % lanes]
             if m is not model:
                 m.grounding_tokenizer_input = copy.copy(tokenizer)
                 m.first_conv_type = model.first_conv_type
@@ -584,8 +585,11 @@ def run(meta, config, starting_noise=None, models=None):
             if r == 0 and starting_noise is not None:
                 return starting_noise
             return torch.randn((B,) + shape[1:], generator=torch.Generator().manual_seed(seed0 + r))[lo:hi].to(device)
-        for _ in range(max(0, int(args.get("warmup") or 0))):
-            generate_stream(model, autoencoder, diffusion, batch, context, uc, [noise(0)] * n_lanes_req, lanes=n_lanes_req, **gkw)
+        n_lanes_req = min(n_lanes_req, repeat)
+        for _ in range(max(0, int(args.get("warmup") or 0))):      # one lane at a time: tile tuning and the timed kernel choices want the chip to themselves
+            for ln in range(n_lanes_req):
+                generate_stream(model, autoencoder, diffusion, batch, context, uc, [noise(0)], lanes=n_lanes_req, first_lane=ln, **gkw)
+                torch.cuda.synchronize()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         outs = generate_stream(model, autoencoder, diffusion, batch, context, uc, [noise(r) for r in range(repeat)], lanes=n_lanes_req, **gkw)
