@@ -372,7 +372,9 @@ class Engine {
         // one captured [cond ; uncond] evaluation per fuser state: [0] fusers on, [1] fusers skipped (gate scale 0)
         hipGraph_t graph[2] = {nullptr, nullptr};
         hipGraphExec_t exec[2] = {nullptr, nullptr};
-        hipStream_t stream = nullptr;  // engine-owned capture/replay stream
+        hipStream_t stream = nullptr;  // engine-owned capture/replay stream (used when the caller hands the legacy default stream)
+        hipStream_t run_stream = nullptr;   // the stream the last sampling run was issued on
+        bool ran = false;
         hipEvent_t ev_in = nullptr, ev_out = nullptr;
         std::vector<hipEvent_t> tev;  // (start, stop) per UNet evaluation of the last run
         int n_evals = 0;

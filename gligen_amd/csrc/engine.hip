@@ -1690,7 +1690,7 @@ void Engine::set_cond(int Beff, const float* context, int n_ctx, const gl_ground
         cond_.obj_Tpad = obj_Tpad;
     }
     if (cond_.ctx_T != n_ctx && (smp_.exec[0] || smp_.exec[1])) {  // captured cross-attention launches bake Nk = ctx_T
-        HIPCK(hipStreamSynchronize(smp_.stream));
+        if (smp_.ran) HIPCK(hipStreamSynchronize(smp_.run_stream));
         sampler_release_graph();
     }
     cond_.ctx_T = n_ctx;
@@ -2136,8 +2136,8 @@ void Engine::vae_encode(int B, int H, int W, const float* img, const float* nois
 // ---------------------------------------------------------------- PLMS sampler (plms.py:65-162)
 // HIP-event time of the UNet evaluations of the last sample_plms call (on the engine's stream).
 void Engine::sampler_timing(float* avg_ms, float* first_ms, int* n) {
-    if (!smp_.stream || smp_.n_evals == 0) throw GlError(GL_ERR_STATE, "no sampling run to report");
-    HIPCK(hipStreamSynchronize(smp_.stream));
+    if (!smp_.ran || smp_.n_evals == 0) throw GlError(GL_ERR_STATE, "no sampling run to report");
+    HIPCK(hipStreamSynchronize(smp_.run_stream));
     double sum = 0;
     int cnt = 0;
     float first = 0.f;
@@ -2164,16 +2164,25 @@ void Engine::sampler_release_graph() {
 
 void Engine::sample_plms(const gl_plms_args& a, hipStream_t caller) {
     if (!has_unet_ || !finalized_) throw GlError(GL_ERR_STATE, "unet not finalized");
-    // The loop runs on an engine-owned non-blocking stream (the legacy default stream cannot be
-    // captured into a hipGraph), ordered after / before the caller's stream with events.
-    if (!smp_.stream) {
+    // The loop runs on the CALLER's stream -- one stream per execution context: with a second, engine-owned stream per context the
+    // lanes of a process are four streams on the chip's few hardware queues, and which lanes overlap depends on the order the streams
+    // were first used (gligen_inference.py --repeat got none, bench.py 13 %, same library; tools/dbg_cli2.py). Only the legacy default
+    // stream, which cannot be captured into a hipGraph, is replaced by an engine-owned non-blocking stream ordered after / before it
+    // with events. GL_SAMPLER_OWN_STREAM=1 (developer A/B): always the engine-owned stream, the round 1-4 behaviour.
+    static const bool own_env = dev_env("GL_SAMPLER_OWN_STREAM") && atoi(dev_env("GL_SAMPLER_OWN_STREAM")) != 0;
+    const bool own = own_env || caller == nullptr;
+    if (own && !smp_.stream) {
         HIPCK(hipStreamCreateWithFlags(&smp_.stream, hipStreamNonBlocking));
         HIPCK(hipEventCreateWithFlags(&smp_.ev_in, hipEventDisableTiming));
         HIPCK(hipEventCreateWithFlags(&smp_.ev_out, hipEventDisableTiming));
     }
-    hipStream_t s = smp_.stream;
-    HIPCK(hipEventRecord(smp_.ev_in, caller));
-    HIPCK(hipStreamWaitEvent(s, smp_.ev_in, 0));
+    hipStream_t s = own ? smp_.stream : caller;
+    if (own) {
+        HIPCK(hipEventRecord(smp_.ev_in, caller));
+        HIPCK(hipStreamWaitEvent(s, smp_.ev_in, 0));
+    }
+    smp_.run_stream = s;
+    smp_.ran = true;
     const gl_unet_config& c = ucfg_;
     if (a.n_steps < 1 || !a.timesteps || !a.a_t || !a.a_prev || !a.x) throw GlError(GL_ERR_ARG, "sample_plms: missing schedule or latent");
     if (a.mask && (!a.x0 || !a.noise || !a.sqrt_ac || !a.sqrt_1mac)) throw GlError(GL_ERR_ARG, "sample_plms: mask needs x0, noise and q_sample coefficients");
@@ -2295,8 +2304,10 @@ void Engine::sample_plms(const gl_plms_args& a, hipStream_t caller) {
             CK(plms_update_launch(P, s));
         }
     }
-    HIPCK(hipEventRecord(smp_.ev_out, s));
-    HIPCK(hipStreamWaitEvent(caller, smp_.ev_out, 0));
+    if (own) {
+        HIPCK(hipEventRecord(smp_.ev_out, s));
+        HIPCK(hipStreamWaitEvent(caller, smp_.ev_out, 0));
+    }
 }
 
 }  // namespace gl
