@@ -53,8 +53,8 @@ def unet(B=8, hw=64, Ng=30, mc=320, mult=(1, 2, 4, 4), nres=2, attn_res=(4, 2, 1
         r.add("gemm", B * Tp, 3 * C, C, 4)        # attn1 q, k, v^T (one EPI_QKV_HEADS launch)
         r.add("attn", B, heads, d, HW, HW)
         r.add("gemm", M, C, C, 0)                 # attn1 out + res
-        r.add("ln", B, HW, Ng, Tf, C)
-        r.add("gemm", B * Tf, 3 * C, C, 4)        # fuser q, k, v^T
+        # (round 5: the grounding tokens' K / V are projected once per prompt -- no [x ; objs] LayerNorm pass, HW rows per sample)
+        r.add("gemm", B * HW, 3 * C, C, 4)        # fuser q, k, v^T of the visual rows
         r.add("attn", B, heads, d, HW, HW + Ng)
         r.add("gemm", M, C, C, 0)
         r.add("ln", B, HW, 0, HW, C)
