@@ -77,7 +77,11 @@ class TrainStep:
     bucket's reduce-scatter + all-gather and its AdamW update go to a communication stream that waits only for that bucket's
     milestone (gl_train_wait_grads), so bucket 0 is on the wire while the encoder blocks are still in backward; the compute stream
     joins the communication stream at the end of the step. overlap=False: backward, then every collective, then every update, on
-    one stream (the round-4 schedule) -- the same numbers bit for bit (same kernels per bucket, same order inside a bucket)."""
+    one stream (the round-4 schedule) -- the same numbers bit for bit (same kernels per bucket, same order inside a bucket).
+
+    Arena: the engine's context must hold one block's recompute working set plus the saved block inputs -- 24 GB covers the shipped
+    topology at batch 4 x 64 x 64 with checkpoint=True (bench.py / tools/train_bench.py create Engine(arena_gb=24)); the library
+    raises 'arena exhausted' (GL_ERR_RUNTIME) rather than spilling when it does not."""
 
     def __init__(self, engine, cfg: Mapping, state_dict: Mapping[str, torch.Tensor], lr: Union[float, Callable[[int], float]] = 5e-5,
                  weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8, bucket_mb: float = 128.0, world: Optional[int] = None,
