@@ -58,6 +58,16 @@ def sum_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
+def broadcast_int(value: int, src: int = 0, device=None) -> int:
+    """`value` of rank `src` on every rank (one run-wide random seed when the caller gave none: the ranks must slice ONE draw)."""
+    if not dist.is_initialized():
+        return int(value)
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    dist.broadcast(t, src=src)
+    return int(t.item())
+
+
 def shutdown() -> None:
     """Tear the process group down (after a final barrier) so that ranks leave together and RCCL exits quietly."""
     if dist.is_initialized():

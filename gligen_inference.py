@@ -485,10 +485,12 @@ def generate_stream(model, autoencoder, diffusion, batch, context, uc, noises, *
     return outs
 
 
-def save_images(samples, output_folder, first_id=None):
+def save_images(samples, output_folder, first_id=None, ids=None):
     os.makedirs(output_folder, exist_ok=True)
-    start = len(os.listdir(output_folder)) if first_id is None else first_id
-    ids = list(range(start, start + samples.shape[0]))
+    if ids is None:
+        start = len(os.listdir(output_folder)) if first_id is None else first_id
+        ids = list(range(start, start + samples.shape[0]))
+    assert len(ids) == samples.shape[0]
     print(ids)
     for image_id, sample in zip(ids, samples):
         sample = torch.clamp(sample, min=-1, max=1) * 0.5 + 0.5
@@ -535,6 +537,12 @@ def run(meta, config, starting_noise=None, models=None):
     else:
         context = text_encoder.encode([meta["prompt"]] * (hi - lo))
         uc = text_encoder.encode((hi - lo) * [args.get("negative_prompt") or ""])
+    if world > 1 and args.get("seed") is None:
+        # no --seed on a sharded run: the reference draws a fresh x_T per invocation, and the ranks must still slice ONE draw --
+        # rank 0 picks this run's seed and every rank takes it (without a process group: the old fixed seed 0)
+        import torch.distributed as tdist
+        if tdist.is_initialized():
+            args["seed"] = gdist.broadcast_int(int(torch.seed() % (1 << 31)))
     if world > 1 or args.get("seed") is not None:
         # one seeded draw for the whole batch, sliced: an N-GPU run reproduces the 1-GPU images. The device generator is
         # seeded too, identically on every rank: the inpainting loop's per-step q_sample noise (randn_like(z0), batch 1 for
@@ -581,9 +589,13 @@ def run(meta, config, starting_noise=None, models=None):
                    grounding_extra_input=grounding_extra_input, grounding_input=grounding_input)
         shape = (hi - lo, model.in_channels, model.image_size, model.image_size)
         seed0 = int(args.get("seed") or 0)
+        seeded = world > 1 or args.get("seed") is not None
         def noise(r):
             if r == 0 and starting_noise is not None:
                 return starting_noise
+            if not seeded:      # no --seed on one GPU: fresh x_T per batch, as the reference's sampler draws it (plms.py:71)
+                return torch.randn(shape, device=device)
+            # seeded (or sharded: every rank must slice the SAME global draw): batch r of the run is seed + r
             return torch.randn((B,) + shape[1:], generator=torch.Generator().manual_seed(seed0 + r))[lo:hi].to(device)
         n_lanes_req = min(n_lanes_req, repeat)
         for _ in range(max(0, int(args.get("warmup") or 0))):      # one lane at a time: tile tuning and the timed kernel choices want the chip to themselves
@@ -615,7 +627,10 @@ def run(meta, config, starting_noise=None, models=None):
         gdist.barrier()
         start = len(os.listdir(folder))     # every rank counts before any rank writes
         gdist.barrier()
-        save_images(samples, folder, first_id=start + lo)
+        # image id = position in the GLOBAL run: batch r of `--repeat` occupies [start + r B, start + (r + 1) B), this rank's slice of it
+        # [lo, hi) -- ranks never overlap, and the numbering is that of a 1-GPU run of the same command
+        n_rounds = samples.shape[0] // (hi - lo)
+        save_images(samples, folder, ids=[start + r * B + lo + i for r in range(n_rounds) for i in range(hi - lo)])
     else:
         save_images(samples, folder)
     return samples

@@ -25,20 +25,12 @@ class FourierEmbedder:
 
 
 def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
-    """fp64 beta schedules (reference util.py:30-52)."""
-    if schedule == "linear":
-        betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2
-    elif schedule == "cosine":
-        t = torch.arange(n_timestep + 1, dtype=torch.float64) / n_timestep + cosine_s
-        a = torch.cos(t / (1 + cosine_s) * np.pi / 2).pow(2)
-        a = a / a[0]
-        betas = torch.from_numpy(np.clip((1 - a[1:] / a[:-1]).numpy(), a_min=0, a_max=0.999))
-    elif schedule == "sqrt_linear":
-        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64)
-    elif schedule == "sqrt":
-        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64) ** 0.5
-    else:
-        raise ValueError(f"schedule '{schedule}' unknown.")
+    """The fp64 "linear" beta schedule (reference util.py:30-34) -- the only one a shipped GLIGEN / SD-1.4 config selects
+    (configs/*.yaml: beta_schedule is never set, ddpm.py:11 defaults to "linear"). `cosine_s` stays in the signature for callers
+    that pass it through; another schedule name is an error here rather than an untested branch."""
+    if schedule != "linear":
+        raise ValueError(f"schedule '{schedule}' is not built: every shipped config uses 'linear' (reference util.py:30-52)")
+    betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2
     return betas.numpy()
 
 

@@ -360,18 +360,20 @@ def plms_spatial_case(name, modality, S=5, hw=16, res=128, alpha_type=(0.6, 0.0,
     print(f"{name}: x_out std {out.std():.4f} first conv now {model.first_conv_type} [{time.time() - t0:.1f}s]")
 
 
-def c2_case(name="c2_end_to_end", S=50, hw=64):
+def c2_case(name="c2_end_to_end", S=50, hw=64, kind="text"):
     """BASELINE config C2 for ONE image at its real size: box+text, 8 boxes, 512x512, 50 PLMS steps (102 UNet forwards), CFG
     7.5, gate on at every step (alpha_type None = [1, 0, 0], the schedule the metric is quoted on), B = 1, fp32 on the CPU
     through the reference's PLMSSampler + UNetModel + AutoencoderKL.decode (gligen_inference.py:389-446). The latent after
-    10 and 25 steps is recorded too (p_sample_plms hooked), so a divergence can be located."""
+    10 and 25 steps is recorded too (p_sample_plms hooked), so a divergence can be located.
+    kind = "text_image" / "keypoint" (round 6): the same run for BASELINE C3 (CLIP image tokens next to the phrase tokens, Ng = 60)
+    and C5 (17 COCO keypoints per person -> Fourier tokens, Ng = 136) -- same seeds, the tokenizer and its batch are what change."""
     t0 = time.time()
     from functools import partial
     diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000)
-    model = build_unet(syn.UNET_CFG, "text")
+    model = build_unet(syn.UNET_CFG, kind)
     ae = AutoencoderKL(ddconfig=syn.VAE_DDCONFIG, embed_dim=4, scale_factor=0.18215).eval()
     syn.fill_module_(ae, 4321)
-    batch = syn.make_batch("text", 1, n_valid=8, seed=1)
+    batch = syn.make_batch(kind, 1, n_valid=8, seed=1)
     g = model.grounding_tokenizer_input.prepare(batch)
     x = syn.make_latent(1, 4, hw, hw, seed=6)
     ctx, uc = syn.make_context(1, seed=1), syn.make_context(1, seed=9)
@@ -394,7 +396,7 @@ def c2_case(name="c2_end_to_end", S=50, hw=64):
         t_s = time.time() - t0
         img = ae.decode(z)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), z=z.numpy(), img=img.numpy().astype(np.float16), **trace,
-                        meta=json.dumps(dict(S=S, hw=hw, alpha_type=None, guidance_scale=7.5, B=1, n_valid=8, img_stored="float16",
+                        meta=json.dumps(dict(S=S, hw=hw, alpha_type=None, guidance_scale=7.5, B=1, n_valid=8, img_stored="float16", kind=kind,
                                              ref_cpu_seconds=round(time.time() - t0, 1), ref_sampler_seconds=round(t_s, 1),
                                              cpu_threads=torch.get_num_threads())))
     print(f"{name}: z std {z.std():.4f} img std {img.std():.4f} [{time.time() - t0:.1f}s]")
@@ -787,6 +789,9 @@ CASES = {
     "unet_full_64_keypoint_b4": lambda: unet_pair_case("unet_full_64_keypoint_b4", "keypoint", 4, 64),
     "c2_end_to_end": c2_case,
     "c4_end_to_end": c4_case,
+    # ---- round 6: C3 / C5 end to end (the other two tokenizers through the whole 50-step run + decode)
+    "c3_end_to_end": lambda: c2_case("c3_end_to_end", kind="text_image"),
+    "c5_end_to_end": lambda: c2_case("c5_end_to_end", kind="keypoint"),
     # ---- round 4: the training slice (gradients through one transformer block, from the reference's autograd)
     "block_backward_gatedsa": block_backward_case,
     "st_backward_gatedsa": st_backward_case,

@@ -418,6 +418,57 @@ def test_sharded_run_slices_one_seeded_batch(monkeypatch):
     assert torch.equal(torch.cat([p[1] for p in parts]), full[1]) and torch.equal(torch.cat([p[2] for p in parts]), full[2])
 
 
+def test_repeat_under_two_ranks_numbers_images_without_overlap(monkeypatch, tmp_path):
+    """--repeat N under WORLD_SIZE 2: rank r writes, for every repeat round, its slice [lo, hi) of that round's global
+    batch -- ids start + round * B + lo + i -- so the two ranks' files never collide and the numbering equals a 1-GPU run's; batch r of
+    the run is seeded seed + r on every rank (the ranks slice one global draw); without --seed on one GPU the batches are fresh draws."""
+    import gligen_inference as gi
+    from gligen_amd.dist import shard_range
+    import gligen_amd.dist as gdist
+    seen = []
+
+    def fake_stream(model, autoencoder, diffusion, batch, context, uc, noises, **kw):
+        seen.append([n.clone() for n in noises])
+        return [torch.zeros(n.shape[0], 3, 8, 8) for n in noises]
+
+    class M:
+        in_channels, image_size = 4, 8
+    saved = []
+    monkeypatch.setattr(gi, "generate_stream", fake_stream)
+    monkeypatch.setattr(gi, "device", "cpu")
+    monkeypatch.setattr(gi, "save_images", lambda samples, folder, first_id=None, ids=None: saved.append((samples.shape[0], first_id, ids)))
+    monkeypatch.setattr(gdist, "barrier", lambda: None)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    B, R = 5, 3
+    meta = dict(ckpt="synthetic_text", prompt="p", save_folder_name="x", locations=[[0.1, 0.1, 0.5, 0.5]], text_embeddings=[torch.ones(768)],
+                context=syn.make_context(B, seed=0), uc=syn.make_context(B, seed=1))
+    cfg = dict(grounding_tokenizer_input=dict(target=GINPUT["text"]))
+    args = dict(batch_size=B, guidance_scale=7.5, negative_prompt=None, no_plms=False, folder=str(tmp_path), seed=11, repeat=R)
+    all_ids, noise_by_rank = [], []
+    for rank in range(2):
+        monkeypatch.setenv("WORLD_SIZE", "2")
+        monkeypatch.setenv("RANK", str(rank))
+        gi.run(meta, dict(args), models=(M(), None, None, None, cfg))
+        lo, hi = shard_range(B, rank, 2)
+        n, first_id, ids = saved.pop()
+        assert n == R * (hi - lo) and first_id is None
+        assert ids == [r * B + lo + i for r in range(R) for i in range(hi - lo)]
+        all_ids += ids
+        noise_by_rank.append(seen.pop())
+    assert sorted(all_ids) == list(range(R * B))                       # every id of a 1-GPU run exactly once
+    for r in range(R):                                                   # the ranks' slices of round r are one global draw, seed + r
+        full = torch.randn((B, 4, 8, 8), generator=torch.Generator().manual_seed(11 + r))
+        assert torch.equal(torch.cat([noise_by_rank[0][r], noise_by_rank[1][r]]), full)
+    # one GPU, no --seed: nothing pins the draws (two invocations differ)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    a = dict(args, seed=None)
+    gi.run(meta, dict(a), models=(M(), None, None, None, cfg))
+    gi.run(meta, dict(a), models=(M(), None, None, None, cfg))
+    second, first = seen.pop(), seen.pop()
+    assert not torch.equal(first[1], second[1]) and not torch.equal(first[0], first[1])
+
+
 def test_lib_load_imports_torch_first():
     """The HIP library must be loaded after torch (two HIP runtimes in one process otherwise: gl_context_create then finds no device
     while torch sees the GPU). _lib.load() pins the order itself; in a fresh interpreter torch must be in sys.modules before the
