@@ -1,6 +1,8 @@
 // gligen_amd engine: owns packed weights + workspace for one device and runs the GLIGEN
 // denoising path (UNet forward, CFG + PLMS loop, VAE decode) as sequences of HIP kernels.
 #pragma once
+#include <array>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -331,7 +333,8 @@ class Engine {
         std::vector<void*> allocs;
     } cond_;
 
-    std::unordered_map<uint64_t, AttnBufs> attn_bufs_;
+    typedef std::array<int, 7> AttnKey;            // B, H, d, Tq_pad, Tk_pad, dpv, slot
+    std::map<AttnKey, AttnBufs> attn_bufs_;
     std::vector<hipEvent_t> train_events_;
 
     // ---- VAE decoder
@@ -376,6 +379,7 @@ class Engine {
         hipStream_t run_stream = nullptr;   // the stream the last sampling run was issued on
         bool ran = false;
         hipEvent_t ev_in = nullptr, ev_out = nullptr;
+        hipEvent_t ev_done = nullptr;       // engine-owned: recorded behind the last launch of every sampling run (what later calls wait for)
         std::vector<hipEvent_t> tev;  // (start, stop) per UNet evaluation of the last run
         int n_evals = 0;
         bool has_extra = false;
@@ -384,6 +388,7 @@ class Engine {
         unsigned policy_epoch = 0;       // ff_policy epoch the graphs were captured under
     } smp_;
     void sampler_release_graph();
+    void sampler_wait_idle();
     // time_embed + every ResBlock's emb_layers (openaimodel.py:436-437, 220-221) depend on the timestep alone, and a sampling run knows
     // its timesteps: one batched pass over the whole schedule at the start of gl_sample_plms instead of 4 tiny GEMM chains per evaluation
     void emb_table_build(const int64_t* t_host, int R, hipStream_t s);

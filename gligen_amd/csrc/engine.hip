@@ -140,6 +140,7 @@ Engine::~Engine() {
     for (hipEvent_t e : smp_.tev) (void)hipEventDestroy(e);
     if (smp_.ev_in) (void)hipEventDestroy(smp_.ev_in);
     if (smp_.ev_out) (void)hipEventDestroy(smp_.ev_out);
+    if (smp_.ev_done) (void)hipEventDestroy(smp_.ev_done);
     if (smp_.stream) (void)hipStreamDestroy(smp_.stream);
     for (hipEvent_t e : train_events_)
         if (e) (void)hipEventDestroy(e);
@@ -1122,8 +1123,7 @@ AttnBufs& Engine::attn_bufs(int B, int H, int d, int Tq, int Tk, int dpv_layout,
     int dp, dpv;
     CK(attn_dims(d, &dp, &dpv));
     if (dpv_layout) dpv = dpv_layout;      // (attn_vt_layout: the 16x16x32 P V kernel reads a 48-row V^T at d = 40)
-    const uint64_t key = (((uint64_t)B << 52) ^ ((uint64_t)H << 44) ^ ((uint64_t)d << 34) ^ ((uint64_t)Tq_pad << 17) ^ (uint64_t)Tk_pad ^ ((uint64_t)dpv << 58)) +
-                         (uint64_t)slot * 0x9E3779B97F4A7C15ull;
+    const AttnKey key{{B, H, d, Tq_pad, Tk_pad, dpv, slot}};    // every field in full (XOR-ed shifted fields let dpv = 64 vanish and 96 / 160 collide)
     auto it = attn_bufs_.find(key);
     if (it != attn_bufs_.end()) return it->second;
     AttnBufs b;
@@ -1276,7 +1276,7 @@ static bool static_rule(int M) { return M / 128 >= 224; }
 }  // namespace ff_policy
 
 int ff_rows_policy_set(int mode) {
-    if (mode < -1 || mode > 1) return set_error(GL_ERR_ARG, "ff_rows policy %d (expected -1 timed, 0 off, 1 wherever supported)", mode);
+    if (mode < -1 || mode > 2) return set_error(GL_ERR_ARG, "ff_rows policy %d (expected -1 timed, 0 off, 1 wherever supported, 2 static rule)", mode);
     if (ff_policy::mode.exchange(mode) != mode) ff_policy::epoch.fetch_add(1);
     return GL_OK;
 }
@@ -1353,6 +1353,7 @@ bool Engine::ff_rows_for(const STW& t, int which, int B, int HW, hipStream_t s) 
     const int mode = ff_policy::mode.load();
     if (mode == 0) return false;
     if (mode == 1) return true;
+    if (mode == 2) return ff_policy::static_rule(M);     // deterministic: the same kernel form -- hence the same output bits -- on every box, rank and run
     const int form = f.chain_stream ? (f.chain_post ? 2 : 1) : 0;
     const uint64_t key = ff_policy::key(device_, which, form, C, M);
     std::unique_lock<std::mutex> lk(ff_policy::mu);   // held across the timing pass: two contexts timing at once would time each other
@@ -1360,15 +1361,23 @@ bool Engine::ff_rows_for(const STW& t, int which, int B, int HW, hipStream_t s) 
     if (it != ff_policy::table.end()) return it->second.rows != 0;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap);
-    if (cap != hipStreamCaptureStatusNone) return ff_policy::static_rule(M);
+    if (cap != hipStreamCaptureStatusNone) {
+        // a shape first met inside a capture cannot be timed: the static rule decides, and the decision is KEPT -- a later eager pass
+        // must take the form the captured graph replays (the two forms differ in their last bits)
+        const bool rows = ff_policy::static_rule(M);
+        ff_policy::table[key] = ff_policy::Entry{rows ? 1 : 0, 0.f, 0.f};
+        return rows;
+    }
 
     // ---- time both forms of this tail on scratch rows (zeros: no kernel on the path is data dependent), real weights. The device is
     // drained first: another lane's batch in flight on its own stream (gligen_inference.generate_stream starts lanes back to back) would
     // otherwise share the chip with the timed launches and decide the table
     HIPCK(hipDeviceSynchronize());
-    const size_t mk = arena_.mark();
-    const int64_t launches0 = n_launches;
-    const bool prof0 = profiling_;
+    // whatever the timed launches throw, the context is left as it was found: arena mark, launch counter, profiling switch
+    struct Restore {
+        Engine* e; size_t mk; int64_t launches; bool prof;
+        ~Restore() { e->arena_.release(mk); e->n_launches = launches; e->profiling_ = prof; }
+    } restore{this, arena_.mark(), n_launches, profiling_};
     profiling_ = false;
     bf16* zo = arena_.get<bf16>((size_t)M * C);
     bf16* zr = arena_.get<bf16>((size_t)M * C);
@@ -1401,9 +1410,6 @@ bool Engine::ff_rows_for(const STW& t, int which, int B, int HW, hipStream_t s) 
             HIPCK(hipEventElapsedTime(&ms, ev[0], ev[1]));
             best[form_i] = std::min(best[form_i], ms * 1e3f / REPS);
         }
-    arena_.release(mk);
-    n_launches = launches0;
-    profiling_ = prof0;
     const ff_policy::Entry e{best[1] < best[0] ? 1 : 0, best[1], best[0]};
     ff_policy::table[key] = e;
     static const bool log = dev_env("GL_FF_POLICY_LOG") != nullptr;
@@ -1654,6 +1660,9 @@ void Engine::set_cond(int Beff, const float* context, int n_ctx, const gl_ground
     const int obj_Tpad = round_up(Ng, 64);
     const int obj_stride = ca ? obj_Tpad : Ng;   // rows per sample of the grounding-token matrix (gatedCA pads to the key tile)
     if (cond_.Beff != Beff || cond_.Ng != Ng || cond_.ctx_Tpad != ctx_Tpad) {
+        // captured graphs bake Nk (= HW + Ng), the conditioning buffers and the batch: a last run -- on whatever stream it was issued --
+        // is over before they and the buffers go
+        sampler_wait_idle();
         HIPCK(hipStreamSynchronize(s));
         sampler_release_graph();
         for (void* p : cond_.allocs) (void)hipFree(p);
@@ -1690,7 +1699,7 @@ void Engine::set_cond(int Beff, const float* context, int n_ctx, const gl_ground
         cond_.obj_Tpad = obj_Tpad;
     }
     if (cond_.ctx_T != n_ctx && (smp_.exec[0] || smp_.exec[1])) {  // captured cross-attention launches bake Nk = ctx_T
-        if (smp_.ran) HIPCK(hipStreamSynchronize(smp_.run_stream));
+        sampler_wait_idle();
         sampler_release_graph();
     }
     cond_.ctx_T = n_ctx;
@@ -2137,7 +2146,7 @@ void Engine::vae_encode(int B, int H, int W, const float* img, const float* nois
 // HIP-event time of the UNet evaluations of the last sample_plms call (on the engine's stream).
 void Engine::sampler_timing(float* avg_ms, float* first_ms, int* n) {
     if (!smp_.ran || smp_.n_evals == 0) throw GlError(GL_ERR_STATE, "no sampling run to report");
-    HIPCK(hipStreamSynchronize(smp_.run_stream));
+    sampler_wait_idle();
     double sum = 0;
     int cnt = 0;
     float first = 0.f;
@@ -2150,6 +2159,12 @@ void Engine::sampler_timing(float* avg_ms, float* first_ms, int* n) {
     *avg_ms = cnt ? (float)(sum / cnt) : 0.f;
     *first_ms = first;
     *n = smp_.n_evals;
+}
+
+// The last sampling run has finished. The engine keeps no caller stream handle across calls (a C-API user may have destroyed the
+// stream since): every run ends in an engine-owned event, and that is what later calls wait for.
+void Engine::sampler_wait_idle() {
+    if (smp_.ran && smp_.ev_done) HIPCK(hipEventSynchronize(smp_.ev_done));
 }
 
 void Engine::sampler_release_graph() {
@@ -2181,8 +2196,14 @@ void Engine::sample_plms(const gl_plms_args& a, hipStream_t caller) {
         HIPCK(hipEventRecord(smp_.ev_in, caller));
         HIPCK(hipStreamWaitEvent(s, smp_.ev_in, 0));
     }
-    smp_.run_stream = s;
-    smp_.ran = true;
+    if (!smp_.ev_done) HIPCK(hipEventCreateWithFlags(&smp_.ev_done, hipEventDisableTiming));
+    // the sampler's buffers (x2, eps_pair, the eps history, the time-embedding row) are per context, not per stream: a run on another
+    // caller stream than the last one is ordered behind that run's end
+    if (smp_.ran && smp_.run_stream != s) HIPCK(hipStreamWaitEvent(s, smp_.ev_done, 0));
+    struct DoneGuard {       // the run's end -- also when it ends in an exception: whatever was issued is what later calls wait for
+        Engine* e; hipStream_t s;
+        ~DoneGuard() { (void)hipEventRecord(e->smp_.ev_done, s); e->smp_.run_stream = s; e->smp_.ran = true; }
+    } done_guard{this, s};
     const gl_unet_config& c = ucfg_;
     if (a.n_steps < 1 || !a.timesteps || !a.a_t || !a.a_prev || !a.x) throw GlError(GL_ERR_ARG, "sample_plms: missing schedule or latent");
     if (a.mask && (!a.x0 || !a.noise || !a.sqrt_ac || !a.sqrt_1mac)) throw GlError(GL_ERR_ARG, "sample_plms: mask needs x0, noise and q_sample coefficients");
@@ -2195,6 +2216,7 @@ void Engine::sample_plms(const gl_plms_args& a, hipStream_t caller) {
     const int Cl = c.in_channels;
     const int64_t n = (int64_t)a.B * Cl * a.h * a.w;
     if (smp_.B != a.B || smp_.h != a.h || smp_.w != a.w || smp_.extra != a.inpaint_extra || smp_.policy_epoch != ff_policy::epoch.load()) {
+        sampler_wait_idle();               // a graph exec still in flight on the PREVIOUS run's stream must not be destroyed
         HIPCK(hipStreamSynchronize(s));
         sampler_release_graph();
         smp_.policy_epoch = ff_policy::epoch.load();

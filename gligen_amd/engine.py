@@ -354,7 +354,8 @@ class Engine:
 
     def set_ff_rows_policy(self, mode: int) -> None:
         """Row-local feed-forward kernel or two GEMMs at C = 320 (gl_set_ff_rows_policy): -1 = decided by on-device timing (default),
-        0 = never, 1 = wherever the kernel exists. Process-wide."""
+        0 = never, 1 = wherever the kernel exists, 2 = static rule (deterministic kernel choice: the same output bits on every box,
+        rank and run -- the timed default may pick the other form, which differs in the last bits). Process-wide."""
         check(self.lib.gl_set_ff_rows_policy(int(mode)))
 
     def ff_rows_policy_report(self) -> str:

@@ -50,18 +50,26 @@ def trainable_names(state_dict: Mapping[str, torch.Tensor]):
     return [k for k in state_dict if ".fuser." in k or k.startswith("position_net.")]
 
 
+def _block_order(prefix: str):
+    """Module order of a SpatialTransformer's path, whatever order the dict was iterated in: input_blocks.N (numeric N, so
+    input_blocks.10 follows input_blocks.2), then middle_block.N, then output_blocks.N -- the order UNetModel.forward walks and
+    gl_unet_train_step numbers the blocks in."""
+    parts = prefix.split(".")
+    stage = {"input_blocks": 0, "middle_block": 1, "output_blocks": 2}.get(parts[0])
+    if stage is None:
+        raise ValueError(f"trainable fuser outside input_blocks / middle_block / output_blocks: {prefix!r}")
+    return (stage,) + tuple(int(p) if p.isdigit() else -1 for p in parts[1:])
+
+
 def gradient_milestones(names):
     """For every trainable tensor the milestone of gl_unet_train_step behind which its gradient is final (gl_train_wait_grads): a fuser
-    tensor's is the number of its SpatialTransformer in module order (= state_dict order: input_blocks .., middle_block,
-    output_blocks ..), position_net's is the number of SpatialTransformers -- the end of the backward. The backward walks the blocks
-    from the last to the first, so milestone j is reached before milestone j - 1."""
-    blocks = []
-    for k in names:
-        if ".fuser." in k:
-            b = k.split(".transformer_blocks.")[0]
-            if b not in blocks:
-                blocks.append(b)
-    return {k: (blocks.index(k.split(".transformer_blocks.")[0]) if ".fuser." in k else len(blocks)) for k in names}
+    tensor's is the number of its SpatialTransformer in MODULE order (input_blocks .., middle_block, output_blocks .., by the numeric
+    index in the path -- not the iteration order of the dict handed in: a re-sorted state_dict puts input_blocks.10 before
+    input_blocks.2 and would point a bucket at the wrong event), position_net's is the number of SpatialTransformers -- the end of the
+    backward. The backward walks the blocks from the last to the first, so milestone j is reached before milestone j - 1."""
+    blocks = sorted({k.split(".transformer_blocks.")[0] for k in names if ".fuser." in k}, key=_block_order)
+    index = {b: i for i, b in enumerate(blocks)}
+    return {k: (index[k.split(".transformer_blocks.")[0]] if ".fuser." in k else len(blocks)) for k in names}
 
 
 class TrainStep:
@@ -95,6 +103,10 @@ class TrainStep:
         names = trainable_names(state_dict)
         self.milestone = gradient_milestones(names)
         n_blocks = max(self.milestone.values(), default=0)
+        # the engine numbers SpatialTransformers by walking the config; both counts must agree or bucket_ready waits on the wrong events
+        n_st = getattr(engine, "count_spatial_transformers", None)
+        if callable(n_st) and any(".fuser." in k for k in names) and n_st(self.cfg) != n_blocks:
+            raise ValueError(f"TrainStep: {n_blocks} fuser blocks in the state_dict, {n_st(self.cfg)} SpatialTransformers in the config")
         # bucket order = the order in which gradients become final: blocks from the last to the first, position_net at the end
         names = sorted(names, key=lambda k: (self.milestone[k] == n_blocks, -self.milestone[k]))
         shapes = {k: tuple(state_dict[k].shape) for k in names}
@@ -157,3 +169,25 @@ class TrainStep:
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         return {k: v.clone() for k, v in self.params.items()}
+
+    def optimizer_state_dict(self) -> Dict[str, object]:
+        """What a resumed run needs beside the parameters (the reference's checkpoint carries opt, scheduler and iters,
+        trainer.py:472-484): AdamW's two moments per trainable tensor and the step count (which also positions the LR schedule)."""
+        m, v = {}, {}
+        for items, mb, vb in zip(self.pbuf.layout, self.m, self.v):
+            for name, off, n, shape in items:
+                m[name] = mb[off:off + n].view(shape).clone()
+                v[name] = vb[off:off + n].view(shape).clone()
+        return {"steps": int(self.steps), "exp_avg": m, "exp_avg_sq": v}
+
+    def load_optimizer_state_dict(self, state: Mapping[str, object]) -> None:
+        for items, mb, vb in zip(self.pbuf.layout, self.m, self.v):
+            for name, off, n, shape in items:
+                mb[off:off + n].view(shape).copy_(state["exp_avg"][name])
+                vb[off:off + n].view(shape).copy_(state["exp_avg_sq"][name])
+        self.steps = int(state["steps"])
+
+    def load_state_dict(self, state_dict: Mapping[str, torch.Tensor]) -> None:
+        """Parameters back into the flat buffers (trainable) / the frozen set, in place: the views the engine reads stay the same."""
+        for k, t in state_dict.items():
+            self.params[k].copy_(t.to(device=self.params[k].device, dtype=torch.float32))

@@ -183,7 +183,10 @@ int gl_launch_count(gl_ctx* ctx, int64_t* n);
  * in two forms at C = 320: ONE row-local launch (ffn.hip) or LayerNorm + GEGLU GEMM + FF-out GEMM (+ separate projections). Which is
  * faster depends on the row count and on the box (the row-local form ran 1.65x slower on a slow-fabric box), so the
  * engine TIMES both on the device at the first eager launch of each (block form, row count) and keeps the faster for the process.
- * mode: -1 = that (default), 0 = never the row-local kernel, 1 = the row-local kernel wherever it exists. Process-wide; contexts drop
+ * mode: -1 = that (default), 0 = never the row-local kernel, 1 = the row-local kernel wherever it exists, 2 = a static rule (launches of
+ * at least 7/8 of the chip's CUs take the row-local kernel): the two forms differ in their last bits, so under -1 identical inputs may
+ * give bitwise different outputs on another box / process; 0, 1 and 2 select the same kernels everywhere. A shape first met inside a
+ * stream capture is decided by the static rule and the decision is kept for the process. Process-wide; contexts drop
  * their captured graphs when it changes. gl_ff_rows_policy_report: "mode=..;<form> C M -> rows|gemm (rows us, gemm us);.." of what
  * has been timed so far. Measurement aids (bench.py's same-box A/B); the reference has no counterpart. */
 int gl_set_ff_rows_policy(int mode);

@@ -29,6 +29,23 @@ class FrozenCLIPEmbedder(AbstractEncoder):
         self.max_length = max_length
         self.freeze()
 
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        """GLIGEN checkpoints were written under transformers 4.x, whose CLIPTextModel wraps the tower in `.text_model`
+        (keys `transformer.text_model.embeddings...`); transformers 5.x dropped that level (`transformer.embeddings...`). Keys are
+        renamed to whatever the installed class uses, so an existing checkpoint loads unchanged under either version."""
+        own = self.state_dict().keys()
+        wrapped_here = any(k.startswith("transformer.text_model.") for k in own)
+        out = {}
+        for k, v in state_dict.items():
+            if k.endswith("position_ids") and k not in own:
+                continue                          # a registered buffer in old versions only
+            if wrapped_here and k.startswith("transformer.") and not k.startswith("transformer.text_model."):
+                k = "transformer.text_model." + k[len("transformer."):]
+            elif not wrapped_here and k.startswith("transformer.text_model."):
+                k = "transformer." + k[len("transformer.text_model."):]
+            out[k] = v
+        return super().load_state_dict(out, strict=strict, **kw)
+
     def freeze(self):
         self.transformer = self.transformer.eval()
         for p in self.parameters():

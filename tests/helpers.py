@@ -141,3 +141,74 @@ def st_backward_inputs(meta):
     context = torch.randn(B, T, D, generator=g)
     target = torch.randn(B, C, hw, hw, generator=g)
     return x, objs, context, target
+
+
+# ---- fabricated checkpoint pieces shared by the CPU loader tests and the GPU file -> image test ----------------------------
+def _fake_omegaconf_pickle(path, payload):
+    """Write `payload` (a dict of state_dicts + a nested config) the way the reference's trainer does
+    (trainer.py:176,472-480: config_dict = vars(OmegaConf DictConfig)), with stand-in classes living in modules NAMED
+    omegaconf.* so that the pickle stream references 'omegaconf.dictconfig DictConfig' etc. exactly like a real checkpoint."""
+    import sys
+    import types
+
+    mods = {n: types.ModuleType(n) for n in ("omegaconf", "omegaconf.dictconfig", "omegaconf.listconfig", "omegaconf.nodes", "omegaconf.base")}
+
+    def cls(mod, name):
+        c = type(name, (), {"__module__": mod, "__getstate__": lambda self: dict(self.__dict__),
+                            "__setstate__": lambda self, st: self.__dict__.update(st)})
+        setattr(mods[mod], name, c)
+        return c
+
+    DictConfig, ListConfig = cls("omegaconf.dictconfig", "DictConfig"), cls("omegaconf.listconfig", "ListConfig")
+    AnyNode, Meta = cls("omegaconf.nodes", "AnyNode"), cls("omegaconf.base", "ContainerMetadata")
+
+    def wrap(v):
+        if isinstance(v, dict):
+            n = DictConfig()
+            n.__dict__.update(_content={k: wrap(x) for k, x in v.items()}, _metadata=Meta(), _parent=None, _flags_cache=None)
+            return n
+        if isinstance(v, (list, tuple)):
+            n = ListConfig()
+            n.__dict__.update(_content=[wrap(x) for x in v], _metadata=Meta(), _parent=None, _flags_cache=None)
+            return n
+        n = AnyNode()
+        n.__dict__.update(_val=v, _metadata=Meta(), _parent=None)
+        return n
+
+    cfg = payload.pop("config")
+    payload["config_dict"] = dict(_content={k: wrap(v) for k, v in cfg.items()}, _metadata=Meta(), _parent=None, _flags_cache=None)
+    saved = {k: sys.modules.get(k) for k in mods}
+    sys.modules.update(mods)
+    try:
+        torch.save(payload, path)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                del sys.modules[k]
+            else:
+                sys.modules[k] = v
+
+
+def _fabricated_clip(tmp_path, hidden=768, proj=768):
+    import json as _json
+    from transformers import CLIPConfig, CLIPImageProcessor, CLIPModel, CLIPProcessor, CLIPTextConfig, CLIPTokenizer, CLIPVisionConfig
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("¡"), ord("¬") + 1)) + list(range(ord("®"), ord("ÿ") + 1))
+    cs, n = bs[:], 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b); cs.append(256 + n); n += 1
+    chars = [chr(c) for c in cs]
+    vocab = {c: i for i, c in enumerate(chars)}
+    vocab.update({c + "</w>": len(chars) + i for i, c in enumerate(chars)})
+    vocab["<|startoftext|>"], vocab["<|endoftext|>"] = len(vocab), len(vocab) + 1
+    (tmp_path / "vocab.json").write_text(_json.dumps(vocab))
+    (tmp_path / "merges.txt").write_text("#version: 0.2\n")
+    tok = CLIPTokenizer(str(tmp_path / "vocab.json"), str(tmp_path / "merges.txt"))
+    tcfg = CLIPTextConfig(vocab_size=49408, hidden_size=hidden, intermediate_size=256, num_hidden_layers=2, num_attention_heads=8,
+                          max_position_embeddings=77, hidden_act="quick_gelu", projection_dim=proj, eos_token_id=vocab["<|endoftext|>"],
+                          bos_token_id=vocab["<|startoftext|>"], pad_token_id=vocab["<|endoftext|>"])
+    vcfg = CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4, image_size=224, patch_size=32,
+                            projection_dim=proj)
+    torch.manual_seed(0)
+    model = CLIPModel(CLIPConfig(text_config=tcfg.to_dict(), vision_config=vcfg.to_dict(), projection_dim=proj)).eval()
+    return model, CLIPProcessor(image_processor=CLIPImageProcessor(), tokenizer=tok), tok

@@ -19,6 +19,10 @@ from gligen_amd import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 EPS_MSE_TOL = 2e-4     # absolute, on eps with std ~0.3 (bar in BASELINE.json: 1e-3)
+# end-to-end runs (20-50 chained CFG evaluations + decode) against the reference's own CPU run, relative MSE: at most 5 x the worst value
+# measured on MI355X over rounds 3-5 (latent 3.7e-5 .. 8e-5, decoded image 0.9e-4 .. 1.7e-4) -- round 5's bars were 50-100 x
+E2E_Z_TOL = 4e-4
+E2E_IMG_TOL = 8.5e-4
 REPORT = {}
 
 
@@ -131,8 +135,8 @@ def test_c1_end_to_end_vs_reference(full_models, tmp_path, monkeypatch):
     REPORT["c1_end_to_end"] = r
     assert img.shape == tuple(img_ref.shape) == (1, 3, 8 * hw, 8 * hw)
     # 42 chained CFG evaluations of a random-weight UNet + the decoder, bf16 against fp32 (measured on MI355X: latent 6.6e-5,
-    # image 1.7e-4 relative MSE)
-    assert r["z_rel_mse"] < 2e-3 and r["img_rel_mse"] < 5e-3, r
+    # image 1.7e-4 relative MSE; the bars are 5 x that -- a kernel regression that costs 10 x in accuracy must fail here)
+    assert r["z_rel_mse"] < E2E_Z_TOL and r["img_rel_mse"] < E2E_IMG_TOL, r
     model._drop_engine()
     ae._drop_engine()
 
@@ -169,8 +173,49 @@ def test_c2_end_to_end_vs_reference(full_models, monkeypatch):
     r["img_rel_mse"] = r["img_mse"] / r["img_var"]
     REPORT["c2_end_to_end"] = r
     assert img.shape == tuple(img_ref.shape) == (1, 3, 8 * hw, 8 * hw)
-    # 102 chained evaluations of a random-weight UNet under CFG 7.5 + the decoder, bf16 against fp32
-    assert r["z_rel_mse"] < 5e-3 and r["img_rel_mse"] < 1e-2, r
+    # 102 chained evaluations of a random-weight UNet under CFG 7.5 + the decoder, bf16 against fp32 (measured: 3.8e-5 / 1.4e-4)
+    assert r["z_rel_mse"] < E2E_Z_TOL and r["img_rel_mse"] < E2E_IMG_TOL, r
+    ae._drop_engine()
+
+
+@pytest.mark.parametrize("name,kind", [("c3_end_to_end", "text_image"), ("c5_end_to_end", "keypoint")])
+def test_c3_c5_end_to_end_vs_reference(name, kind, full_models, monkeypatch):
+    """BASELINE configs C3 (box + text + CLIP image tokens, Ng = 60) and C5 (17 COCO keypoints per person -> Fourier tokens, Ng = 136) for
+    one image at full size: 50 PLMS steps = 51 CFG evaluations of the shipped UNet with that tokenizer at the 64x64 latent, gate on at every
+    step, decode -- gligen_inference.generate against the reference's own PLMSSampler + UNetModel + AutoencoderKL.decode run on the CPU
+    (oracle/make_golden.py:c2_case with kind = ...; round 6). Until now these two tokenizers were pinned for one evaluation only."""
+    dev = _dev()
+    import gligen_inference as gi
+    from ldm.models.diffusion.ldm import LatentDiffusion
+    g = load_golden(name)
+    meta = g["meta"]
+    assert meta["kind"] == kind
+    hw, S = meta["hw"], meta["S"]
+    monkeypatch.setattr(gi, "device", dev)
+    model = full_models(kind)
+    ae = build_product_vae(syn.VAE_DDCONFIG, device=dev)
+    diffusion = LatentDiffusion(linear_start=0.00085, linear_end=0.012, timesteps=1000).to(dev)
+    batch = _to(syn.make_batch(kind, 1, n_valid=meta["n_valid"], seed=1), dev)
+    ctx, uc = syn.make_context(1, seed=1).to(dev), syn.make_context(1, seed=9).to(dev)
+    captured = {}
+    real_decode = type(ae).decode
+
+    def decode(self, z):
+        captured["z"] = z.clone()
+        return real_decode(self, z)
+    monkeypatch.setattr(type(ae), "decode", decode)
+    img = gi.generate(model, ae, diffusion, batch, ctx, uc, steps=S, guidance_scale=meta["guidance_scale"], alpha_type=meta["alpha_type"],
+                      starting_noise=syn.make_latent(1, 4, hw, hw, seed=6).to(dev))
+    z_ref, img_ref = g["z"], g["img"].astype(np.float32)
+    r = dict(z_rel_mse=mse(captured["z"], z_ref) / float(z_ref.var()), z_std=float(z_ref.std()),
+             img_mse=mse(img, img_ref), img_var=float(img_ref.var()), ref_cpu_seconds=meta["ref_cpu_seconds"])
+    r["img_rel_mse"] = r["img_mse"] / r["img_var"]
+    for k in ("z_step10", "z_step25"):       # where along the run an error would have entered
+        if k in g:
+            r[k + "_ref_std"] = float(g[k].std())
+    REPORT[name] = r
+    assert img.shape == tuple(img_ref.shape) == (1, 3, 8 * hw, 8 * hw)
+    assert r["z_rel_mse"] < E2E_Z_TOL and r["img_rel_mse"] < E2E_IMG_TOL, r
     ae._drop_engine()
 
 
@@ -221,7 +266,7 @@ def test_c4_end_to_end_vs_reference(full_models, monkeypatch):
     r["img_rel_mse"] = r["img_mse"] / r["img_var"]
     REPORT["c4_end_to_end"] = r
     assert img.shape == tuple(img_ref.shape) == (1, 3, 8 * hw, 8 * hw)
-    assert r["z0_rel_mse"] < 5e-3 and r["z_rel_mse"] < 5e-3 and r["img_rel_mse"] < 1e-2, r
+    assert r["z0_rel_mse"] < 2.5e-4 and r["z_rel_mse"] < E2E_Z_TOL and r["img_rel_mse"] < E2E_IMG_TOL, r     # (measured: 4.2e-5, 4-8e-5, 1-2e-4)
     ae._drop_engine()
 
 
@@ -259,7 +304,7 @@ def test_c2_end_to_end_b4_vs_reference(full_models, monkeypatch):
     for i in range(B):
         per.append(dict(z_rel_mse=mse(captured["z"][i], z_ref[i]) / float(z_ref[i].var()), img_rel_mse=mse(pooled[i], img_ref[i]) / float(img_ref[i].var())))
     REPORT["c2_end_to_end_b4"] = dict(per_image=per, ref_cpu_seconds=meta["ref_cpu_seconds"])
-    assert all(p["z_rel_mse"] < 5e-3 and p["img_rel_mse"] < 1e-2 for p in per), per
+    assert all(p["z_rel_mse"] < E2E_Z_TOL and p["img_rel_mse"] < E2E_IMG_TOL for p in per), per           # (measured: 3.7-4.0e-5 / 8.4-9.1e-5)
     # the four images are four different images (no cross-talk, nothing broadcast)
     assert all(mse(z_ref[0], z_ref[i]) / float(z_ref[0].var()) > 0.5 for i in range(1, B))
     ae._drop_engine()
@@ -422,6 +467,75 @@ def test_run_entry_inpaint_batch(tmp_path, monkeypatch):
     # and the known region really is the (re-noised, at the last step barely noised) input latent: inside the mask's kept
     # area the final latent tracks z0, so the broadcast of the single z0 reached every sample of the batch
     model._drop_engine()
+    ae._drop_engine()
+
+
+def test_run_from_checkpoint_file(tmp_path, monkeypatch):
+    """SURVEY section 8 f1 on the GPU: the reference's entry as it is used -- run(meta, args) with NO `models=` -- from a checkpoint
+    FILE in the reference's format (trainer.py:472-484: model / autoencoder / text_encoder / diffusion state_dicts + a pickled-OmegaConf
+    config_dict) through load_ckpt (instantiate_from_config x 4 + load_state_dict x 4, gligen_inference.py:70-86), the CLIP front-end
+    (text_encoder.encode for prompt and negative prompt, get_clip_feature for the phrases: :104-128, 146-187, 379-383), sampling, decode
+    and PNG files (:389-446). The images must be those of generate() on modules built directly from the same weights and inputs.
+    HF weights are not available offline: the CLIP towers are random-init (the classes of the real ones, small depth), the tokenizer a
+    fabricated byte-level BPE vocabulary -- what is pinned is the file -> engine -> image chain, not the pretrained numbers."""
+    dev = _dev()
+    import transformers
+    import gligen_inference as gi
+    from PIL import Image
+    from helpers import _fabricated_clip, _fake_omegaconf_pickle
+    from ldm.modules.encoders.modules import FrozenCLIPEmbedder
+    monkeypatch.setattr(gi, "device", dev)
+    monkeypatch.chdir(tmp_path)
+    B, hw, steps, seed = 2, 16, 4, 5
+    clip_model, processor, tok = _fabricated_clip(tmp_path)
+    clip_model = clip_model.to(dev)
+    monkeypatch.setattr(gi, "_CLIP", {"model": clip_model, "processor": processor})           # the phrase tower (reference :104-128)
+    tcfg = transformers.CLIPTextConfig(vocab_size=49408, hidden_size=768, intermediate_size=256, num_hidden_layers=2, num_attention_heads=8,
+                                       max_position_embeddings=77, hidden_act="quick_gelu", projection_dim=768, eos_token_id=tok.eos_token_id,
+                                       bos_token_id=tok.bos_token_id, pad_token_id=tok.eos_token_id)
+    # "from_pretrained" offline: the text tower's architecture (two layers instead of twelve) and the tokenizer files
+    monkeypatch.setattr(transformers.CLIPTokenizer, "from_pretrained", classmethod(lambda cls, *a, **k: tok))
+    monkeypatch.setattr(transformers.CLIPTextModel, "from_pretrained", classmethod(lambda cls, *a, **k: transformers.CLIPTextModel(tcfg)))
+    cfg = gi.synthetic_config("text", inpaint=False, image_size=hw)
+    cfg["model"]["params"].update(syn.UNET_CFG_SMALL, image_size=hw, grounding_tokenizer=syn.GROUNDING_TOKENIZERS["text"])
+    cfg["autoencoder"]["params"]["ddconfig"] = dict(syn.VAE_DDCONFIG_SMALL)
+    cfg["text_encoder"] = dict(target="ldm.modules.encoders.modules.FrozenCLIPEmbedder")      # as configs/*.yaml name it
+    # ---- the modules whose weights go into the file (and serve as the directly-built side of the comparison)
+    unet = syn.fill_module_(gi.instantiate_from_config(cfg["model"]).eval(), 1234)
+    ae = syn.fill_module_(gi.instantiate_from_config(cfg["autoencoder"]).eval(), 4321)
+    torch.manual_seed(7)
+    enc = FrozenCLIPEmbedder(device=str(dev)).to(dev)
+    tower = getattr(enc.transformer, "text_model", enc.transformer)       # transformers 4.x wraps the tower in .text_model, 5.x does not
+    assert enc.tokenizer is tok and len(tower.encoder.layers) == 2
+    diffusion = gi.instantiate_from_config(cfg["diffusion"])
+    path = tmp_path / "diffusion_pytorch_model.bin"
+    # the file carries the text tower under the key names real GLIGEN checkpoints have (transformers 4.x: transformer.text_model.*)
+    te_sd = {("transformer.text_model." + k[len("transformer."):] if not k.startswith("transformer.text_model.") else k): v.cpu() for k, v in enc.state_dict().items()}
+    _fake_omegaconf_pickle(path, dict(model=unet.state_dict(), autoencoder=ae.state_dict(), text_encoder=te_sd,
+                                      diffusion=diffusion.state_dict(), iters=1, config={k: v for k, v in cfg.items()}))
+    boxes, _ = syn.make_boxes(1, 2, seed=4)
+    meta = dict(ckpt=str(path), prompt="a teddy bear sitting next to a bird", phrases=["a teddy bear", "a bird"], locations=boxes[0, :2].tolist(),
+                alpha_type=[0.5, 0.0, 0.5], save_folder_name="from_file")
+    args = dict(batch_size=B, guidance_scale=7.5, negative_prompt="blurry", no_plms=False, folder=str(tmp_path / "out"), steps=steps, seed=seed)
+    torch.save(syn.sd_first_conv_state(), tmp_path / "SD_input_conv_weight_bias.pth")           # the alpha schedule swaps the first conv mid-run
+    samples = gi.run(dict(meta), dict(args))                                                    # <- no models=: everything comes from the file
+    files = sorted(os.listdir(tmp_path / "out" / "from_file"))
+    assert files == ["0.png", "1.png"] and samples.shape == (B, 3, 2 * hw, 2 * hw) and torch.isfinite(samples).all()
+    png = np.asarray(Image.open(tmp_path / "out" / "from_file" / "1.png"))
+    assert np.array_equal(png, ((torch.clamp(samples[1], -1, 1) * 0.5 + 0.5).cpu().numpy().transpose(1, 2, 0) * 255).astype(np.uint8))
+    # ---- the same images from generate() on the directly-built modules: same weights, same CLIP outputs, same seeded x_T
+    unet, ae, diffusion = unet.to(dev), ae.to(dev), diffusion.to(dev)
+    unet.grounding_tokenizer_input = gi.instantiate_from_config(cfg["grounding_tokenizer_input"])
+    context, uc = enc.encode([meta["prompt"]] * B), enc.encode(["blurry"] * B)
+    assert context.shape == (B, 77, 768) and not torch.equal(context, uc)
+    batch = gi.prepare_batch(dict(meta), B)
+    assert float(batch["text_embeddings"][0, :2].abs().sum()) > 0 and batch["masks"][0].tolist()[:3] == [1, 1, 0]     # the phrases went through CLIP
+    x_T = torch.randn((B, 4, hw, hw), generator=torch.Generator().manual_seed(seed)).to(dev)
+    ref = gi.generate(unet, ae, diffusion, batch, context, uc, steps=steps, guidance_scale=7.5, alpha_type=meta["alpha_type"], starting_noise=x_T)
+    rel = mse(ref, samples) / float(ref.float().var())
+    REPORT["run_from_checkpoint_file"] = dict(rel_mse_vs_generate=rel, bit_equal=bool(torch.equal(ref, samples)))
+    assert rel < 1e-6, REPORT["run_from_checkpoint_file"]       # (same kernels on the same inputs: bit-equal in practice; the bar allows a re-tuned tile)
+    unet._drop_engine()
     ae._drop_engine()
 
 

@@ -232,52 +232,10 @@ def test_prepare_batch_with_precomputed_features():
         gi.device = gi_device
 
 
+from helpers import _fabricated_clip, _fake_omegaconf_pickle  # noqa: E402  (shared with the GPU file -> image test)
+
+
 # ---- round 2: checkpoint loader, demo prompt list, spatial-map host classes ------------------------------------------
-def _fake_omegaconf_pickle(path, payload):
-    """Write `payload` (a dict of state_dicts + a nested config) the way the reference's trainer does
-    (trainer.py:176,472-480: config_dict = vars(OmegaConf DictConfig)), with stand-in classes living in modules NAMED
-    omegaconf.* so that the pickle stream references 'omegaconf.dictconfig DictConfig' etc. exactly like a real checkpoint."""
-    import sys
-    import types
-
-    mods = {n: types.ModuleType(n) for n in ("omegaconf", "omegaconf.dictconfig", "omegaconf.listconfig", "omegaconf.nodes", "omegaconf.base")}
-
-    def cls(mod, name):
-        c = type(name, (), {"__module__": mod, "__getstate__": lambda self: dict(self.__dict__),
-                            "__setstate__": lambda self, st: self.__dict__.update(st)})
-        setattr(mods[mod], name, c)
-        return c
-
-    DictConfig, ListConfig = cls("omegaconf.dictconfig", "DictConfig"), cls("omegaconf.listconfig", "ListConfig")
-    AnyNode, Meta = cls("omegaconf.nodes", "AnyNode"), cls("omegaconf.base", "ContainerMetadata")
-
-    def wrap(v):
-        if isinstance(v, dict):
-            n = DictConfig()
-            n.__dict__.update(_content={k: wrap(x) for k, x in v.items()}, _metadata=Meta(), _parent=None, _flags_cache=None)
-            return n
-        if isinstance(v, (list, tuple)):
-            n = ListConfig()
-            n.__dict__.update(_content=[wrap(x) for x in v], _metadata=Meta(), _parent=None, _flags_cache=None)
-            return n
-        n = AnyNode()
-        n.__dict__.update(_val=v, _metadata=Meta(), _parent=None)
-        return n
-
-    cfg = payload.pop("config")
-    payload["config_dict"] = dict(_content={k: wrap(v) for k, v in cfg.items()}, _metadata=Meta(), _parent=None, _flags_cache=None)
-    saved = {k: sys.modules.get(k) for k in mods}
-    sys.modules.update(mods)
-    try:
-        torch.save(payload, path)
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                del sys.modules[k]
-            else:
-                sys.modules[k] = v
-
-
 def test_load_ckpt_reads_pickled_omegaconf_config(tmp_path, monkeypatch):
     """load_ckpt (reference gligen_inference.py:70-86) on a checkpoint whose config_dict is a pickled OmegaConf node graph,
     with omegaconf not importable: the shim unpickler rebuilds the config, the four modules are instantiated from their
@@ -311,6 +269,35 @@ def test_load_ckpt_reads_pickled_omegaconf_config(tmp_path, monkeypatch):
     assert type(model.position_net).__module__.endswith("text_image_grounding_net")
     gin = gi.instantiate_from_config(config["grounding_tokenizer_input"])
     assert type(gin).__module__ == "grounding_input.text_image_grounding_tokinzer_input"
+
+
+def test_text_encoder_loads_checkpoint_keys_of_either_transformers_layout():
+    """Real GLIGEN checkpoints hold the CLIP text tower as transformer.text_model.* (transformers 4.x); the installed transformers may
+    name the same tensors transformer.* (5.x). FrozenCLIPEmbedder.load_state_dict takes both, strictly (load_ckpt, reference
+    gligen_inference.py:80-84), plus the position_ids buffer old files carry."""
+    import transformers
+    from ldm.modules.encoders.modules import FrozenCLIPEmbedder
+    tcfg = transformers.CLIPTextConfig(vocab_size=512, hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2,
+                                       max_position_embeddings=77, projection_dim=32, bos_token_id=1, eos_token_id=2, pad_token_id=2)
+
+    class Small(FrozenCLIPEmbedder):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            self.tokenizer, self.transformer, self.device, self.max_length = None, transformers.CLIPTextModel(tcfg), "cpu", 77
+            self.freeze()
+
+    torch.manual_seed(0)
+    src, dst = Small(), Small()
+    own = src.state_dict()
+    bare = {("transformer." + k[len("transformer.text_model."):] if k.startswith("transformer.text_model.") else k): v for k, v in own.items()}
+    wrapped = {"transformer.text_model." + k[len("transformer."):]: v for k, v in bare.items()}
+    wrapped["transformer.text_model.embeddings.position_ids"] = torch.arange(77).unsqueeze(0)      # old checkpoints carry this buffer
+    for sd in (bare, wrapped):
+        for p_ in dst.parameters():
+            p_.data.zero_()
+        res = dst.load_state_dict(sd)
+        assert not res.missing_keys and not res.unexpected_keys
+        assert all(torch.equal(a, b) for a, b in zip(dst.state_dict().values(), own.values()))
 
 
 def test_meta_list_matches_reference():
@@ -538,31 +525,6 @@ def test_halo_kernel_geometry(H, W, B):
 
 
 # ---- CLIP front-end: executed offline with random-init HF models and a fabricated byte-level BPE vocabulary
-def _fabricated_clip(tmp_path, hidden=768, proj=768):
-    import json as _json
-    from transformers import CLIPConfig, CLIPImageProcessor, CLIPModel, CLIPProcessor, CLIPTextConfig, CLIPTokenizer, CLIPVisionConfig
-    bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("¡"), ord("¬") + 1)) + list(range(ord("®"), ord("ÿ") + 1))
-    cs, n = bs[:], 0
-    for b in range(256):
-        if b not in bs:
-            bs.append(b); cs.append(256 + n); n += 1
-    chars = [chr(c) for c in cs]
-    vocab = {c: i for i, c in enumerate(chars)}
-    vocab.update({c + "</w>": len(chars) + i for i, c in enumerate(chars)})
-    vocab["<|startoftext|>"], vocab["<|endoftext|>"] = len(vocab), len(vocab) + 1
-    (tmp_path / "vocab.json").write_text(_json.dumps(vocab))
-    (tmp_path / "merges.txt").write_text("#version: 0.2\n")
-    tok = CLIPTokenizer(str(tmp_path / "vocab.json"), str(tmp_path / "merges.txt"))
-    tcfg = CLIPTextConfig(vocab_size=49408, hidden_size=hidden, intermediate_size=256, num_hidden_layers=2, num_attention_heads=8,
-                          max_position_embeddings=77, hidden_act="quick_gelu", projection_dim=proj, eos_token_id=vocab["<|endoftext|>"],
-                          bos_token_id=vocab["<|startoftext|>"], pad_token_id=vocab["<|endoftext|>"])
-    vcfg = CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4, image_size=224, patch_size=32,
-                            projection_dim=proj)
-    torch.manual_seed(0)
-    model = CLIPModel(CLIPConfig(text_config=tcfg.to_dict(), vision_config=vcfg.to_dict(), projection_dim=proj)).eval()
-    return model, CLIPProcessor(image_processor=CLIPImageProcessor(), tokenizer=tok), tok
-
-
 def test_clip_front_end_executes(tmp_path, monkeypatch):
     """FrozenCLIPEmbedder.encode, get_clip_feature (text: pooler output before the projection; image: image_embeds re-projected
     with `projection_matrix` and scaled to norm 28.7) and prepare_batch WITHOUT precomputed features, executed end to end and
@@ -745,6 +707,24 @@ def test_train_step_bookkeeping_on_flat_buckets():
     ts2.step({})
     ts2.step({})
     assert not any(c[0] == "wait" for c in eng2.calls) and all(torch.equal(ts2.state_dict()[k], out[k]) for k in out)
+    # block ordinals come from the numeric module path, not from the dict's iteration order: lexicographic order puts
+    # input_blocks.10 before input_blocks.2; the engine numbers SpatialTransformers input_blocks.2 < input_blocks.10 < middle < output
+    keys = ["input_blocks.10.1.transformer_blocks.0.fuser.linear.bias", "input_blocks.2.1.transformer_blocks.0.fuser.linear.bias",
+            "output_blocks.11.1.transformer_blocks.0.fuser.linear.bias", "output_blocks.3.1.transformer_blocks.0.fuser.linear.bias",
+            "middle_block.1.transformer_blocks.0.fuser.linear.bias", "position_net.null.bias"]
+    want = {keys[1]: 0, keys[0]: 1, keys[4]: 2, keys[3]: 3, keys[2]: 4, keys[5]: 5}
+    assert gradient_milestones(sorted(keys)) == want and gradient_milestones(list(reversed(keys))) == want
+    # optimizer state travels with a checkpoint (the reference saves opt + iters, trainer.py:472-484): moments and the step count
+    st = ts.optimizer_state_dict()
+    assert st["steps"] == 2 and set(st["exp_avg"]) == set(ts.gbuf.views) == set(st["exp_avg_sq"])
+    ts3 = TrainStep(FakeEngine(), {}, sd, lr=0.5, bucket_mb=1e-4, world=1)
+    st["exp_avg"]["position_net.linears.0.bias"].fill_(3.0)
+    ts3.load_optimizer_state_dict(st)
+    ts3.load_state_dict(out)
+    assert ts3.steps == 2 and torch.all(ts3.optimizer_state_dict()["exp_avg"]["position_net.linears.0.bias"] == 3.0)
+    assert all(torch.equal(ts3.state_dict()[k], out[k]) for k in out) and ts3.params["position_net.linears.0.bias"].data_ptr() == ts3.pbuf.views["position_net.linears.0.bias"].data_ptr()
+    ts3.step({})
+    assert [c[3] for c in ts3.engine.calls if c[0] == "adamw"] == [3, 3, 3]          # the schedule continues where the checkpoint stopped
 
 
 def test_attn3_operand_handover_model():
