@@ -65,6 +65,10 @@ class BoxCalibration(C.Structure):   # = gl_box_calibration
     _fields_ = [("hbm_copy_gbs", C.c_float), ("lds_dma_tbs", C.c_float), ("mfma_bf16_tflops", C.c_float)]
 
 
+class MfmaCalibration(C.Structure):   # = gl_mfma_calibration
+    _fields_ = [("tflops", C.c_float), ("sclk_mhz", C.c_float), ("ms", C.c_float), ("cycles_per_mfma", C.c_float)]
+
+
 class ProfRec(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("calls", C.c_int), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
 
@@ -101,6 +105,7 @@ SYMBOLS = {
     "gl_set_ff_rows_policy": (_I, [_I]),
     "gl_ff_rows_policy_report": (_I, [C.c_char_p, C.c_size_t]),
     "gl_box_calibrate": (_I, [_P, C.POINTER(BoxCalibration), _P]),
+    "gl_mfma_calibrate": (_I, [_P, _I, _I, _I, _I, C.c_float, C.POINTER(MfmaCalibration), _P]),
     "gl_op_linear": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "gl_op_geglu": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "gl_op_ln_linear": (_I, [_P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, C.POINTER(_I), _P]),

@@ -319,6 +319,25 @@ int gl_box_calibrate(gl_ctx* ctx, gl_box_calibration* out, gl_stream s) {
     GL_API_END
 }
 
+int gl_mfma_calibrate(gl_ctx* ctx, int shape, int waves_per_simd, int n_acc, int zero_data, float target_ms, gl_mfma_calibration* out, gl_stream s) {
+    NEED(ctx);
+    if (!out) return gl::set_error(GL_ERR_ARG, "gl_mfma_calibrate: null out pointer");
+    GL_API_BEGIN
+    Arena& ar = ctx->eng->arena();
+    const size_t mk = ar.mark();
+    void* scratch = ar.alloc(4096);
+    HIPCK_API(hipMemsetAsync(scratch, 0, 4096, S(s)));
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    int rc = mfma_calibrate_launch(shape, waves_per_simd, n_acc, zero_data, target_ms, scratch, v, S(s));
+    ar.release(mk);
+    if (rc != GL_OK) throw GlError(rc, gl::last_error());
+    out->tflops = v[0];
+    out->sclk_mhz = v[1];
+    out->ms = v[2];
+    out->cycles_per_mfma = v[3];
+    GL_API_END
+}
+
 // ------------------------------------------------------------------ single operators
 int gl_op_linear(gl_ctx* ctx, const void* x, const void* w, const float* bias, const void* res, void* y,
                  int M, int N, int K, int act, int out_f32, gl_stream s) {

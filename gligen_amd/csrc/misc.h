@@ -102,6 +102,8 @@ int vae_posterior_launch(const float* h, const float* wq, const float* bq, const
 int fill_i64_launch(int64_t* dst, int64_t v, int n, hipStream_t stream);
 // box calibration (gl_box_calibrate): out3 = {float4-copy GB/s (read + write), LDS-DMA TB/s from L2 (chip), sustained bf16 MFMA TFLOP/s}
 int box_calibrate_launch(void* scratch, size_t scratch_bytes, float* out3, hipStream_t stream);
+// gl_mfma_calibrate: out4 = {TFLOP/s, shader clock in MHz measured inside the loop, ms, SIMD cycles per MFMA at that clock}; scratch >= 4 KiB
+int mfma_calibrate_launch(int shape, int waves_per_simd, int n_acc, int zero_data, float target_ms, void* scratch, float* out4, hipStream_t stream);
 int zero_launch(void* dst, size_t bytes, hipStream_t stream);
 
 }  // namespace gl

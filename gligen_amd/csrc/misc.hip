@@ -3,6 +3,9 @@
 // packing, fuser gates, the CFG + PLMS update, inpainting blend, uint8 image epilogue.
 #include "misc.h"
 
+#include <algorithm>
+#include <type_traits>
+
 namespace gl {
 
 static inline int grid_for(int64_t n, int block = 256, int cap = 4096) {
@@ -623,6 +626,101 @@ __global__ void __launch_bounds__(256, 2) calib_mfma_kernel(int iters, float* si
         for (int r = 0; r < 16; ++r) s += acc[i][r];
     if (s == 12345.678f) sink[0] = s;
 }
+// ---- the MFMA ceiling with the clock that explains it (gl_mfma_calibrate)
+// The same back-to-back issue loop, by MFMA shape, independent accumulators per wave, waves per SIMD and operand data, for >= 20 ms,
+// and the kernel measures ITS OWN shader clock over the loop: s_memtime ticks at the shader clock, s_memrealtime at the constant
+// 100 MHz reference, so sclk = 100 MHz x d(memtime) / d(memrealtime) -- the clock the chip sustained while every SIMD issued MFMAs
+// (a power-limited clock shows up here and nowhere in a sysfs sample taken before or after the loop).
+template <int SHAPE, int NACC>
+__global__ void __launch_bounds__(256, 2) calib_mfma2_kernel(int iters, int zero_data, unsigned long long* clk_out, float* sink) {
+    bf16x8 a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        // pseudo-random operands in [-1, 1) (power draw depends on the toggling data: all-zero operands clock higher, MI355X_MICROARCH.md DVFS)
+        const unsigned h1 = (threadIdx.x * 2654435761u + e * 40503u + blockIdx.x * 97u) >> 8, h2 = (threadIdx.x * 40503u + e * 2654435761u + 17u) >> 8;
+        a[e] = f2bf(zero_data ? 0.f : (float)(h1 & 0xffff) * (1.f / 32768.f) - 1.f);
+        b[e] = f2bf(zero_data ? 0.f : (float)(h2 & 0xffff) * (1.f / 32768.f) - 1.f);
+    }
+    typedef typename std::conditional<SHAPE == 0, f32x16, f32x4>::type acc_t;
+    acc_t acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int r = 0; r < (SHAPE == 0 ? 16 : 4); ++r) acc[i][r] = 0.f;
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) {
+                if constexpr (SHAPE == 0) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+                else acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) asm volatile("" : "+v"(acc[i]));      // every chain has landed before the second clock read
+    const unsigned long long c1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int r = 0; r < (SHAPE == 0 ? 16 : 4); ++r) s += acc[i][r];
+    if (s == 12345.678f) sink[0] = s;
+    if (threadIdx.x == 0 && blockIdx.x < 8) {     // one wave per XCD (blocks 0..7 land on XCDs 0..7)
+        clk_out[2 * blockIdx.x] = c1 - c0;
+        clk_out[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+
+int mfma_calibrate_launch(int shape, int waves_per_simd, int n_acc, int zero_data, float target_ms, void* scratch, float* out4, hipStream_t stream) {
+    if ((shape != 0 && shape != 1) || (waves_per_simd != 1 && waves_per_simd != 2) || (n_acc != 4 && n_acc != 8) || !scratch || !out4)
+        return set_error(GL_ERR_ARG, "mfma_calibrate: shape 0|1 (32x32x16 | 16x16x32), waves per SIMD 1|2, accumulators 4|8");
+    int dev = 0, cus = 256;
+    GL_HIP(hipGetDevice(&dev));
+    GL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    hipEvent_t e0, e1;
+    GL_HIP(hipEventCreate(&e0));
+    GL_HIP(hipEventCreate(&e1));
+    struct Guard { hipEvent_t a, b; ~Guard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } guard{e0, e1};
+    unsigned long long* clk = reinterpret_cast<unsigned long long*>(scratch);
+    float* sink = reinterpret_cast<float*>(clk + 16);
+    const dim3 grid(cus * waves_per_simd), block(256);      // 256 threads = one wave on each of the CU's four SIMDs
+    auto launch = [&](int iters) {
+#define GL_CAL(S_, N_) hipLaunchKernelGGL((calib_mfma2_kernel<S_, N_>), grid, block, 0, stream, iters, zero_data, clk, sink)
+        if (shape == 0 && n_acc == 4) GL_CAL(0, 4);
+        else if (shape == 0) GL_CAL(0, 8);
+        else if (n_acc == 4) GL_CAL(1, 4);
+        else GL_CAL(1, 8);
+#undef GL_CAL
+    };
+    // 32 cycles per 32x32x16 (16 per 16x16x32) per SIMD at ~2.4 GHz: iterations for the requested duration, then one warm-up + one timed launch
+    const double cyc = shape == 0 ? 32.0 : 16.0;
+    int iters = (int)std::max(1.0, (double)target_ms * 1e-3 * 2.4e9 / (cyc * 4 * n_acc * waves_per_simd));
+    launch(std::max(1, iters / 20));
+    GL_HIP(hipEventRecord(e0, stream));
+    launch(iters);
+    GL_HIP(hipEventRecord(e1, stream));
+    GL_HIP(hipEventSynchronize(e1));
+    GL_LAUNCH_CHECK();
+    float ms = 0.f;
+    GL_HIP(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long h[16];
+    GL_HIP(hipMemcpy(h, clk, sizeof h, hipMemcpyDeviceToHost));
+    double sclk = 0;
+    int n = 0;
+    for (int i = 0; i < 8; ++i)
+        if (h[2 * i + 1]) { sclk += 100.0 * (double)h[2 * i] / (double)h[2 * i + 1]; ++n; }
+    const double flops_per = shape == 0 ? 2.0 * 32 * 32 * 16 : 2.0 * 16 * 16 * 32;
+    const double total = (double)cus * waves_per_simd * 4 /* waves per block */ * 4.0 * n_acc * iters * flops_per;
+    out4[0] = (float)(total / (ms * 1e-3) / 1e12);          // TFLOP/s
+    out4[1] = n ? (float)(sclk / n) : 0.f;                   // MHz, measured inside the loop (mean over one wave per XCD)
+    out4[2] = ms;
+    // issue cycles per MFMA per SIMD at that clock: (SIMD-cycles available) / (MFMAs issued per SIMD)
+    const double mfma_per_simd = (double)waves_per_simd * 4.0 * n_acc * iters;
+    out4[3] = n ? (float)((sclk / n) * 1e6 * ms * 1e-3 / mfma_per_simd) : 0.f;
+    return GL_OK;
+}
+
 int box_calibrate_launch(void* scratch, size_t scratch_bytes, float* out3, hipStream_t stream) {
     if (!scratch || scratch_bytes < (size_t(64) << 20) || !out3) return set_error(GL_ERR_ARG, "box_calibrate: needs >= 64 MiB of scratch");
     int dev = 0, cus = 256;

@@ -352,6 +352,29 @@ class Engine:
         return {"hbm_copy_GBps": round(float(c.hbm_copy_gbs), 1), "lds_dma_TBps": round(float(c.lds_dma_tbs), 2),
                 "mfma_bf16_TFLOPs": round(float(c.mfma_bf16_tflops), 1)}
 
+    def mfma_calibrate(self, shape: int = 0, waves_per_simd: int = 2, n_acc: int = 4, zero_data: bool = False, target_ms: float = 25.0) -> dict:
+        """gl_mfma_calibrate: back-to-back bf16 MFMA issue on every SIMD for target_ms, with the shader clock the kernel measured over
+        its own loop. shape 0 = 32x32x16, 1 = 16x16x32."""
+        from ._lib import MfmaCalibration
+        c = MfmaCalibration()
+        check(self.lib.gl_mfma_calibrate(self._ctx, int(shape), int(waves_per_simd), int(n_acc), int(bool(zero_data)), float(target_ms), C.byref(c),
+                                         _stream(self.device)))
+        return {"shape": "32x32x16" if shape == 0 else "16x16x32", "waves_per_simd": int(waves_per_simd), "accumulators": int(n_acc),
+                "data": "zeros" if zero_data else "random", "TFLOPs": round(float(c.tflops), 1), "sclk_MHz": round(float(c.sclk_mhz), 1),
+                "ms": round(float(c.ms), 2), "cycles_per_mfma": round(float(c.cycles_per_mfma), 2),
+                "frac_of_2.5PF": round(float(c.tflops) / 2500.0, 3)}
+
+    def mfma_calibration_table(self, target_ms: float = 25.0) -> list:
+        """The matrix VERDICT round 5 asked for: both shapes x 1 / 2 waves per SIMD x 8 accumulators (+ the 4-accumulator form of
+        gl_box_calibrate and an all-zeros run), each >= 20 ms."""
+        rows = []
+        for shape in (0, 1):
+            for wps in (1, 2):
+                rows.append(self.mfma_calibrate(shape, wps, 8, False, target_ms))
+        rows.append(self.mfma_calibrate(0, 2, 4, False, target_ms))
+        rows.append(self.mfma_calibrate(0, 2, 8, True, target_ms))
+        return rows
+
     def set_ff_rows_policy(self, mode: int) -> None:
         """Row-local feed-forward kernel or two GEMMs at C = 320 (gl_set_ff_rows_policy): -1 = decided by on-device timing (default),
         0 = never, 1 = wherever the kernel exists, 2 = static rule (deterministic kernel choice: the same output bits on every box,

@@ -202,6 +202,19 @@ typedef struct gl_box_calibration {
     float mfma_bf16_tflops;
 } gl_box_calibration;
 int gl_box_calibrate(gl_ctx* ctx, gl_box_calibration* out, gl_stream s);
+/* The dense bf16 MFMA ceiling of THIS box with the clock that explains it: every SIMD issues independent MFMAs back to back for
+ * target_ms (>= 20 ms: long enough for the power management to settle) -- shape 0 = v_mfma_f32_32x32x16_bf16, 1 = 16x16x32; 1 or 2 waves
+ * per SIMD; 4 or 8 independent accumulators per wave; zero_data = 1 multiplies zeros (no operand toggling: the chip clocks higher).
+ * The kernel reads its own shader clock over the loop (s_memtime against the constant 100 MHz s_memrealtime), so tflops / 2500 is
+ * explained by sclk_mhz / 2400 and by cycles_per_mfma (32 for 32x32x16, 16 for 16x16x32 when the pipe is fully paced). A measurement
+ * aid like gl_box_calibrate (bench.py prints the table as box_calibration.mfma); the reference has no counterpart. */
+typedef struct gl_mfma_calibration {
+    float tflops;
+    float sclk_mhz;
+    float ms;
+    float cycles_per_mfma;
+} gl_mfma_calibration;
+int gl_mfma_calibrate(gl_ctx* ctx, int shape, int waves_per_simd, int n_acc, int zero_data, float target_ms, gl_mfma_calibration* out, gl_stream s);
 
 /* PositionNet.forward of the spatial-map modalities (reference canny_/hed_/depth_/normal_/sem_grounding_net.py:38-62):
  * image fp32 [B][C][H][W] (the map as RGB in [-1,1], or in_dim one-hot planes), mask fp32 [B] -> nearest resize to

@@ -998,7 +998,7 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     import subprocess
     from gligen_amd import _lib, engine
     pairs = {"gl_unet_config": _lib.UNetConfig, "gl_vae_config": _lib.VaeConfig, "gl_grounding": _lib.Grounding, "gl_plms_args": _lib.PlmsArgs,
-             "gl_train_unet_in": _lib.TrainUNetIn, "gl_box_calibration": _lib.BoxCalibration, "gl_prof_rec": _lib.ProfRec, "gl_train_block_dims": engine.TrainBlockDims, "gl_train_resblock_dims": engine.TrainResDims}
+             "gl_train_unet_in": _lib.TrainUNetIn, "gl_box_calibration": _lib.BoxCalibration, "gl_mfma_calibration": _lib.MfmaCalibration, "gl_prof_rec": _lib.ProfRec, "gl_train_block_dims": engine.TrainBlockDims, "gl_train_resblock_dims": engine.TrainResDims}
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "gligen_amd.h"\nint main(void) {\n' +
                    "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in pairs) + "  return 0;\n}\n")

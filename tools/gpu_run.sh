@@ -16,6 +16,8 @@
 #   train            tools/train_bench.py $TRAIN_ARGS (default --b4only: the bench line's train_step shape; --full64: every configuration)
 #                    + rocprofv3 stats of one B = 4 iteration with TRAIN_PROF=1
 #   ab VAR A B [N]   same-box A/B of a developer switch: bench.py alternated N times (default 2) with VAR=A / VAR=B
+#   abn VAR N v1 v2 .. --   the same for several values of VAR, N rounds (end the value list with --)
+#   calib            gl_mfma_calibrate table (tools/calib_mfma.py): MFMA ceiling by shape / waves per SIMD / accumulators with the in-loop clock
 #   lib DIR          swap in the variant library built by tools/build_variant.sh for the tasks that follow
 export TMPDIR=/tmp
 R=$PWD
@@ -55,6 +57,12 @@ while [ $# -gt 0 ]; do
            for i in $(seq $n); do for v in $a $b; do
              ( export $var=$v; timeout 500 python bench.py --steps 4 --no-cpu-baseline --no-train-step --no-ff-ab 2>/dev/null ) | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$var=$v value %.3f one_lane %.3f unet_step_ms %.3f eager_sum %.3f' % (d['value'], d['value_one_lane'], d['unet_step_ms'], d['roofline']['eager_sum_ms']))" | tee -a $O/ab_$var.txt
            done; done ;;
+    abn) dev; var=$1; n=$2; shift 2; vals=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do vals+=("$1"); shift; done; [ "$1" = "--" ] && shift
+           : > $O/ab_$var.txt
+           for i in $(seq $n); do for v in "${vals[@]}"; do
+             ( export $var=$v; timeout 500 python bench.py --steps 4 --no-cpu-baseline --no-train-step --no-ff-ab 2>/dev/null ) | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$var=$v value %.3f one_lane %.3f unet_step_ms %.3f eager_sum %.3f' % (d['value'], d['value_one_lane'], d['unet_step_ms'], d['roofline']['eager_sum_ms']))" | tee -a $O/ab_$var.txt
+           done; done ;;
+    calib) dev; ( PYTHONPATH=. timeout 300 python tools/calib_mfma.py ${CALIB_MS:-40} ) > $O/calib_mfma.txt 2> $O/calib_mfma.err; cat $O/calib_mfma.txt | cut -c1-200; tail -2 $O/calib_mfma.err | cut -c1-200 ;;
     lib) d=$1; shift; cp $d/libgligen_amd.so gligen_amd/libgligen_amd.so; [ -f $d/kbench ] && cp $d/kbench $K; echo "library <- $d" ;;
     *) echo "unknown task $task"; exit 2 ;;
   esac
