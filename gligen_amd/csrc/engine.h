@@ -239,14 +239,7 @@ class Engine {
     void build_vae();
 
     // execution helpers
-    void gemm(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, hipStream_t s, float* ws = nullptr, size_t ws_bytes = 0);
-    // side branches of the launch stream (independent work forked / joined with events: the ResBlocks' skip projections)
-    hipStream_t side_branch_begin(hipStream_t s, hipEvent_t* join);
-    hipStream_t side_stream_ = nullptr;
-    std::vector<hipEvent_t> side_events_;
-    int side_cursor_ = 0;
-    float* side_ws_ = nullptr;
-    size_t side_ws_bytes_ = 0;
+    void gemm(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, hipStream_t s);
     bf16* linear_rows(const bf16* x, int M, const LinW& L, int act, const bf16* res, const float* gate, hipStream_t s, RowStats* stats = nullptr);
     bf16* layernorm_plain(const bf16* x, int B, int N, int C, bool pad64, hipStream_t s);   // (x - mean) * rstd, no affine
     bf16* groupnorm(const TRef& x, int B, int HW, const NormW& n, float eps, bool silu, hipStream_t s);

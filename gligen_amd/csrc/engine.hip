@@ -141,8 +141,6 @@ Engine::~Engine() {
     if (smp_.ev_in) (void)hipEventDestroy(smp_.ev_in);
     if (smp_.ev_out) (void)hipEventDestroy(smp_.ev_out);
     if (smp_.ev_done) (void)hipEventDestroy(smp_.ev_done);
-    for (hipEvent_t e : side_events_) (void)hipEventDestroy(e);
-    if (side_stream_) (void)hipStreamDestroy(side_stream_);
     if (smp_.stream) (void)hipStreamDestroy(smp_.stream);
     for (hipEvent_t e : train_events_)
         if (e) (void)hipEventDestroy(e);
@@ -232,7 +230,6 @@ std::shared_ptr<Engine> Engine::fork(const std::shared_ptr<Engine>& parent, size
     e.cond_ = Cond{};
     e.attn_bufs_.clear();
     e.smp_ = Sampler{};
-    e.side_stream_ = nullptr; e.side_events_.clear(); e.side_cursor_ = 0; e.side_ws_ = nullptr; e.side_ws_bytes_ = 0;
     e.train_events_.clear();
     e.fuser_kv_.clear();
     e.emb_table_ = nullptr; e.emb_cur_ = nullptr; e.emb_t_dev_ = nullptr; e.emb_table_cap_ = 0; e.emb_t_cache_.clear();
@@ -979,9 +976,9 @@ static void log_attention(const char* sym, int B, int H, int Nq, int Nk, int d) 
     }
 }
 
-void Engine::gemm(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, hipStream_t s, float* ws, size_t ws_bytes) {
+void Engine::gemm(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, hipStream_t s) {
     ProfScope ps(this, s, "gemm", 2.0 * M * N * K, 0.0);
-    CK(gemm_launch(A, W, M, N, K, E, ws ? ws : ws_, ws ? ws_bytes : ws_bytes_, s));
+    CK(gemm_launch(A, W, M, N, K, E, ws_, ws_bytes_, s));
     if (profiling_) {
         static const bool by_shape = dev_env("GL_PROF_SHAPES") != nullptr;  // developer aid: one record per problem, not per symbol
         std::string nm = gemm_last_kernel_name();  // the symbol the tile selection actually launched
@@ -1086,44 +1083,15 @@ bf16* Engine::conv3x3(const TRef& x, int B, int Hin, int Win, const ConvW& c, in
     return out;
 }
 
-// A side branch of the launch stream s: an engine-owned stream that has waited for everything enqueued on s so far. Returns nullptr
-// when side branches are off (GL_SIDE_BRANCH=0, developer A/B) or the pass is a profiled one; *join is the event the caller records on
-// the side stream behind its last launch and makes s wait for. Events come from a per-context pool, one pair per use within a forward
-// (side_cursor_ restarts with every forward, so an eager pass and the capture of the same forward use the same objects in the same order).
-hipStream_t Engine::side_branch_begin(hipStream_t s, hipEvent_t* join) {
-    static const bool on = !(dev_env("GL_SIDE_BRANCH") && atoi(dev_env("GL_SIDE_BRANCH")) == 0);
-    if (!on || profiling_) return nullptr;
-    if (!side_stream_) {
-        HIPCK(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
-        side_ws_bytes_ = size_t(64) << 20;
-        side_ws_ = reinterpret_cast<float*>(persist(side_ws_bytes_, false));
-    }
-    while (side_events_.size() < 2 * (size_t)(side_cursor_ + 1)) {
-        hipEvent_t e = nullptr;
-        HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        side_events_.push_back(e);
-    }
-    hipEvent_t fork = side_events_[2 * side_cursor_];
-    *join = side_events_[2 * side_cursor_ + 1];
-    ++side_cursor_;
-    HIPCK(hipEventRecord(fork, s));
-    HIPCK(hipStreamWaitEvent(side_stream_, fork, 0));
-    return side_stream_;
-}
-
 // ResBlock._forward (openaimodel.py:212-232) / VAE ResnetBlock.forward (model.py:118-141)
 bf16* Engine::resblock(const ResW& r, const TRef& x, int B, int H, int W, const float* embout, int emb_ld, float eps, hipStream_t s) {
     const int HW = H * W, M = B * HW;
     bf16* out = arena_.get<bf16>((size_t)M * r.Cout);
     const size_t mk = arena_.mark();
-    // skip_connection (a 1 x 1 conv of x, openaimodel.py:230) depends on nothing the in_layers / out_layers chain computes: it runs on a
-    // SIDE branch -- forked here, joined in front of the second conv, whose epilogue adds it -- beside GroupNorm, conv, GroupNorm. Captured
-    // into the evaluation's hipGraph the fork / join are two edges; the projection's launch floor and tail then cost nothing on the
-    // critical path (12 launches of 20-29 us per evaluation). Its own split-K slab: the main branch's convs use theirs meanwhile.
-    // Same kernel, same inputs: the output bits do not depend on the branch. Profiled passes (per-kernel event timing) stay on one stream.
+    bf16* a = groupnorm(x, B, HW, r.n1, eps, true, s);
+    bf16* h = conv3x3(TRef{a, r.Cin, nullptr, 0}, B, H, W, r.c1, 1, 0, 1, embout ? embout + r.emb_off : nullptr, emb_ld, nullptr, s);
+    bf16* a2 = groupnorm(TRef{h, r.Cout, nullptr, 0}, B, HW, r.n2, eps, true, s);
     const bf16* sk;
-    bool joined = true;
-    hipEvent_t ev_join = nullptr;
     if (r.has_skip) {
         bf16* skb = arena_.get<bf16>((size_t)M * r.Cout);
         AOperand A{};
@@ -1131,23 +1099,12 @@ bf16* Engine::resblock(const ResW& r, const TRef& x, int B, int H, int W, const 
         Epilogue E;
         epilogue_defaults(E);
         E.out = skb; E.ldo = r.Cout; E.bias = r.skip.b;
-        hipStream_t ss = side_branch_begin(s, &ev_join);
-        if (ss) {
-            gemm(A, r.skip.w, M, r.Cout, r.Cin, E, ss, side_ws_, side_ws_bytes_);
-            HIPCK(hipEventRecord(ev_join, ss));
-            joined = false;
-        } else {
-            gemm(A, r.skip.w, M, r.Cout, r.Cin, E, s);
-        }
+        gemm(A, r.skip.w, M, r.Cout, r.Cin, E, s);
         sk = skb;
     } else {
         if (x.p1) throw GlError(GL_ERR_STATE, "identity skip over a concatenated input");
         sk = x.p0;
     }
-    bf16* a = groupnorm(x, B, HW, r.n1, eps, true, s);
-    bf16* h = conv3x3(TRef{a, r.Cin, nullptr, 0}, B, H, W, r.c1, 1, 0, 1, embout ? embout + r.emb_off : nullptr, emb_ld, nullptr, s);
-    bf16* a2 = groupnorm(TRef{h, r.Cout, nullptr, 0}, B, HW, r.n2, eps, true, s);
-    if (!joined) HIPCK(hipStreamWaitEvent(s, ev_join, 0));
     {
         AOperand A{};
         A.p0 = a2; A.C0 = r.Cout; A.ld0 = r.Cout; A.mode = A_CONV3;
@@ -1909,7 +1866,6 @@ void Engine::unet_forward(int Beff, int h, int w, const float* x, int xB, const 
     if (xB <= 0 || Beff % xB != 0) throw GlError(GL_ERR_ARG, "x batch must divide the effective batch");
     const int mc = c.model_channels;
     arena_.reset();
-    side_cursor_ = 0;
 
     // time embedding: emb = time_embed(timestep_embedding(t)); every ResBlock consumes SiLU(emb)
     const float* embout = emb_row;
@@ -2082,7 +2038,6 @@ void Engine::vae_decode(int B, int h, int w, const float* z, float* out, hipStre
     if (!has_vae_ || !finalized_) throw GlError(GL_ERR_STATE, "vae not finalized");
     const gl_vae_config& c = vcfg_;
     arena_.reset();
-    side_cursor_ = 0;
     int H = h, W = w;
     bf16* cur;
     int C = vae_in_small_.Cout;
@@ -2137,7 +2092,6 @@ void Engine::vae_encode(int B, int H, int W, const float* img, const float* nois
     const int total_stride = 1 << (c.n_mult - 1);
     if (H % total_stride || W % total_stride) throw GlError(GL_ERR_ARG, "vae_encode: image size must be divisible by the encoder stride");
     arena_.reset();
-    side_cursor_ = 0;
     int C = venc_in_small_.Cout;
     bf16* cur;
     {

@@ -873,15 +873,14 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
 
     // DMA of K tile l_kt into ring slot `slot`, then advance the cursor by one tile
     bool more = true;
-    // the two halves of a K tile's DMA (activation rows, weight rows) and the cursor advance: issue_next is the three in a row;
-    // GL_U_ORDER (developer A/B, tools/build_variant.sh) places them differently around the multiply (see the main loop)
-    auto issue_x = [&](int slot_) {
+    auto issue_next = [&](int slot_) {
         // the cursor is wave-uniform by construction; say so, or one value merged through a divergent
         // branch makes hipcc wrap every buffer_load in a waterfall loop (descriptor / soffset / m0 "divergent")
         const int slot = __builtin_amdgcn_readfirstlane(slot_);
         l_cc = __builtin_amdgcn_readfirstlane(l_cc);
         l_kt = __builtin_amdgcn_readfirstlane(l_kt);
         unsigned char* xs = smem + slot * STAGE + wave * 1024;
+        unsigned char* wsm = xs + BM * 128;
         const bool first = l_cc < A.C0;
         const int soff = (first ? l_cc : l_cc - A.C0) * 2;
         if (first) {
@@ -891,16 +890,10 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
 #pragma unroll
             for (int i = 0; i < XP; ++i) GL_BLDS16(ra1, xs + i * RPP * 128, va[i], soff);
         }
-    };
-    auto issue_w = [&](int slot_) {
-        const int slot = __builtin_amdgcn_readfirstlane(slot_);
-        l_kt = __builtin_amdgcn_readfirstlane(l_kt);
-        unsigned char* wsm = smem + slot * STAGE + wave * 1024 + BM * 128;
         const int woff = l_kt << 7;
 #pragma unroll
         for (int i = 0; i < WP; ++i) GL_BLDS16(rw, wsm + i * RPP * 128, vw[i], woff);
-    };
-    auto issue_advance = [&]() {
+        // advance
         l_cc += 64;
         if (++l_kt >= l_kt_end) {
             l_item += gridDim.x;
@@ -917,11 +910,6 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
         } else {
             if (A.C1 && l_cc == A.C0) a_offsets();
         }
-    };
-    auto issue_next = [&](int slot_) {
-        issue_x(slot_);
-        issue_w(slot_);
-        issue_advance();
     };
 
     f32x4 acc[TM][TN];
@@ -944,13 +932,7 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     // swapv (wave-uniform, EPI_QKV_HEADS items in the V third): MFMA operand roles exchanged -- lane (l15, q) then holds
     // feature l15 and tokens 4q .. 4q+3 of every 16x16 tile (the v^T store pattern) instead of token l15, features 4q .. 4q+3
-#ifndef GL_U_ORDER
-#define GL_U_ORDER 0
-#endif
-    // GL_U_ORDER: where the NEXT tile's DMA is issued relative to this tile's multiply. 0 (shipped): all of it right behind the barrier,
-    // in front of the fragment reads. 1: behind the fragment reads' issue (the DMA issue runs in the shadow of the LDS round trip).
-    // 2: activation rows behind the reads, weight rows between the two K steps' MFMAs (the TA works while the matrix pipe does).
-    auto compute = [&](int slot, bool swapv, bool dma_more) {
+    auto compute = [&](int slot, bool swapv) {
         const unsigned st = lds0 + slot * STAGE;
         const unsigned ax0 = st + xrow0 + foff0, ax1 = st + xrow0 + foff1;
         const unsigned aw0 = st + wrow0 + foff0, aw1 = st + wrow0 + foff1;
@@ -959,11 +941,6 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
         lds_rd16_n<TN, 2048>(wa, aw0);
         lds_rd16_n<TM, 2048>(xb, ax1);
         lds_rd16_n<TN, 2048>(wb, aw1);
-        if constexpr (GL_U_ORDER == 1) {
-            if (dma_more) issue_next(slot ^ 1);
-        } else if constexpr (GL_U_ORDER == 2) {
-            if (dma_more) issue_x(slot ^ 1);
-        }
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN));  // the k-step 0 fragments have returned
         pin_regs(xa);
         pin_regs(wa);
@@ -980,10 +957,6 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i], wa[j], acc[i][j], 0, 0, 0);
-        }
-        if constexpr (GL_U_ORDER == 2) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (dma_more) { issue_w(slot ^ 1); issue_advance(); }
         }
         asm volatile("s_waitcnt lgkmcnt(0)");
         pin_regs(xb);
@@ -1515,11 +1488,8 @@ gemm_u_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilo
         // tile c is in LDS for every wave after this barrier, and every wave has finished reading tile c-1
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const bool dma_more = more;
-        if constexpr (GL_U_ORDER == 0) {
-            if (more) issue_next(slot_c ^ 1);
-        }
-        compute(slot_c, c_swap, dma_more);
+        if (more) issue_next(slot_c ^ 1);
+        compute(slot_c, c_swap);
         const int slot_done = slot_c;
         slot_c ^= 1;
         if (--c_left == 0) {
@@ -2034,17 +2004,7 @@ gemm_wide_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
     unsigned vx0 = 0, vx1 = 0, vw0 = 0;   // byte offsets of this lane's chunk of row (tile's first row + r0) in p0 / p1 / W; pass i adds 64 rows
     auto setup = [&](int item_) {
         int item = item_;
-        if (wd.xcd >= 16) {
-            // XCD boxes (wd.xcd = a << 4 | b, a b = 8, unsplit problems): XCD x owns row-tile group x % a and column-tile group x / a, and
-            // walks its box column by column -- its 32 workgroups then hold ALL the box's row tiles against a few column tiles at a time:
-            // a weight tile crosses the fabric once per box and is shared by tiles_m / a workgroups while it is hot, and the box's
-            // activation rows (M / a of them) are what is re-streamed
-            const int a = wd.xcd >> 4, b = wd.xcd & 15;
-            const int xcd = item & 7, idx = item >> 3;
-            const int rm = (M / BM) / a, rn = wd.tiles_n / b;
-            const int tnl = idx / rm, tml = idx - tnl * rm;
-            item = ((xcd % a) * rm + tml) * wd.tiles_n + (xcd / a) * rn + tnl;
-        } else if (wd.xcd) {
+        if (wd.xcd) {
             // block b sits on XCD b % 8 and the grid is a multiple of 8, so item & 7 is this workgroup's XCD: give every XCD a
             // contiguous range of the (tile_m, tile_n) order -- the 32 workgroups of an XCD then walk the column tiles of the same
             // one or two 256-row stripes together and the stripe crosses the fabric once, not once per XCD
@@ -2099,12 +2059,7 @@ gemm_wide_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xb[i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
-#ifndef GL_W_ORDER
-#define GL_W_ORDER 0
-#endif
-    // GL_W_ORDER (developer A/B): 0 (shipped) = the next tile's DMA right behind the barrier; 1 = behind the deferred K step and the
-    // fragment reads' issue (in the shadow of the LDS round trip); 2 = between K step 0's MFMAs and the wait for K step 1's fragments
-    auto compute = [&](int stg, bool pending, int dma_kt) {
+    auto compute = [&](int stg, bool pending) {
         const unsigned st = lds0 + stg * STAGE;
         const unsigned ax0 = st + xrow0 + foff0, ax1 = st + xrow0 + foff1;
         const unsigned aw0 = st + wrow0 + foff0, aw1 = st + wrow0 + foff1;
@@ -2114,9 +2069,6 @@ gemm_wide_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
         lds_rd16_n<TN, 2048>(wa, aw0);
         lds_rd16_n<TM, 2048>(xb, ax1);
         lds_rd16_n<TN, 2048>(wb, aw1);
-        if constexpr (GL_W_ORDER == 1) {
-            if (dma_kt >= 0) issue(dma_kt, stg ^ 1);
-        }
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN));  // the k-step 0 fragments have returned
         pin_regs(xa);
         pin_regs(wa);
@@ -2127,10 +2079,6 @@ gemm_wide_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
             for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xa[i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);   // (keeps K step 0's MFMAs in front of the wait below: they only need the first TM + TN reads)
-        if constexpr (GL_W_ORDER == 2) {
-            if (dma_kt >= 0) issue(dma_kt, stg ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
         // every fragment read of this stage has RETURNED before the wave reaches the next barrier: behind that barrier the stage is
         // overwritten by DMA, and K step 1's fragments are consumed (the asm reads are invisible to hipcc's own lgkmcnt tracking)
         asm volatile("s_waitcnt lgkmcnt(0)");
@@ -2297,13 +2245,9 @@ gemm_wide_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        int dma_kt = -1;
         if (NST == 3) { if (kt + 2 < kt_end) issue(kt + 2, ring_next(ring_next(stg))); }
-        else if (kt + 1 < kt_end) {
-            if constexpr (GL_W_ORDER == 0) issue(kt + 1, stg ^ 1);
-            else dma_kt = kt + 1;
-        }
-        compute(stg, !first, dma_kt);
+        else if (kt + 1 < kt_end) issue(kt + 1, stg ^ 1);
+        compute(stg, !first);
         stg_done = stg;
         stg = ring_next(stg);
         ++kt;
@@ -2581,10 +2525,6 @@ int launch_wide(const AOperand& A, const bf16* W, int M, int N, int K, const Epi
     static const char* xcd_env = dev_env("GL_WIDE_XCD");
     wd.xcd = xcd_env ? atoi(xcd_env) : (wd.tiles_n % 8 != 0 && wd.n_items >= 512);
     if (wd.n_items < 256 || std::min(wd.n_items, 256) % 8) wd.xcd = 0;
-    if (wd.xcd >= 16) {   // a box partition must be exact, and the item count a multiple of 8 (every XCD the same number of items)
-        const int a = wd.xcd >> 4, b = wd.xcd & 15;
-        if (a * b != 8 || wd.splits != 1 || (M / 256) % a || wd.tiles_n % b || wd.n_items % 8) wd.xcd = 0;
-    }
     g_last_cfg[0] = 8; g_last_cfg[1] = tn; g_last_cfg[2] = wd.splits;
     snprintf(g_last_name, sizeof g_last_name, "gemm_wide_kernel<%d>%s", tn, wd.splits > 1 ? " + splitk_reduce_kernel" : "");
     dim3 grid(std::min(wd.n_items, 256)), block(512);

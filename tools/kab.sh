@@ -17,7 +17,7 @@ tab, order, chk = {}, [], {}
 for v in vs:
     for r in range(1, rounds + 1):
         for line in open(f"{O}/kab_{b}_{v}_{r}.txt"):
-            m = re.match(r"^((?:gemm|conv|attn|gn|ln)[ \d]+?)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+(\d+)\s+(\S+)", line)
+            m = re.match(r"^((?:gemm|conv|attn|gn|ln)(?: \d+)+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+(\d+)\s+(\S+)", line)
             if m:
                 key, us, cnt = m.group(1).strip(), float(m.group(2)), int(m.group(5))
                 if key not in order: order.append(key)
