@@ -481,18 +481,19 @@ int main(int argc, char** argv) {
             continue;
         }
         if (sweep && c <= 1) {
-            static const int tms[6] = {4, 4, 2, 2, 8, 8}, tns[6] = {5, 4, 5, 4, 5, 4};
+            static const int tms[7] = {4, 4, 2, 2, 8, 8, 2}, tns[7] = {5, 4, 5, 4, 5, 4, 2};
             static const int sps[8] = {1, 2, 3, 4, 6, 8, 12, 16};
             float best = 1e30f;
             int btm = 0, btn = 0, bsp = 0, bgrid = 0;
             std::string all;
-            for (int gi = 0; gi < 2; ++gi)
-                for (int ci = 0; ci < 6; ++ci)
+            for (int gi = 0; gi < 3; ++gi)
+                for (int ci = 0; ci < 7; ++ci)
                     for (int si = 0; si < 8; ++si) {
                         if (c == 0 && v[3] == 1 && (tns[ci] & 1)) continue;
                         if (tms[ci] >= 8 && gi) continue;  // the wide / deep kernels always run one workgroup per CU
-                        const int grid = gi ? 768 : 512;
-                        if (gi && (tms[ci] >= 8 || tms[ci] * 32 + tns[ci] * 32 > 192)) continue;  // 3 blocks/CU only fit for <= 48 KB of LDS
+                        const int grid = gi == 0 ? 512 : gi == 1 ? 768 : 1024;
+                        if (gi == 1 && (tms[ci] >= 8 || tms[ci] * 32 + tns[ci] * 32 > 192)) continue;  // 3 blocks/CU only fit for <= 48 KB of LDS
+                        if (gi == 2 && tms[ci] * 32 + tns[ci] * 32 > 128) continue;                     // 4 blocks/CU: the 64 x 64 tile
                         gemm_force_cfg(tms[ci], tns[ci], sps[si]);
                         gemm_force_grid(grid);
                         const int nk = gK / 64;
