@@ -123,6 +123,7 @@ SYMBOLS = {
     "gl_op_ff_chain": (_I, [_P, _P, _I, _I] + [_P] * 16),
     "gl_op_conv3x3": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "gl_op_groupnorm": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, C.c_float, _I, _P, _P]),
+    "gl_op_gn_silu_conv3x3": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, C.c_float, _P, _P, _I, _P, _P, _P, _I, _P, _P]),
     "gl_op_layernorm": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, C.c_float, _P, _P]),
     "gl_op_attention": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
 }

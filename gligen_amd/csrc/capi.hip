@@ -698,6 +698,38 @@ int gl_op_conv3x3(gl_ctx* ctx, const void* x0, int C0, const void* x1, int C1, i
     GL_API_END
 }
 
+int gl_op_gn_silu_conv3x3(gl_ctx* ctx, const void* x0, int C0, const void* x1, int C1, int B, int H, int W, const float* gamma, const float* beta,
+                          float eps, const float* w_oihw, const float* bias, int Cout, const float* bias2, const void* res, void* y, int mode,
+                          int* used_prologue, gl_stream s) {
+    NEED(ctx);
+    if (!x0 || !gamma || !beta || !w_oihw || !y || !used_prologue) return gl::set_error(GL_ERR_ARG, "gl_op_gn_silu_conv3x3: null pointer");
+    GL_API_BEGIN
+    Engine& eng = *ctx->eng;
+    Arena& ar = eng.arena();
+    ar.reset();
+    const int Cin = C0 + C1;
+    bf16* wp = ar.get<bf16>((size_t)Cout * 9 * Cin);
+    int r = pack_conv_weight_launch(w_oihw, wp, Cout, Cin, 3, 3, Cout, S(s));
+    if (r != GL_OK) throw GlError(r, gl::last_error());
+    NormW n;
+    n.g = gamma; n.b = beta; n.C = Cin;
+    ConvW c;
+    c.w = wp; c.b = bias; c.Cin = Cin; c.Cout = Cout;
+    const bool saved = eng.gn_prologue_;
+    if (mode >= 0) eng.gn_prologue_ = mode != 0;
+    const int64_t n0 = eng.n_prologue_convs;
+    try {
+        eng.gn_silu_conv3x3(TRef{(const bf16*)x0, C0, (const bf16*)x1, C1}, B, H, W, n, eps, c, bias2, Cout, (const bf16*)res, (bf16*)y, S(s));
+    } catch (...) {
+        eng.gn_prologue_ = saved;
+        throw;
+    }
+    eng.gn_prologue_ = saved;
+    *used_prologue = eng.n_prologue_convs > n0 ? 1 : 0;
+    if (mode == 1 && !*used_prologue) throw GlError(GL_ERR_UNSUPPORTED, "gl_op_gn_silu_conv3x3: this shape has no GroupNorm prologue (conv_halo_kernel, H W % 256 == 0)");
+    GL_API_END
+}
+
 int gl_op_groupnorm(gl_ctx* ctx, const void* x0, int C0, const void* x1, int C1, int B, int HW,
                     const float* gamma, const float* beta, float eps, int silu, void* y, gl_stream s) {
     NEED(ctx);

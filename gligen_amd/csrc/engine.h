@@ -188,6 +188,15 @@ class Engine {
     void init_workspace();
     AttnBufs& attn_bufs(int B, int H, int d, int Tq, int Tk, int dpv_layout = 0, int slot = 0);   // dpv_layout: V^T rows when not attn_dims' (attn_vt_layout)
 
+    // GroupNorm32 -> SiLU -> conv3x3 (stride 1, pad 1); out = nullptr: from the arena. GroupNorm-apply + SiLU run inside the conv's
+    // loader where conv_halo_kernel takes the problem (gn_prologue_), as a separate pass elsewhere
+    bf16* gn_silu_conv3x3(const TRef& x, int B, int H, int W, const NormW& n, float eps, const ConvW& c, const float* bias2, int bias2_ld,
+                          const bf16* res, bf16* out, hipStream_t s);
+    // Off by default: measured on MI355X (profiles/r6/gnconv_kbench.txt) the prologue costs conv_halo_kernel more (LDS port + VALU slots,
+    // the two things that kernel is short of) than the apply pass it removes; GL_GN_PROLOGUE=1 (developer switch) turns it on in the
+    // engine, gl_op_gn_silu_conv3x3(mode = 1) runs it for one operator
+    bool gn_prologue_ = dev_env("GL_GN_PROLOGUE") && atoi(dev_env("GL_GN_PROLOGUE")) == 1;
+    int64_t n_prologue_convs = 0;   // convs launched with the GroupNorm prologue so far (gl_op_gn_silu_conv3x3 reports which form ran)
     int device() const { return device_; }
     int64_t n_launches = 0;
     // events of the training step's gradient milestones (train.h unet_train_step: grad_events), created on first use

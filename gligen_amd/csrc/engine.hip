@@ -1043,6 +1043,47 @@ bf16* Engine::groupnorm(const TRef& x, int B, int HW, const NormW& n, float eps,
     return y;
 }
 
+// GroupNorm32 -> SiLU -> conv3x3 (reference openaimodel.py:212-232 in_layers / out_layers; VAE model.py:118-141). Where the conv runs
+// on conv_halo_kernel the GroupNorm keeps only its statistics pass (groupnorm_coef_launch) and the conv normalises + activates
+// its input while staging it (AOperand::gn): the normalised copy is never written to HBM. Elsewhere: the two passes of rounds 1-5.
+bf16* Engine::gn_silu_conv3x3(const TRef& x, int B, int H, int W, const NormW& n, float eps, const ConvW& c, const float* bias2, int bias2_ld,
+                              const bf16* res, bf16* out, hipStream_t s) {
+    if (x.C() != c.Cin || n.C != c.Cin) throw GlError(GL_ERR_ARG, fmt("gn_silu_conv3x3: %d channels into a norm of %d and a conv of %d", x.C(), n.C, c.Cin));
+    const int HW = H * W, M = B * HW;
+    if (!out) out = arena_.get<bf16>((size_t)M * c.Cout);
+    AOperand A{};
+    A.p0 = x.p0; A.C0 = x.C0; A.ld0 = x.C0;
+    A.p1 = x.p1; A.C1 = x.C1; A.ld1 = x.C1;
+    A.mode = A_CONV3;
+    A.Hin = H; A.Win = W; A.Ho = H; A.Wo = W; A.stride = 1; A.ups = 0; A.pad_lo = 1;
+    Epilogue E;
+    epilogue_defaults(E);
+    E.out = out; E.ldo = c.Cout; E.bias = c.b;
+    E.bias2 = bias2; E.bias2_ld = bias2_ld; E.rows_per_b = HW;
+    E.res = res; E.ldres = c.Cout;
+    if (gn_prologue_ && gemm_gn_prologue_supported(A, M, c.Cout, 9 * c.Cin, E)) {
+        GNParams P{};
+        P.x0 = x.p0; P.C0 = x.C0; P.x1 = x.p1; P.C1 = x.C1;
+        P.B = B; P.HW = HW; P.eps = eps; P.gamma = n.g; P.beta = n.b; P.silu = 1;
+        P.partial = reinterpret_cast<float*>(arena_.alloc(gn_partial_bytes(B, HW)));
+        P.coef = reinterpret_cast<float*>(arena_.alloc(gn_coef_bytes(B, c.Cin)));
+        {
+            const int nl = groupnorm_coef_launches(HW, x.C0, x.C1);
+            ProfScope ps(this, s, nl == 1 ? "gn_small_coef_kernel" : "gn_stats_kernel + gn_coef_kernel", 0.0, 1.0 * B * HW * (double)c.Cin * 2);
+            CK(groupnorm_coef_launch(P, s));
+            n_launches += nl;
+        }
+        A.gn = P.coef;
+        gemm(A, c.w, M, c.Cout, 9 * c.Cin, E, s);
+        ++n_prologue_convs;
+        return out;
+    }
+    bf16* a = groupnorm(x, B, HW, n, eps, true, s);
+    A.p0 = a; A.C0 = c.Cin; A.ld0 = c.Cin; A.p1 = nullptr; A.C1 = 0; A.ld1 = 0;
+    gemm(A, c.w, M, c.Cout, 9 * c.Cin, E, s);
+    return out;
+}
+
 bf16* Engine::layernorm(const bf16* x, int B, int N, int C, const NormW& n, bool pad64, hipStream_t s) {
     const int Tp = pad64 ? round_up(N, 64) : N;
     bf16* y = arena_.get<bf16>((size_t)B * Tp * C);
@@ -1088,9 +1129,7 @@ bf16* Engine::resblock(const ResW& r, const TRef& x, int B, int H, int W, const 
     const int HW = H * W, M = B * HW;
     bf16* out = arena_.get<bf16>((size_t)M * r.Cout);
     const size_t mk = arena_.mark();
-    bf16* a = groupnorm(x, B, HW, r.n1, eps, true, s);
-    bf16* h = conv3x3(TRef{a, r.Cin, nullptr, 0}, B, H, W, r.c1, 1, 0, 1, embout ? embout + r.emb_off : nullptr, emb_ld, nullptr, s);
-    bf16* a2 = groupnorm(TRef{h, r.Cout, nullptr, 0}, B, HW, r.n2, eps, true, s);
+    bf16* h = gn_silu_conv3x3(x, B, H, W, r.n1, eps, r.c1, embout ? embout + r.emb_off : nullptr, emb_ld, nullptr, nullptr, s);
     const bf16* sk;
     if (r.has_skip) {
         bf16* skb = arena_.get<bf16>((size_t)M * r.Cout);
@@ -1105,15 +1144,7 @@ bf16* Engine::resblock(const ResW& r, const TRef& x, int B, int H, int W, const 
         if (x.p1) throw GlError(GL_ERR_STATE, "identity skip over a concatenated input");
         sk = x.p0;
     }
-    {
-        AOperand A{};
-        A.p0 = a2; A.C0 = r.Cout; A.ld0 = r.Cout; A.mode = A_CONV3;
-        A.Hin = H; A.Win = W; A.Ho = H; A.Wo = W; A.stride = 1; A.ups = 0; A.pad_lo = 1;
-        Epilogue E;
-        epilogue_defaults(E);
-        E.out = out; E.ldo = r.Cout; E.bias = r.c2.b; E.res = sk; E.ldres = r.Cout;
-        gemm(A, r.c2.w, M, r.Cout, 9 * r.Cout, E, s);
-    }
+    gn_silu_conv3x3(TRef{h, r.Cout, nullptr, 0}, B, H, W, r.n2, eps, r.c2, nullptr, 0, sk, out, s);
     arena_.release(mk);
     return out;
 }

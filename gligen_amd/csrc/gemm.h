@@ -18,6 +18,11 @@ struct AOperand {
     int mode;
     int Hin, Win, Ho, Wo;  // conv geometry (source dims are pre-upsample)
     int stride, ups, pad_lo;
+    // GroupNorm + SiLU as the conv's prologue (round 6; reference openaimodel.py:212-232 in_layers / out_layers: GroupNorm32 -> SiLU ->
+    // conv): coefficients [B][(C0+C1) / 8][16] from groupnorm_coef_launch (norm.h); the kernel stages the RAW tensor and applies
+    // y = silu(x * a + c) to every real pixel inside LDS (padding stays zero). Only conv_halo_kernel implements it:
+    // ask gemm_gn_prologue_supported() first.
+    const float* gn = nullptr;
 };
 
 // EPI_QKV_HEADS: one GEMM over the concatenated [to_q ; to_k ; to_v] rows: columns [0,C) -> q, [C,2C) -> k (as EPI_QK_HEADS),
@@ -103,6 +108,7 @@ void gemm_force_grid(int blocks);                  // 0 = automatic (512)
 void gemm_set_autotune(int on);                    // 1 (default): time candidates at the first eager launch of a problem
 void gemm_last_cfg(int* tm, int* tn, int* splits);
 const char* gemm_last_kernel_name();  // kernel symbol (template arguments included) of the most recent gemm_launch
+bool gemm_gn_prologue_supported(const AOperand& A, int M, int N, int K, const Epilogue& E);   // may this launch take AOperand::gn?
 bool gemm_ln_fold_supported(const AOperand& A, int M, int N, int K, const Epilogue& E);   // may this launch take Epilogue::ln_stats?
 int gemm_last_stats_nb();             // column blocks per row written to Epilogue::stats_out by the most recent gemm_launch (0: none)
 void aoperand_rows(AOperand& A, const bf16* p, int K, int ld);

@@ -1631,7 +1631,13 @@ struct HaloDesc {
     int lgW, lgH;   // image width / height (powers of two)
 };
 
-template <int TN, int NW>
+// GN = true (round 6): GroupNorm-apply + SiLU as the conv's prologue (reference openaimodel.py:212-232: GroupNorm32 -> SiLU -> conv).
+// The RAW tensor is staged; every lane then normalises, in LDS, exactly the 16-byte piece its own DMA wrote (pass p of the next
+// chunk is issued with tap p, has landed behind tap p + 1's vmcnt(0) and is rewritten during tap p + 1: no extra barrier, the
+// chunk is first read two or more barriers later), from the chunk's 64 x (a, c) coefficients that one more 512-byte DMA brings
+// into LDS beside the halo. Padding pixels never pass through the transform and stay zero, as the reference pads the ACTIVATED
+// tensor. An item's first chunk (all seven passes issued at once by begin_item) is rewritten in front of its first barrier.
+template <int TN, int NW, bool GN = false>
 __global__ void __launch_bounds__(NW * 64, 1)
 conv_halo_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Epilogue E, float* __restrict__ ws, HaloDesc hd) {
     constexpr int NT = NW * 64;
@@ -1647,7 +1653,9 @@ conv_halo_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
     constexpr int WP = (BN + RPP - 1) / RPP;    // weight DMA passes; the last one is partial when BN % RPP != 0
     constexpr int WREM = BN % RPP;
     constexpr unsigned SENT = 0x80000000u;
+    constexpr int COEF0 = 2 * HBUF + 2 * WSLOT;  // GN: two 1 KiB coefficient slots behind the weight slots (a DMA writes 64 x 16 B)
     static_assert(HPASS * RPP == HROWS && HPT * 7 >= HPASS && WREM % 8 == 0, "loader geometry");
+    static_assert(!GN || (HPT == 1 && HPASS == 7), "the prologue rewrites pass p of the next chunk during tap p + 1");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -1728,7 +1736,10 @@ conv_halo_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
         const bool first = cc < A.C0;
         const unsigned ld2 = (unsigned)(first ? A.ld0 : A.ld1) * 2u;
         const int soff = (first ? cc : cc - A.C0) * 2;
-        const int h = p * RPP + r0;
+        int h = p * RPP + r0;
+        // GN: the row map really is recomputed per pass -- without this hipcc hoists the seven item-invariant (pixel, mask) pairs out of
+        // the chunk loop, and with the prologue's registers on top of the accumulators they no longer fit (spills inside the K loop)
+        if constexpr (GN) asm volatile("" : "+v"(h));
         const int blk = (int)(((unsigned)h * inv_blk) >> 22);
         const int rem = h - blk * blkrows;
         const int hy = (int)(((unsigned)rem * inv_w2) >> 22);
@@ -1750,6 +1761,77 @@ conv_halo_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
             if (WREM && i == WP - 1 && wave >= WREM / 8) continue;   // wave-uniform
             GL_BLDS16(rw, dst + i * RPP * 128, vw0, soff + i * RPP * K * 2);
         }
+    };
+
+    // GN: the 64 x (a, c) coefficients of channel chunk cc of the tile's sample (a 256-pixel tile lies inside one image: H W >= 256,
+    // checked on the host) into coefficient slot hb: 512 contiguous bytes, lanes 0..31 of wave 0 (the other lanes write zeros)
+    auto issue_coef = [&](int cc_, int hb_) {
+        if constexpr (GN) {
+            if (wave == 0) {
+                const int cc = __builtin_amdgcn_readfirstlane(cc_);
+                const int hb = __builtin_amdgcn_readfirstlane(hb_);
+                const int smp = m0 >> (hd.lgW + hd.lgH);
+                // (flat-address DMA: a fourth buffer descriptor would cost four SGPRs this kernel does not have; lanes 32..63 fetch the
+                // same 512 bytes again into the slot's unused upper half)
+                // scalar base + 32-bit lane offset, the lane id taken from v_mbcnt on the spot: any lane constant that lives across the
+                // tap loop for this one instruction is a register the loop does not have (it was spilled, and its reload drained the DMA)
+                unsigned lo;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
+                lo = (lo & 31u) * 16u;
+                GL_GLDS16(reinterpret_cast<const unsigned char*>(A.gn) + (size_t)(unsigned)((smp * Cin + cc) * 8) + lo, smem + COEF0 + hb * 1024);
+            }
+        }
+    };
+    // GN: rewrite the 16-byte piece this lane's DMA of pass p wrote into halo buffer hb (8 channels of halo row p RPP + r0) as
+    // bf16(silu(x a + c)) -- the arithmetic of gn_apply_kernel (norm.hip), so the conv multiplies the very values the two-pass form
+    // would have read back from HBM. Lanes whose halo row is padding hold zeros and skip. LDS accesses in asm: a compiler-visible
+    // LDS access behind an LDS-DMA issue would drain vmcnt(0) (see lds_rd16).
+    // pass = PC::value + prt: the compile-time part rides in the DS instructions' offset field (a per-pass address in a VGPR is
+    // loop invariant, hipcc hoists all seven out of the chunk loop and spills them), prt is the run-time pass of the first-chunk loop.
+    // Three steps so that the caller can put matrix work between them: xf_read (five LDS reads), xf_math (after the caller's lgkmcnt
+    // wait; branch-free: lanes whose halo row is padding compute on their zeros and select zero -- MFMAs can then be interleaved), xf_write.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    struct XF { f32x4 a0, a1, c0, c1; };
+    struct XP1 { u32x4 v; unsigned addr; bool ok; };
+    // rsh: 0 = the piece this lane's own DMA wrote (a row shift reaches another wave's piece: valid behind a barrier only)
+    auto xf_piece = [&](auto PC, int prt, int hb, int rsh, XP1& x) {
+        constexpr int PI = decltype(PC)::value;
+        int h = (PI + prt) * RPP + r0 + rsh;
+        asm volatile("" : "+v"(h));       // (recomputed per call, see issue_halo)
+        const int blk = (int)(((unsigned)h * inv_blk) >> 22);
+        const int rem = h - blk * blkrows;
+        const int hy = (int)(((unsigned)rem * inv_w2) >> 22);
+        const int hx = rem - hy * W2;
+        x.ok = h < NH && hx >= 1 && hx <= Wd && (hy != 0 || top_ok) && (hy != HB + 1 || bot_ok);
+        x.addr = lds0 + hb * HBUF + (prt * RPP + rsh) * 128 + t * 16;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x.v) : "v"(x.addr), "n"(PI * RPP * 128));
+    };
+    auto xf_coef = [&](int hb, XF& x) {
+        const unsigned caddr = lds0 + COEF0 + hb * 1024 + (((t & 7) ^ (r0 & 6)) << 6);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(x.a0) : "v"(caddr));
+        asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(x.c0) : "v"(caddr));
+        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(x.a1) : "v"(caddr));
+        asm volatile("ds_read_b128 %0, %1 offset:48" : "=v"(x.c1) : "v"(caddr));
+    };
+    auto xf_wait = [&](XF& x, XP1& p) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p.v), "+v"(x.a0), "+v"(x.a1), "+v"(x.c0), "+v"(x.c1)); };
+    auto xf_math = [&](const XF& x, const XP1& p) -> u32x4 {
+        const float a[8] = {x.a0[0], x.a0[1], x.a0[2], x.a0[3], x.a1[0], x.a1[1], x.a1[2], x.a1[3]};
+        const float c[8] = {x.c0[0], x.c0[1], x.c0[2], x.c0[3], x.c1[0], x.c1[1], x.c1[2], x.c1[3]};
+        union { u32x4 u; bf16 e[8]; } o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned w = p.v[i];
+            const float x0 = __uint_as_float(w << 16), x1 = __uint_as_float(w & 0xffff0000u);
+            o.e[2 * i] = f2bf(silu_f(fmaf(x0, a[2 * i], c[2 * i])));
+            o.e[2 * i + 1] = f2bf(silu_f(fmaf(x1, a[2 * i + 1], c[2 * i + 1])));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o.u[i] = p.ok ? o.u[i] : 0u;
+        return o.u;
+    };
+    auto xf_write = [&](auto PC, const XP1& p, u32x4 o) {
+        constexpr int PI = decltype(PC)::value;
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(p.addr), "v"(o), "n"(PI * RPP * 128));
     };
 
     f32x4 acc[TM][TN];
@@ -1802,6 +1884,48 @@ conv_halo_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xb[i], acc[i][j], 0, 0, 0);
+    };
+
+    // GN variant: the same tile with K step 1 deferred BY HAND (what hipcc does by itself above: its MFMAs sink behind the next barrier
+    // down to the first inline asm). Written out because the prologue's arithmetic has to sit between those MFMAs: k1_mfma(lo, hi)
+    // issues MFMAs lo..hi-1 of the pending K step 1 (fragments xbp / wbp stay in registers across the barrier).
+    bf16x8 xbp[TM], wbp[TN];
+    auto k1_mfma = [&](auto LO, auto HI) {
+#pragma unroll
+        for (int ij = decltype(LO)::value; ij < decltype(HI)::value; ++ij)
+            acc[ij / TN][ij % TN] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbp[ij % TN], xbp[ij / TN], acc[ij / TN][ij % TN], 0, 0, 0);
+    };
+    auto compute_k0 = [&](int tapoff, int hb, int wsl) {   // fragment reads of both K steps, K step 0's MFMAs; K step 1 stays pending
+        const unsigned hbase = lds0 + hb * HBUF;
+        const unsigned wbase = lds0 + 2 * HBUF + wsl * WSLOT + wrow0;
+        unsigned ax0[TM], ax1[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const unsigned hr = (unsigned)(hr00 + hr_delta(i) + tapoff);
+            ax0[i] = hbase + hr * 128u + (((unsigned)q ^ (hr & 6u)) << 4);
+            ax1[i] = ax0[i] ^ 64u;
+        }
+        const unsigned aw0 = wbase + foff0, aw1 = wbase + foff1;
+        bf16x8 xa[TM], wa[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) lds_rd16<0>(xa[i], ax0[i]);
+        lds_rd16_n<TN, 2048>(wa, aw0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) lds_rd16<0>(xbp[i], ax1[i]);
+        lds_rd16_n<TN, 2048>(wbp, aw1);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN));
+        pin_regs(xa);
+        pin_regs(wa);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xa[i], acc[i][j], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)");
+        pin_regs(xbp);
+        pin_regs(wbp);
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     auto store_row = [&](int m, int n0, float (&v)[4]) {   // EPI_ROWMAJOR only (checked on the host)
@@ -1901,6 +2025,7 @@ conv_halo_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
         cc_end = min(Cin, cc + hd.chunks_per_split * 64);
 #pragma unroll
         for (int p = 0; p < HPASS; ++p) issue_halo(p, cc, hb);
+        issue_coef(cc, hb);
         issue_w(0, cc, wsl);
     };
     begin_item(item);
@@ -1911,9 +2036,26 @@ conv_halo_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
         cc = __builtin_amdgcn_readfirstlane(cc);
         cc_end = __builtin_amdgcn_readfirstlane(cc_end);
         const bool next_chunk = cc + 64 < cc_end;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        auto one_tap = [&](auto TC) {
+            constexpr int tap = decltype(TC)::value;
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this tile's weights (tap 0: and the chunk's halo) have landed
+            bool first_chunk = false;
+            if constexpr (GN) {
+                first_chunk = tap == 0 && cc == c_z * hd.chunks_per_split * 64;
+                if (tap == 0 && first_chunk) {   // an item's first chunk (still raw): all seven pieces, before anyone reads them
+                    __builtin_amdgcn_s_barrier();      // (the coefficients are wave 0's DMA: landed for everybody only behind a barrier)
+                    XF x;
+                    xf_coef(hb, x);
+#pragma unroll 1
+                    for (int p = 0; p < HPASS; ++p) {
+                        XP1 pc;
+                        xf_piece(std::integral_constant<int, 0>{}, p, hb, 0, pc);
+                        xf_wait(x, pc);
+                        xf_write(std::integral_constant<int, 0>{}, pc, xf_math(x, pc));
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)");
+                }
+            }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (tap < 8) issue_w(tap + 1, cc, wsl ^ 1);
@@ -1922,13 +2064,48 @@ conv_halo_kernel(AOperand A, const bf16* __restrict__ W, int M, int N, int K, Ep
 #pragma unroll
                 for (int pp = 0; pp < HPT; ++pp)
                     if (tap * HPT + pp < HPASS) issue_halo(tap * HPT + pp, cc + 64, hb ^ 1);
+                if (tap == 0) issue_coef(cc + 64, hb ^ 1);
             }
-            compute((tap / 3) * W2 + tap % 3, hb, wsl);
+            if constexpr (GN) {
+                constexpr int NMF = TM * TN, HALF = NMF / 2;
+                using I0 = std::integral_constant<int, 0>;
+                using IH = std::integral_constant<int, HALF>;
+                using IN = std::integral_constant<int, NMF>;
+                constexpr int PX = (tap >= 1 && tap <= HPASS) ? tap - 1 : -1;   // the pass whose piece is rewritten during this tap
+                if (PX >= 0 && next_chunk) {
+                    // the piece of pass tap - 1 (landed behind this tap's vmcnt(0)): its reads fly under the first half of the pending
+                    // MFMAs, its arithmetic is interleaved with the second half
+                    constexpr int PXC = PX >= 0 ? PX : 0;
+                    XF x;
+                    XP1 p1;
+                    xf_piece(std::integral_constant<int, PXC>{}, 0, hb ^ 1, 0, p1);
+                    xf_coef(hb ^ 1, x);
+                    k1_mfma(I0{}, IH{});
+                    xf_wait(x, p1);
+                    const u32x4 o = xf_math(x, p1);
+                    k1_mfma(IH{}, IN{});
+#pragma unroll
+                    for (int g = 0; g < NMF - HALF; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);   // eight VALU
+                    }
+                    xf_write(std::integral_constant<int, PXC>{}, p1, o);
+                } else if (!first_chunk) {
+                    k1_mfma(I0{}, IN{});
+                }
+                compute_k0((tap / 3) * W2 + tap % 3, hb, wsl);
+            } else {
+                compute((tap / 3) * W2 + tap % 3, hb, wsl);
+            }
             wsl ^= 1;
-        }
+        };
+        one_tap(std::integral_constant<int, 0>{}); one_tap(std::integral_constant<int, 1>{}); one_tap(std::integral_constant<int, 2>{});
+        one_tap(std::integral_constant<int, 3>{}); one_tap(std::integral_constant<int, 4>{}); one_tap(std::integral_constant<int, 5>{});
+        one_tap(std::integral_constant<int, 6>{}); one_tap(std::integral_constant<int, 7>{}); one_tap(std::integral_constant<int, 8>{});
         cc += 64;
         hb ^= 1;
         if (cc < cc_end) continue;
+        if constexpr (GN) k1_mfma(std::integral_constant<int, 0>{}, std::integral_constant<int, TM * TN>{});   // the item's last K step 1
         // item done: start the next item's DMA (into the halo buffer / weight slot not read by the last tile), then store
         const int done_m0 = m0, done_tn = c_tn, done_z = c_z;
         item += gridDim.x;
@@ -2461,9 +2638,9 @@ int launch_halo(const AOperand& A, const bf16* W, int M, int N, int K, const Epi
     hd.n_items = tiles * hd.splits;
     const int halo_waves = 8;
     g_last_cfg[0] = 8; g_last_cfg[1] = tn; g_last_cfg[2] = hd.splits;
-    snprintf(g_last_name, sizeof g_last_name, "conv_halo_kernel<%d, %d>%s", tn, halo_waves, hd.splits > 1 ? " + splitk_reduce_kernel" : "");
+    snprintf(g_last_name, sizeof g_last_name, "conv_halo_kernel<%d, %d%s>%s", tn, halo_waves, A.gn ? ", gn" : "", hd.splits > 1 ? " + splitk_reduce_kernel" : "");
     dim3 grid(std::min(hd.n_items, 256)), block(halo_waves * 64);
-    const size_t lds = 2 * 7 * 64 * 128 + 2 * bn * 128;
+    const size_t lds = 2 * 7 * 64 * 128 + 2 * bn * 128 + (A.gn ? 2048 : 0);
 #define GL_LAUNCH_HALO(KFN)                                                                                      \
     do {                                                                                                         \
         auto kfn = KFN;                                                                                          \
@@ -2474,8 +2651,13 @@ int launch_halo(const AOperand& A, const bf16* W, int M, int N, int K, const Epi
         }                                                                                                        \
         hipLaunchKernelGGL(kfn, grid, block, lds, stream, A, W, M, N, K, E, ws, hd);                             \
     } while (0)
-    if (tn == 5) GL_LAUNCH_HALO((conv_halo_kernel<5, 8>));
-    else GL_LAUNCH_HALO((conv_halo_kernel<4, 8>));
+    if (A.gn) {
+        if (tn == 5) GL_LAUNCH_HALO((conv_halo_kernel<5, 8, true>));
+        else GL_LAUNCH_HALO((conv_halo_kernel<4, 8, true>));
+    } else {
+        if (tn == 5) GL_LAUNCH_HALO((conv_halo_kernel<5, 8>));
+        else GL_LAUNCH_HALO((conv_halo_kernel<4, 8>));
+    }
 #undef GL_LAUNCH_HALO
     GL_LAUNCH_CHECK();
     if (hd.splits > 1) {
@@ -2558,6 +2740,14 @@ static std::mutex g_tune_mu;
 static int g_autotune = -1;
 void gemm_set_autotune_impl(int on) { g_autotune = on; }
 
+// Does this problem go to conv_halo_kernel? (one predicate for the launcher and for gemm_gn_prologue_supported)
+// eligible 3x3 convs with M >= 256 * GL_CONV_HALO (default 8; 0 = never) go to the halo kernel: at M = 512 (the 8 x 8 level) its
+// 16 tiles x deep split lose to the 64 x 160 tiles of gemm_u_kernel
+static bool routes_to_halo(const AOperand& A, int M, int N, int K, const Epilogue& E) {
+    static const int halo = dev_env("GL_CONV_HALO") ? atoi(dev_env("GL_CONV_HALO")) : 8;
+    if (!halo || gemm_variant() != 4 || g_force_tm || N < 128 || (E.bias2 && E.res)) return false;
+    return halo_eligible(A, M, N, K, E) && M >= halo * 256;   // (halo_eligible includes the 2 GiB operand limit of the buffer loader)
+}
 int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const Epilogue& E, float* ws, size_t ws_bytes,
                   hipStream_t stream) {
     // candidates 0-3: 4 waves on a 2-stage ring, two (or three) workgroups per CU.
@@ -2575,11 +2765,9 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
     const bool fits32 = a_rows * (size_t)std::max(A.ld0, A.ld1) * 2 < 0x7fff0000ull && (size_t)N * K * 2 < 0x7fff0000ull;
     // v5's epilogue has no bias2 + residual form, and the per-sample bias only in its conv instantiations
     const bool use_u = gemm_variant() == 4 && fits32 && !(E.bias2 && (E.res || A.mode == A_ROWS));
-    // eligible 3x3 convs with M >= 256 * GL_CONV_HALO (default 8; 0 = never) go to the halo kernel (GL_CONV_HALO_SPLITS=n forces its
-    // K split): at M = 512 (the 8 x 8 level) its 16 tiles x deep split lose to the 64 x 160 tiles of the kernel above
-    static const int halo = dev_env("GL_CONV_HALO") ? atoi(dev_env("GL_CONV_HALO")) : 8;
+    // (GL_CONV_HALO_SPLITS=n forces the halo kernel's K split)
     static const int halo_splits = dev_env("GL_CONV_HALO_SPLITS") ? atoi(dev_env("GL_CONV_HALO_SPLITS")) : 0;
-    if (halo && use_u && !g_force_tm && halo_eligible(A, M, N, K, E) && M >= halo * 256)
+    if (use_u && routes_to_halo(A, M, N, K, E))
         return launch_halo(A, W, M, N, K, E, ws, ws_bytes, halo_splits, stream);
     // The wide kernel takes the GEGLU projections (GL_GEMM_WIDE=1, default): 0.78-0.82x the time of gemm_u_kernel's 128x128 tiles at the
     // 64x64 / 32x32 levels, even below. Everything else it is eligible for is slower there (narrow N: 256-row tiles leave CUs idle or
@@ -2792,6 +2980,12 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
 
 void gemm_set_autotune(int on) { gemm_set_autotune_impl(on); }
 
+// AOperand::gn (GroupNorm-apply + SiLU inside the conv's loader) exists in conv_halo_kernel only, for tiles that lie inside one
+// image (H W a multiple of 256: the tile's 256 pixels share one sample's coefficients)
+bool gemm_gn_prologue_supported(const AOperand& A, int M, int N, int K, const Epilogue& E) {
+    return K % 64 == 0 && routes_to_halo(A, M, N, K, E) && (A.Hin * A.Win) % 256 == 0;
+}
+
 // Can a GEMM with this epilogue consume raw rows + row statistics instead of LayerNorm'ed rows (Epilogue::ln_stats)?
 // Mirrors the routing of gemm_launch: the head-layout epilogues of gemm_u_kernel, the GEGLU epilogue of gemm_wide_kernel.
 bool gemm_ln_fold_supported(const AOperand& A, int M, int N, int K, const Epilogue& E) {
@@ -2819,6 +3013,8 @@ int gemm_launch(const AOperand& A, const bf16* W, int M, int N, int K, const Epi
         return set_error(GL_ERR_UNSUPPORTED, "gemm: folded LayerNorm needs csum + folded bias + statistics, and an epilogue that applies them");
     if (K % 64 != 0) return set_error(GL_ERR_ARG, "gemm: K=%d must be a multiple of 64", K);
     if (N % 4 != 0) return set_error(GL_ERR_ARG, "gemm: N=%d must be a multiple of 4", N);
+    if (A.gn && !gemm_gn_prologue_supported(A, M, N, K, E))
+        return set_error(GL_ERR_UNSUPPORTED, "gemm: the GroupNorm prologue (AOperand::gn) exists in conv_halo_kernel only (3x3, stride 1, H W %% 256 == 0)");
     if (A.mode == A_CONV3) {
         if ((A.C0 + A.C1) % 64 != 0 || A.C0 % 64 != 0 || K != 9 * (A.C0 + A.C1))
             return set_error(GL_ERR_ARG, "conv3x3: channels (%d,%d) must be multiples of 64 and K=9*Cin (K=%d)", A.C0, A.C1, K);

@@ -441,6 +441,50 @@ int main(int argc, char** argv) {
             if (Cout == 32) { E.mode = EPI_NCHW_F32; E.n_real = 4; E.bias2 = nullptr; }
             relaunch = [=] { GC(gemm_launch(A, w, M, Cout, K, E, cur_s == s ? ws : ws2, ws_bytes, cur_s)); };
             us = time_us(relaunch, reps, s);
+        } else if (!strcmp(kind, "gnconv")) {
+            // GroupNorm32 -> SiLU -> conv3x3 (reference openaimodel.py:212-232): "gnconv B H W C0 C1 Cout count". Two forms on the same
+            // buffers: GroupNorm + SiLU as its own pass (stats + apply) in front of the conv, and statistics + coefficients with the
+            // apply inside the conv's loader (AOperand::gn); outputs compared bit for bit
+            const int B = v[0], H = v[1], W = v[2], C0 = v[3], C1 = v[4], Cout = v[5];
+            count = v[6]; c = 1;
+            const int M = B * H * W, Cin = C0 + C1, K = 9 * Cin;
+            flop = 2.0 * M * Cout * K;
+            gM = M; gN = Cout; gK = K;
+            bf16* y_norm = a2;                                 // normalised copy of the two-pass form
+            bf16* out1 = a2 + ((size_t)96 << 20);
+            bf16* out2 = a2 + ((size_t)160 << 20);
+            float* coef = partial + (1 << 17);
+            GNParams P{};
+            P.x0 = a0; P.C0 = C0; P.x1 = C1 ? a1 : nullptr; P.C1 = C1; P.B = B; P.HW = H * W; P.eps = 1e-5f;
+            P.gamma = gam; P.beta = bias; P.y = y_norm; P.silu = 1; P.partial = partial; P.coef = coef;
+            AOperand A{};
+            A.mode = A_CONV3; A.Hin = H; A.Win = W; A.Ho = H; A.Wo = W; A.stride = 1; A.ups = 0; A.pad_lo = 1;
+            Epilogue E;
+            epilogue_defaults(E);
+            E.ldo = Cout; E.bias = bias; E.bias2 = gam; E.bias2_ld = Cout; E.rows_per_b = H * W;
+            AOperand A1 = A, A2 = A;
+            A1.p0 = y_norm; A1.C0 = Cin; A1.ld0 = Cin;
+            A2.p0 = a0; A2.C0 = C0; A2.ld0 = C0; A2.p1 = C1 ? a1 : nullptr; A2.C1 = C1; A2.ld1 = C1; A2.gn = coef;
+            Epilogue E1 = E, E2 = E;
+            E1.out = out1; E2.out = out2;
+            if (!gemm_gn_prologue_supported(A2, M, Cout, K, E2)) { printf("%-58s no GroupNorm prologue for this shape\n", line); continue; }
+            auto two_pass = [=] { GC(groupnorm_launch(P, cur_s)); GC(gemm_launch(A1, w, M, Cout, K, E1, cur_s == s ? ws : ws2, ws_bytes, cur_s)); };
+            auto gn_only = [=] { GC(groupnorm_launch(P, cur_s)); };
+            auto conv_only = [=] { GC(gemm_launch(A1, w, M, Cout, K, E1, cur_s == s ? ws : ws2, ws_bytes, cur_s)); };
+            auto coef_only = [=] { GC(groupnorm_coef_launch(P, cur_s)); };
+            auto conv_pro = [=] { GC(gemm_launch(A2, w, M, Cout, K, E2, cur_s == s ? ws : ws2, ws_bytes, cur_s)); };
+            relaunch = [=] { GC(groupnorm_coef_launch(P, cur_s)); GC(gemm_launch(A2, w, M, Cout, K, E2, cur_s == s ? ws : ws2, ws_bytes, cur_s)); };
+            const float us2 = time_us(two_pass, reps, s);
+            us = time_us(relaunch, reps, s);
+            const float t_gn = time_us(gn_only, reps, s), t_cv = time_us(conv_only, reps, s), t_cf = time_us(coef_only, reps, s), t_cp = time_us(conv_pro, reps, s);
+            float d, m;
+            maxdiff(out1, out2, (size_t)M * Cout, s, &d, &m);
+            // (H W <= 256: the separate pass is gn_small_kernel's (x - mean) rstd gamma + beta, the same value with another rounding)
+            const bool exact = H * W > 256;
+            const bool ok = exact ? d == 0.f : d <= 0.01f * m;
+            if (!ok) ++n_bad;
+            printf("GNCONV %-44s two passes %.1f us (gn %.1f + conv %.1f) | prologue %.1f us (stats %.1f + conv %.1f)  maxdiff %g of %g %s\n", line, us2, t_gn, t_cv,
+                   us, t_cf, t_cp, d, m, !ok ? "MISMATCH" : d == 0.f ? "bit-equal" : "within a bf16 step");
         } else if (!strcmp(kind, "attn")) {
             const int B = v[0], H = v[1], d = v[2], Nq = v[3], Nk = v[4];
             count = v[5]; c = 2;

@@ -16,10 +16,16 @@ struct GNParams {
     bf16* y;       // [B][HW][C0+C1]
     int silu;
     float* partial;  // scratch [B][nsplit][32][2]
+    float* coef;     // groupnorm_coef_launch only: [B][(C0+C1) / 8][16] = a of 8 channels, then c; y = silu(x * a + c) is the CONSUMER's job
 };
 int gn_nsplit(int HW);
 size_t gn_partial_bytes(int B, int HW);
 int groupnorm_launch(const GNParams& P, hipStream_t stream);
+// Statistics only (round 6): per-(sample, channel) coefficients for a consumer that applies GroupNorm + SiLU while it stages its input
+// (conv_halo_kernel, AOperand::gn). P.y is not written. 1 or 2 launches (groupnorm_coef_launches).
+int groupnorm_coef_launch(const GNParams& P, hipStream_t stream);
+int groupnorm_coef_launches(int HW, int C0, int C1);
+inline size_t gn_coef_bytes(int B, int C) { return (size_t)B * C * 2 * sizeof(float); }
 
 // LayerNorm over the last dim (C <= 1536, C % 8 == 0) of bf16 rows. Output rows are laid out
 // [B][Tpad]: t < N1 from x, N1 <= t < N1+N2 from x2 (the GLIGEN fuser's [visual ; grounding]

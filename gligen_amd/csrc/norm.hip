@@ -228,6 +228,142 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(GNParams P, int cpg) {
     }
 }
 
+// ---- GroupNorm as the consumer's prologue (round 6): the statistics pass stays, the apply pass does not. The conv that follows
+// (conv_halo_kernel, gemm.hip) normalises + SiLUs its input tile while staging it, from per-(sample, channel) coefficients
+//     y = silu(x * a + c),  a = rstd * gamma,  c = beta - mean * a          (reference openaimodel.py:212-232: GroupNorm32 -> SiLU -> conv)
+// written here as coef[b][C / 8][16]: a of 8 consecutive channels, then their c -- 64 bytes per 16-byte activation chunk, so a
+// 64-channel chunk of the conv's K loop is one contiguous 512-byte block that the conv fetches by LDS-DMA beside its halo.
+// Same fp64 fixed-order combination of the partials as gn_apply_kernel: (a, c) are bit-identical to the ones that kernel uses.
+__global__ void gn_coef_kernel(GNParams P, int nsplit, int cpg) {
+    __shared__ float mean_s[32], rstd_s[32];
+    __shared__ double red_s[4][32][2];
+    const int t = threadIdx.x;
+    const int b = blockIdx.x;
+    if (t < 128) {
+        const int g = t & 31, part = t >> 5;
+        double s = 0.0, q = 0.0;
+        const float2* src = reinterpret_cast<const float2*>(P.partial) + (size_t)b * nsplit * 32 + g;
+        float2 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = src[(size_t)min(part + 4 * i, nsplit - 1) * 32];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bool ok = part + 4 * i < nsplit;
+            s += ok ? (double)v[i].x : 0.0;
+            q += ok ? (double)v[i].y : 0.0;
+        }
+        red_s[part][g][0] = s;
+        red_s[part][g][1] = q;
+    }
+    __syncthreads();
+    if (t < 32) {
+        const double s = ((red_s[0][t][0] + red_s[1][t][0]) + red_s[2][t][0]) + red_s[3][t][0];
+        const double q = ((red_s[0][t][1] + red_s[1][t][1]) + red_s[2][t][1]) + red_s[3][t][1];
+        const double n = (double)P.HW * cpg;
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mean_s[t] = (float)mean;
+        rstd_s[t] = (float)(1.0 / sqrt(var + (double)P.eps));
+    }
+    __syncthreads();
+    const int C = P.C0 + P.C1;
+    float* dst = P.coef + (size_t)b * C * 2;
+    for (int c = t; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        const float a = rstd_s[g] * P.gamma[c];
+        const float cc = P.beta[c] - mean_s[g] * a;
+        dst[(c >> 3) * 16 + (c & 7)] = a;
+        dst[(c >> 3) * 16 + 8 + (c & 7)] = cc;
+    }
+}
+
+// HW <= 256 (the 16 x 16 level): gn_small_kernel's statistics half -- one workgroup per (sample, group), one read of its slab --
+// writing the group's coefficients directly: one launch, no partials
+template <int NT>
+__global__ void __launch_bounds__(NT) gn_small_coef_kernel(GNParams P, int cpg) {
+    constexpr int NW = NT / 64;
+    __shared__ double red_s[NW][2];
+    __shared__ float stat_s[2];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int C = P.C0 + P.C1;
+    const int hp = cpg >> 2;
+    const int n_q = P.HW * hp;
+    const int c_base = g * cpg;
+    auto src_of = [&](int pix, int c) -> const bf16* {
+        return c < P.C0 ? P.x0 + ((size_t)b * P.HW + pix) * P.C0 + c : P.x1 + ((size_t)b * P.HW + pix) * P.C1 + (c - P.C0);
+    };
+    float s = 0.f, q = 0.f;
+    for (int idx = t; idx < n_q; idx += NT) {
+        const int pix = idx / hp;
+        const int c = c_base + 4 * (idx - pix * hp);
+        const uint2 v = *reinterpret_cast<const uint2*>(src_of(pix, c));
+        const float a0 = __uint_as_float(v.x << 16), a1 = __uint_as_float(v.x & 0xffff0000u);
+        const float a2 = __uint_as_float(v.y << 16), a3 = __uint_as_float(v.y & 0xffff0000u);
+        s += (a0 + a1) + (a2 + a3);
+        q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (lane == 0) { red_s[wave][0] = s; red_s[wave][1] = q; }
+    __syncthreads();
+    if (t == 0) {
+        double ss = 0.0, qq = 0.0;
+        for (int w = 0; w < NW; ++w) { ss += red_s[w][0]; qq += red_s[w][1]; }
+        const double n = (double)P.HW * cpg;
+        const double mean = ss / n;
+        double var = qq / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stat_s[0] = (float)mean;
+        stat_s[1] = (float)(1.0 / sqrt(var + (double)P.eps));
+    }
+    __syncthreads();
+    if (t < cpg) {
+        const int c = c_base + t;
+        const float a = stat_s[1] * P.gamma[c];
+        const float cc = P.beta[c] - stat_s[0] * a;
+        float* dst = P.coef + (size_t)b * C * 2;
+        dst[(c >> 3) * 16 + (c & 7)] = a;
+        dst[(c >> 3) * 16 + 8 + (c & 7)] = cc;
+    }
+}
+
+static int gn_check(const GNParams& P, int* cpg_out) {
+    const int C = P.C0 + P.C1;
+    if (C % 64 != 0 || (P.C1 && P.C0 % 8 != 0)) return set_error(GL_ERR_ARG, "groupnorm: C=%d (C0=%d) unsupported", C, P.C0);
+    const int cpg = C / 32;
+    if (cpg < 4 || (cpg & 1)) return set_error(GL_ERR_UNSUPPORTED, "groupnorm: %d channels per group (need an even number >= 4)", cpg);
+    if (C / 8 > 1024) return set_error(GL_ERR_ARG, "groupnorm: C=%d too large", C);
+    *cpg_out = cpg;
+    return GL_OK;
+}
+
+int groupnorm_coef_launch(const GNParams& P, hipStream_t stream) {
+    int cpg;
+    GL_TRY(gn_check(P, &cpg));
+    if (!P.coef) return set_error(GL_ERR_ARG, "groupnorm_coef: no coefficient buffer");
+    const int C = P.C0 + P.C1, C8 = C / 8;
+    if (P.HW <= 256 && (P.C0 & 3) == 0 && (cpg & 3) == 0) {
+        if (P.HW * cpg >= 8192) hipLaunchKernelGGL(gn_small_coef_kernel<1024>, dim3(32, P.B), dim3(1024), 0, stream, P, cpg);
+        else hipLaunchKernelGGL(gn_small_coef_kernel<256>, dim3(32, P.B), dim3(256), 0, stream, P, cpg);
+        GL_LAUNCH_CHECK();
+        return GL_OK;
+    }
+    const int R = gn_rows(C8);
+    const int nsplit = gn_nsplit_c(P.HW, C8);
+    const int T = C8 * R;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, P.B), dim3(T), T * sizeof(float4), stream, P, nsplit, C8, R, cpg);
+    GL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_coef_kernel, dim3(P.B), dim3(256), 0, stream, P, nsplit, cpg);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+int groupnorm_coef_launches(int HW, int C0, int C1) {
+    const int cpg = (C0 + C1) / 32;
+    return (HW <= 256 && (C0 & 3) == 0 && (cpg & 3) == 0) ? 1 : 2;
+}
+
 int groupnorm_launch(const GNParams& P, hipStream_t stream) {
     const int C = P.C0 + P.C1;
     if (C % 64 != 0 || (P.C1 && P.C0 % 8 != 0)) return set_error(GL_ERR_ARG, "groupnorm: C=%d (C0=%d) unsupported", C, P.C0);

@@ -608,6 +608,18 @@ class Engine:
                                      stride, ups, pad_lo, _ptr(res), _ptr(y), _stream(self.device)))
         return y
 
+    def op_gn_silu_conv3x3(self, x0, gamma, beta, eps, w_oihw, bias, x1=None, bias2=None, res=None, mode=-1):
+        """GroupNorm32 -> SiLU -> conv3x3 (reference openaimodel.py:212-232). Returns (y, used_prologue)."""
+        B, H, W, C0 = x0.shape
+        C1 = 0 if x1 is None else x1.shape[3]
+        Cout = w_oihw.shape[0]
+        y = torch.empty((B, H, W, Cout), device=x0.device, dtype=torch.bfloat16)
+        used = C.c_int(0)
+        check(self.lib.gl_op_gn_silu_conv3x3(self._ctx, _ptr(x0), C0, _ptr(x1), C1, B, H, W, _ptr(gamma), _ptr(beta), C.c_float(eps),
+                                             _ptr(w_oihw), _ptr(bias), Cout, _ptr(bias2), _ptr(res), _ptr(y), int(mode), C.byref(used),
+                                             _stream(self.device)))
+        return y, bool(used.value)
+
     def op_groupnorm(self, x0, gamma, beta, eps, silu, x1=None):
         B, HW, C0 = x0.shape
         C1 = 0 if x1 is None else x1.shape[2]

@@ -367,6 +367,18 @@ int gl_op_adamw_step(gl_ctx* ctx, float* p, const float* g, float* m, float* v, 
 int gl_op_conv3x3(gl_ctx* ctx, const void* x0, int C0, const void* x1, int C1, int B, int H, int W,
                   const float* w_oihw, const float* bias, int Cout, int stride, int ups, int pad_lo,
                   const void* res, void* y, gl_stream s);
+/* GroupNorm32 -> SiLU -> conv3x3 (stride 1, pad 1) over NHWC bf16 (channel-concat of x0,x1): the in_layers / out_layers of the
+ * reference's ResBlock (ldm/modules/diffusionmodules/openaimodel.py:212-232; VAE ResnetBlock model.py:118-141) as one operator.
+ * bias2: optional [B][Cout] per-sample bias (the time-embedding term), res: optional residual [B*H*W][Cout] bf16 (never both).
+ * Two forms. Separate pass: GroupNorm + SiLU write a normalised copy that the conv reads (two kernels + conv). Prologue: where the
+ * conv runs on conv_halo_kernel (M >= 2048, power-of-two images up to 64 wide with H*W % 256 == 0) GroupNorm keeps only its
+ * statistics pass and the conv normalises + activates its input tile while staging it in LDS -- no normalised copy in HBM.
+ * mode -1: the engine's choice (the separate pass: on MI355X it is the faster form at every UNet shape);
+ * mode 0: the separate pass; mode 1: the prologue form or GL_ERR_UNSUPPORTED. *used_prologue tells which form ran. Same
+ * coefficients, same arithmetic: the two outputs are bit-identical for H*W > 256. */
+int gl_op_gn_silu_conv3x3(gl_ctx* ctx, const void* x0, int C0, const void* x1, int C1, int B, int H, int W, const float* gamma, const float* beta,
+                          float eps, const float* w_oihw, const float* bias, int Cout, const float* bias2, const void* res, void* y, int mode,
+                          int* used_prologue, gl_stream s);
 /* GroupNorm(32)+optional SiLU over NHWC bf16 (channel-concat of x0,x1) */
 int gl_op_groupnorm(gl_ctx* ctx, const void* x0, int C0, const void* x1, int C1, int B, int HW,
                     const float* gamma, const float* beta, float eps, int silu, void* y, gl_stream s);

@@ -102,6 +102,48 @@ def test_unet_full_size_pair_vs_reference(name, full_models):
     assert r["objs_rel_mse"] < 1e-3, r                         # three bf16 GEMMs of a 832 -> 512 -> 512 -> 768 MLP
 
 
+_GN_PROLOGUE_SNIPPET = r"""
+import sys, json, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from helpers import build_product_unet, load_golden, mse
+from gligen_amd import synthetic as syn
+dev = torch.device("cuda:0")
+g = load_golden("unet_full_64_text"); meta = g["meta"]
+kind, B, hw = meta["kind"], meta["B"], meta["hw"]
+model = build_product_unet(syn.UNET_CFG, kind, False, device=dev)
+batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in syn.make_batch(kind, B, n_valid=meta["n_valid"], seed=3).items()}
+gin = model.grounding_tokenizer_input.prepare(batch)
+g_null = model.grounding_tokenizer_input.get_null_input()
+x = syn.make_latent(B, 4, hw, hw, seed=3).to(dev)
+ctx2 = torch.cat([syn.make_context(B, seed=3), syn.make_context(B, seed=9)]).to(dev)
+t = torch.full((2 * B,), meta["t"], device=dev, dtype=torch.long)
+model.set_conditioning(ctx2, {k: torch.cat([gin[k], g_null[k].to(gin[k])]) for k in gin})
+model.engine.set_fuser_scale(1.0)
+eps = model.engine.unet_forward(x, t, None, batch=2 * B)
+prof = model.engine.unet_profile(x, t, None, batch=2 * B)
+print(json.dumps(dict(eps_cond=mse(eps[:B], g["eps"].astype(np.float32)), eps_uncond=mse(eps[B:], g["eps_uncond"].astype(np.float32)),
+                      kernels=[p["name"] for p in prof])))
+"""
+
+
+def test_unet_full_size_pair_with_groupnorm_prologue():
+    """The same evaluation with GL_GN_PROLOGUE=1 (read once per process, hence the subprocess): every ResBlock conv of the 64x64 / 32x32 /
+    16x16 levels applies its GroupNorm + SiLU inside conv_halo_kernel's loader (reference openaimodel.py:212-232), the apply pass
+    is gone from the launch list, and eps still matches the reference's two forwards."""
+    _dev()
+    import subprocess
+    import sys
+    env = dict(os.environ, GL_DEV_SWITCHES="1", GL_GN_PROLOGUE="1")
+    r = subprocess.run([sys.executable, "-c", _GN_PROLOGUE_SNIPPET % (ROOT, os.path.join(ROOT, "tests"))], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    REPORT["unet_full_64_text_gn_prologue"] = {k: v for k, v in out.items() if k != "kernels"}
+    assert out["eps_cond"] < EPS_MSE_TOL and out["eps_uncond"] < EPS_MSE_TOL, out
+    names = " | ".join(out["kernels"])
+    assert "conv_halo_kernel<5, 8, gn>" in names and "gn_stats_kernel + gn_coef_kernel" in names and "gn_small_coef_kernel" in names, names
+
+
 def test_c1_end_to_end_vs_reference(full_models, tmp_path, monkeypatch):
     """BASELINE config C1 (256x256, 20 PLMS steps, 1 box, CFG 7.5, B=1) through gligen_inference.generate: final latent and
     decoded image against the reference's own PLMSSampler + UNetModel + AutoencoderKL.decode run on the CPU."""

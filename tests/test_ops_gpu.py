@@ -139,6 +139,59 @@ def test_conv3x3(engine, cfg):
         assert rel_err(y, ref + res.float()) < TOL
 
 
+@pytest.mark.parametrize("cfg", [
+    # GroupNorm32 -> SiLU -> conv3x3 (reference openaimodel.py:212-232 in_layers / out_layers). Shapes where conv_halo_kernel carries the
+    # GroupNorm-apply + SiLU in its loader (used_prologue): tiles that are some rows of one image (top / bottom padding per tile), whole
+    # 16 x 16 images, two sources (the decoder's skip concat) with channel groups that straddle the source boundary (960 / 32 = 30
+    # channels per group over 640 + 320), 128-wide tiles + split-K, per-sample bias / residual epilogues, both eps values
+    dict(B=2, H=32, W=32, C0=128, C1=64, Cout=320, pro=True),
+    dict(B=8, H=16, W=16, C0=256, Cout=256, pro=True, eps=1e-6),
+    dict(B=1, H=64, W=64, C0=128, Cout=128, pro=True),
+    dict(B=2, H=32, W=32, C0=640, C1=320, Cout=320, pro=True, bias2=True),
+    dict(B=8, H=16, W=16, C0=1280, Cout=1280, pro=True, res=True),
+    dict(B=2, H=64, W=64, C0=320, Cout=320, pro=True, bias2=True),
+    dict(B=4, H=32, W=16, C0=128, Cout=160, pro=True, eps=1e-6),
+    # no prologue: the 8 x 8 level (M = 512 runs the implicit-GEMM kernel; a 256-pixel halo tile would span four samples), odd sizes
+    dict(B=8, H=8, W=8, C0=1280, Cout=1280, pro=False),
+    dict(B=32, H=8, W=8, C0=192, Cout=160, pro=False),
+    dict(B=2, H=12, W=20, C0=128, C1=64, Cout=64, pro=False),
+])
+def test_gn_silu_conv3x3(engine, cfg):
+    B, H, W, C0, Cout = cfg["B"], cfg["H"], cfg["W"], cfg["C0"], cfg["Cout"]
+    C1, eps = cfg.get("C1", 0), cfg.get("eps", 1e-5)
+    C = C0 + C1
+    x0 = bf(rnd(B, H, W, C0, seed=1) * 2 + 0.5)
+    x1 = bf(rnd(B, H, W, C1, seed=2) - 1.0) if C1 else None
+    g, bt = rnd(C, seed=3) * 0.2 + 1, rnd(C, seed=4) * 0.2
+    w = rnd(Cout, C, 3, 3, scale=(9 * C) ** -0.5, seed=5)
+    b = rnd(Cout, seed=6)
+    bias2 = rnd(B, Cout, seed=7) if cfg.get("bias2") else None
+    res = bf(rnd(B, H, W, Cout, seed=8)) if cfg.get("res") else None
+    xin = x0 if x1 is None else torch.cat([x0, x1], dim=-1)
+    a = F.silu(F.group_norm(xin.float().permute(0, 3, 1, 2), 32, g, bt, eps))
+    ref = F.conv2d(a, w.to(torch.bfloat16).float(), b, padding=1).permute(0, 2, 3, 1)
+    if bias2 is not None:
+        ref = ref + bias2[:, None, None, :]
+    if res is not None:
+        ref = ref + res.float()
+    y, used = engine.op_gn_silu_conv3x3(x0, g, bt, eps, w, b, x1=x1, bias2=bias2, res=res, mode=1 if cfg["pro"] else -1)
+    assert used == cfg["pro"]
+    assert rel_err(y, ref) < TOL
+    _, used_default = engine.op_gn_silu_conv3x3(x0, g, bt, eps, w, b, x1=x1, bias2=bias2, res=res)
+    assert not used_default, "the engine's default is the separate GroupNorm pass (the faster form on MI355X)"
+    # the separate-pass form on the same inputs: same coefficients, same arithmetic, so the same bits wherever both forms exist
+    y0, used0 = engine.op_gn_silu_conv3x3(x0, g, bt, eps, w, b, x1=x1, bias2=bias2, res=res, mode=0)
+    assert not used0
+    assert rel_err(y0, ref) < TOL
+    if used and H * W > 256:       # (at H W <= 256 the separate pass is gn_small_kernel's (x - mean) rstd gamma + beta: same value, other rounding)
+        assert torch.equal(y, y0), "GroupNorm prologue and GroupNorm pass disagree bitwise"
+    y2, _ = engine.op_gn_silu_conv3x3(x0, g, bt, eps, w, b, x1=x1, bias2=bias2, res=res, mode=1 if cfg["pro"] else -1)
+    assert torch.equal(y, y2), "must be bit-reproducible"
+    if not cfg["pro"]:
+        with pytest.raises(Exception):
+            engine.op_gn_silu_conv3x3(x0, g, bt, eps, w, b, x1=x1, bias2=bias2, res=res, mode=1)
+
+
 @pytest.mark.parametrize("B,HW,C0,C1,silu,eps", [
     (2, 256, 320, 0, True, 1e-5), (2, 1024, 128, 0, True, 1e-6), (1, 4096, 640, 320, True, 1e-5),
     (3, 64, 1280, 1280, False, 1e-6), (2, 4, 1280, 0, True, 1e-5), (1, 16384, 256, 0, True, 1e-6),
