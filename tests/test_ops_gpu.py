@@ -246,6 +246,10 @@ def attn_ref(xq, xkv, wq, wk, wv, H):
     (2, 256, 286, 640, 640, 8), (2, 64, 94, 1280, 1280, 8), (1, 64, 77, 1280, 768, 8),
     (1, 16, 46, 1280, 1280, 8), (1, 4096, 4126, 320, 320, 8),
     (2, 1024, 1024, 640, 640, 8), (2, 256, 256, 1280, 1280, 8), (1, 4096, 4096, 320, 320, 8),   # self-attention: the fused q,k,v^T projection
+    # 65..96 keys at head dims 40 / 80: the benchmark's cross-attention at the 64 x 64 and 32 x 32 levels (batch 8), a ragged query
+    # count (last query block partly empty), 65 / 94 / 96 keys
+    (8, 4096, 77, 320, 768, 8), (8, 1024, 77, 640, 768, 8), (1, 100, 77, 320, 768, 8), (2, 256, 65, 320, 768, 8), (2, 256, 94, 640, 640, 8),
+    (3, 64, 96, 640, 768, 8),
 ])
 def test_attention(engine, B, Nq, Nk, C, Ck, H):
     xq = bf(rnd(B, Nq, C, seed=1))
