@@ -830,4 +830,77 @@ int gl_op_attention(gl_ctx* ctx, const void* xq, const void* xkv, int B, int Nq,
     GL_API_END
 }
 
+
+int gl_op_proj_attention(gl_ctx* ctx, const void* x, int B, int N, int C, int H, const float* pre_w, const float* pre_b, const void* pre_res,
+                         const float* gamma, const float* beta, const float* wq, const float* wk, const float* wv, int Nkv_extra,
+                         void* mid, void* o, int* used_rows, gl_stream s) {
+    NEED(ctx);
+    if (!x || !pre_w || !pre_b || !gamma || !beta || !wq || !wk || !wv || !mid || !o || !used_rows)
+        return gl::set_error(GL_ERR_ARG, "gl_op_proj_attention: null pointer");
+    GL_API_BEGIN
+    Engine& eng = *ctx->eng;
+    Arena& ar = eng.arena();
+    ar.reset();
+    auto ck = [&](int rc) { if (rc != GL_OK) throw GlError(rc, gl::last_error()); };
+    if (C % H != 0 || N % 64 != 0 || Nkv_extra != 0) throw GlError(GL_ERR_ARG, "gl_op_proj_attention: C % H == 0, N % 64 == 0");
+    const int d = C / H, M = B * N;
+    int dp, dpv;
+    ck(attn_dims(d, &dp, &dpv));
+    const int vt_layout = attn_vt_layout(d, N, &dpv);
+    AttnBufs& bufs = eng.attn_bufs(B, H, d, N, N, dpv);
+    // LayerNorm folded into the three projections: W gamma (bf16), bias W beta
+    bf16* wqkv = ar.get<bf16>((size_t)3 * C * C);
+    float* bias = ar.get<float>((size_t)3 * C);
+    {
+        float* wf = ar.get<float>((size_t)C * C);
+        const float* ws[3] = {wq, wk, wv};
+        for (int i = 0; i < 3; ++i) {
+            ck(ln_fold_launch(ws[i], nullptr, gamma, beta, wf, bias + (size_t)i * C, C, C, S(s)));
+            ck(cast_f32_bf16_launch(wf, wqkv + (size_t)i * C * C, (int64_t)C * C, S(s)));
+        }
+    }
+    const bool want = *used_rows != 0;
+    const bool rows = want && qkv_rows_supported(M, C, d, N) && vt_layout == 1;
+    *used_rows = rows ? 1 : 0;
+    if (rows) {
+        void* st = ar.alloc(qkv_rows_stream_bytes(C, true, 3));
+        ck(qkv_rows_pack_launch(pre_w, wqkv, 3, st, C, S(s)));
+        QkvRowsParams P{};
+        P.x = (const bf16*)x; P.ldx = C; P.eps = 1e-5f; P.stream = st; P.M = M;
+        P.pre = 1; P.pre_b = pre_b; P.pre_res = (const bf16*)pre_res; P.ld_pre_res = C; P.mid_out = (bf16*)mid; P.ld_mid = C;
+        P.np = 3; P.bias = bias; P.q = bufs.q; P.k = bufs.k; P.vt = bufs.vt;
+        P.H = H; P.d = d; P.DP = dp; P.DPV = dpv; P.T = N; P.Tpad_q = bufs.Tq_pad; P.Tpad_k = bufs.Tk_pad; P.vt_perm32 = vt_layout;
+        ck(qkv_rows_launch(P, C, S(s)));
+    } else {
+        // the form it replaces: projection GEMM (+ residual), LayerNorm kernel without affine, fused q,k,v^T GEMM
+        bf16* pw = ar.get<bf16>((size_t)C * C);
+        ck(cast_f32_bf16_launch(pre_w, pw, (int64_t)C * C, S(s)));
+        {
+            AOperand A;
+            aoperand_rows(A, (const bf16*)x, C, C);
+            Epilogue E;
+            epilogue_defaults(E);
+            E.out = mid; E.ldo = C; E.bias = pre_b; E.res = (const bf16*)pre_res; E.ldres = C;
+            ck(gemm_launch(A, pw, M, C, C, E, eng.splitk_ws(), eng.splitk_ws_bytes(), S(s)));
+        }
+        bf16* xn = ar.get<bf16>((size_t)M * C);
+        LNParams L{};
+        L.x = (const bf16*)mid; L.B = 1; L.N1 = M; L.N2 = 0; L.Tpad = M; L.C = C; L.eps = 1e-5f; L.y = xn;
+        ck(layernorm_launch(L, S(s)));
+        AOperand A;
+        aoperand_rows(A, xn, C, C);
+        Epilogue E;
+        epilogue_defaults(E);
+        E.mode = EPI_QKV_HEADS; E.q = bufs.q; E.k = bufs.k; E.vt = bufs.vt; E.C = C; E.H = H; E.d = d; E.DP = dp; E.DPV = dpv; E.T = N; E.vt_perm32 = vt_layout;
+        E.Tpad_q = bufs.Tq_pad; E.Tpad_k = bufs.Tk_pad; E.bias = bias;
+        ck(gemm_launch(A, wqkv, M, 3 * C, C, E, nullptr, 0, S(s)));
+    }
+    AttnParams P{};
+    P.q = bufs.q; P.k = bufs.k; P.vt = bufs.vt; P.o = (bf16*)o; P.H = H; P.d = d; P.Nq = N; P.Nk = N;
+    P.Tq_pad = bufs.Tq_pad; P.Tk_pad = bufs.Tk_pad; P.ldo = C; P.o_rows_per_b = N; P.vt_layout = vt_layout;
+    P.scale_log2e = (float)(1.4426950408889634 / std::sqrt((double)d));
+    ck(attn_launch(P, B, S(s)));
+    GL_API_END
+}
+
 }  // extern "C"

@@ -83,6 +83,9 @@ struct SelfAttnW {
     const float* b = nullptr;    // folded: [3C] bias, [3C] csum
     const float* csum = nullptr;
     LinW out;
+    // the row-local form (ffn.h qkv_rows_kernel, C = 320 / d = 40): [the C x C projection in front of this attention's LayerNorm]
+    // [to_q][to_k][to_v] as one fragment stream -- attn1: SpatialTransformer.proj_in, fuser.attn: attn1.to_out
+    const void* rows_stream = nullptr;
 };
 struct CrossAttnW { LinW q; const bf16* wk = nullptr; const bf16* wv = nullptr; LinW out; int ctx_dim = 0; bool folded = false; const float* q_csum = nullptr; };
 struct FFW {
@@ -278,8 +281,15 @@ class Engine {
                             const LinW* post, const bf16* post_res, bf16* out, hipStream_t s, RowStats* out_stats);
     // Tbuf / slot: the head-layout buffers are sized for Tbuf tokens per sample (0: T) and private to attention number `slot`
     // (0: shared by every attention of this shape) -- the fuser's attention with hoisted grounding-token keys (fuser_kv_fill)
+    // projected: q / k / v^T of this attention are already in its head-layout buffers (qkv_rows_project): launch the attention only
     void self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, int Nq, int Nk, int C, int d, bf16* o, hipStream_t s,
-                        const RowStats* in_stats = nullptr, int Tbuf = 0, int slot = 0);
+                        const RowStats* in_stats = nullptr, int Tbuf = 0, int slot = 0, bool projected = false);
+    // The row-local projection launch (ffn.h QkvRowsParams): mid = pre_res + (x Wpre^T + pre_b) -> LayerNorm in registers -> q, k, v^T
+    // of attention `a` into its head-layout buffers; T tokens per sample, Nk keys decide the V^T form (attn_vt_layout)
+    bool qkv_rows_ok(const SelfAttnW& a, int B, int T, int Nk, int C, int d) const;
+    void qkv_rows_project(const SelfAttnW& a, const bf16* x, int B, int T, int Nk, int C, int d, const LinW& pre, const bf16* pre_res, bf16* mid,
+                          RowStats* mid_stats, int Tbuf, int slot, hipStream_t s);
+    int qkv_rows_ = 1;           // GL_QKV_ROWS (developer A/B): 0 = off, 1 = where a launch fills the chip (default), 2 = wherever the kernel exists
     // GatedSelfAttentionDense (attention.py:236-244): the K / V rows of the grounding tokens linear(objs) do not depend on the step.
     // They are projected ONCE per prompt into the tail (tokens HW .. HW + Ng - 1) of this block's own K / V^T buffers; per step only
     // the HW visual rows go through the (LayerNorm-folded) q,k,v^T projection -- no [x ; objs] concat LayerNorm pass.

@@ -511,7 +511,9 @@ void Engine::build_unet() {
         ff_rows_ = !(dev_env("GL_FF_ROWS") && atoi(dev_env("GL_FF_ROWS")) == 0);   // row-local feed-forward kernel (ffn.hip) where it exists
         ff_chain_ = dev_env("GL_FF_CHAIN") ? atoi(dev_env("GL_FF_CHAIN")) : 2;
         fuser_hoist_ = !(dev_env("GL_FUSER_KV_HOIST") && atoi(dev_env("GL_FUSER_KV_HOIST")) == 0);
-        auto self_attn_w = [&](const std::string& a, const NormW* ln) {
+        qkv_rows_ = dev_env("GL_QKV_ROWS") ? atoi(dev_env("GL_QKV_ROWS")) : 1;
+        // pre_key: weight of the C x C projection in front of this attention's LayerNorm (row-local form, ffn.h qkv_rows_kernel)
+        auto self_attn_w = [&](const std::string& a, const NormW* ln, const std::string& pre_key) {
             SelfAttnW w;
             w.fused = fuse_qkv;
             if (fuse_qkv && ln) {
@@ -527,6 +529,11 @@ void Engine::build_unet() {
                 }
                 CK(rowsum_bf16_launch(dst, cs, 3 * C, C, 0));
                 w.wqk = dst; w.b = bias; w.csum = cs; w.folded = true;
+                if (qkv_rows_ && !pre_key.empty() && t.d == 40 && qkv_rows_stream_bytes(C, true, 3)) {
+                    void* st = persist(qkv_rows_stream_bytes(C, true, 3), false);
+                    CK(qkv_rows_pack_launch(raw(pre_key).p, dst, 3, st, C, 0));
+                    w.rows_stream = st;
+                }
             } else if (fuse_qkv) {
                 w.wqk = cast_rows({a + ".to_q.weight", a + ".to_k.weight", a + ".to_v.weight"});
             } else {
@@ -535,7 +542,7 @@ void Engine::build_unet() {
             }
             return w;
         };
-        t.a1 = self_attn_w(tb + ".attn1", fold ? &t.ln1 : nullptr);
+        t.a1 = self_attn_w(tb + ".attn1", fold ? &t.ln1 : nullptr, p + ".proj_in.weight");
         t.a1.out = linear(tb + ".attn1.to_out.0");
         if (fold) {
             const FoldTmp q = fold_ln(tb + ".attn2.to_q.weight", nullptr, t.ln2);
@@ -561,7 +568,7 @@ void Engine::build_unet() {
         t.fn2 = norm(tb + ".fuser.norm2");
         if (c.fuser_kind != 2) {  // gatedSA and gatedSA2 hold the same parameters
             t.flin = linear(tb + ".fuser.linear");
-            t.fa = self_attn_w(tb + ".fuser.attn", fold ? &t.fn1 : nullptr);
+            t.fa = self_attn_w(tb + ".fuser.attn", fold ? &t.fn1 : nullptr, tb + ".attn1.to_out.0.weight");
             t.fa.out = linear(tb + ".fuser.attn.to_out.0");
         } else {  // gatedCA: CrossAttention(query_dim, key_dim = value_dim = grounding-token dim) -- attention.py:194
             t.fca.q = linear(tb + ".fuser.attn.to_q", false);
@@ -1201,15 +1208,55 @@ void Engine::fuser_kv_fill(const STW& t, int B, int HW, hipStream_t s) {
     fuser_kv_[t.idx] = FuserKV{cond_epoch_, B, HW};
 }
 
+bool Engine::qkv_rows_ok(const SelfAttnW& a, int B, int T, int Nk, int C, int d) const {
+    if (!qkv_rows_ || !a.rows_stream || !a.fused || !a.folded || !qkv_rows_supported(B * T, C, d, T)) return false;
+    int dpv = 0;
+    if (attn_vt_layout(d, Nk, &dpv) != 1) return false;          // the kernel writes V^T in the 32-token form of attn3_kernel only
+    return qkv_rows_ >= 2 || B * T / 128 >= 224;                 // one 128-row workgroup per CU: a launch that fills the chip
+}
+
+void Engine::qkv_rows_project(const SelfAttnW& a, const bf16* x, int B, int T, int Nk, int C, int d, const LinW& pre, const bf16* pre_res, bf16* mid,
+                              RowStats* mid_stats, int Tbuf, int slot, hipStream_t s) {
+    const int H = C / d, M = B * T;
+    int dp, dpv;
+    CK(attn_dims(d, &dp, &dpv));
+    const int vt_layout = attn_vt_layout(d, Nk, &dpv);
+    AttnBufs& bufs = attn_bufs(B, H, d, Tbuf ? Tbuf : T, Tbuf ? Tbuf : T, dpv, slot);
+    QkvRowsParams P{};
+    P.x = x; P.ldx = C; P.eps = 1e-5f; P.stream = a.rows_stream; P.M = M;
+    P.pre = 1; P.pre_b = pre.b; P.pre_res = pre_res; P.ld_pre_res = C; P.mid_out = mid; P.ld_mid = C;
+    if (mid_stats) {
+        *mid_stats = RowStats{};
+        if (ln_fold_) {
+            mid_stats->ld = 1; mid_stats->nb = 1;
+            mid_stats->p = arena_.get<float2>((size_t)M);
+            P.stats_out = mid_stats->p;
+        }
+    }
+    P.np = 3; P.bias = a.b; P.q = bufs.q; P.k = bufs.k; P.vt = bufs.vt;
+    P.H = H; P.d = d; P.DP = dp; P.DPV = dpv; P.T = T; P.Tpad_q = bufs.Tq_pad; P.Tpad_k = bufs.Tk_pad; P.vt_perm32 = vt_layout;
+    ProfScope ps(this, s, "qkv_rows_kernel<pre, 3>", 8.0 * M * (double)C * C, 0.0);
+    CK(qkv_rows_launch(P, C, s));
+    FILE* launch_log = launch_log_file();
+    if (launch_log) {
+        fprintf(launch_log, "qkv_rows_kernel<320, 40, true, 3>|%d|%d|%d|0|%.0f\n", M, 4 * C, C,
+                (double)qkv_rows_stream_bytes(C, true, 3) + (pre_res ? 6.0 : 4.0) * M * C + 2.0 * M * H * (2.0 * dp + dpv));
+        fflush(launch_log);
+    }
+    ++n_launches;
+}
+
 void Engine::self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, int Nq, int Nk, int C, int d, bf16* o, hipStream_t s,
-                            const RowStats* in_stats, int Tbuf, int slot) {
+                            const RowStats* in_stats, int Tbuf, int slot, bool projected) {
     const int H = C / d;
     int dp, dpv;
     CK(attn_dims(d, &dp, &dpv));
     const int vt_layout = attn_vt_layout(d, Nk, &dpv);    // which V^T form the attention kernel for this (d, Nk) reads
     AttnBufs& bufs = attn_bufs(B, H, d, Tbuf ? Tbuf : T, Tbuf ? Tbuf : T, dpv, slot);
     if (in_stats && !(a.fused && a.folded)) throw GlError(GL_ERR_STATE, "self_attention: row statistics given to an unfolded projection");
-    if (a.fused) {
+    if (projected) {
+        // (q, k, v^T were written by qkv_rows_project)
+    } else if (a.fused) {
         AOperand A;
         aoperand_rows(A, ln, C, C);
         Epilogue E;
@@ -1515,16 +1562,29 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
     RowStats st0, st1, st2, st3;
     // the row-local feed-forward kernel normalises its raw input rows itself: their producers need not write statistics
     const bool r2 = !fuser_off_ && ff_rows_for(t, 1, B, HW, s), r4 = ff_rows_for(t, 2, B, HW, s);
-    bf16* t0 = linear_rows(n, M, t.proj_in, ACT_NONE, nullptr, nullptr, s, &st0);
-
-    // x = attn1(norm1(x)) + x
-    const bool f1 = t.a1.folded && can_fold(st0, M, C, 3 * C, EPI_QKV_HEADS, ACT_NONE, aligned);
-    const bf16* ln = normed(t0, t.ln1, t.a1.folded, f1, true);
-    bf16* o = arena_.get<bf16>((size_t)M * C);
-    self_attention(t.a1, ln, B, Tp, HW, HW, C, d, o, s, f1 ? &st0 : nullptr);
-    bf16* t1 = linear_rows(o, M, t.a1.out, ACT_NONE, t0, nullptr, s, &st1);
-
+    // proj_in -> norm1 -> attn1's q,k,v^T: one row-local launch where that kernel exists and fills the chip (ffn.h qkv_rows_kernel)
+    const bool rq1 = aligned && qkv_rows_ok(t.a1, B, HW, HW, C, d);
+    bf16* t0;
+    const bf16* ln = nullptr;
+    bf16* o = nullptr;
+    if (rq1) {
+        t0 = arena_.get<bf16>((size_t)M * C);
+        o = arena_.get<bf16>((size_t)M * C);
+        qkv_rows_project(t.a1, n, B, HW, HW, C, d, t.proj_in, nullptr, t0, nullptr, 0, 0, s);
+        self_attention(t.a1, nullptr, B, Tp, HW, HW, C, d, o, s, nullptr, 0, 0, true);
+    } else {
+        t0 = linear_rows(n, M, t.proj_in, ACT_NONE, nullptr, nullptr, s, &st0);
+        // x = attn1(norm1(x)) + x
+        const bool f1 = t.a1.folded && can_fold(st0, M, C, 3 * C, EPI_QKV_HEADS, ACT_NONE, aligned);
+        ln = normed(t0, t.ln1, t.a1.folded, f1, true);
+        o = arena_.get<bf16>((size_t)M * C);
+        self_attention(t.a1, ln, B, Tp, HW, HW, C, d, o, s, f1 ? &st0 : nullptr);
+    }
     const int Ng = cond_.Ng;
+    // attn1.to_out + residual -> fuser.norm1 -> the fuser's q,k,v^T over the visual rows: the same launch shape
+    const bool rq2 = !fuser_off_ && ucfg_.fuser_kind == 0 && fuser_hoist_ && aligned && qkv_rows_ok(t.fa, B, HW, HW + Ng, C, d);
+    bf16* t1 = rq2 ? arena_.get<bf16>((size_t)M * C) : linear_rows(o, M, t.a1.out, ACT_NONE, t0, nullptr, s, &st1);
+
     bf16* t3;
     if (fuser_off_) {
         t3 = t1;
@@ -1532,7 +1592,19 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
     } else if (ucfg_.fuser_kind == 0) {
         // fuser (gatedSA): x = x + scale*tanh(alpha_attn) * attn(norm1([x ; linear(objs)]))[:, :N]
         const int Tf = round_up(HW + Ng, 64);
-        if (fuser_hoist_ && t.fa.fused && t.fa.folded && aligned) {
+        if (rq2) {
+            if (fuser_kv_.size() < st_.size()) fuser_kv_.resize(st_.size());
+            const FuserKV& kv = fuser_kv_[t.idx];
+            if (kv.epoch != cond_epoch_ || kv.B != B || kv.HW != HW) {
+                hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+                (void)hipStreamIsCapturing(s, &cap);
+                if (cap != hipStreamCaptureStatusNone) throw GlError(GL_ERR_STATE, "fuser keys of this prompt / shape were not projected before the graph capture");
+                fuser_kv_fill(t, B, HW, s);
+                n_launches += 2;
+            }
+            qkv_rows_project(t.fa, o, B, HW, HW + Ng, C, d, t.a1.out, t0, t1, nullptr, Tf, t.idx + 1, s);
+            self_attention(t.fa, nullptr, B, HW, HW, HW + Ng, C, d, o, s, nullptr, Tf, t.idx + 1, true);
+        } else if (fuser_hoist_ && t.fa.fused && t.fa.folded && aligned) {
             // the grounding tokens' keys / values are in this block's buffers since the prompt was set (fuser_kv_fill); only the visual
             // rows are projected, raw, with the statistics attn1.to_out wrote (or through the plain LayerNorm where it wrote none)
             if (fuser_kv_.size() < st_.size()) fuser_kv_.resize(st_.size());

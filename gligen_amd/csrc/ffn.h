@@ -54,4 +54,35 @@ int ff_rows_launch(const FFRowsParams& p, int C, hipStream_t s);
 size_t ff_chain_stream_bytes(int C, bool pre, bool post);
 int ff_chain_pack_launch(const float* w1, const float* b1, const float* w2, const float* pre_w, const float* post_w, void* stream, int C, hipStream_t s);
 
+// ---- Row-local q,k,v^T projection (ffn.hip qkv_rows_kernel): [leading C x C projection + residual ->] LayerNorm in registers ->
+// to_q / to_k / to_v with the attention kernels' head layouts, ONE launch; rows stay in registers, weights stream through LDS.
+// Replaces (C = 320, d = 40, the 64 x 64 level) SpatialTransformer.proj_in or attn1.to_out + residual (reference
+// ldm/modules/attention.py:366-368, 183-186, 335) together with the fused q,k,v^T GEMM behind the next LayerNorm (:167-176).
+struct QkvRowsParams {
+    const bf16* x;          // [M][ldx]: input of the leading projection (pre = 1) or the raw residual rows (pre = 0)
+    int ldx;
+    int normalize;          // pre = 0: 1 = (x - mean) * rstd per row in registers first. pre = 1 always normalises t
+    float eps;
+    const void* stream;     // qkv_rows_pack_launch
+    int M;
+    int pre;                // 1: t = pre_res + (x Wpre^T + pre_b) -> mid_out; q,k,v are projections of LN(t)
+    const float* pre_b;     // [C]
+    const bf16* pre_res;    // [M][ld_pre_res] or null
+    int ld_pre_res;
+    bf16* mid_out;          // [M][ld_mid]
+    int ld_mid;
+    float2* stats_out;      // optional [M]: (sum, sum of squares) of each row of t (Epilogue::ln_stats with nb = 1)
+    int np;                 // 3: q, k, v^T; 1: q only (cross-attention to_q)
+    const float* bias;      // [np * C] (W beta of the folded LayerNorm) or null
+    bf16* q;                // [B*H][Tpad_q][DP]
+    bf16* k;                // key-tile layout (gemm.h ktile_off), [B*H][Tpad_k / 64][DP / 8][64][8]
+    bf16* vt;               // [B*H][DPV][Tpad_k], tokens permuted within groups of 32 (vt_perm32 = 1)
+    int H, d, DP, DPV, T, Tpad_q, Tpad_k, vt_perm32;   // T = rows per sample (a multiple of 128)
+};
+bool qkv_rows_supported(int M, int C, int d, int T);
+size_t qkv_rows_stream_bytes(int C, bool pre, int np);
+// pre_w [C][C] fp32 or null; w [np * C][C] bf16: the (LayerNorm-folded) to_q [; to_k ; to_v] rows
+int qkv_rows_pack_launch(const float* pre_w, const bf16* w, int np, void* stream, int C, hipStream_t s);
+int qkv_rows_launch(const QkvRowsParams& p, int C, hipStream_t s);
+
 }  // namespace gl

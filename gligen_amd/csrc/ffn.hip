@@ -657,6 +657,286 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Row-local q,k,v^T projection (round 6; reference ldm/modules/attention.py:167-186 SelfAttention.to_q / to_k / to_v behind
+// BasicTransformerBlock.norm1 / GatedSelfAttentionDense.norm1, :366-368 SpatialTransformer.proj_in, :183-186 to_out + residual).
+//
+// As a tiled GEMM the fused q,k,v^T projection at the 64 x 64 level (M = 32768, N = 960, K = 320) stages both operands through
+// the LDS-DMA once per 128 x 128 tile and runs at 0.40 PFLOP/s; the K = C projection in front of it (proj_in, or attn1.to_out with
+// its residual) is one more launch and one more round trip of the residual stream. Here a wave keeps its 32 rows in registers
+// as in ff_rows_kernel and runs the projections back to back:
+//   PRE : t = pre_res + (x Wpre^T + pre_b)  -> mid_out (the residual stream), normalised in registers (LayerNorm without affine:
+//         gamma / beta live in the folded q,k,v weights) -> operand of
+//   q, k: features as MFMA rows (weights = A operand), so a lane holds 4 consecutive head dims of ONE token: the 8-byte store of the
+//         row-major q layout and of the key-tile k layout (gemm.h ktile_off);
+//   v^T : the SAME fragments with the operand roles exchanged (rows in the A slot, weights in the B slot -- both layouts are
+//         lane = row / column, 8 k-slots per half), so a lane holds 16 TOKENS of one feature, contiguous under the 32-token
+//         permutation of attn3_kernel (gemm.hip perm_tok4): two 16-byte stores per feature block.
+// Weights: one stream of projection segments (5 stages x 40 blocks of 1 KiB each, k-step major), the main loop is proj_phase's
+// fixed instruction order; the epilogues between the segments are hipcc's. A segment's first stage is fetched under the last
+// stage of the segment before it and waited for BEFORE the epilogue's stores join the vmcnt counter, so the stores drain under
+// the next segment's first MFMAs instead of in front of them.
+template <int C, int D, bool PRE, int NP>
+__global__ void __launch_bounds__(256, 1) qkv_rows_kernel(QkvRowsParams p) {
+    using G = FFGeom<C>;
+    static_assert(C % D == 0 && D % 8 == 0, "head geometry");
+    constexpr int KS = G::KS, NCB = G::NCB, PJ_BLK = G::PJ_BLK, PJ_ST = G::PJ_ST, PJ_KS = G::PJ_KS;
+    constexpr int PSTAGE = PJ_BLK * 1024;
+    constexpr int RD = 8, NR = RD + 4;
+    constexpr int NSEG = (PRE ? 1 : 0) + NP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int h = lane >> 5, l31 = lane & 31;
+    const int row0 = blockIdx.x * 128 + wave * 32;     // the wave's first row (32 consecutive tokens of one sample: T % 32 == 0)
+    const int row = row0 + l31;
+    const unsigned lane16 = (unsigned)lane * 16u;
+
+    u32x4 rs;
+    {
+        const unsigned long long a = (unsigned long long)(uintptr_t)p.stream;
+        rs.x = (unsigned)a;
+        rs.y = (unsigned)(a >> 32);
+        rs.z = (unsigned)((size_t)NSEG * G::PJ_BYTES);
+        rs.w = 0x00020000u;
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned lds_w = lds0 + (unsigned)wave * 1024u;
+    unsigned dma_lds = lds_w;
+    unsigned dma_off = (unsigned)wave * 1024u;
+#pragma unroll
+    for (int i = 0; i < PJ_BLK / 4; ++i) ffr_dma<true>(rs, lane16, dma_lds, dma_off);
+
+    bf16x8 xf[KS];
+    {
+        const bf16* src = p.x + (size_t)row * p.ldx + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(src + ks * 16);
+    }
+    if (!PRE && p.normalize) {
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = bf2f(xf[ks][e]);
+                s += v;
+                ss = fmaf(v, v, ss);
+            }
+        s += __shfl_xor(s, 32, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        const float mean = s * (1.f / C);
+        const float var = fmaxf(ss * (1.f / C) - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + p.eps);
+        const float nm = -mean * rstd;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xf[ks][e] = f2bf(fmaf(bf2f(xf[ks][e]), rstd, nm));
+    }
+
+    f32x16 acc[NCB];
+    const unsigned ra_st[2] = {lds0 + lane16, lds0 + (unsigned)PSTAGE + lane16};
+
+    // One projection segment: acc[cb] = sum over k-steps of W-block(ks, cb) x xin[ks] (SWAP: xin[ks] x W-block), first k-step with C = 0.
+    // BUF0: LDS buffer of its first stage; NEXT: blocks per wave of the next segment's first stage, fetched under the last stage and
+    // waited for before this function returns; SKIP: the first stage is known to have landed (the previous segment waited for it)
+    auto phase = [&](bf16x8 (&xin)[KS], auto buf0_c, auto next_c, auto swap_c, auto skip_c) {
+        constexpr int BUF0 = decltype(buf0_c)::value, NEXT = decltype(next_c)::value;
+        constexpr bool SWAP = decltype(swap_c)::value, SKIP = decltype(skip_c)::value;
+        static_for<PJ_ST>([&](auto sc) {
+            constexpr int st = decltype(sc)::value, BUF = (BUF0 + st) & 1;
+            constexpr int pieces = st + 1 < PJ_ST ? PJ_BLK / 4 : NEXT;
+            if constexpr (!(SKIP && st == 0)) asm volatile("s_waitcnt vmcnt(0)");
+            __builtin_amdgcn_s_barrier();
+            const unsigned ra = ra_st[BUF];
+            dma_lds = lds_w + (BUF ? 0u : (unsigned)PSTAGE);
+            bf16x8 fr[NR];
+            static_for<RD>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                ffr_rd16<i * 1024>(fr[i % NR], ra);
+            });
+            static_for<PJ_BLK>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i % 4 == 0) {
+                    constexpr int last = (i + RD - 1 < PJ_BLK - 1) ? i + RD - 1 : PJ_BLK - 1;
+                    constexpr int need = (i + 3 < PJ_BLK - 1) ? i + 3 : PJ_BLK - 1;
+                    ffr_wait_lgkm<last - need>();
+                }
+                constexpr int ks = st * PJ_KS + i / NCB, cb = i % NCB;
+                if constexpr (ks == 0) {
+                    if constexpr (SWAP) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&a"(acc[cb]) : "a"(xin[0]), "v"(fr[i % NR]));
+                    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&a"(acc[cb]) : "v"(fr[i % NR]), "a"(xin[0]));
+                } else {
+                    if constexpr (SWAP) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[cb]) : "a"(xin[ks]), "v"(fr[i % NR]));
+                    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[cb]) : "v"(fr[i % NR]), "a"(xin[ks]));
+                }
+                if constexpr (i + RD < PJ_BLK) ffr_rd16<(i + RD) * 1024>(fr[(i + RD) % NR], ra);
+                if constexpr (i % 2 == 1 && i / 2 < pieces) ffr_dma(rs, lane16, dma_lds, dma_off);
+            });
+        });
+        ffr_settle(acc);
+        if constexpr (NEXT > 0) asm volatile("s_waitcnt vmcnt(0)");
+    };
+    auto pin_x = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(xf[ks]));
+        asm volatile("s_nop 7\n\ts_nop 7");
+    };
+
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    using NX = std::integral_constant<int, PJ_BLK / 4>;
+    using N0 = std::integral_constant<int, 0>;
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // the x rows are back before the first asm DMA of the main loop (its waits do not count them)
+    pin_x();
+    if constexpr (PRE) {
+        phase(xf, B0{}, NX{}, F_{}, F_{});
+        // t = pre_res + (x Wpre^T + pre_b), rounded to bf16: the residual stream. Lane holds features 32 cb + 8 j + 4 h + e of its row
+        float tv[NCB][16];
+        float s = 0.f, ss = 0.f;
+        auto pre_epi = [&](auto res_c) {
+            constexpr bool RES = decltype(res_c)::value;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                float4 bv[4];
+                uint2 rv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bv[j] = *reinterpret_cast<const float4*>(p.pre_b + cb * 32 + j * 8 + h * 4);
+                    if constexpr (RES) rv[j] = *reinterpret_cast<const uint2*>(p.pre_res + (size_t)row * p.ld_pre_res + cb * 32 + j * 8 + h * 4);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    U2BF4 r, o;
+                    if constexpr (RES) r.u = rv[j];
+                    const float bj[4] = {bv[j].x, bv[j].y, bv[j].z, bv[j].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[cb][4 * j + e] + bj[e];
+                        if constexpr (RES) v += bf2f(r.e[e]);
+                        o.e[e] = f2bf(v);
+                        const float t_ = bf2f(o.e[e]);
+                        tv[cb][4 * j + e] = t_;
+                        s += t_;
+                        ss = fmaf(t_, t_, ss);
+                    }
+                    *reinterpret_cast<uint2*>(p.mid_out + (size_t)row * p.ld_mid + cb * 32 + j * 8 + h * 4) = o.u;
+                }
+            }
+        };
+        if (p.pre_res) pre_epi(T_{});
+        else pre_epi(F_{});
+        s += __shfl_xor(s, 32, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        if (p.stats_out && h == 0) p.stats_out[row] = make_float2(s, ss);
+        const float mean = s * (1.f / C);
+        const float var = fmaxf(ss * (1.f / C) - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + p.eps);
+        const float nm = -mean * rstd;
+        // accumulator layout -> B / A operand fragments in the permuted k-slot order (ff_kidx, kperm)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xf[ks][e] = f2bf(fmaf(tv[ks >> 1][4 * (2 * (ks & 1) + (e >> 2)) + (e & 3)], rstd, nm));
+        pin_x();
+    }
+
+    // ---- heads. b, token of the wave's rows: uniform sample, consecutive tokens
+    const int b = row0 / p.T;
+    const int tw = row0 - b * p.T;                 // multiple of 32
+    const int tok = tw + l31;
+    auto heads_qk = [&](auto which_c) {
+        constexpr int WHICH = decltype(which_c)::value;
+        const int tp = WHICH ? p.Tpad_k : p.Tpad_q;
+        const size_t head_stride = (size_t)tp * p.DP;
+        bf16* base = (WHICH ? p.k : p.q) + (size_t)b * p.H * head_stride +
+                     (WHICH ? (size_t)(tok & ~63) * p.DP + (size_t)(tok & 63) * 8 + 4 * h : (size_t)tok * p.DP + 4 * h);
+        const float* bias = p.bias + WHICH * C + 4 * h;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            float4 bv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = p.bias ? *reinterpret_cast<const float4*>(bias + cb * 32 + j * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                constexpr int dummy = 0; (void)dummy;
+                const int f0 = cb * 32 + j * 8, hd = f0 / D, dd = f0 % D;      // (compile-time after unrolling; + 4 h stays inside the head: D % 8 == 0)
+                const float v[4] = {acc[cb][4 * j] + bv[j].x, acc[cb][4 * j + 1] + bv[j].y, acc[cb][4 * j + 2] + bv[j].z, acc[cb][4 * j + 3] + bv[j].w};
+                U2BF4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.e[e] = f2bf(v[e]);
+                bf16* dst = base + (size_t)hd * head_stride + (WHICH ? (size_t)(dd >> 3) * 512 : (size_t)dd);
+                *reinterpret_cast<uint2*>(dst) = o.u;
+            }
+        }
+    };
+    auto heads_vt = [&]() {
+        // lane: feature 32 cb + l31, registers 4 j + e = token tw + 8 j + 4 h + e -> position tw + 16 h + 4 j + e of the permuted row
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int f = cb * 32 + l31, hd = f / D, dd = f - hd * D;
+            const float bn = p.bias ? p.bias[2 * C + f] : 0.f;
+            bf16* dst = p.vt + ((size_t)(b * p.H + hd) * p.DPV + dd) * p.Tpad_k + tw + 16 * h;
+            U4BF8 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o0.e[e] = f2bf(acc[cb][e] + bn);
+                o1.e[e] = f2bf(acc[cb][8 + e] + bn);
+            }
+            *reinterpret_cast<uint4*>(dst) = o0.u;
+            *reinterpret_cast<uint4*>(dst + 8) = o1.u;
+        }
+    };
+    constexpr int P0 = PRE ? 1 : 0;      // buffer parity of the first head segment (every segment has an odd number of stages)
+    if constexpr (NP == 1) {
+        if constexpr (P0) phase(xf, B1{}, N0{}, F_{}, T_{}); else phase(xf, B0{}, N0{}, F_{}, F_{});
+        heads_qk(B0{});
+    } else {
+        if constexpr (P0) phase(xf, B1{}, NX{}, F_{}, T_{}); else phase(xf, B0{}, NX{}, F_{}, F_{});
+        heads_qk(B0{});
+        if constexpr (P0) phase(xf, B0{}, NX{}, F_{}, T_{}); else phase(xf, B1{}, NX{}, F_{}, T_{});
+        heads_qk(B1{});
+        if constexpr (P0) phase(xf, B1{}, N0{}, T_{}, T_{}); else phase(xf, B0{}, N0{}, T_{}, T_{});
+        heads_vt();
+    }
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) qkv_rows_pack_kernel(const float* __restrict__ pre_w, const bf16* __restrict__ w, int np,
+                                                            unsigned char* __restrict__ stream) {
+    using G = FFGeom<C>;
+    const size_t pre_bytes = pre_w ? G::PJ_BYTES : 0;
+    const size_t n_pieces = (pre_bytes + (size_t)np * G::PJ_BYTES) / 16;
+    for (size_t pc = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pc < n_pieces; pc += (size_t)gridDim.x * blockDim.x) {
+        const size_t byte = pc * 16;
+        const int L = (int)(byte >> 4) & 63, r = L & 31, h = L >> 5;
+        const bool pre = byte < pre_bytes;
+        const size_t sb = pre ? byte : byte - pre_bytes;
+        const int seg = (int)(sb / G::PJ_BYTES);
+        const int blk = (int)((sb % G::PJ_BYTES) >> 10);
+        const int st = blk / G::PJ_BLK, i = blk % G::PJ_BLK, ks = st * G::PJ_KS + i / G::NCB, cb = i % G::NCB;
+        U4BF8 o;
+        if (pre) {
+            const float* src = pre_w + (size_t)(cb * 32 + r) * C;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.e[e] = f2bf(src[ff_kidx(ks, h, e, false)]);
+        } else {
+            // behind a leading projection the operand comes out of accumulator registers: permuted k-slots (ff_kidx)
+            const bf16* src = w + (size_t)(seg * C + cb * 32 + r) * C;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.e[e] = src[ff_kidx(ks, h, e, pre_w != nullptr)];
+        }
+        *reinterpret_cast<uint4*>(stream + byte) = o.u;
+    }
+}
+
 }  // namespace
 
 bool ff_rows_supported(int M, int C) { return C == 320 && M > 0 && M % 128 == 0; }
@@ -737,6 +1017,49 @@ int ff_rows_launch(const FFRowsParams& p, int C, hipStream_t s) {
     else if (p.pre) FF_LAUNCH(true, false);
     else FF_LAUNCH(false, false);
 #undef FF_LAUNCH
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+
+bool qkv_rows_supported(int M, int C, int d, int T) { return C == 320 && d == 40 && M > 0 && M % 128 == 0 && T > 0 && T % 128 == 0 && M % T == 0; }
+
+size_t qkv_rows_stream_bytes(int C, bool pre, int np) {
+    if (C != 320 || (np != 1 && np != 3)) return 0;
+    return ((pre ? 1 : 0) + (size_t)np) * FFGeom<320>::PJ_BYTES;
+}
+
+int qkv_rows_pack_launch(const float* pre_w, const bf16* w, int np, void* stream, int C, hipStream_t s) {
+    if (C != 320 || (np != 1 && np != 3) || !w || !stream) return set_error(GL_ERR_UNSUPPORTED, "qkv_rows_pack: C = %d, np = %d has no row-local projection kernel", C, np);
+    hipLaunchKernelGGL(qkv_rows_pack_kernel<320>, dim3(512), dim3(256), 0, s, pre_w, w, np, reinterpret_cast<unsigned char*>(stream));
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+int qkv_rows_launch(const QkvRowsParams& p, int C, hipStream_t s) {
+    if (!qkv_rows_supported(p.M, C, p.d, p.T)) return set_error(GL_ERR_UNSUPPORTED, "qkv_rows: M = %d, C = %d, d = %d, T = %d has no row-local projection kernel", p.M, C, p.d, p.T);
+    if (p.np != 1 && p.np != 3) return set_error(GL_ERR_ARG, "qkv_rows: np must be 1 (q) or 3 (q, k, v^T)");
+    if (p.ldx % 8 || !p.x || !p.stream || !p.q || (p.np == 3 && (!p.k || !p.vt))) return set_error(GL_ERR_ARG, "qkv_rows: null pointer / unaligned rows");
+    if (p.np == 3 && (p.vt_perm32 != 1 || p.Tpad_k % 32)) return set_error(GL_ERR_UNSUPPORTED, "qkv_rows: v^T is written in the 32-token form only (attn3_kernel)");
+    if (p.H * p.d != C || p.DP < p.d || p.DP % 8 || (p.np == 3 && p.DPV < p.d)) return set_error(GL_ERR_ARG, "qkv_rows: head geometry");
+    if (p.pre && (!p.pre_b || !p.mid_out || p.ld_mid % 4 || (p.pre_res && p.ld_pre_res % 4))) return set_error(GL_ERR_ARG, "qkv_rows: the leading projection needs its bias and the buffer for its result");
+    using G = FFGeom<320>;
+    constexpr int LDS = 2 * G::PJ_BLK * 1024;
+#define QKV_LAUNCH(PRE_, NP_)                                                                                                \
+    do {                                                                                                                     \
+        auto kfn = qkv_rows_kernel<320, 40, PRE_, NP_>;                                                                      \
+        static bool attr_done = false;                                                                                       \
+        if (!attr_done) {                                                                                                    \
+            GL_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));                  \
+            attr_done = true;                                                                                                \
+        }                                                                                                                    \
+        hipLaunchKernelGGL(kfn, dim3(p.M / 128), dim3(256), LDS, s, p);                                                      \
+    } while (0)
+    if (p.pre && p.np == 3) QKV_LAUNCH(true, 3);
+    else if (p.pre) QKV_LAUNCH(true, 1);
+    else if (p.np == 3) QKV_LAUNCH(false, 3);
+    else QKV_LAUNCH(false, 1);
+#undef QKV_LAUNCH
     GL_LAUNCH_CHECK();
     return GL_OK;
 }

@@ -2942,6 +2942,18 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
     TunedCfg win{best_c, best_sp, 0};
     float win_ms = 1e30f;
     static const int tune_reps = dev_env("GL_GEMM_TUNE_REPS") ? std::max(1, atoi(dev_env("GL_GEMM_TUNE_REPS"))) : 3;
+    // GL_GEMM_TUNE_CORUN=1 (developer): the candidates are timed as TWO streams running the same launches side by side -- the cost of a
+    // launch while another batch shares the chip (bench.py / the CLI keep two batches in flight), not its latency on a quiet chip: a
+    // tile that leaves CUs to the neighbour is credited for it. Adds resident-grid caps below two workgroups per CU to the candidates.
+    static const bool corun = dev_env("GL_GEMM_TUNE_CORUN") && atoi(dev_env("GL_GEMM_TUNE_CORUN")) != 0;
+    hipStream_t s2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    struct CoGuard { hipStream_t& s; hipEvent_t &a, &b; ~CoGuard() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); if (s) (void)hipStreamDestroy(s); } } co_guard{s2, ev_fork, ev_join};
+    if (corun) {
+        GL_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        GL_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        GL_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
     for (int c = 0; c < NC; ++c) {
         const int tiles = cdiv(M, kTm[c] * 32) * cdiv(N, kTn[c] * 32);
         if (c == 4 && ((size_t)M * N > ((size_t)1 << 23) || N % 64)) continue;   // small problems only (M N <= 8 M outputs: 2048 x 3840, 8192 x 640 ..)
@@ -2951,12 +2963,28 @@ int gemm_p_launch(const AOperand& A, const bf16* W, int M, int N, int K, const E
             if (!feasible(c, sp) || sp == last_sp) continue;
             last_sp = sp;
             if (sp > 1 && tiles * sp > 4096) continue;      // splitting an already over-subscribed grid never paid
-            for (int gi = 0; gi < 3; ++gi) {
-                const int grid = gi == 0 ? 0 : gi == 1 ? 768 : 1024;
+            for (int gi = 0; gi < (corun ? 5 : 3); ++gi) {
+                const int grid = gi == 0 ? 0 : gi == 1 ? 768 : gi == 2 ? 1024 : gi == 3 ? 256 : 128;
                 if (gi == 1 && (kTm[c] * 32 + kTn[c] * 32 > 192 || tiles * sp <= 512)) continue;  // 3 workgroups/CU need <= 48 KB LDS each
                 if (gi == 2 && (kTm[c] * 32 + kTn[c] * 32 > 128 || tiles * sp <= 768)) continue;  // 4 workgroups/CU: the 64 x 64 tile (32 KB)
+                if (gi == 3 && tiles * sp <= 256) continue;                                        // (co-run tuning) one workgroup per CU
+                if (gi == 4 && tiles * sp <= 128) continue;                                        // (co-run tuning) half the CUs
                 GL_TRY(run_cfg(c, sp, grid));  // warm-up (also sets the kernel's LDS attribute outside the timed region)
                 GL_HIP(hipEventRecord(g_tune_ev[0], stream));
+                if (corun) {
+                    GL_HIP(hipEventRecord(ev_fork, stream));
+                    GL_HIP(hipStreamWaitEvent(s2, ev_fork, 0));
+                    for (int r = 0; r < tune_reps; ++r) {
+                        GL_TRY(run_cfg(c, sp, grid));
+                        hipStream_t keep = stream;
+                        stream = s2;                       // run_cfg launches on `stream` (captured by reference)
+                        const int rc2 = run_cfg(c, sp, grid);
+                        stream = keep;
+                        GL_TRY(rc2);
+                    }
+                    GL_HIP(hipEventRecord(ev_join, s2));
+                    GL_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+                } else
                 for (int r = 0; r < tune_reps; ++r) GL_TRY(run_cfg(c, sp, grid));
                 GL_HIP(hipEventRecord(g_tune_ev[1], stream));
                 GL_HIP(hipEventSynchronize(g_tune_ev[1]));

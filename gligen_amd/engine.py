@@ -637,6 +637,17 @@ class Engine:
                                        C.c_float(eps), _ptr(y), _stream(self.device)))
         return y
 
+    def op_proj_attention(self, x, pre_w, pre_b, pre_res, gamma, beta, wq, wk, wv, heads, rows=True):
+        """mid = pre_res + x Wpre^T + pre_b; o = self-attention of LN(mid) without to_out (gl_op_proj_attention).
+        Returns (mid, o, used_rows): used_rows = 1 when the row-local projection kernel ran."""
+        B, N, Cc = x.shape
+        mid = torch.empty_like(x)
+        o = torch.empty_like(x)
+        used = C.c_int(1 if rows else 0)
+        check(self.lib.gl_op_proj_attention(self._ctx, _ptr(x), B, N, Cc, heads, _ptr(pre_w), _ptr(pre_b), _ptr(pre_res), _ptr(gamma), _ptr(beta),
+                                            _ptr(wq), _ptr(wk), _ptr(wv), 0, _ptr(mid), _ptr(o), C.byref(used), _stream(self.device)))
+        return mid, o, used.value
+
     def op_attention(self, xq, xkv, wq, wk, wv, heads):
         B, Nq, Cc = xq.shape
         _, Nk, Ck = xkv.shape

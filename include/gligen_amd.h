@@ -389,6 +389,19 @@ int gl_op_layernorm(gl_ctx* ctx, const void* x, const void* x2, int B, int N1, i
 int gl_op_attention(gl_ctx* ctx, const void* xq, const void* xkv, int B, int Nq, int Nk, int C, int Ck, int H,
                     const float* wq, const float* wk, const float* wv, void* o, gl_stream s);
 
+/* A projection, the LayerNorm behind it and the self-attention behind that, as the engine runs them at the 64 x 64 level (reference
+ * ldm/modules/attention.py:366-368 SpatialTransformer.proj_in -> :335 norm1 -> attn1, and :183-186 attn1.to_out + residual ->
+ * :240 fuser.norm1 -> fuser.attn):
+ *   mid = pre_res + (x Wpre^T + pre_b)              (pre_res may be NULL)
+ *   o   = softmax(q k^T d^-0.5) v,  q / k / v = LN(mid; gamma, beta) Wq^T / Wk^T / Wv^T     (no to_out)
+ * x / pre_res / mid / o [B][N][C] bf16, Wpre / Wq / Wk / Wv [C][C] fp32, N % 64 == 0, Nkv_extra must be 0.
+ * *used_rows in: 1 = take the row-local projection kernel (qkv_rows_kernel: one launch for the projection, the LayerNorm and q,k,v^T;
+ * C = 320, H = 8, B N % 128 == 0, N % 128 == 0, N > 128) where it exists, 0 = the three-launch form (GEMM, LayerNorm kernel, fused q,k,v^T
+ * GEMM); out: which one ran. Both are product paths. */
+int gl_op_proj_attention(gl_ctx* ctx, const void* x, int B, int N, int C, int H, const float* pre_w, const float* pre_b, const void* pre_res,
+                         const float* gamma, const float* beta, const float* wq, const float* wk, const float* wv, int Nkv_extra,
+                         void* mid, void* o, int* used_rows, gl_stream s);
+
 #ifdef __cplusplus
 }
 #endif

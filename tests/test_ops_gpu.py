@@ -746,3 +746,42 @@ def test_ff_chain(engine, M, post, gates):
     assert rel_err(y, ref) < TOL, rel_err(y, ref)
     y2 = engine.op_ff_chain(x, pre_w, pre_b, pre_res, gamma, beta, w1, b1, w2, b2, pre_gate=g1, gate=g2, post_w=post_w, post_b=post_b, post_res=post_res)
     assert torch.equal(y, y2)
+
+
+# ---- the row-local q,k,v^T projection (ffn.hip qkv_rows_kernel): a C x C projection (+ residual), the LayerNorm behind it and
+# to_q / to_k / to_v with the attention kernels' head layouts in ONE launch, checked through the attention that reads those
+# layouts, against fp32 torch and against the three-launch form it replaces (reference attention.py:366-368 proj_in, :183-186
+# to_out + residual, :335 / :240 norm1, :167-176 to_q / to_k / to_v).
+@pytest.mark.parametrize("B,N", [(1, 256), (2, 1024), (3, 384)])
+@pytest.mark.parametrize("res", [False, True])
+def test_proj_attention_rows(engine, B, N, res):
+    C, H = 320, 8
+    x = bf(rnd(B, N, C, seed=1))
+    pre_w, pre_b = rnd(C, C, scale=C ** -0.5, seed=2), 0.1 * rnd(C, seed=3)
+    pre_res = bf(rnd(B, N, C, seed=4) * 1.3 + 0.2) if res else None
+    gamma, beta = 1.0 + 0.3 * rnd(C, seed=5), 0.2 * rnd(C, seed=6)
+    s = 1.5
+    wq, wk, wv = rnd(C, C, scale=s * C ** -0.5, seed=7), rnd(C, C, scale=s * C ** -0.5, seed=8), rnd(C, C, scale=C ** -0.5, seed=9)
+    mid, o, used = engine.op_proj_attention(x, pre_w, pre_b, pre_res, gamma, beta, wq, wk, wv, H, rows=True)
+    assert used == 1, "the row-local projection kernel did not run"
+    t = x.float() @ bf(pre_w).float().t() + pre_b
+    if res:
+        t = t + pre_res.float()
+    assert rel_err(mid, t) < TOL
+    tb = mid.float()                                   # the kernel normalises its own bf16-rounded rows
+    ln = F.layer_norm(tb, (C,), gamma, beta, 1e-5)
+    d = C // H
+    q, k, v = (ln @ w.t() for w in (wq, wk, wv))
+    hs = lambda z: z.view(B, N, H, d).transpose(1, 2)
+    ref = torch.softmax(hs(q) @ hs(k).transpose(-1, -2) * d ** -0.5, dim=-1) @ hs(v)
+    ref = ref.transpose(1, 2).reshape(B, N, C)
+    assert torch.isfinite(o.float()).all()
+    assert rel_err(o, ref) < 2.5e-2, rel_err(o, ref)
+    assert ((o.float() - ref).abs().mean() / ref.abs().mean()).item() < 1e-2
+    # against the three-launch form (GEMM + residual, LayerNorm kernel, fused q,k,v^T GEMM): same mathematics, other rounding points
+    mid0, o0, used0 = engine.op_proj_attention(x, pre_w, pre_b, pre_res, gamma, beta, wq, wk, wv, H, rows=False)
+    assert used0 == 0
+    assert rel_err(mid, mid0.float()) < 8e-3
+    assert rel_err(o, o0.float()) < 1.2e-2
+    mid2, o2, _ = engine.op_proj_attention(x, pre_w, pre_b, pre_res, gamma, beta, wq, wk, wv, H, rows=True)
+    assert torch.equal(mid, mid2) and torch.equal(o, o2)

@@ -17,6 +17,8 @@
 #                    + rocprofv3 stats of one B = 4 iteration with TRAIN_PROF=1
 #   ab VAR A B [N]   same-box A/B of a developer switch: bench.py alternated N times (default 2) with VAR=A / VAR=B
 #   abn VAR N v1 v2 .. --   the same for several values of VAR, N rounds (end the value list with --)
+#   tune NAME [ENV=V ..] --   bench.py with the tile table ignored and every GEMM problem tuned on the device under the given switches
+#                    (GL_GEMM_TUNE_CORUN=1: candidates timed as two streams side by side); log -> tune_NAME.log (input of make_tuned_table.py)
 #   calib            gl_mfma_calibrate table (tools/calib_mfma.py): MFMA ceiling by shape / waves per SIMD / accumulators with the in-loop clock
 #   lib DIR          swap in the variant library built by tools/build_variant.sh for the tasks that follow
 export TMPDIR=/tmp
@@ -62,6 +64,9 @@ while [ $# -gt 0 ]; do
            for i in $(seq $n); do for v in "${vals[@]}"; do
              ( export $var=$v; timeout 500 python bench.py --steps 4 --no-cpu-baseline --no-train-step --no-ff-ab 2>/dev/null ) | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$var=$v value %.3f one_lane %.3f unet_step_ms %.3f eager_sum %.3f' % (d['value'], d['value_one_lane'], d['unet_step_ms'], d['roofline']['eager_sum_ms']))" | tee -a $O/ab_$var.txt
            done; done ;;
+    tune) dev; name=$1; shift; envs=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do envs+=("$1"); shift; done; [ "$1" = "--" ] && shift
+           ( export GL_GEMM_NO_TABLE=1 GL_GEMM_TUNE_LOG=1 GL_GEMM_TUNE_REPS=${TUNE_REPS:-10} "${envs[@]}"; timeout 800 python bench.py --steps 4 --no-cpu-baseline --no-train-step --no-ff-ab 2> $O/tune_$name.log ) | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('tune $name value %.3f one_lane %.3f unet_step_ms %.3f eager_sum %.3f' % (d['value'], d['value_one_lane'], d['unet_step_ms'], d['roofline']['eager_sum_ms']))" | tee -a $O/tune_summary.txt
+           grep -c "gemm autotune" $O/tune_$name.log ;;
     calib) dev; ( PYTHONPATH=. timeout 300 python tools/calib_mfma.py ${CALIB_MS:-40} ) > $O/calib_mfma.txt 2> $O/calib_mfma.err; cat $O/calib_mfma.txt | cut -c1-200; tail -2 $O/calib_mfma.err | cut -c1-200 ;;
     lib) d=$1; shift; cp $d/libgligen_amd.so gligen_amd/libgligen_amd.so; [ -f $d/kbench ] && cp $d/kbench $K; echo "library <- $d" ;;
     *) echo "unknown task $task"; exit 2 ;;
