@@ -287,9 +287,11 @@ class Engine {
     // The row-local projection launch (ffn.h QkvRowsParams): mid = pre_res + (x Wpre^T + pre_b) -> LayerNorm in registers -> q, k, v^T
     // of attention `a` into its head-layout buffers; T tokens per sample, Nk keys decide the V^T form (attn_vt_layout)
     bool qkv_rows_ok(const SelfAttnW& a, int B, int T, int Nk, int C, int d) const;
+    bool qkv_rows_for(const STW& t, int which, int B, int HW, int Nk, hipStream_t s);   // the timed choice (ff_policy), which: 0 = attn1, 1 = fuser.attn
+    void qkv_project_gemm(const SelfAttnW& a, const bf16* ln, int B, int T, int Nk, int C, int d, hipStream_t s, const RowStats* in_stats, int Tbuf, int slot);
     void qkv_rows_project(const SelfAttnW& a, const bf16* x, int B, int T, int Nk, int C, int d, const LinW& pre, const bf16* pre_res, bf16* mid,
                           RowStats* mid_stats, int Tbuf, int slot, hipStream_t s);
-    int qkv_rows_ = 1;           // GL_QKV_ROWS (developer A/B): 0 = off, 1 = where a launch fills the chip (default), 2 = wherever the kernel exists
+    int qkv_rows_ = 1;           // GL_QKV_ROWS (developer A/B): 0 = off, 1 = by the timed policy (default), 2 = wherever the kernel exists
     // GatedSelfAttentionDense (attention.py:236-244): the K / V rows of the grounding tokens linear(objs) do not depend on the step.
     // They are projected ONCE per prompt into the tail (tokens HW .. HW + Ng - 1) of this block's own K / V^T buffers; per step only
     // the HW visual rows go through the (LayerNorm-folded) q,k,v^T projection -- no [x ; objs] concat LayerNorm pass.

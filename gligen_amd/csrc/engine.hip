@@ -1211,8 +1211,7 @@ void Engine::fuser_kv_fill(const STW& t, int B, int HW, hipStream_t s) {
 bool Engine::qkv_rows_ok(const SelfAttnW& a, int B, int T, int Nk, int C, int d) const {
     if (!qkv_rows_ || !a.rows_stream || !a.fused || !a.folded || !qkv_rows_supported(B * T, C, d, T)) return false;
     int dpv = 0;
-    if (attn_vt_layout(d, Nk, &dpv) != 1) return false;          // the kernel writes V^T in the 32-token form of attn3_kernel only
-    return qkv_rows_ >= 2 || B * T / 128 >= 224;                 // one 128-row workgroup per CU: a launch that fills the chip
+    return attn_vt_layout(d, Nk, &dpv) == 1;                     // the kernel writes V^T in the 32-token form of attn3_kernel only
 }
 
 void Engine::qkv_rows_project(const SelfAttnW& a, const bf16* x, int B, int T, int Nk, int C, int d, const LinW& pre, const bf16* pre_res, bf16* mid,
@@ -1254,9 +1253,28 @@ void Engine::self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, in
     const int vt_layout = attn_vt_layout(d, Nk, &dpv);    // which V^T form the attention kernel for this (d, Nk) reads
     AttnBufs& bufs = attn_bufs(B, H, d, Tbuf ? Tbuf : T, Tbuf ? Tbuf : T, dpv, slot);
     if (in_stats && !(a.fused && a.folded)) throw GlError(GL_ERR_STATE, "self_attention: row statistics given to an unfolded projection");
-    if (projected) {
-        // (q, k, v^T were written by qkv_rows_project)
-    } else if (a.fused) {
+    if (!projected) qkv_project_gemm(a, ln, B, T, Nk, C, d, s, in_stats, Tbuf, slot);
+    AttnParams P{};
+    P.q = bufs.q; P.k = bufs.k; P.vt = bufs.vt; P.o = o;
+    P.H = H; P.d = d; P.Nq = Nq; P.Nk = Nk; P.Tq_pad = bufs.Tq_pad; P.Tk_pad = bufs.Tk_pad;
+    P.ldo = C; P.o_rows_per_b = Nq; P.vt_layout = vt_layout;
+    P.scale_log2e = (float)(1.4426950408889634 / std::sqrt((double)d));
+    {
+        ProfScope ps(this, s, attn_kernel_name(d, Nk, vt_layout), 4.0 * B * H * (double)Nq * Nk * d, 0.0);
+        CK(attn_launch(P, B, s));
+        log_attention(attn_kernel_name(d, Nk, vt_layout), B, H, Nq, Nk, d);
+    }
+    ++n_launches;
+}
+
+// q, k, v^T of a self-attention by GEMM: the fused EPI_QKV_HEADS launch (or the q,k GEMM + operand-swapped v^T GEMM)
+void Engine::qkv_project_gemm(const SelfAttnW& a, const bf16* ln, int B, int T, int Nk, int C, int d, hipStream_t s, const RowStats* in_stats, int Tbuf, int slot) {
+    const int H = C / d;
+    int dp, dpv;
+    CK(attn_dims(d, &dp, &dpv));
+    const int vt_layout = attn_vt_layout(d, Nk, &dpv);
+    AttnBufs& bufs = attn_bufs(B, H, d, Tbuf ? Tbuf : T, Tbuf ? Tbuf : T, dpv, slot);
+    if (a.fused) {
         AOperand A;
         aoperand_rows(A, ln, C, C);
         Epilogue E;
@@ -1290,17 +1308,6 @@ void Engine::self_attention(const SelfAttnW& a, const bf16* ln, int B, int T, in
         if (profiling_) ps.rename(gemm_last_kernel_name());
         ++n_launches;
     }
-    AttnParams P{};
-    P.q = bufs.q; P.k = bufs.k; P.vt = bufs.vt; P.o = o;
-    P.H = H; P.d = d; P.Nq = Nq; P.Nk = Nk; P.Tq_pad = bufs.Tq_pad; P.Tk_pad = bufs.Tk_pad;
-    P.ldo = C; P.o_rows_per_b = Nq; P.vt_layout = vt_layout;
-    P.scale_log2e = (float)(1.4426950408889634 / std::sqrt((double)d));
-    {
-        ProfScope ps(this, s, attn_kernel_name(d, Nk, vt_layout), 4.0 * B * H * (double)Nq * Nk * d, 0.0);
-        CK(attn_launch(P, B, s));
-        log_attention(attn_kernel_name(d, Nk, vt_layout), B, H, Nq, Nk, d);
-    }
-    ++n_launches;
 }
 
 bf16* Engine::feedforward_chain(const FFW& f, const bf16* x, int M, const LinW& pre, const bf16* pre_res, const float* pre_gate, const float* gate,
@@ -1366,7 +1373,7 @@ int ff_rows_policy_report(char* buf, size_t cap) {
         if (n + 96 >= cap) break;
         const uint64_t k = kv.first;
         n += (size_t)snprintf(buf + n, cap - n, ";dev%d %s form%d C%d M%d -> %s (rows %.1f us, gemm %.1f us)", (int)(k >> 56),
-                              ((k >> 52) & 15) == 1 ? "fuser.ff" : "ff", (int)((k >> 48) & 15), (int)((k >> 32) & 0xffff), (int)(k & 0xffffffffu),
+                              ((k >> 52) & 15) == 1 ? "fuser.ff" : ((k >> 52) & 15) == 2 ? "ff" : ((k >> 52) & 15) == 3 ? "proj_in+attn1.qkv" : "attn1.to_out+fuser.qkv", (int)((k >> 48) & 15), (int)((k >> 32) & 0xffff), (int)(k & 0xffffffffu),
                               kv.second.rows ? "rows" : "gemm", kv.second.us_rows, kv.second.us_gemm);
     }
     return GL_OK;
@@ -1495,6 +1502,84 @@ bool Engine::ff_rows_for(const STW& t, int which, int B, int HW, hipStream_t s) 
     return e.rows != 0;
 }
 
+// Row-local projection launch or GEMM + LayerNorm-folded q,k,v^T GEMM for attention `which` (0 = attn1 behind proj_in, 1 = fuser.attn
+// behind attn1.to_out) of block t: the same policy as the row-local feed-forward (ff_policy: timed at the first eager launch per
+// device and shape, gl_set_ff_rows_policy forces it) -- on a box whose fabric is slow the kernel's exposed row loads / stores lose
+// what its fused launch wins (profiles/r6: 54 against 72 us on one box, 57 against 58 in the graph on another).
+bool Engine::qkv_rows_for(const STW& t, int which, int B, int HW, int Nk, hipStream_t s) {
+    const SelfAttnW& a = which ? t.fa : t.a1;
+    const int M = B * HW, C = t.C, d = t.d;
+    if (!qkv_rows_ok(a, B, HW, Nk, C, d)) return false;
+    if (qkv_rows_ >= 2) return true;
+    const int mode = ff_policy::mode.load();
+    if (mode == 0) return false;
+    if (mode == 1) return true;
+    if (mode == 2) return ff_policy::static_rule(M);
+    const uint64_t key = ff_policy::key(device_, 3 + which, 0, C, M);
+    std::unique_lock<std::mutex> lk(ff_policy::mu);
+    auto it = ff_policy::table.find(key);
+    if (it != ff_policy::table.end()) return it->second.rows != 0;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    if (cap != hipStreamCaptureStatusNone) {
+        const bool rows = ff_policy::static_rule(M);
+        ff_policy::table[key] = ff_policy::Entry{rows ? 1 : 0, 0.f, 0.f};
+        return rows;
+    }
+    HIPCK(hipDeviceSynchronize());
+    struct Restore {
+        Engine* e; size_t mk; int64_t launches; bool prof;
+        ~Restore() { e->arena_.release(mk); e->n_launches = launches; e->profiling_ = prof; }
+    } restore{this, arena_.mark(), n_launches, profiling_};
+    profiling_ = false;
+    bf16* zx = arena_.get<bf16>((size_t)M * C);
+    bf16* zr = arena_.get<bf16>((size_t)M * C);
+    bf16* zm = arena_.get<bf16>((size_t)M * C);
+    bf16* zm2 = arena_.get<bf16>((size_t)M * C);
+    HIPCK(hipMemsetAsync(zx, 0, (size_t)M * C * sizeof(bf16), s));
+    HIPCK(hipMemsetAsync(zr, 0, (size_t)M * C * sizeof(bf16), s));
+    const LinW& pre = which ? t.a1.out : t.proj_in;
+    const int Tf = which ? round_up(Nk, 64) : 0, slot = which ? t.idx + 1 : 0;
+    auto run = [&](bool rows) {
+        const size_t m2 = arena_.mark();
+        if (rows) {
+            qkv_rows_project(a, zx, B, HW, Nk, C, d, pre, which ? zr : nullptr, zm, nullptr, Tf, slot, s);
+        } else {
+            RowStats st;
+            bf16* mid = linear_rows(zx, M, pre, ACT_NONE, which ? zr : nullptr, nullptr, s, &st);
+            const bool f = can_fold(st, M, C, 3 * C, EPI_QKV_HEADS, ACT_NONE, true);
+            const bf16* ln = f ? mid : layernorm_plain(mid, B, HW, C, !which, s);
+            qkv_project_gemm(a, ln, B, HW, Nk, C, d, s, f ? &st : nullptr, Tf, slot);
+        }
+        // ... and the attention that reads what was projected: the row-local launch leaves q / k / v^T (and the clocks) in another
+        // state than the GEMM does, and the attention behind it was measured 4 us slower in situ -- time the pair, not the projection
+        self_attention(a, nullptr, B, HW, HW, Nk, C, d, zm2, s, nullptr, Tf, slot, true);
+        arena_.release(m2);
+    };
+    hipEvent_t ev[2];
+    HIPCK(hipEventCreate(&ev[0]));
+    HIPCK(hipEventCreate(&ev[1]));
+    struct EvGuard { hipEvent_t* e; ~EvGuard() { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); } } guard{ev};
+    float best[2] = {1e30f, 1e30f};
+    constexpr int REPS = 4, ROUNDS = 3;
+    for (int form_i = 0; form_i < 2; ++form_i) run(form_i == 1);
+    for (int r = 0; r < ROUNDS; ++r)
+        for (int form_i = 0; form_i < 2; ++form_i) {
+            HIPCK(hipEventRecord(ev[0], s));
+            for (int i = 0; i < REPS; ++i) run(form_i == 1);
+            HIPCK(hipEventRecord(ev[1], s));
+            HIPCK(hipEventSynchronize(ev[1]));
+            float ms = 0.f;
+            HIPCK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+            best[form_i] = std::min(best[form_i], ms * 1e3f / REPS);
+        }
+    const ff_policy::Entry e{best[1] < best[0] ? 1 : 0, best[1], best[0]};
+    ff_policy::table[key] = e;
+    static const bool log = dev_env("GL_FF_POLICY_LOG") != nullptr;
+    if (log) fprintf(stderr, "[ff policy] %s C %d M %d: rows %.1f us, gemm %.1f us -> %s\n", which ? "attn1.to_out+fuser.qkv" : "proj_in+attn1.qkv", C, M, e.us_rows, e.us_gemm, e.rows ? "rows" : "gemm");
+    return e.rows != 0;
+}
+
 bf16* Engine::feedforward(const FFW& f, const bf16* ln, int M, const bf16* res, const float* gate, hipStream_t s, const RowStats* in_stats,
                           RowStats* out_stats, bool raw_rows, bool use_rows) {
     const int C = f.C;
@@ -1563,7 +1648,7 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
     // the row-local feed-forward kernel normalises its raw input rows itself: their producers need not write statistics
     const bool r2 = !fuser_off_ && ff_rows_for(t, 1, B, HW, s), r4 = ff_rows_for(t, 2, B, HW, s);
     // proj_in -> norm1 -> attn1's q,k,v^T: one row-local launch where that kernel exists and fills the chip (ffn.h qkv_rows_kernel)
-    const bool rq1 = aligned && qkv_rows_ok(t.a1, B, HW, HW, C, d);
+    const bool rq1 = aligned && qkv_rows_for(t, 0, B, HW, HW, s);
     bf16* t0;
     const bf16* ln = nullptr;
     bf16* o = nullptr;
@@ -1582,7 +1667,7 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
     }
     const int Ng = cond_.Ng;
     // attn1.to_out + residual -> fuser.norm1 -> the fuser's q,k,v^T over the visual rows: the same launch shape
-    const bool rq2 = !fuser_off_ && ucfg_.fuser_kind == 0 && fuser_hoist_ && aligned && qkv_rows_ok(t.fa, B, HW, HW + Ng, C, d);
+    const bool rq2 = !fuser_off_ && ucfg_.fuser_kind == 0 && fuser_hoist_ && aligned && cond_.Ng > 0 && qkv_rows_for(t, 1, B, HW, HW + Ng, s);
     bf16* t1 = rq2 ? arena_.get<bf16>((size_t)M * C) : linear_rows(o, M, t.a1.out, ACT_NONE, t0, nullptr, s, &st1);
 
     bf16* t3;

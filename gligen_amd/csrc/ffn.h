@@ -73,7 +73,7 @@ struct QkvRowsParams {
     int ld_mid;
     float2* stats_out;      // optional [M]: (sum, sum of squares) of each row of t (Epilogue::ln_stats with nb = 1)
     int np;                 // 3: q, k, v^T; 1: q only (cross-attention to_q)
-    const float* bias;      // [np * C] (W beta of the folded LayerNorm) or null
+    const float* bias;      // [np * C] (W beta of the folded LayerNorm)
     bf16* q;                // [B*H][Tpad_q][DP]
     bf16* k;                // key-tile layout (gemm.h ktile_off), [B*H][Tpad_k / 64][DP / 8][64][8]
     bf16* vt;               // [B*H][DPV][Tpad_k], tokens permuted within groups of 32 (vt_perm32 = 1)

@@ -677,6 +677,9 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
 // fixed instruction order; the epilogues between the segments are hipcc's. A segment's first stage is fetched under the last
 // stage of the segment before it and waited for BEFORE the epilogue's stores join the vmcnt counter, so the stores drain under
 // the next segment's first MFMAs instead of in front of them.
+#ifndef GL_QKV_ABL
+#define GL_QKV_ABL 0      // developer ablation (tools/build_ffn_variant.sh -DGL_QKV_ABL=n): 1 no head stores, 2 no mid store, 4 no head MFMA streams
+#endif
 template <int C, int D, bool PRE, int NP>
 __global__ void __launch_bounds__(256, 1) qkv_rows_kernel(QkvRowsParams p) {
     using G = FFGeom<C>;
@@ -685,6 +688,7 @@ __global__ void __launch_bounds__(256, 1) qkv_rows_kernel(QkvRowsParams p) {
     constexpr int PSTAGE = PJ_BLK * 1024;
     constexpr int RD = 8, NR = RD + 4;
     constexpr int NSEG = (PRE ? 1 : 0) + NP;
+    constexpr int NBIAS = NSEG * C;            // [pre_b][bias of q (, k, v)] as floats behind the three stage slots
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int t = threadIdx.x;
@@ -708,13 +712,39 @@ __global__ void __launch_bounds__(256, 1) qkv_rows_kernel(QkvRowsParams p) {
     unsigned dma_lds = lds_w;
     unsigned dma_off = (unsigned)wave * 1024u;
 #pragma unroll
-    for (int i = 0; i < PJ_BLK / 4; ++i) ffr_dma<true>(rs, lane16, dma_lds, dma_off);
+    for (int i = 0; i < 2 * (PJ_BLK / 4); ++i) ffr_dma<true>(rs, lane16, dma_lds, dma_off);   // stages 0 and 1 (slots 0 and 1 are adjacent)
 
+    // Every global LOAD of the kernel happens here, in front of the MFMA streams: the rows, the leading projection's residual rows
+    // and the biases (into LDS). The epilogues between the streams then issue stores only -- a load among them would make hipcc
+    // wait vmcnt(0) per feature block, i.e. for every store issued before it (measured: 65 us per launch instead of 3 x 5 + epilogues).
     bf16x8 xf[KS];
     {
         const bf16* src = p.x + (size_t)row * p.ldx + h * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(src + ks * 16);
+    }
+    uint2 rv[PRE ? NCB : 1][4];
+    const bool has_res = PRE && p.pre_res != nullptr;
+    if constexpr (PRE) {
+        if (has_res) {
+            const bf16* src = p.pre_res + (size_t)row * p.ld_pre_res + h * 4;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rv[cb][j] = *reinterpret_cast<const uint2*>(src + cb * 32 + j * 8);
+        } else {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rv[cb][j] = make_uint2(0u, 0u);
+        }
+    }
+    float* lbias = reinterpret_cast<float*>(smem + 3 * PSTAGE);
+    for (int i = t; i < NBIAS; i += 256) {
+        float v;
+        if (PRE && i < C) v = p.pre_b[i];
+        else v = p.bias[i - (PRE ? C : 0)];
+        lbias[i] = v;
     }
     if (!PRE && p.normalize) {
         float s = 0.f, ss = 0.f;
@@ -739,21 +769,28 @@ __global__ void __launch_bounds__(256, 1) qkv_rows_kernel(QkvRowsParams p) {
     }
 
     f32x16 acc[NCB];
-    const unsigned ra_st[2] = {lds0 + lane16, lds0 + (unsigned)PSTAGE + lane16};
+    // Three LDS slots, the DMA two stages ahead: global stage g (segment-major, PJ_ST per segment) lives in slot g % 3 and is fetched
+    // while stage g - 2 multiplies. At a segment boundary both of the next segment's first stages have landed BEFORE the epilogue
+    // (the wait at the end of phase()), so those two stages run on barriers alone and the epilogue's stores -- which share the
+    // vmcnt counter with the DMA and complete out of order with it -- get two stages of MFMAs to drain under.
+    // (Measured and not kept: the next segment's THIRD stage fetched at the boundary as well, epilogue arithmetic first, then
+    // vmcnt(0) and the 40 stores as one burst, three wait-free stages: 65 against 54-58 us -- the burst behind a wait is worse than
+    // stores interleaved with their conversions.)
+    const unsigned ra_st[3] = {lds0 + lane16, lds0 + (unsigned)PSTAGE + lane16, lds0 + 2u * (unsigned)PSTAGE + lane16};
+    constexpr int NSTG = NSEG * PJ_ST;       // stages of the whole stream
 
-    // One projection segment: acc[cb] = sum over k-steps of W-block(ks, cb) x xin[ks] (SWAP: xin[ks] x W-block), first k-step with C = 0.
-    // BUF0: LDS buffer of its first stage; NEXT: blocks per wave of the next segment's first stage, fetched under the last stage and
-    // waited for before this function returns; SKIP: the first stage is known to have landed (the previous segment waited for it)
-    auto phase = [&](bf16x8 (&xin)[KS], auto buf0_c, auto next_c, auto swap_c, auto skip_c) {
-        constexpr int BUF0 = decltype(buf0_c)::value, NEXT = decltype(next_c)::value;
+    // One projection segment SEG: acc[cb] = sum over k-steps of W-block(ks, cb) x xin[ks] (SWAP: xin[ks] x W-block), first k-step with
+    // C = 0. SKIP: its first two stages are known to have landed (the previous segment's closing wait)
+    auto phase = [&](bf16x8 (&xin)[KS], auto seg_c, auto swap_c, auto skip_c) {
+        constexpr int SEG = decltype(seg_c)::value;
         constexpr bool SWAP = decltype(swap_c)::value, SKIP = decltype(skip_c)::value;
         static_for<PJ_ST>([&](auto sc) {
-            constexpr int st = decltype(sc)::value, BUF = (BUF0 + st) & 1;
-            constexpr int pieces = st + 1 < PJ_ST ? PJ_BLK / 4 : NEXT;
-            if constexpr (!(SKIP && st == 0)) asm volatile("s_waitcnt vmcnt(0)");
+            constexpr int st = decltype(sc)::value, g = SEG * PJ_ST + st, BUF = g % 3;
+            constexpr int pieces = g + 2 < NSTG ? PJ_BLK / 4 : 0;
+            if constexpr (!(SKIP && st < 2)) asm volatile("s_waitcnt vmcnt(0)");
             __builtin_amdgcn_s_barrier();
             const unsigned ra = ra_st[BUF];
-            dma_lds = lds_w + (BUF ? 0u : (unsigned)PSTAGE);
+            dma_lds = lds_w + (unsigned)((g + 2) % 3) * (unsigned)PSTAGE;
             bf16x8 fr[NR];
             static_for<RD>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
@@ -779,7 +816,7 @@ __global__ void __launch_bounds__(256, 1) qkv_rows_kernel(QkvRowsParams p) {
             });
         });
         ffr_settle(acc);
-        if constexpr (NEXT > 0) asm volatile("s_waitcnt vmcnt(0)");
+        if constexpr (SEG + 1 < NSEG) asm volatile("s_waitcnt vmcnt(0)");
     };
     auto pin_x = [&]() {
 #pragma unroll
@@ -787,52 +824,51 @@ __global__ void __launch_bounds__(256, 1) qkv_rows_kernel(QkvRowsParams p) {
         asm volatile("s_nop 7\n\ts_nop 7");
     };
 
-    using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
-    using NX = std::integral_constant<int, PJ_BLK / 4>;
-    using N0 = std::integral_constant<int, 0>;
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    using S3 = std::integral_constant<int, 3>;
     using T_ = std::true_type;
     using F_ = std::false_type;
 
-    __builtin_amdgcn_s_waitcnt(0x0F70);            // the x rows are back before the first asm DMA of the main loop (its waits do not count them)
+    // the rows, the residual rows and this thread's bias words are back (and in LDS) before the first asm DMA wait of the main loop;
+    // the first stage's barrier publishes the biases
+    __builtin_amdgcn_s_waitcnt(0x0070);            // vmcnt(0) lgkmcnt(0)
+    if constexpr (PRE) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(rv[cb][j].x), "+v"(rv[cb][j].y));
+    }
     pin_x();
     if constexpr (PRE) {
-        phase(xf, B0{}, NX{}, F_{}, F_{});
+        phase(xf, S0{}, F_{}, F_{});
         // t = pre_res + (x Wpre^T + pre_b), rounded to bf16: the residual stream. Lane holds features 32 cb + 8 j + 4 h + e of its row
         float tv[NCB][16];
         float s = 0.f, ss = 0.f;
-        auto pre_epi = [&](auto res_c) {
-            constexpr bool RES = decltype(res_c)::value;
+        bf16* mrow = p.mid_out + (size_t)row * p.ld_mid + h * 4;
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
-                float4 bv[4];
-                uint2 rv[4];
+        for (int cb = 0; cb < NCB; ++cb) {
+            float4 bv[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    bv[j] = *reinterpret_cast<const float4*>(p.pre_b + cb * 32 + j * 8 + h * 4);
-                    if constexpr (RES) rv[j] = *reinterpret_cast<const uint2*>(p.pre_res + (size_t)row * p.ld_pre_res + cb * 32 + j * 8 + h * 4);
+            for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const float4*>(lbias + cb * 32 + j * 8 + h * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                U2BF4 r, o;
+                r.u = rv[cb][j];
+                const float bj[4] = {bv[j].x, bv[j].y, bv[j].z, bv[j].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o.e[e] = f2bf(acc[cb][4 * j + e] + bj[e] + bf2f(r.e[e]));
+                    const float t_ = bf2f(o.e[e]);
+                    tv[cb][4 * j + e] = t_;
+                    s += t_;
+                    ss = fmaf(t_, t_, ss);
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    U2BF4 r, o;
-                    if constexpr (RES) r.u = rv[j];
-                    const float bj[4] = {bv[j].x, bv[j].y, bv[j].z, bv[j].w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = acc[cb][4 * j + e] + bj[e];
-                        if constexpr (RES) v += bf2f(r.e[e]);
-                        o.e[e] = f2bf(v);
-                        const float t_ = bf2f(o.e[e]);
-                        tv[cb][4 * j + e] = t_;
-                        s += t_;
-                        ss = fmaf(t_, t_, ss);
-                    }
-                    *reinterpret_cast<uint2*>(p.mid_out + (size_t)row * p.ld_mid + cb * 32 + j * 8 + h * 4) = o.u;
-                }
+                if constexpr (GL_QKV_ABL & 2) asm volatile("" ::"v"(o.u.x), "v"(o.u.y));
+                else *reinterpret_cast<uint2*>(mrow + cb * 32 + j * 8) = o.u;
             }
-        };
-        if (p.pre_res) pre_epi(T_{});
-        else pre_epi(F_{});
+        }
         s += __shfl_xor(s, 32, 64);
         ss += __shfl_xor(ss, 32, 64);
         if (p.stats_out && h == 0) p.stats_out[row] = make_float2(s, ss);
@@ -852,28 +888,29 @@ __global__ void __launch_bounds__(256, 1) qkv_rows_kernel(QkvRowsParams p) {
     const int b = row0 / p.T;
     const int tw = row0 - b * p.T;                 // multiple of 32
     const int tok = tw + l31;
+    const float* hbias = lbias + (PRE ? C : 0);
     auto heads_qk = [&](auto which_c) {
         constexpr int WHICH = decltype(which_c)::value;
         const int tp = WHICH ? p.Tpad_k : p.Tpad_q;
         const size_t head_stride = (size_t)tp * p.DP;
         bf16* base = (WHICH ? p.k : p.q) + (size_t)b * p.H * head_stride +
                      (WHICH ? (size_t)(tok & ~63) * p.DP + (size_t)(tok & 63) * 8 + 4 * h : (size_t)tok * p.DP + 4 * h);
-        const float* bias = p.bias + WHICH * C + 4 * h;
+        const float* bias = hbias + WHICH * C + 4 * h;
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             float4 bv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = p.bias ? *reinterpret_cast<const float4*>(bias + cb * 32 + j * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const float4*>(bias + cb * 32 + j * 8);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                constexpr int dummy = 0; (void)dummy;
                 const int f0 = cb * 32 + j * 8, hd = f0 / D, dd = f0 % D;      // (compile-time after unrolling; + 4 h stays inside the head: D % 8 == 0)
                 const float v[4] = {acc[cb][4 * j] + bv[j].x, acc[cb][4 * j + 1] + bv[j].y, acc[cb][4 * j + 2] + bv[j].z, acc[cb][4 * j + 3] + bv[j].w};
                 U2BF4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o.e[e] = f2bf(v[e]);
                 bf16* dst = base + (size_t)hd * head_stride + (WHICH ? (size_t)(dd >> 3) * 512 : (size_t)dd);
-                *reinterpret_cast<uint2*>(dst) = o.u;
+                if constexpr (GL_QKV_ABL & 1) asm volatile("" ::"v"(o.u.x), "v"(o.u.y), "v"(dst));
+                else *reinterpret_cast<uint2*>(dst) = o.u;
             }
         }
     };
@@ -882,7 +919,7 @@ __global__ void __launch_bounds__(256, 1) qkv_rows_kernel(QkvRowsParams p) {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             const int f = cb * 32 + l31, hd = f / D, dd = f - hd * D;
-            const float bn = p.bias ? p.bias[2 * C + f] : 0.f;
+            const float bn = hbias[2 * C + f];
             bf16* dst = p.vt + ((size_t)(b * p.H + hd) * p.DPV + dd) * p.Tpad_k + tw + 16 * h;
             U4BF8 o0, o1;
 #pragma unroll
@@ -890,20 +927,26 @@ __global__ void __launch_bounds__(256, 1) qkv_rows_kernel(QkvRowsParams p) {
                 o0.e[e] = f2bf(acc[cb][e] + bn);
                 o1.e[e] = f2bf(acc[cb][8 + e] + bn);
             }
-            *reinterpret_cast<uint4*>(dst) = o0.u;
-            *reinterpret_cast<uint4*>(dst + 8) = o1.u;
+            if constexpr (GL_QKV_ABL & 1) asm volatile("" ::"v"(o0.u.x), "v"(o0.u.w), "v"(o1.u.x), "v"(o1.u.w), "v"(dst));
+            else {
+                *reinterpret_cast<uint4*>(dst) = o0.u;
+                *reinterpret_cast<uint4*>(dst + 8) = o1.u;
+            }
         }
     };
-    constexpr int P0 = PRE ? 1 : 0;      // buffer parity of the first head segment (every segment has an odd number of stages)
     if constexpr (NP == 1) {
-        if constexpr (P0) phase(xf, B1{}, N0{}, F_{}, T_{}); else phase(xf, B0{}, N0{}, F_{}, F_{});
-        heads_qk(B0{});
+        if constexpr (PRE) phase(xf, S1{}, F_{}, T_{}); else phase(xf, S0{}, F_{}, F_{});
+        heads_qk(S0{});
+    } else if constexpr ((GL_QKV_ABL & 4) != 0) {
+        heads_qk(S0{});
+        heads_qk(S1{});
+        heads_vt();
     } else {
-        if constexpr (P0) phase(xf, B1{}, NX{}, F_{}, T_{}); else phase(xf, B0{}, NX{}, F_{}, F_{});
-        heads_qk(B0{});
-        if constexpr (P0) phase(xf, B0{}, NX{}, F_{}, T_{}); else phase(xf, B1{}, NX{}, F_{}, T_{});
-        heads_qk(B1{});
-        if constexpr (P0) phase(xf, B1{}, N0{}, T_{}, T_{}); else phase(xf, B0{}, N0{}, T_{}, T_{});
+        if constexpr (PRE) phase(xf, S1{}, F_{}, T_{}); else phase(xf, S0{}, F_{}, F_{});
+        heads_qk(S0{});
+        if constexpr (PRE) phase(xf, S2{}, F_{}, T_{}); else phase(xf, S1{}, F_{}, T_{});
+        heads_qk(S1{});
+        if constexpr (PRE) phase(xf, S3{}, T_{}, T_{}); else phase(xf, S2{}, T_{}, T_{});
         heads_vt();
     }
 }
@@ -1039,12 +1082,12 @@ int qkv_rows_pack_launch(const float* pre_w, const bf16* w, int np, void* stream
 int qkv_rows_launch(const QkvRowsParams& p, int C, hipStream_t s) {
     if (!qkv_rows_supported(p.M, C, p.d, p.T)) return set_error(GL_ERR_UNSUPPORTED, "qkv_rows: M = %d, C = %d, d = %d, T = %d has no row-local projection kernel", p.M, C, p.d, p.T);
     if (p.np != 1 && p.np != 3) return set_error(GL_ERR_ARG, "qkv_rows: np must be 1 (q) or 3 (q, k, v^T)");
-    if (p.ldx % 8 || !p.x || !p.stream || !p.q || (p.np == 3 && (!p.k || !p.vt))) return set_error(GL_ERR_ARG, "qkv_rows: null pointer / unaligned rows");
+    if (p.ldx % 8 || !p.x || !p.stream || !p.q || !p.bias || (p.np == 3 && (!p.k || !p.vt))) return set_error(GL_ERR_ARG, "qkv_rows: null pointer / unaligned rows");
     if (p.np == 3 && (p.vt_perm32 != 1 || p.Tpad_k % 32)) return set_error(GL_ERR_UNSUPPORTED, "qkv_rows: v^T is written in the 32-token form only (attn3_kernel)");
     if (p.H * p.d != C || p.DP < p.d || p.DP % 8 || (p.np == 3 && p.DPV < p.d)) return set_error(GL_ERR_ARG, "qkv_rows: head geometry");
     if (p.pre && (!p.pre_b || !p.mid_out || p.ld_mid % 4 || (p.pre_res && p.ld_pre_res % 4))) return set_error(GL_ERR_ARG, "qkv_rows: the leading projection needs its bias and the buffer for its result");
     using G = FFGeom<320>;
-    constexpr int LDS = 2 * G::PJ_BLK * 1024;
+    constexpr int LDS = 3 * G::PJ_BLK * 1024 + 4 * 320 * (int)sizeof(float);
 #define QKV_LAUNCH(PRE_, NP_)                                                                                                \
     do {                                                                                                                     \
         auto kfn = qkv_rows_kernel<320, 40, PRE_, NP_>;                                                                      \
