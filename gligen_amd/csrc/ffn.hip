@@ -52,7 +52,7 @@ struct FFGeom {
     static_assert((NBLK - 1) * 1024 < 65536, "fragment reads address a stage through the 16-bit offset field");
     static constexpr int NSTAGE = NCH + 1;       // stage c = [W1(c) + b1(c)][W2(c-1)], c = 0 .. NCH
     static constexpr size_t STREAM_BYTES = (size_t)NSTAGE * STAGE;
-    static constexpr int LDS_BYTES = 2 * STAGE;
+    static constexpr int LDS_BYTES = 2 * STAGE + 3 * C * 4;      // two stages + [b2][pre_b][post_b] as floats (the epilogues read their biases from LDS)
     static_assert(NCH % 2 == 0, "chunk parity of the last chunk");
     // a chained C x C projection: KS k-steps x NCB feature blocks = KS * NCB blocks, in PJ_ST stages of PJ_BLK (k-step major inside a stage)
     static constexpr int PJ_KS = 4;                   // k-steps per stage
@@ -304,6 +304,24 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(src + ks * 16);
     }
+    // Round 6: no global load sits between an epilogue's stores. A load inside the per-feature-block loop makes hipcc wait vmcnt(0)
+    // in front of its use, i.e. for every store issued before it (loads and stores share the counter): ten serialised round trips
+    // per epilogue. The biases go through LDS, the leading projection's residual rows are fetched here, the other epilogues issue
+    // all their residual loads in one block in front of their loop.
+    uint2 prv[PRE ? NCB : 1][4];
+    if constexpr (PRE) {
+        const bf16* src = p.pre_res + (size_t)row * p.ld_pre_res + h * 4;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) prv[cb][j] = *reinterpret_cast<const uint2*>(src + cb * 32 + j * 8);
+    }
+    float* lbias = reinterpret_cast<float*>(smem + 2 * STAGE);       // [b2][pre_b][post_b]
+    for (int i = t; i < C * (1 + (PRE ? 1 : 0) + (POST ? 1 : 0)); i += 256)
+        lbias[i] = i < C ? p.b2[i] : (PRE && i < 2 * C) ? p.pre_b[i - C] : p.post_b[i - C * (PRE ? 2 : 1)];
+    const float* lb2 = lbias;
+    const float* lpre = lbias + C;
+    const float* lpost = lbias + C * (PRE ? 2 : 1);
     const float gate = ((p.res || PRE) && p.gate) ? *p.gate : 1.f;
     const float pre_gate = (PRE && p.pre_gate) ? *p.pre_gate : 1.f;
     const float res_in_acc = (PRE && fabsf(gate) > 1e-20f) ? 1.f / gate : 0.f;   // chained form: the feed-forward's residual rides in its accumulator
@@ -468,7 +486,13 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
     // vmcnt waits do not see those. And the x fragments have to be IN the AGPR half here, not copied there in front of their first
     // MFMA: a v_accvgpr_write needs wait states before an MFMA may read the register, and hipcc does not pad in front of an asm
     // statement (seen as lane-local NaNs -- whatever the previous kernel had left in those AGPRs -- that came and went between runs).
-    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+    __builtin_amdgcn_s_waitcnt(0x0070);            // vmcnt(0) lgkmcnt(0): the rows are back, this thread's bias words are in LDS (the first barrier publishes them)
+    if constexpr (PRE) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(prv[cb][j].x), "+v"(prv[cb][j].y));
+    }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(xf[ks]));
 #pragma unroll
@@ -485,16 +509,12 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             float4 bv[4];
-            uint2 rv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                bv[j] = *reinterpret_cast<const float4*>(p.pre_b + cb * 32 + j * 8 + h * 4);
-                rv[j] = *reinterpret_cast<const uint2*>(p.pre_res + (size_t)row * p.ld_pre_res + cb * 32 + j * 8 + h * 4);
-            }
+            for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const float4*>(lpre + cb * 32 + j * 8 + h * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 U2BF4 r, o;
-                r.u = rv[j];
+                r.u = prv[cb][j];
                 const float bj[4] = {bv[j].x, bv[j].y, bv[j].z, bv[j].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -567,21 +587,29 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
         const int ldr = PRE ? p.ld_mid : p.ldres;
         float s = 0.f, ss = 0.f;
         bf16* dst = p.out + (size_t)row * p.ldo + h * 4;
+        uint2 rvv[RES ? NCB : 1][4];
+        if constexpr (RES) {       // all residual loads in one block, one wait, then a loop that only stores
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rvv[cb][j] = *reinterpret_cast<const uint2*>(resp + (size_t)row * ldr + cb * 32 + j * 8 + h * 4);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(rvv[cb][j].x), "+v"(rvv[cb][j].y));
+        }
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             float4 bv[4];
-            uint2 rv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                bv[j] = *reinterpret_cast<const float4*>(p.b2 + cb * 32 + j * 8 + h * 4);
-                if constexpr (RES) rv[j] = *reinterpret_cast<const uint2*>(resp + (size_t)row * ldr + cb * 32 + j * 8 + h * 4);
-            }
+            for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const float4*>(lb2 + cb * 32 + j * 8 + h * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float v[4] = {acc2[cb][4 * j] + bv[j].x, acc2[cb][4 * j + 1] + bv[j].y, acc2[cb][4 * j + 2] + bv[j].z, acc2[cb][4 * j + 3] + bv[j].w};
                 if constexpr (RES) {
                     U2BF4 r;
-                    r.u = rv[j];
+                    r.u = rvv[cb][j];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = bf2f(r.e[e]) + gate * v[e];
                 } else if constexpr (PRE) {
@@ -616,7 +644,20 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
         if (PRE ? res_in_acc == 0.f : p.res != nullptr) ff_result(std::true_type{}, std::false_type{}, yv);
         else ff_result(std::false_type{}, std::false_type{}, yv);
         to_fragments(yv, xf, 1.f, 0.f);
+        // x_in of the trailing projection: fetched here, under the projection's MFMA stream (its stage waits are vmcnt(0) anyway)
+        uint2 qrv[NCB][4];
+        {
+            const bf16* src = p.post_res + (size_t)row * p.ld_post_res + h * 4;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qrv[cb][j] = *reinterpret_cast<const uint2*>(src + cb * 32 + j * 8);
+        }
         __builtin_amdgcn_s_waitcnt(0x0F70);        // (hipcc's loads above before the next asm DMA)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(qrv[cb][j].x), "+v"(qrv[cb][j].y));
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(xf[ks]));
 #pragma unroll
@@ -628,16 +669,12 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             float4 bv[4];
-            uint2 rv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                bv[j] = *reinterpret_cast<const float4*>(p.post_b + cb * 32 + j * 8 + h * 4);
-                rv[j] = *reinterpret_cast<const uint2*>(p.post_res + (size_t)row * p.ld_post_res + cb * 32 + j * 8 + h * 4);
-            }
+            for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const float4*>(lpost + cb * 32 + j * 8 + h * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 U2BF4 r, o;
-                r.u = rv[j];
+                r.u = qrv[cb][j];
                 const float bj[4] = {bv[j].x, bv[j].y, bv[j].z, bv[j].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
