@@ -126,6 +126,7 @@ SYMBOLS = {
     "gl_op_gn_silu_conv3x3": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, C.c_float, _P, _P, _I, _P, _P, _P, _I, _P, _P]),
     "gl_op_layernorm": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, C.c_float, _P, _P]),
     "gl_op_attention": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "gl_op_ff_chain_q": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gl_op_proj_attention": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, C.POINTER(_I), _P]),
 }
 

@@ -532,6 +532,36 @@ int gl_op_ff_chain(gl_ctx* ctx, const void* x, int M, int C, const float* pre_w,
     GL_API_END
 }
 
+int gl_op_ff_chain_q(gl_ctx* ctx, const void* x, int B, int N, int C, const float* pre_w, const float* pre_b, const void* pre_res, const float* pre_gate,
+                     const float* gamma, const float* beta, const float* w1, const float* b1, const float* w2, const float* b2, const float* gate,
+                     const float* gamma_q, const float* beta_q, const float* wq, void* y, void* q, gl_stream s) {
+    NEED(ctx);
+    if (!x || !pre_w || !pre_b || !pre_res || !gamma || !beta || !w1 || !b1 || !w2 || !b2 || !gamma_q || !beta_q || !wq || !y || !q)
+        return gl::set_error(GL_ERR_ARG, "gl_op_ff_chain_q: null pointer");
+    GL_API_BEGIN
+    Engine& eng = *ctx->eng;
+    Arena& ar = eng.arena();
+    ar.reset();
+    auto ck = [&](int rc) { if (rc != GL_OK) throw GlError(rc, gl::last_error()); };
+    const int M = B * N;
+    if (!ff_rows_supported(M, C) || N % 128) throw GlError(GL_ERR_UNSUPPORTED, "gl_op_ff_chain_q: no row-local kernel for this shape (C = 320, N % 128 == 0)");
+    float* wf = ar.get<float>((size_t)8 * C * C);
+    float* bf = ar.get<float>((size_t)8 * C);
+    ck(ln_fold_launch(w1, b1, gamma, beta, wf, bf, 8 * C, C, S(s)));
+    float* wqf = ar.get<float>((size_t)C * C);
+    float* bqf = ar.get<float>((size_t)C);
+    ck(ln_fold_launch(wq, nullptr, gamma_q, beta_q, wqf, bqf, C, C, S(s)));
+    void* st = ar.alloc(ff_chain_stream_bytes(C, true, true));
+    ck(ff_chain_pack_launch(wf, bf, w2, pre_w, wqf, st, C, S(s)));
+    FFRowsParams P{};
+    P.x = (const bf16*)x; P.ldx = C; P.normalize = 1; P.eps = 1e-5f; P.stream = st; P.b2 = b2; P.gate = gate; P.out = (bf16*)y; P.ldo = C; P.M = M;
+    P.pre = 1; P.pre_b = pre_b; P.pre_res = (const bf16*)pre_res; P.ld_pre_res = C; P.pre_gate = pre_gate;
+    P.mid_out = ar.get<bf16>((size_t)M * C); P.ld_mid = C;
+    P.post = 2; P.post_b = bqf; P.q = (bf16*)q; P.qDP = 48; P.qT = N; P.qTpad = N;
+    ck(ff_rows_launch(P, C, S(s)));
+    GL_API_END
+}
+
 int gl_op_adamw_step(gl_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
                      double weight_decay, int step, gl_stream s) {
     NEED(ctx);

@@ -94,6 +94,10 @@ struct FFW {
     // the chained form (ffn.h FFRowsParams::pre / post): [projection in front][this feed-forward][projection behind] as ONE stream
     const void* chain_stream = nullptr;
     bool chain_post = false;
+    // fuser.ff only: [fuser.attn.to_out][fuser.ff][attn2.to_q behind norm2] -- the cross-attention's query projection as the trailing
+    // projection (FFRowsParams::post = 2); qb = its folded bias W beta
+    const void* chain_q_stream = nullptr;
+    const float* chain_q_bias = nullptr;
 };
 // partial row statistics written by the GEMM that produced a residual-stream tensor (nb = 0: none)
 struct RowStats { float2* p = nullptr; int nb = 0, ld = 0; };
@@ -238,7 +242,9 @@ class Engine {
     LinW conv1(const std::string& prefix);
     const bf16* cast_rows(const std::vector<std::string>& weight_keys);
     // pre_key / post_key: weights of the C x C projections chained in front of / behind this feed-forward ("" = none)
-    FFW ffw(const std::string& prefix, int C, const NormW* fold = nullptr, const std::string& pre_key = "", const std::string& post_key = "");
+    // post_q_w / post_q_b: LayerNorm-folded fp32 to_q weight [C][C] and bias of the cross-attention behind this feed-forward (chain_q_stream)
+    FFW ffw(const std::string& prefix, int C, const NormW* fold = nullptr, const std::string& pre_key = "", const std::string& post_key = "",
+            const float* post_q_w = nullptr, const float* post_q_b = nullptr);
     // fp32 temporaries W * gamma, b + W beta of one linear layer (freed at the end of build_unet)
     struct FoldTmp { float* w = nullptr; float* b = nullptr; int N = 0, K = 0; };
     FoldTmp fold_ln(const std::string& weight_key, const float* bias, const NormW& n);
@@ -270,15 +276,19 @@ class Engine {
     // (ff_policy.* below, gl_set_ff_rows_policy); under a stream capture an undecided shape takes the static rule
     bool ff_rows_for(const STW& t, int which, int B, int HW, hipStream_t s);
     // fuser.attn.to_out (+ gated residual) -> LayerNorm -> fuser.ff (+ gated residual)  [gatedSA, attention.py:236-244]
-    bf16* fuser_ff_tail(const STW& t, const bf16* o, const bf16* t1, int B, int HW, bool rows, hipStream_t s, RowStats* st3);
+    // q_done (optional, out): the launch also projected attn2.to_q(norm2(.)) into the cross-attention's q buffer (chain_q_stream)
+    bf16* fuser_ff_tail(const STW& t, const bf16* o, const bf16* t1, int B, int HW, bool rows, hipStream_t s, RowStats* st3, bool* q_done = nullptr);
+    // attn2.to_q(norm2(rows)) by GEMM into the cross-attention's q buffer (st: the rows' statistics, if their producer wrote any)
+    void cross_q_gemm(const STW& t, const bf16* rows, const RowStats& st, int B, int HW, hipStream_t s);
     // attn2.to_out (+ residual) -> LayerNorm -> ff (+ residual) -> proj_out + x_in  [attention.py:337-338, 374-376]
     void block_ff_tail(const STW& t, const bf16* o, const bf16* t3, const bf16* x, bf16* out, int B, int HW, bool rows, hipStream_t s);
     bf16* ff_behind(const FFW& f, const NormW& nw, const bf16* rows_in, RowStats& st_in, int B, int HW, const float* gate, bool rows, hipStream_t s,
                     RowStats* out_stats);
     bool can_fold(const RowStats& st, int M, int C, int Nc, int mode, int act, bool aligned);
     // the chained launch: t = pre_res + pre_gate (x Wpre^T + pre_b); y = t + gate ff(LN(t)); out = y, or post_res + y Wpost^T + post_b
+    struct ChainQ { bf16* q; int DP, T, Tpad; };    // post = 2: where the trailing to_q projection writes
     bf16* feedforward_chain(const FFW& f, const bf16* x, int M, const LinW& pre, const bf16* pre_res, const float* pre_gate, const float* gate,
-                            const LinW* post, const bf16* post_res, bf16* out, hipStream_t s, RowStats* out_stats);
+                            const LinW* post, const bf16* post_res, bf16* out, hipStream_t s, RowStats* out_stats, const ChainQ* cq = nullptr);
     // Tbuf / slot: the head-layout buffers are sized for Tbuf tokens per sample (0: T) and private to attention number `slot`
     // (0: shared by every attention of this shape) -- the fuser's attention with hoisted grounding-token keys (fuser_kv_fill)
     // projected: q / k / v^T of this attention are already in its head-layout buffers (qkv_rows_project): launch the attention only

@@ -377,7 +377,8 @@ Engine::FoldTmp Engine::fold_ln(const std::string& wkey, const float* bias, cons
     return t;
 }
 
-FFW Engine::ffw(const std::string& p, int C, const NormW* fold, const std::string& pre_key, const std::string& post_key) {
+FFW Engine::ffw(const std::string& p, int C, const NormW* fold, const std::string& pre_key, const std::string& post_key, const float* post_q_w,
+                const float* post_q_b) {
     FFW f;
     f.C = C;
     const RawTensor& w = raw(p + ".net.0.proj.weight");
@@ -413,6 +414,14 @@ FFW Engine::ffw(const std::string& p, int C, const NormW* fold, const std::strin
             CK(ff_chain_pack_launch(wsrc, bsrc, raw(p + ".net.2.weight").p, raw(pre_key).p, post ? raw(post_key).p : nullptr, cs, C, 0));
             f.chain_stream = cs;
             f.chain_post = post;
+            if (!post && post_q_w && post_q_b && C == 320) {     // + the cross-attention's to_q behind the next LayerNorm (d = 40: C / 8 heads)
+                void* cq = persist(ff_chain_stream_bytes(C, true, true), false);
+                CK(ff_chain_pack_launch(wsrc, bsrc, raw(p + ".net.2.weight").p, raw(pre_key).p, post_q_w, cq, C, 0));
+                float* qb = reinterpret_cast<float*>(persist((size_t)C * sizeof(float), false));
+                HIPCK(hipMemcpy(qb, post_q_b, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice));
+                f.chain_q_stream = cq;
+                f.chain_q_bias = qb;
+            }
         }
     }
     return f;
@@ -509,7 +518,7 @@ void Engine::build_unet() {
         const bool fold = fuse_qkv && !(dev_env("GL_LN_FOLD") && atoi(dev_env("GL_LN_FOLD")) == 0);
         ln_fold_ = fold;
         ff_rows_ = !(dev_env("GL_FF_ROWS") && atoi(dev_env("GL_FF_ROWS")) == 0);   // row-local feed-forward kernel (ffn.hip) where it exists
-        ff_chain_ = dev_env("GL_FF_CHAIN") ? atoi(dev_env("GL_FF_CHAIN")) : 2;
+        ff_chain_ = dev_env("GL_FF_CHAIN") ? atoi(dev_env("GL_FF_CHAIN")) : 3;
         fuser_hoist_ = !(dev_env("GL_FUSER_KV_HOIST") && atoi(dev_env("GL_FUSER_KV_HOIST")) == 0);
         qkv_rows_ = dev_env("GL_QKV_ROWS") ? atoi(dev_env("GL_QKV_ROWS")) : 1;
         // pre_key: weight of the C x C projection in front of this attention's LayerNorm (row-local form, ffn.h qkv_rows_kernel)
@@ -544,8 +553,10 @@ void Engine::build_unet() {
         };
         t.a1 = self_attn_w(tb + ".attn1", fold ? &t.ln1 : nullptr, p + ".proj_in.weight");
         t.a1.out = linear(tb + ".attn1.to_out.0");
+        FoldTmp qfold;
         if (fold) {
             const FoldTmp q = fold_ln(tb + ".attn2.to_q.weight", nullptr, t.ln2);
+            qfold = q;
             bf16* dst = reinterpret_cast<bf16*>(persist((size_t)q.N * q.K * sizeof(bf16), false));
             float* bias = reinterpret_cast<float*>(persist((size_t)q.N * sizeof(float), false));
             float* cs = reinterpret_cast<float*>(persist((size_t)q.N * sizeof(float), false));
@@ -579,7 +590,9 @@ void Engine::build_unet() {
                 throw GlError(GL_ERR_ARG, "gatedCA: fuser.attn key / value dim must equal the grounding-token dim");
             t.fca.out = linear(tb + ".fuser.attn.to_out.0");
         }
-        t.fff = ffw(tb + ".fuser.ff", C, fold ? &t.fn2 : nullptr, (ff_chain_ >= 2 && c.fuser_kind == 0) ? tb + ".fuser.attn.to_out.0.weight" : "");
+        const bool chain_q = ff_chain_ >= 3 && c.fuser_kind == 0 && fold && t.d == 40 && qfold.N == C && qfold.K == C;
+        t.fff = ffw(tb + ".fuser.ff", C, fold ? &t.fn2 : nullptr, (ff_chain_ >= 2 && c.fuser_kind == 0) ? tb + ".fuser.attn.to_out.0.weight" : "", "",
+                    chain_q ? qfold.w : nullptr, chain_q ? qfold.b : nullptr);
         raw(tb + ".fuser.alpha_attn");
         raw(tb + ".fuser.alpha_dense");
         st_.push_back(t);
@@ -1311,9 +1324,10 @@ void Engine::qkv_project_gemm(const SelfAttnW& a, const bf16* ln, int B, int T, 
 }
 
 bf16* Engine::feedforward_chain(const FFW& f, const bf16* x, int M, const LinW& pre, const bf16* pre_res, const float* pre_gate, const float* gate,
-                                const LinW* post, const bf16* post_res, bf16* out, hipStream_t s, RowStats* out_stats) {
+                                const LinW* post, const bf16* post_res, bf16* out, hipStream_t s, RowStats* out_stats, const ChainQ* cq) {
     const int C = f.C;
-    if (!f.chain_stream || !ff_rows_supported(M, C) || (post != nullptr) != f.chain_post) throw GlError(GL_ERR_STATE, "feedforward_chain: no chained stream of this shape");
+    if (!f.chain_stream || !ff_rows_supported(M, C) || (post != nullptr) != f.chain_post || (cq && (post || !f.chain_q_stream)))
+        throw GlError(GL_ERR_STATE, "feedforward_chain: no chained stream of this shape");
     if (!out) out = arena_.get<bf16>((size_t)M * C);
     FFRowsParams P{};
     P.x = x; P.ldx = C; P.normalize = 1; P.eps = 1e-5f; P.stream = f.chain_stream; P.b2 = f.w2.b; P.gate = gate; P.out = out; P.ldo = C; P.M = M;
@@ -1321,6 +1335,7 @@ bf16* Engine::feedforward_chain(const FFW& f, const bf16* x, int M, const LinW& 
     P.mid_out = arena_.get<bf16>((size_t)M * C);     // (only written when the gate is too small for the residual to ride in the accumulator)
     P.ld_mid = C;
     if (post) { P.post = 1; P.post_b = post->b; P.post_res = post_res; P.ld_post_res = C; }
+    if (cq) { P.post = 2; P.stream = f.chain_q_stream; P.post_b = f.chain_q_bias; P.q = cq->q; P.qDP = cq->DP; P.qT = cq->T; P.qTpad = cq->Tpad; }
     if (out_stats) {
         *out_stats = RowStats{};
         if (ln_fold_) {
@@ -1329,12 +1344,12 @@ bf16* Engine::feedforward_chain(const FFW& f, const bf16* x, int M, const LinW& 
             P.stats_out = out_stats->p; P.stats_ld = 1;
         }
     }
-    ProfScope ps(this, s, post ? "ff_rows_kernel<pre, post>" : "ff_rows_kernel<pre>", (24.0 + (post ? 4.0 : 2.0)) * M * (double)C * C, 0.0);
+    ProfScope ps(this, s, post ? "ff_rows_kernel<pre, post>" : cq ? "ff_rows_kernel<pre, to_q>" : "ff_rows_kernel<pre>", (24.0 + ((post || cq) ? 4.0 : 2.0)) * M * (double)C * C, 0.0);
     CK(ff_rows_launch(P, C, s));
     FILE* launch_log = launch_log_file();
     if (launch_log) {
-        fprintf(launch_log, "ff_rows_kernel<320, 0, true, %s>|%d|%d|%d|0|%.0f\n", post ? "true" : "false", M, C, 4 * C,
-                (double)ff_chain_stream_bytes(C, true, post != nullptr) + (post ? 8.0 : 6.0) * M * C);   // (the symbol as rocprofv3 prints it: pmc_summarize.py joins on it)
+        fprintf(launch_log, "ff_rows_kernel<320, 0, true, %d>|%d|%d|%d|0|%.0f\n", post ? 1 : cq ? 2 : 0, M, C, 4 * C,
+                (double)ff_chain_stream_bytes(C, true, post != nullptr || cq != nullptr) + (post ? 8.0 : 6.0) * M * C + (cq ? 2.0 * M * (C / 40) * cq->DP : 0.0));   // (the symbol as rocprofv3 prints it: pmc_summarize.py joins on it)
         fflush(launch_log);
     }
     ++n_launches;
@@ -1398,11 +1413,22 @@ bf16* Engine::ff_behind(const FFW& f, const NormW& nw, const bf16* rows_in, RowS
     return feedforward(f, ln, M, rows_in, gate, s, (fold && !rows) ? &st_in : nullptr, out_stats, rows, rows);
 }
 
-bf16* Engine::fuser_ff_tail(const STW& t, const bf16* o, const bf16* t1, int B, int HW, bool rows, hipStream_t s, RowStats* st3) {
+bf16* Engine::fuser_ff_tail(const STW& t, const bf16* o, const bf16* t1, int B, int HW, bool rows, hipStream_t s, RowStats* st3, bool* q_done) {
     const int M = B * HW;
     const float* g_attn = gates_ + 2 * t.idx;
-    if (rows && t.fff.chain_stream && !t.fff.chain_post)   // one row-local launch for the three
+    if (q_done) *q_done = false;
+    if (rows && t.fff.chain_stream && !t.fff.chain_post) {   // one row-local launch for the three
+        if (q_done && t.fff.chain_q_stream && t.a2.folded && HW % 128 == 0) {
+            // ... and attn2.to_q(norm2(.)) behind them: the cross-attention's q buffer is filled by the same launch
+            int dp, dpv;
+            CK(attn_dims(t.d, &dp, &dpv));
+            AttnBufs& bufs = attn_bufs(B, t.C / t.d, t.d, HW, cond_.ctx_Tpad);
+            const ChainQ cq{bufs.q, dp, HW, bufs.Tq_pad};
+            *q_done = true;
+            return feedforward_chain(t.fff, o, M, t.fa.out, t1, g_attn, g_attn + 1, nullptr, nullptr, nullptr, s, st3, &cq);
+        }
         return feedforward_chain(t.fff, o, M, t.fa.out, t1, g_attn, g_attn + 1, nullptr, nullptr, nullptr, s, st3);
+    }
     RowStats st2;
     bf16* t2 = linear_rows(o, M, t.fa.out, ACT_NONE, t1, g_attn, s, rows ? nullptr : &st2);
     return ff_behind(t.fff, t.fn2, t2, st2, B, HW, g_attn + 1, rows, s, st3);
@@ -1474,8 +1500,11 @@ bool Engine::ff_rows_for(const STW& t, int which, int B, int HW, hipStream_t s) 
     auto run = [&](bool rows) {
         const size_t m2 = arena_.mark();
         RowStats st;
-        if (which == 1) fuser_ff_tail(t, zo, zr, B, HW, rows, s, &st);
-        else block_ff_tail(t, zo, zr, zx, zout, B, HW, rows, s);
+        if (which == 1) {
+            bool qd = false;
+            bf16* t3z = fuser_ff_tail(t, zo, zr, B, HW, rows, s, &st, &qd);
+            if (!qd && ucfg_.fuser_kind == 0 && t.fff.chain_q_stream) cross_q_gemm(t, t3z, st, B, HW, s);   // (the form that folds to_q in is timed against the form that launches it)
+        } else block_ff_tail(t, zo, zr, zx, zout, B, HW, rows, s);
         arena_.release(m2);
     };
     hipEvent_t ev[2];
@@ -1625,6 +1654,30 @@ bf16* Engine::feedforward(const FFW& f, const bf16* ln, int M, const bf16* res, 
     return linear_rows(hbuf, M, f.w2, ACT_NONE, res, gate, s, out_stats);
 }
 
+// attn2.to_q(norm2(rows)) (attention.py:336, 136): LayerNorm folded into the GEMM where the rows came with statistics, else ln_kernel
+void Engine::cross_q_gemm(const STW& t, const bf16* rows, const RowStats& st, int B, int HW, hipStream_t s) {
+    const int C = t.C, d = t.d, heads = C / d, M = B * HW;
+    const int Tp = round_up(HW, 64);
+    const bool aligned = Tp == HW;
+    const bool f3 = t.a2.folded && can_fold(st, M, C, C, EPI_QK_HEADS, ACT_NONE, aligned);
+    const bf16* ln = f3 ? rows : (t.a2.folded ? layernorm_plain(rows, B, HW, C, true, s) : layernorm(rows, B, HW, C, t.ln2, true, s));
+    int dp, dpv;
+    CK(attn_dims(d, &dp, &dpv));
+    AttnBufs& bufs = attn_bufs(B, heads, d, Tp, cond_.ctx_Tpad);
+    AOperand A;
+    aoperand_rows(A, ln, C, C);
+    Epilogue E;
+    epilogue_defaults(E);
+    E.mode = EPI_QK_HEADS;
+    E.q = bufs.q; E.k = nullptr; E.C = C; E.H = heads; E.d = d; E.DP = dp; E.T = Tp; E.Tpad_q = bufs.Tq_pad; E.Tpad_k = 0;
+    E.bias = t.a2.q.b;               // null unless the LayerNorm is folded (to_q has no bias of its own)
+    if (f3) {
+        E.ln_stats = st.p; E.ln_nb = st.nb; E.ln_ld = st.ld; E.ln_csum = t.a2.q_csum;
+        E.ln_inv_c = 1.f / (float)C; E.ln_eps = 1e-5f;
+    }
+    gemm(A, t.a2.q.w, B * Tp, C, C, E, s);
+}
+
 // SpatialTransformer.forward + BasicTransformerBlock._forward + GatedSelfAttentionDense.forward
 // (attention.py:366-376, 333-338, 236-244)
 bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipStream_t s) {
@@ -1671,6 +1724,7 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
     bf16* t1 = rq2 ? arena_.get<bf16>((size_t)M * C) : linear_rows(o, M, t.a1.out, ACT_NONE, t0, nullptr, s, &st1);
 
     bf16* t3;
+    bool q_done = false;
     if (fuser_off_) {
         t3 = t1;
         st3 = st1;
@@ -1717,7 +1771,7 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
         self_attention(t.fa, lnc, B, Tf, HW, HW + Ng, C, d, o, s);
         }
         //    x = x + scale*tanh(alpha_dense) * ff(norm2(x))
-        t3 = fuser_ff_tail(t, o, t1, B, HW, r2, s, &st3);
+        t3 = fuser_ff_tail(t, o, t1, B, HW, r2, s, &st3, &q_done);
     } else {
         bf16* t2;
         if (ucfg_.fuser_kind == 1) {
@@ -1774,24 +1828,11 @@ bf16* Engine::transformer(const STW& t, const bf16* x, int B, int H, int W, hipS
     }
 
     // x = attn2(norm2(x), context) + x
-    const bool f3 = t.a2.folded && can_fold(st3, M, C, C, EPI_QK_HEADS, ACT_NONE, aligned);
-    ln = normed(t3, t.ln2, t.a2.folded, f3, true);
+    if (!q_done) cross_q_gemm(t, t3, st3, B, HW, s);
     {
         int dp, dpv;
         CK(attn_dims(d, &dp, &dpv));
         AttnBufs& bufs = attn_bufs(B, heads, d, Tp, cond_.ctx_Tpad);
-        AOperand A;
-        aoperand_rows(A, ln, C, C);
-        Epilogue E;
-        epilogue_defaults(E);
-        E.mode = EPI_QK_HEADS;
-        E.q = bufs.q; E.k = nullptr; E.C = C; E.H = heads; E.d = d; E.DP = dp; E.T = Tp; E.Tpad_q = bufs.Tq_pad; E.Tpad_k = 0;
-        E.bias = t.a2.q.b;               // null unless the LayerNorm is folded (to_q has no bias of its own)
-        if (f3) {
-            E.ln_stats = st3.p; E.ln_nb = st3.nb; E.ln_ld = st3.ld; E.ln_csum = t.a2.q_csum;
-            E.ln_inv_c = 1.f / (float)C; E.ln_eps = 1e-5f;
-        }
-        gemm(A, t.a2.q.w, B * Tp, C, C, E, s);
         AttnParams P{};
         P.q = bufs.q; P.k = cond_.ctx_k[t.idx]; P.vt = cond_.ctx_vt[t.idx]; P.o = o;
         P.H = heads; P.d = d; P.Nq = HW; P.Nk = cond_.ctx_T; P.Tq_pad = bufs.Tq_pad; P.Tk_pad = cond_.ctx_Tpad;

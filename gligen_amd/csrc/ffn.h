@@ -40,6 +40,11 @@ struct FFRowsParams {
     const float* post_b;
     const bf16* post_res;
     int ld_post_res;
+    //  post = 2: the trailing projection is the cross-attention's to_q behind the next LayerNorm (attention.py:336): `out` receives y
+    //            (the residual stream, + stats_out), q = LN(y) Wq'^T + post_b goes to q [B*H][qTpad][qDP] (H = C / 40), the stream's
+    //            trailing segment holds the LayerNorm-folded Wq', post_b the folded bias W beta; qT = rows per sample
+    bf16* q;
+    int qDP, qT, qTpad;
 };
 
 // is there a row-local feed-forward kernel for this problem? (C = 320, M a multiple of 128)

@@ -256,7 +256,9 @@ __device__ __forceinline__ void geglu_step(GegluState& s, float v0, float v1, fl
 // ABL: developer ablation bits (tools/gpu_r4b.sh; only ABL = 0 is in the product library): 1 no GEGLU arithmetic, 2 no DMA behind the
 // prologue's, 8 no projection MFMAs, 16 no FF-out MFMAs, 32 no barrier
 // PRE / POST: a row-local C x C projection in front of / behind the feed-forward in the same launch (FFRowsParams::pre / post)
-template <int C, int ABL = 0, bool PRE = false, bool POST = false>
+// POST = 2 (round 6): the trailing projection is a cross-attention's to_q behind the NEXT LayerNorm (attention.py:336 attn2(norm2(x))):
+// y is stored (it is the residual stream), normalised in registers, projected, and q leaves in the attention kernels' head layout
+template <int C, int ABL = 0, bool PRE = false, int POST = 0>
 __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
     using G = FFGeom<C>;
     constexpr int KS = G::KS, NKP = G::NKP, NCB = G::NCB, NCH = G::NCH, NPB = G::NPB, NBLK = G::NBLK, STAGE = G::STAGE;
@@ -286,7 +288,7 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
         const unsigned long long a = (unsigned long long)(uintptr_t)p.stream;
         rs.x = (unsigned)a;
         rs.y = (unsigned)(a >> 32);           // base[47:32], stride 0
-        rs.z = (unsigned)G::chain_bytes(PRE, POST);     // num_records
+        rs.z = (unsigned)G::chain_bytes(PRE, POST != 0);     // num_records
         rs.w = 0x00020000u;                   // raw buffer, dword format (as __builtin_amdgcn_make_buffer_rsrc builds it for gfx950)
     }
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -368,13 +370,14 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
 
     // A chained projection: acc[cb] += W-block(ks, cb) x xin[ks] over PJ_ST stages of PJ_BLK blocks; buffer parity of its first stage
     // BUF0; NEXT = blocks per wave of whatever follows its last stage in the stream (0: nothing), fetched under that last stage
-    auto proj_phase = [&](f32x16 (&acc)[NCB], bf16x8 (&xin)[KS], auto buf0_c, auto next_c) {
+    auto proj_phase = [&](f32x16 (&acc)[NCB], bf16x8 (&xin)[KS], auto buf0_c, auto next_c, auto skip0_c) {
         constexpr int BUF0 = decltype(buf0_c)::value, NEXT = decltype(next_c)::value;
+        constexpr bool SKIP0 = decltype(skip0_c)::value;     // the first stage has been waited for already (in front of a store burst)
         static_for<PJ_ST>([&](auto sc) {
             constexpr int st = decltype(sc)::value, BUF = (BUF0 + st) & 1;
             constexpr int pieces = st + 1 < PJ_ST ? PJ_BLK / 4 : NEXT;
             constexpr int every = pieces > PJ_BLK / 4 ? 2 : (DEV < 4 ? 2 : 4);      // (16 blocks of a feed-forward stage do not fit one per four gaps)
-            asm volatile("s_waitcnt vmcnt(0)");
+            if constexpr (!(SKIP0 && st == 0)) asm volatile("s_waitcnt vmcnt(0)");
             if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
             const unsigned ra = ra_st[BUF];
             dma_lds = lds_w + (BUF ? 0u : (unsigned)STAGE);
@@ -500,7 +503,7 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
     asm volatile("s_nop 7" : "+v"(xb));
     if constexpr (PRE) {
         // leading projection: t = pre_res + pre_gate (x Wpre^T + pre_b), written to mid_out, normalised into the feed-forward's operand
-        proj_phase(acc2, xf, std::integral_constant<int, 0>{}, std::integral_constant<int, G::NBS / 4>{});
+        proj_phase(acc2, xf, std::integral_constant<int, 0>{}, std::integral_constant<int, G::NBS / 4>{}, std::false_type{});
         // The feed-forward's residual is t itself. It rides in the accumulator -- Y^T starts at t / gate, so gate (Y^T + b2) is
         // t + gate (ff + b2) -- and t is neither stored nor read back; only when the gate is too small to divide by does t take the
         // way through mid_out (fp32 accumulation: the detour through t / gate costs ~2^-24 |t| per chunk, nothing next to bf16).
@@ -581,8 +584,13 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
     // ---- epilogue: lane holds features 32 cb + 8 j + 4 h + e of its row. Copies under uniform branches
     // (a residual load behind a per-use guard is waited for in place)
     // y = res + gate (acc2 + b2); FINAL: stored to out (+ statistics); else kept (bf16-rounded) for the trailing projection
+    // final_c: true / 1 = stored to out (+ statistics); false / 0 = kept (bf16-rounded) in yv for the trailing projection;
+    // 2 = both, the row sums handed back in (sum_o, sq_o)
+    float sum_o = 0.f, sq_o = 0.f;
     auto ff_result = [&](auto res_c, auto final_c, float (&yv)[NCB][16]) {
-        constexpr bool RES = decltype(res_c)::value, FINAL = decltype(final_c)::value;
+        constexpr bool RES = decltype(res_c)::value;
+        constexpr int FMODE = (int)decltype(final_c)::value;
+        constexpr bool FINAL = FMODE != 0, KEEP = FMODE != 1;
         const bf16* resp = PRE ? p.mid_out : p.res;
         const int ldr = PRE ? p.ld_mid : p.ldres;
         float s = 0.f, ss = 0.f;
@@ -622,19 +630,62 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
                     o.e[e] = f2bf(v[e]);
                     const float r = bf2f(o.e[e]);
                     if constexpr (FINAL) { s += r; ss = fmaf(r, r, ss); }
-                    else { yv[cb][4 * j + e] = r; acc2[cb][4 * j + e] = 0.f; }
+                    if constexpr (KEEP) { yv[cb][4 * j + e] = r; acc2[cb][4 * j + e] = 0.f; }
                 }
                 if constexpr (FINAL) *reinterpret_cast<uint2*>(dst + cb * 32 + j * 8) = o.u;
             }
         }
-        if constexpr (FINAL)
-            if (p.stats_out) {
-                s += __shfl_xor(s, 32, 64);
-                ss += __shfl_xor(ss, 32, 64);
-                if (h == 0) p.stats_out[(size_t)row * p.stats_ld] = make_float2(s, ss);
-            }
+        if constexpr (FINAL) {
+            s += __shfl_xor(s, 32, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            if (p.stats_out && h == 0) p.stats_out[(size_t)row * p.stats_ld] = make_float2(s, ss);
+            sum_o = s;
+            sq_o = ss;
+        }
     };
-    if constexpr (!POST) {
+    if constexpr (POST == 2) {
+        // y = the feed-forward's result is stored AND kept; q = LN(y) Wq'^T + bq' (gamma / beta folded into Wq', bq') leaves in the
+        // head layout [B*H][Tpad_q][DP]. The projection's first stage came in under the last feed-forward stage: it is waited for
+        // here, in front of the store burst, and that stage then runs on its barrier alone
+        float yv[NCB][16];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        using M2 = std::integral_constant<int, 2>;
+        if (PRE ? res_in_acc == 0.f : p.res != nullptr) ff_result(std::true_type{}, M2{}, yv);
+        else ff_result(std::false_type{}, M2{}, yv);
+        const float mean = sum_o * (1.f / C);
+        const float var = fmaxf(sq_o * (1.f / C) - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + p.eps);
+        to_fragments(yv, xf, rstd, -mean * rstd);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(xf[ks]));
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) asm volatile("" : "+a"(acc2[cb]));
+        asm volatile("s_nop 7" : "+v"(xb));
+        proj_phase(acc2, xf, std::integral_constant<int, ((NCH & 1) ^ FB) ^ 1>{}, std::integral_constant<int, 0>{}, std::true_type{});
+        constexpr int D = 40;
+        static_assert(C % D == 0, "head geometry of the q epilogue");
+        const int row0 = blockIdx.x * 128 + wave * 32;
+        const int b = row0 / p.qT;
+        const int tok = row0 - b * p.qT + (lane & 31);
+        const size_t head_stride = (size_t)p.qTpad * p.qDP;
+        bf16* base = p.q + (size_t)b * (C / D) * head_stride + (size_t)tok * p.qDP + 4 * h;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            float4 bv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const float4*>(lpost + cb * 32 + j * 8 + h * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f0 = cb * 32 + j * 8, hd = f0 / D, dd = f0 % D;
+                U2BF4 o;
+                o.e[0] = f2bf(acc2[cb][4 * j] + bv[j].x);
+                o.e[1] = f2bf(acc2[cb][4 * j + 1] + bv[j].y);
+                o.e[2] = f2bf(acc2[cb][4 * j + 2] + bv[j].z);
+                o.e[3] = f2bf(acc2[cb][4 * j + 3] + bv[j].w);
+                *reinterpret_cast<uint2*>(base + (size_t)hd * head_stride + dd) = o.u;
+            }
+        }
+    } else if constexpr (!POST) {
         float unused[NCB][16];
         if (PRE ? res_in_acc == 0.f : p.res != nullptr) ff_result(std::true_type{}, std::true_type{}, unused);
         else ff_result(std::false_type{}, std::true_type{}, unused);
@@ -663,7 +714,7 @@ __global__ void __launch_bounds__(256, 1) ff_rows_kernel(FFRowsParams p) {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) asm volatile("" : "+a"(acc2[cb]));
         asm volatile("s_nop 7" : "+v"(xb));
-        proj_phase(acc2, xf, std::integral_constant<int, ((NCH & 1) ^ FB) ^ 1>{}, std::integral_constant<int, 0>{});
+        proj_phase(acc2, xf, std::integral_constant<int, ((NCH & 1) ^ FB) ^ 1>{}, std::integral_constant<int, 0>{}, std::false_type{});
         float s = 0.f, ss = 0.f;
         bf16* dst = p.out + (size_t)row * p.ldo + h * 4;
 #pragma unroll
@@ -1079,9 +1130,11 @@ int ff_rows_launch(const FFRowsParams& p, int C, hipStream_t s) {
     if (p.ldx % 8 || p.ldo % 4 || (p.res && p.ldres % 4)) return set_error(GL_ERR_ARG, "ff_rows: row strides must keep 16-byte loads / 8-byte stores aligned");
     using G = FFGeom<320>;
     if (p.post && !p.pre) return set_error(GL_ERR_UNSUPPORTED, "ff_rows: a trailing projection is built only together with a leading one");
+    if (p.post == 2 && (!p.post_b || !p.q || p.qT <= 0 || p.M % p.qT || p.qT % 32 || p.qDP < 40 || p.qDP % 4))
+        return set_error(GL_ERR_ARG, "ff_rows: the trailing to_q projection needs its folded bias, the q buffer and its geometry");
     if (p.pre && (!p.normalize || !p.pre_b || !p.pre_res || !p.mid_out || p.ld_pre_res % 4 || p.ld_mid % 4))
         return set_error(GL_ERR_ARG, "ff_rows: the leading projection needs normalize = 1, its bias, residual and the buffer for its result");
-    if (p.post && (!p.post_b || !p.post_res || p.ld_post_res % 4)) return set_error(GL_ERR_ARG, "ff_rows: the trailing projection needs its bias and residual");
+    if (p.post == 1 && (!p.post_b || !p.post_res || p.ld_post_res % 4)) return set_error(GL_ERR_ARG, "ff_rows: the trailing projection needs its bias and residual");
     // once per process and kernel; never inside a stream capture (the first call of each form is an eager one)
 #define FF_LAUNCH(PRE_, POST_)                                                                                               \
     do {                                                                                                                     \
@@ -1093,9 +1146,10 @@ int ff_rows_launch(const FFRowsParams& p, int C, hipStream_t s) {
         }                                                                                                                    \
         hipLaunchKernelGGL(kfn, dim3(p.M / 128), dim3(256), G::LDS_BYTES, s, p);                                             \
     } while (0)
-    if (p.pre && p.post) FF_LAUNCH(true, true);
-    else if (p.pre) FF_LAUNCH(true, false);
-    else FF_LAUNCH(false, false);
+    if (p.pre && p.post == 2) FF_LAUNCH(true, 2);
+    else if (p.pre && p.post) FF_LAUNCH(true, 1);
+    else if (p.pre) FF_LAUNCH(true, 0);
+    else FF_LAUNCH(false, 0);
 #undef FF_LAUNCH
     GL_LAUNCH_CHECK();
     return GL_OK;

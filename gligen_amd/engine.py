@@ -637,6 +637,17 @@ class Engine:
                                        C.c_float(eps), _ptr(y), _stream(self.device)))
         return y
 
+    def op_ff_chain_q(self, x, pre_w, pre_b, pre_res, gamma, beta, w1, b1, w2, b2, gamma_q, beta_q, wq, pre_gate=None, gate=None):
+        """The fuser's chained launch with attn2.to_q(norm2(.)) as its trailing projection (gl_op_ff_chain_q). x [B][N][320].
+        Returns (y [B][N][C], q [B][8][N][40]) -- q decoded from the attention kernels' head layout."""
+        B, N, Cc = x.shape
+        y = torch.empty_like(x)
+        qbuf = torch.zeros((B * 8, N, 48), device=x.device, dtype=torch.bfloat16)
+        check(self.lib.gl_op_ff_chain_q(self._ctx, _ptr(x), B, N, Cc, _ptr(pre_w), _ptr(pre_b), _ptr(pre_res), _ptr(pre_gate), _ptr(gamma), _ptr(beta),
+                                        _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(gate), _ptr(gamma_q), _ptr(beta_q), _ptr(wq), _ptr(y), _ptr(qbuf),
+                                        _stream(self.device)))
+        return y, qbuf.view(B, 8, N, 48)[..., :40]
+
     def op_proj_attention(self, x, pre_w, pre_b, pre_res, gamma, beta, wq, wk, wv, heads, rows=True):
         """mid = pre_res + x Wpre^T + pre_b; o = self-attention of LN(mid) without to_out (gl_op_proj_attention).
         Returns (mid, o, used_rows): used_rows = 1 when the row-local projection kernel ran."""

@@ -270,6 +270,16 @@ int gl_op_ff_chain(gl_ctx* ctx, const void* x, int M, int C, const float* pre_w,
                    const float* gamma, const float* beta, const float* w1, const float* b1, const float* w2, const float* b2, const float* gate,
                    const float* post_w, const float* post_b, const void* post_res, void* y, gl_stream s);
 
+/* The fuser's chained launch with the cross-attention's query projection as its trailing projection (reference attention.py:236-244
+ * GatedSelfAttentionDense, then :336 attn2(norm2(x)): to_q of the NEXT LayerNorm):
+ *   t = pre_res + pre_gate * (x Wpre^T + pre_b);  y = t + gate * ff(LN(t; gamma, beta))  -> y [B][N][C] bf16 (the residual stream)
+ *   q = LN(y; gamma_q, beta_q) Wq^T                                                       -> q [B * 8][N][48] bf16 (head layout of the
+ *       attention kernels at d = 40: head-major, 48-column rows whose columns 40..47 are left untouched)
+ * C = 320, N % 128 == 0; Wq [C][C] fp32 (no bias). GL_ERR_UNSUPPORTED otherwise. */
+int gl_op_ff_chain_q(gl_ctx* ctx, const void* x, int B, int N, int C, const float* pre_w, const float* pre_b, const void* pre_res, const float* pre_gate,
+                     const float* gamma, const float* beta, const float* w1, const float* b1, const float* w2, const float* b2, const float* gate,
+                     const float* gamma_q, const float* beta_q, const float* wq, void* y, void* q, gl_stream s);
+
 /* ---- training slice: one BasicTransformerBlock, forward + backward ---------------------------------
  * Forward of the reference's BasicTransformerBlock with a gatedSA fuser (ldm/modules/attention.py:333-338, 236-244), the
  * reference's loss on its output (trainer.py:366: mse_loss(model_output, noise)) and the backward pass, with the gradients the

@@ -785,3 +785,30 @@ def test_proj_attention_rows(engine, B, N, res):
     assert rel_err(o, o0.float()) < 1.2e-2
     mid2, o2, _ = engine.op_proj_attention(x, pre_w, pre_b, pre_res, gamma, beta, wq, wk, wv, H, rows=True)
     assert torch.equal(mid, mid2) and torch.equal(o, o2)
+
+
+# ---- the fuser's chained launch with the cross-attention's to_q as its trailing projection (ffn.hip FFRowsParams::post = 2): y is
+# stored, normalised in registers, projected, q leaves in the head layout (reference attention.py:236-244, then :336 attn2(norm2(x)))
+@pytest.mark.parametrize("B,N", [(1, 128), (2, 1024)])
+def test_ff_chain_with_to_q(engine, B, N):
+    C = 320
+    x = bf(rnd(B, N, C, seed=1))
+    pre_w, pre_b = rnd(C, C, scale=C ** -0.5, seed=2), 0.1 * rnd(C, seed=3)
+    pre_res = bf(rnd(B, N, C, seed=4) * 1.3 + 0.2)
+    gamma, beta = 1.0 + 0.3 * rnd(C, seed=5), 0.2 * rnd(C, seed=6)
+    w1, b1 = rnd(8 * C, C, scale=C ** -0.5, seed=7), 0.5 * rnd(8 * C, seed=8)
+    w2, b2 = rnd(C, 4 * C, scale=(4 * C) ** -0.5, seed=9), 0.1 * rnd(C, seed=10)
+    gq, bq, wq = 1.0 + 0.3 * rnd(C, seed=11), 0.2 * rnd(C, seed=12), rnd(C, C, scale=C ** -0.5, seed=13)
+    g1, g2 = torch.tensor([0.37], device="cuda"), torch.tensor([-0.6], device="cuda")
+    y, q = engine.op_ff_chain_q(x, pre_w, pre_b, pre_res, gamma, beta, w1, b1, w2, b2, gq, bq, wq, pre_gate=g1, gate=g2)
+    t = bf(pre_res.float() + 0.37 * (x.float() @ bf(pre_w).float().t() + pre_b)).float()
+    h = F.layer_norm(t, (C,), gamma, beta, 1e-5) @ w1.t() + b1
+    val, g = h.chunk(2, dim=-1)
+    u = t - 0.6 * ((val * F.gelu(g)) @ w2.t() + b2)
+    assert torch.isfinite(y.float()).all() and torch.isfinite(q.float()).all()
+    assert rel_err(y, u) < TOL, rel_err(y, u)
+    qref = (F.layer_norm(y.float(), (C,), gq, bq, 1e-5) @ wq.t()).view(B, N, 8, 40).transpose(1, 2)   # from the kernel's own bf16 y
+    assert rel_err(q, qref) < TOL, rel_err(q, qref)
+    # the plain chained launch gives the same y
+    y0 = engine.op_ff_chain(x.view(B * N, C), pre_w, pre_b, pre_res.view(B * N, C), gamma, beta, w1, b1, w2, b2, pre_gate=g1, gate=g2)
+    assert torch.equal(y.view(B * N, C), y0)
