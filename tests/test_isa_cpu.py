@@ -424,6 +424,38 @@ def test_ffn_accumulators_are_never_touched_next_to_their_mfmas(ffn_asm):
                                 break
 
 
+def test_row_local_epilogues_issue_no_global_load_between_their_stores(ffn_asm):
+    """Round 6: a global load inside an epilogue's per-feature-block loop makes hipcc wait vmcnt(0) in front of its use -- for every
+    store issued before it, loads and stores share the counter: ten serialised round trips per epilogue (qkv_rows_kernel 65 -> 54 us,
+    ff_rows_kernel<pre, post> 117 -> 112 us when they went). What is pinned: the q,k,v^T kernels have no scratch, every global load of
+    theirs sits in front of the first MFMA, and every vmcnt wait in them is a full one (the asm stream's own: stage boundaries and the
+    wait in front of an epilogue) -- hipcc found no load to wait for among the stores. In the feed-forward kernels no global load
+    is followed by a global store before the next wait."""
+    names = re.findall(r"^(_ZN2gl12_GLOBAL__N_115qkv_rows_kernelI[^:\s]*):", ffn_asm, re.M)
+    assert len(names) == 4, names          # {leading projection or not} x {q,k,v^T or q only}
+    for name in names:
+        a = ffn_asm.index(name + ":")
+        meta = ffn_asm[a:ffn_asm.index(".end_amdhsa_kernel", a)]
+        body = [l.strip() for l in meta.split("\n") if l.strip() and not l.strip().startswith(";") and not l.strip().startswith(".")]
+        assert "scratch_load" not in meta and "scratch_store" not in meta, name
+        assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1)) <= 512, name
+        first_mfma = next(i for i, l in enumerate(body) if l.startswith("v_mfma"))
+        loads = [i for i, l in enumerate(body) if l.startswith("global_load")]
+        assert loads and max(loads) < first_mfma, (name, [body[i] for i in loads if i > first_mfma][:3])
+        waits = [l.replace(" ", "") for l in body[first_mfma:] if l.startswith("s_waitcnt") and "vmcnt" in l]
+        assert waits and all(w == "s_waitcntvmcnt(0)" for w in waits), (name, sorted(set(waits)))
+        assert sum(1 for l in body if l.startswith("global_store")) >= 40, name
+    for name, meta, body in _ffn_kernels(ffn_asm):
+        pending_load = False
+        for l in body:
+            if l.startswith("global_load"):
+                pending_load = True
+            elif l.startswith("s_waitcnt") and "vmcnt" in l:
+                pending_load = False
+            elif l.startswith("global_store"):
+                assert not pending_load, (name, "a store behind an unwaited load: the next use of that load waits for the store too")
+
+
 def test_ffn_dma_statements_declare_what_they_clobber():
     """The LDS-DMA asm steps its cursors with s_add_u32: SCC has to be in the clobber list (without it hipcc kept the loop
     condition in SCC across the statement and the loop ran until the 32-bit stream offset overflowed)."""
