@@ -58,7 +58,7 @@ class PlmsArgs(C.Structure):
 class TrainUNetIn(C.Structure):   # = gl_train_unet_in
     _fields_ = [(n, C.c_int) for n in ("B", "H", "W", "ctx_T", "Ng")] + \
                [(n, C.c_void_p) for n in ("x", "timesteps", "context", "boxes", "masks", "positive_embeddings", "target")] + \
-               [("fuser_scale", C.c_float)] + [(n, C.c_void_p) for n in ("text_masks", "image_masks", "image_embeddings")] + [("checkpoint", C.c_int)]
+               [("fuser_scale", C.c_float)] + [(n, C.c_void_p) for n in ("text_masks", "image_masks", "image_embeddings")] + [("checkpoint", C.c_int), ("use_weight_cache", C.c_int)]
 
 
 class BoxCalibration(C.Structure):   # = gl_box_calibration
@@ -119,6 +119,7 @@ SYMBOLS = {
     "gl_op_resample_train": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gl_unet_train_step": (_I, [_P, C.POINTER(UNetConfig), C.POINTER(TrainUNetIn), _I, C.POINTER(C.c_char_p), C.POINTER(_P), C.POINTER(_P), _P, _P, _P]),
     "gl_train_wait_grads": (_I, [_P, _I, _P]),
+    "gl_train_weight_cache": (_I, [_P, _I, C.POINTER(C.c_size_t)]),
     "gl_op_adamw_step": (_I, [_P, _P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _I, _P]),
     "gl_op_ff_chain": (_I, [_P, _P, _I, _I] + [_P] * 16),
     "gl_op_conv3x3": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),

@@ -687,9 +687,23 @@ int gl_unet_train_step(gl_ctx* ctx, const gl_unet_config* cfg, const gl_train_un
     gl::TrainUNetIn u{in->B, in->H, in->W, in->ctx_T, cfg->grounding_kind == 1 ? 2 * in->Ng : in->Ng, in->Ng, in->x, in->timesteps, in->context, in->boxes,
                       in->masks, in->positive_embeddings, in->text_masks, in->image_masks, in->image_embeddings, in->target, in->fuser_scale, in->checkpoint};
     int rc = gl::unet_train_step(eng.arena(), eng.splitk_ws(), eng.splitk_ws_bytes(), c, u, n_params, names, params, grads, k_train_block_names, eps_out, loss, S(s),
-                                 eng.train_events(), Engine::kTrainEvents);
+                                 eng.train_events(), Engine::kTrainEvents, in->use_weight_cache ? eng.train_cache : nullptr);
     if (rc != GL_OK) throw GlError(rc, gl::last_error());
     eng.train_events_recorded = true;
+    GL_API_END
+}
+
+int gl_train_weight_cache(gl_ctx* ctx, int enable, size_t* bytes) {
+    NEED(ctx);
+    GL_API_BEGIN
+    Engine& eng = *ctx->eng;
+    if (enable && !eng.train_cache) eng.train_cache = gl::train_cache_create();
+    if (!enable && eng.train_cache) {
+        HIPCK_API(hipDeviceSynchronize());    // (a step that reads the copies may still be in flight)
+        gl::train_cache_destroy(eng.train_cache);
+        eng.train_cache = nullptr;
+    }
+    if (bytes) *bytes = gl::train_cache_bytes(eng.train_cache);
     GL_API_END
 }
 

@@ -17,6 +17,7 @@
 #include "gemm.h"
 #include "misc.h"
 #include "norm.h"
+#include "train.h"
 #include "../../include/gligen_amd.h"
 
 namespace gl {
@@ -210,6 +211,7 @@ class Engine {
     static constexpr int kTrainEvents = 64;
     hipEvent_t* train_events();
     bool train_events_recorded = false;
+    TrainWeightCache* train_cache = nullptr;   // gl_train_weight_cache: operand copies of the frozen parameters kept across training steps
 
     // ---- per-kernel profile of one eager UNetModel.forward: HIP events around every GEMM / conv / attention /
     // norm launch on the stream it is launched on, aggregated by kernel symbol (bench.py's roofline block)

@@ -147,6 +147,7 @@ Engine::~Engine() {
     if (!parent_)
         for (auto& kv : raw_)
             if (kv.second.p) (void)hipFree(kv.second.p);
+    train_cache_destroy(train_cache);
     for (void* p : owned_) (void)hipFree(p);
     for (void* p : cond_.allocs) (void)hipFree(p);
     arena_.destroy();

@@ -78,9 +78,16 @@ struct TrainUNetIn {
 };
 // names / params / grads: the model's state_dict (fp32 device pointers; grads[i] non-null only for fuser.* and position_net.* entries:
 // the reference's trainable set, trainer.py:217-245). block_names: the TP_* state_dict keys. eps_out (optional) [B][H*W][out_channels].
+// cache (optional, round 6): the bf16 operand copies -- (hi | hi | lo) rows / transposes, packed conv weights and their dgrad forms -- of
+// every parameter whose grads[i] is null are built once and reused by later calls: the caller promises that it only ever changes the
+// parameters it asked gradients for (gligen_amd.train.TrainStep does; reference trainer.py:217-245 freezes everything else).
+struct TrainWeightCache;
+TrainWeightCache* train_cache_create();
+void train_cache_destroy(TrainWeightCache* c);      // frees every cached copy
+size_t train_cache_bytes(const TrainWeightCache* c);
 int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& cfg, const TrainUNetIn& in, int n_params, const char* const* names,
                     const float* const* params, float* const* grads, const char* const* block_names, float* eps_out, float* loss, hipStream_t s,
-                    hipEvent_t* grad_events = nullptr, int n_grad_events = 0);
+                    hipEvent_t* grad_events = nullptr, int n_grad_events = 0, TrainWeightCache* cache = nullptr);
 // grad_events (optional): event j is recorded on `s` when the backward of the j-th SpatialTransformer (module order) has written its
 // fuser gradients -- the backward runs from the last block to the first, so high j come early --, event [number of SpatialTransformers]
 // when position_net's (the last gradients of the step) are written

@@ -15,6 +15,10 @@
 // reference's own autograd (tests/golden/block_backward_gatedsa.npz), not yet tuned.
 #include "train.h"
 
+#include <map>
+#include <tuple>
+#include <unordered_set>
+
 #include "engine.h"
 
 #include <cstdarg>
@@ -791,11 +795,55 @@ __global__ void sum2x2_kernel(const float* __restrict__ du, int H, int W, int Cc
     dx[i] = (p[0] + p[Cc]) + (p[(size_t)2 * W * Cc] + p[(size_t)2 * W * Cc + Cc]);
 }
 
+}  // namespace
+
+// operand copies of frozen parameters, kept across training steps (train.h)
+struct TrainWeightCache {
+    struct Key {
+        const void* p; int kind, a, b, c;
+        bool operator<(const Key& o) const { return std::tie(p, kind, a, b, c) < std::tie(o.p, o.kind, o.a, o.b, o.c); }
+    };
+    std::map<Key, void*> m;
+    size_t bytes = 0;
+};
+TrainWeightCache* train_cache_create() { return new TrainWeightCache(); }
+void train_cache_destroy(TrainWeightCache* c) {
+    if (!c) return;
+    for (auto& kv : c->m) (void)hipFree(kv.second);
+    delete c;
+}
+size_t train_cache_bytes(const TrainWeightCache* c) { return c ? c->bytes : 0; }
+
+namespace {
+
 struct Ctx {
     Arena& ar;
     float* ws;
     size_t ws_bytes;
     hipStream_t s;
+    TrainWeightCache* wc = nullptr;                            // null: every operand copy is built per product in the arena
+    const std::unordered_set<const void*>* frozen = nullptr;   // parameter tensors the caller does not update (no gradient asked for)
+    // a bf16 operand copy of weight W: from the cache when W is frozen and a cache is attached (built on first use, on this stream), else
+    // from the arena (released with the product's mark as before)
+    template <class F>
+    bf16* weight_operand(const float* W, int kind, int a, int b, int c, size_t n_elems, F&& build) const {
+        if (wc && frozen && frozen->count(W)) {
+            const TrainWeightCache::Key key{W, kind, a, b, c};
+            auto it = wc->m.find(key);
+            if (it != wc->m.end()) return reinterpret_cast<bf16*>(it->second);
+            void* p = nullptr;
+            hip(hipMalloc(&p, n_elems * sizeof(bf16)), "hipMalloc (training weight cache)");
+            const size_t mk = ar.mark();
+            build(reinterpret_cast<bf16*>(p));
+            ar.release(mk);               // (fp32 temporaries of the build; stream order keeps their reuse safe)
+            wc->m.emplace(key, p);
+            wc->bytes += n_elems * sizeof(bf16);
+            return reinterpret_cast<bf16*>(p);
+        }
+        bf16* d = ar.get<bf16>(n_elems);
+        build(d);
+        return d;
+    }
     void ck(int rc) const { if (rc != GL_OK) throw GlError(rc, gl::last_error()); }
     void hip(hipError_t e, const char* what) const { if (e != hipSuccess) throw GlError(GL_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
     float* f32(size_t n) const { return ar.get<float>(n); }
@@ -858,11 +906,22 @@ struct Ctx {
         hipLaunchKernelGGL(cat3_transposed_kernel, dim3(cdiv(Cc, 32), cdiv(Rpad, 32)), dim3(32, 8), 0, s, src, R, Cc, Cc, side, d, Rpad);
         return d;
     }
+    // the weight side of a product (side = 1): cached for frozen parameters
+    bf16* cat3_rows_w(const float* W, int N, int K) const {
+        return weight_operand(W, 1, N, K, 0, (size_t)N * 3 * K, [&](bf16* d) {
+            hipLaunchKernelGGL(cat3_rows_kernel, g1((size_t)N * K), dim3(256), 0, s, W, (size_t)N * K, K, 1, d);
+        });
+    }
+    bf16* cat3_transposed_w(const float* W, int N, int K) const {
+        return weight_operand(W, 2, N, K, 0, (size_t)K * 3 * N, [&](bf16* d) {
+            hipLaunchKernelGGL(cat3_transposed_kernel, dim3(cdiv(K, 32), cdiv(N, 32)), dim3(32, 8), 0, s, W, N, K, K, 1, d, N);
+        });
+    }
     // y = x W^T + b
     float* lin_fwd(const float* x, int M, int K, const float* W, const float* b, int N) const {
         float* y = f32((size_t)M * N);
         const size_t mk = ar.mark();       // the bf16 operand copies live for this product only (stream order keeps their reuse safe)
-        if (one_launch()) mm1(cat3_rows(x, M, K, 0), cat3_rows(W, N, K, 1), M, N, 3 * K, b, y);
+        if (one_launch()) mm1(cat3_rows(x, M, K, 0), cat3_rows_w(W, N, K), M, N, 3 * K, b, y);
         else mm(to_bf16(x, (size_t)M * K), to_bf16(W, (size_t)N * K), M, N, K, b, y);
         ar.release(mk);
         return y;
@@ -871,7 +930,7 @@ struct Ctx {
     float* lin_dgrad(const float* dy, int M, int N, const float* W, int K) const {
         float* dx = f32((size_t)M * K);
         const size_t mk = ar.mark();
-        if (one_launch()) mm1(cat3_rows(dy, M, N, 0), cat3_transposed(W, N, K, N, 1), M, K, 3 * N, nullptr, dx);
+        if (one_launch()) mm1(cat3_rows(dy, M, N, 0), cat3_transposed_w(W, N, K), M, K, 3 * N, nullptr, dx);
         else mm(to_bf16(dy, (size_t)M * N), transposed(W, N, K, N), M, K, N, nullptr, dx);
         ar.release(mk);
         return dx;
@@ -1018,20 +1077,21 @@ struct Ctx {
         const int Ci = dgrad ? Cout : Cin, Co = dgrad ? Cin : Cout, M = B * Ho * Wo;
         float* out = f32((size_t)M * Co);
         const size_t mk_ops = ar.mark();   // packed weights / bf16 activation copies: this product's, released behind it
-        const float* wsrc = w_oihw;
-        if (dgrad) {
-            float* wt = f32((size_t)Cin * Cout * 9);
-            hipLaunchKernelGGL(conv_dgrad_weight_kernel, g1((size_t)Cin * Cout * 9), dim3(256), 0, s, w_oihw, Cout, Cin, wt);
-            wsrc = wt;
-        }
         if (one_launch() && Ci % 64 == 0) {
             // one implicit-GEMM launch over 3 Ci input channels: activations (hi | lo | hi) as a two-source concat of the (hi | lo) buffer
-            // with its own first half, weights (hi | hi | lo) along I
+            // with its own first half, weights (hi | hi | lo) along I (cached for frozen convs: flip / transpose for dgrad, split, pack -- once)
             const size_t nw = (size_t)Co * 9 * Ci;
-            float* w3 = f32(3 * nw);
-            hipLaunchKernelGGL(conv_w_cat3_kernel, g1(nw), dim3(256), 0, s, wsrc, Co, Ci, w3);
-            bf16* wp3 = ar.get<bf16>(3 * nw);
-            ck(pack_conv_weight_launch(w3, wp3, Co, 3 * Ci, 3, 3, Co, s));
+            bf16* wp3 = weight_operand(w_oihw, dgrad ? 4 : 3, Cout, Cin, 0, 3 * nw, [&](bf16* d) {
+                const float* src = w_oihw;
+                if (dgrad) {
+                    float* wt = f32((size_t)Cin * Cout * 9);
+                    hipLaunchKernelGGL(conv_dgrad_weight_kernel, g1((size_t)Cin * Cout * 9), dim3(256), 0, s, w_oihw, Cout, Cin, wt);
+                    src = wt;
+                }
+                float* w3 = f32(3 * nw);
+                hipLaunchKernelGGL(conv_w_cat3_kernel, g1(nw), dim3(256), 0, s, src, Co, Ci, w3);
+                ck(pack_conv_weight_launch(w3, d, Co, 3 * Ci, 3, 3, Co, s));
+            });
             const size_t na = (size_t)B * H * W * Ci;
             bf16* a2 = ar.get<bf16>(2 * na);
             hipLaunchKernelGGL(cat2_rows_kernel, g1(na), dim3(256), 0, s, a, na, Ci, a2);
@@ -1044,6 +1104,12 @@ struct Ctx {
             ck(gemm_launch(A, wp3, M, Co, 27 * Ci, E, ws, ws_bytes, s));
             ar.release(mk_ops);
             return out;
+        }
+        const float* wsrc = w_oihw;
+        if (dgrad) {
+            float* wt = f32((size_t)Cin * Cout * 9);
+            hipLaunchKernelGGL(conv_dgrad_weight_kernel, g1((size_t)Cin * Cout * 9), dim3(256), 0, s, w_oihw, Cout, Cin, wt);
+            wsrc = wt;
         }
         bf16* wp = ar.get<bf16>((size_t)Co * 9 * Ci);
         ck(pack_conv_weight_launch(wsrc, wp, Co, Ci, 3, 3, Co, s));
@@ -1575,7 +1641,8 @@ struct Names {
 }  // namespace
 
 int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& cfg, const TrainUNetIn& in, int n_params, const char* const* names,
-                    const float* const* params, float* const* grads, const char* const* block_names, float* eps_out, float* loss, hipStream_t s, hipEvent_t* grad_events, int n_grad_events) {
+                    const float* const* params, float* const* grads, const char* const* block_names, float* eps_out, float* loss, hipStream_t s, hipEvent_t* grad_events, int n_grad_events,
+                    TrainWeightCache* cache) {
     try {
         Names nm;
         nm.params = params;
@@ -1585,6 +1652,13 @@ int unet_train_step(Arena& ar, float* ws, size_t ws_bytes, const TrainUNetCfg& c
             if (grads[i] && !(strstr(names[i], ".fuser.") || !strncmp(names[i], "position_net.", 13)))
                 throw GlError(GL_ERR_ARG, fmt("unet_train_step: a gradient was asked for '%s', which the reference keeps frozen", names[i]));
         Ctx c{ar, ws, ws_bytes, s};
+        std::unordered_set<const void*> frozen;
+        if (cache) {
+            for (int i = 0; i < n_params; ++i)
+                if (params[i] && !grads[i]) frozen.insert(params[i]);
+            c.wc = cache;
+            c.frozen = &frozen;
+        }
         const int B = in.B, H0 = in.H, W0 = in.W, mc = cfg.model_channels, ED = 4 * mc, KD = cfg.context_dim, Ng = in.Ng;
         if (mc % 64 || KD % 64 || cfg.gr_dim % 64 || B < 1) throw GlError(GL_ERR_ARG, "unet_train_step: model_channels / context_dim / grounding dim must be multiples of 64");
         auto in_attn = [&](int ds) { for (int i = 0; i < cfg.n_attn; ++i) if (cfg.attention_resolutions[i] == ds) return true; return false; };

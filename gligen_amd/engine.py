@@ -444,15 +444,23 @@ class Engine:
         check(self.lib.gl_op_adamw_step(self._ctx, _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(betas[0]), float(betas[1]),
                                         float(eps), float(weight_decay), int(step), _stream(self.device)))
 
+    def train_weight_cache(self, enable: bool = True) -> int:
+        """Keep the bf16 operand copies of the frozen parameters across unet_train_step calls (gl_train_weight_cache); returns the bytes
+        held. Only for callers that change nothing but the parameters they ask gradients for (TrainStep does); enable=False frees them."""
+        n = C.c_size_t(0)
+        check(self.lib.gl_train_weight_cache(self._ctx, 1 if enable else 0, C.byref(n)))
+        return int(n.value)
+
     def unet_train_step(self, cfg: Mapping, state_dict: Mapping[str, torch.Tensor], batch: Mapping[str, torch.Tensor], fuser_scale: float = 1.0,
-                        trainable=None, grads: Optional[Mapping[str, torch.Tensor]] = None, checkpoint: bool = False):
+                        trainable=None, grads: Optional[Mapping[str, torch.Tensor]] = None, checkpoint: bool = False, use_weight_cache: bool = False):
         """One training iteration of the reference (trainer.py:353-392: model(input), mse_loss(model_output, noise), backward) on the
         device (gl_unet_train_step). cfg: UNetModel kwargs (text tokenizer, gatedSA); state_dict: the model's parameters (fp32, on this
         device: they are used in place); batch: x [B, 4, H, W] (noised latent), timesteps [B], context [B, 77, 768], boxes, masks,
         positive_embeddings (or, for the text+image tokenizer, text_embeddings, image_embeddings, text_masks, image_masks), target [B, 4, H, W] (the noise). Returns (loss, eps [B, 4, H, W], grads) with grads over the reference's
         trainable set (trainer.py:217-245: '*.fuser.*' and 'position_net.*' keys) or the `trainable` names given; `grads`: buffers to
         write into instead of fresh ones (every entry is overwritten); `checkpoint`: keep only block inputs / outputs and recompute each block's
-        forward in its backward (the same gradients bit for bit, a fraction of the arena)."""
+        forward in its backward (the same gradients bit for bit, a fraction of the arena); `use_weight_cache`: keep / reuse the bf16
+        operand copies of the tensors no gradient is asked for (train_weight_cache: only when those tensors never change)."""
         dev = self.device
         c = UNetConfig()
         c.in_channels, c.out_channels, c.model_channels = cfg["in_channels"], cfg["out_channels"], cfg["model_channels"]
@@ -487,7 +495,7 @@ class Engine:
         u = _lib.TrainUNetIn(int(B), int(H), int(W), int(keep["ctx"].shape[1]), int(keep["boxes"].shape[1]), keep["x"].data_ptr(), keep["t"].data_ptr(),
                              keep["ctx"].data_ptr(), keep["boxes"].data_ptr(), keep["masks"].data_ptr(), None if kp else keep["pe"].data_ptr(), keep["target"].data_ptr(),
                              float(fuser_scale), keep["tm"].data_ptr() if ti else None, keep["im"].data_ptr() if ti else None,
-                             keep["ie"].data_ptr() if ti else None, int(bool(checkpoint)))
+                             keep["ie"].data_ptr() if ti else None, int(bool(checkpoint)), int(bool(use_weight_cache)))
         n = len(names)
         narr = (C.c_char_p * n)(*[k.encode() for k in names])
         parr = (C.c_void_p * n)(*[p.data_ptr() for p in params])

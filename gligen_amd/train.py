@@ -93,7 +93,8 @@ class TrainStep:
 
     def __init__(self, engine, cfg: Mapping, state_dict: Mapping[str, torch.Tensor], lr: Union[float, Callable[[int], float]] = 5e-5,
                  weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8, bucket_mb: float = 128.0, world: Optional[int] = None,
-                 checkpoint: bool = True, drop_prob: float = 0.0, rng: Optional[random.Random] = None, broadcast: bool = True, overlap: bool = True):
+                 checkpoint: bool = True, drop_prob: float = 0.0, rng: Optional[random.Random] = None, broadcast: bool = True, overlap: bool = True,
+                 cache_frozen: bool = True):
         self.engine, self.cfg = engine, dict(cfg)
         dev = engine.device
         self.lr = lr if callable(lr) else float(lr)
@@ -134,6 +135,12 @@ class TrainStep:
         self.overlap = bool(overlap) and hasattr(engine, "train_wait_grads")
         self._comm = torch.cuda.Stream(device=dev) if (self.overlap and torch.device(dev).type == "cuda") else None
         self.steps = 0
+        # the bf16 operand copies of the frozen parameters are built once and kept on the device (gl_train_weight_cache): this step
+        # changes nothing but the tensors it asks gradients for, and load_state_dict drops the copies
+        self.cache_frozen = bool(cache_frozen) and hasattr(engine, "train_weight_cache")
+        if self.cache_frozen:
+            engine.train_weight_cache(False)       # (copies keyed by the addresses of another TrainStep's tensors must not outlive them)
+            engine.train_weight_cache(True)
 
     def lr_at(self, step: int) -> float:
         return float(self.lr(step)) if callable(self.lr) else self.lr
@@ -142,7 +149,8 @@ class TrainStep:
         """One iteration: forward, loss, backward, gradient average over the ranks, AdamW. Returns (loss of this rank, eps)."""
         if self.drop_prob > 0.0 and self.rng.random() < self.drop_prob:      # random drop for guidance (openaimodel.py:428)
             batch = null_grounding(batch)
-        loss, eps, _ = self.engine.unet_train_step(self.cfg, self.params, batch, fuser_scale=fuser_scale, grads=self.gbuf.views, checkpoint=self.checkpoint)
+        kw = dict(use_weight_cache=True) if self.cache_frozen else {}
+        loss, eps, _ = self.engine.unet_train_step(self.cfg, self.params, batch, fuser_scale=fuser_scale, grads=self.gbuf.views, checkpoint=self.checkpoint, **kw)
         self.steps += 1
         lr = self.lr_at(self.steps)
         upd = lambda i: self.engine.op_adamw_step(self.pbuf.buckets[i], self.gbuf.buckets[i], self.m[i], self.v[i], self.steps, lr=lr, betas=self.betas,
@@ -191,3 +199,6 @@ class TrainStep:
         """Parameters back into the flat buffers (trainable) / the frozen set, in place: the views the engine reads stay the same."""
         for k, t in state_dict.items():
             self.params[k].copy_(t.to(device=self.params[k].device, dtype=torch.float32))
+        if self.cache_frozen:              # frozen tensors may have changed under the cached operand copies
+            self.engine.train_weight_cache(False)
+            self.engine.train_weight_cache(True)

@@ -353,9 +353,19 @@ typedef struct gl_train_unet_in {
     const float* image_embeddings;      /* [B][Ng][gr_in_dim] */
     int checkpoint;                     /* activation checkpointing per ResBlock / SpatialTransformer: 1 = keep block inputs and outputs only and
                                            recompute a block's forward in its backward (same gradients bit for bit, a fraction of the memory) */
+    int use_weight_cache;               /* 1: take / leave the frozen parameters' operand copies in the context's cache (gl_train_weight_cache) */
 } gl_train_unet_in;
 int gl_unet_train_step(gl_ctx* ctx, const gl_unet_config* cfg, const gl_train_unet_in* in, int n_params, const char* const* names,
                        const float* const* params, float* const* grads, float* eps_out, float* loss, gl_stream s);
+
+/* Operand copies of the FROZEN parameters across training steps (reference trainer.py:217-245: only fuser.* / position_net.* are ever
+ * updated). gl_unet_train_step multiplies every fp32 weight as (hi | hi | lo) bf16 operands -- rows for the forward, transposes for the
+ * data gradient, packed / flipped filters for the convs --, built per product. With the cache enabled those copies are built once for every
+ * parameter whose grads[i] is NULL and reused by later steps of this context that set gl_train_unet_in.use_weight_cache: the caller
+ * promises to change only the parameters it asks gradients for, and that a frozen tensor's device address means the same values for as
+ * long as the cache lives (enable = 0 frees the copies: after loading other weights into the same buffers, or before buffers are
+ * re-allocated). *bytes (optional): device memory the cache holds now. */
+int gl_train_weight_cache(gl_ctx* ctx, int enable, size_t* bytes);
 
 /* Gradient milestones of the last gl_unet_train_step on this context: make stream `s` wait until the fuser gradients of the
  * index-th SpatialTransformer (module order: input_blocks .., middle_block, output_blocks ..) are written -- the backward runs from the

@@ -604,6 +604,15 @@ def test_train_two_optimizer_steps_vs_reference(engine):
     torch.cuda.synchronize()
     p3 = ts3.state_dict()
     assert all(torch.equal(p2[k], p3[k]) for k in p2), [k for k in p2 if not torch.equal(p2[k], p3[k])][:5]
+    # the frozen parameters' operand copies kept across steps (gl_train_weight_cache, on by default) against copies rebuilt per product:
+    # the same bits; the cache holds memory after a step and none after it is dropped
+    assert ts3.cache_frozen and engine.train_weight_cache(True) > 0
+    ts4 = TrainStep(engine, meta["cfg"], sd, lr=meta["lr"], weight_decay=0.0, world=1, overlap=False, cache_frozen=False)
+    ts4.step(batch); ts4.step(batch)
+    torch.cuda.synchronize()
+    p4 = ts4.state_dict()
+    assert all(torch.equal(p3[k], p4[k]) for k in p3), [k for k in p3 if not torch.equal(p3[k], p4[k])][:5]
+    assert engine.train_weight_cache(False) == 0
 
 
 def test_spatial_transformer_backward_vs_reference(engine):
