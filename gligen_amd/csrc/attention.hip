@@ -770,11 +770,24 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn3_kernel(AttnPar
 #pragma unroll
             for (int r = 0; r < 4; ++r) ot[qh][i][r] = 0.f;
     float m_run = BIAS ? 0.f : -1e30f;   // BIAS: the stabiliser baked into Q column 40; else subtracted in front of the exps
+    // Round 6, d = 40 (BIAS): the stabiliser follows the DENOMINATOR, not the row maximum. The per-tile maximum of the scores (15 v_max3 +
+    // 6 v_max + a lane swap per tile: a sixth of the loop's VALU issue time, which is what bounds the kernel) only ever decided whether
+    // exp2(s - m) might overflow; the running denominator l = row d of O^T says the same two tiles later: once it exceeds 2^LAZY_LOG2 the
+    // stabiliser moves up by floor(log2 l) (O^T, the pending scores and the Q column rescaled as before). A single tile may overshoot by
+    // ~2^60 before the products with V near fp32's range; should that ever happen the denominator comes out beyond 2^100 (or non-finite), and the workgroup
+    // runs its tiles again with the exact per-tile maximum (safe: the loop of rounds 3-5). The first tile's maximum is still taken.
+    constexpr bool LAZY = BIAS;
+    constexpr int LAZY_LOG2 = 40;
+    constexpr int D_ROW = BIAS ? 40 : DP;   // the ones row of V^T (P.d): 40 at DP = 48, 80 at DP = 80
+    constexpr int OB = D_ROW >> 4, OG = (D_ROW & 15) >> 2, ORR = D_ROW & 3;
+    bool overshoot = false;                 // a lazy move found a denominator beyond 2^100: some P v product may have left fp32's range
 
     const unsigned k_lane = (unsigned)(lrow * 16 + half * 1024);
     const unsigned v_lane = KBYTES + (unsigned)(l15 * 128) + (unsigned)((g4 ^ ((l15 >> 1) & 7)) << 4);
 
-    auto iter = [&](int j, f32x16 (&sc)[2], f32x16 (&sn)[2], auto slot_c, auto issue_c, auto sm_c, auto qk_c, auto tail_c, auto first_c) {
+    // safe_c: the exact per-tile maximum (the only form without LAZY; with it, the rerun of a workgroup whose lazy pass overflowed)
+    auto iter = [&](int j, f32x16 (&sc)[2], f32x16 (&sn)[2], auto slot_c, auto issue_c, auto sm_c, auto qk_c, auto tail_c, auto first_c, auto safe_c) {
+        constexpr bool SAFE = !LAZY || decltype(safe_c)::value;
         constexpr int SLOT = decltype(slot_c)::value, ISSUE = decltype(issue_c)::value;
         constexpr bool SM = decltype(sm_c)::value, QK = decltype(qk_c)::value, TAILCK = decltype(tail_c)::value, FIRSTMOVE = decltype(first_c)::value;
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): stage j has landed (this wave's pieces; the barrier covers the others')
@@ -785,6 +798,35 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn3_kernel(AttnPar
             if constexpr (ISSUE == 1) issue_k(j + 1, slot ^ 1);
             if constexpr (ISSUE == 3) { if (j + 1 < nt) issue_k(j + 1, slot ^ 1); }
             issue_v(j + 1, slot ^ 1);
+        }
+        if constexpr (LAZY && SM && !SAFE) {
+            {
+                // the denominators accumulated through tile j - 2 (their MFMAs retired an iteration ago: no wait here): row d of O^T, lanes 16 OG ..
+                const bool big = g4 == OG && (ot[0][OB][ORR] > __builtin_ldexpf(1.f, LAZY_LOG2) || ot[1][OB][ORR] > __builtin_ldexpf(1.f, LAZY_LOG2));
+                if (__builtin_amdgcn_ballot_w64(big) != 0) {
+                    const float la = __shfl(ot[0][OB][ORR], 16 * OG + l15, 64), lb = __shfl(ot[1][OB][ORR], 16 * OG + l15, 64);
+                    const float lq = lrow < 16 ? la : lb;                        // this lane's query = lane & 31
+                    overshoot |= !(lq < 1.0e30f);      // (sticky: the move below brings l back into range, not an O^T entry that has overflowed)
+                    const float e = lq > __builtin_ldexpf(1.f, LAZY_LOG2) ? (float)((int)((__float_as_uint(lq) >> 23) & 0xffu) - 127) : 0.f;
+                    const bf16 mb = f2bf(m_run + e);
+                    const float m_upd = (float)mb;
+                    const float delta = m_upd - m_run;   // exact: both are bf16 values
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+                    const auto ar = __builtin_amdgcn_permlane16_swap(__float_as_uint(alpha), __float_as_uint(alpha), false, false);
+                    const float a0 = __uint_as_float(ar[0]), a1 = __uint_as_float(ar[1]);
+#pragma unroll
+                    for (int i = 0; i < DB; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { ot[0][i][r] *= a0; ot[1][i][r] *= a1; }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sc[u][r] -= delta;          // the scores whose exps this iteration takes carry the old stabiliser
+                    m_run = m_upd;
+                    const bf16 nb = f2bf(-m_upd);
+                    if (half == 1) qf[2][0] = nb;
+                }
+            }
         }
         const unsigned sb = (unsigned)(slot * STAGE);
         const unsigned ak = k_lane + sb;
@@ -871,6 +913,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn3_kernel(AttnPar
                         }
                 }
             }
+          if constexpr (FIRSTMOVE || SAFE) {
             float mx = sn[0][0];
 #pragma unroll
             for (int u = 0; u < 2; ++u)
@@ -914,6 +957,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn3_kernel(AttnPar
                     m_run = m_upd;
                 }
             }
+          }
         }
     };
 
@@ -926,25 +970,60 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn3_kernel(AttnPar
     using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>;
     f32x16 sa[2], sb2[2];
-    iter(0, sb2, sa, S0{}, I3{}, F_{}, T_{}, T_{}, T_{});                      // S(0) -> sa
-    if (nt == 1) {
-        iter(1, sa, sb2, S1{}, I0{}, T_{}, F_{}, F_{}, F_{});                  // drain
-    } else {
-        int j = 1;
-        for (; j + 1 <= nt - 2; j += 2) {
-            iter(j, sa, sb2, S1{}, I1{}, T_{}, T_{}, F_{}, F_{});
-            iter(j + 1, sb2, sa, S0{}, I1{}, T_{}, T_{}, F_{}, F_{});
-        }
-        if (j <= nt - 2) {
-            iter(j, sa, sb2, S1{}, I1{}, T_{}, T_{}, F_{}, F_{});
-            ++j;
-            iter(j, sb2, sa, S0{}, I2{}, T_{}, T_{}, T_{}, F_{});
-            iter(j + 1, sa, sb2, S1{}, I0{}, T_{}, F_{}, F_{}, F_{});
-        } else {
-            iter(j, sa, sb2, S1{}, I2{}, T_{}, T_{}, T_{}, F_{});
-            iter(j + 1, sb2, sa, S0{}, I0{}, T_{}, F_{}, F_{}, F_{});
+#define GL_ATTN3_TILES(SAFE_T) \
+    iter(0, sb2, sa, S0{}, I3{}, F_{}, T_{}, T_{}, T_{}, SAFE_T{}); \
+    if (nt == 1) { \
+        iter(1, sa, sb2, S1{}, I0{}, T_{}, F_{}, F_{}, F_{}, SAFE_T{}); \
+    } else { \
+        int j = 1; \
+        for (; j + 1 <= nt - 2; j += 2) { \
+            iter(j, sa, sb2, S1{}, I1{}, T_{}, T_{}, F_{}, F_{}, SAFE_T{}); \
+            iter(j + 1, sb2, sa, S0{}, I1{}, T_{}, T_{}, F_{}, F_{}, SAFE_T{}); \
+        } \
+        if (j <= nt - 2) { \
+            iter(j, sa, sb2, S1{}, I1{}, T_{}, T_{}, F_{}, F_{}, SAFE_T{}); \
+            ++j; \
+            iter(j, sb2, sa, S0{}, I2{}, T_{}, T_{}, T_{}, F_{}, SAFE_T{}); \
+            iter(j + 1, sa, sb2, S1{}, I0{}, T_{}, F_{}, F_{}, F_{}, SAFE_T{}); \
+        } else { \
+            iter(j, sa, sb2, S1{}, I2{}, T_{}, T_{}, T_{}, F_{}, SAFE_T{}); \
+            iter(j + 1, sb2, sa, S0{}, I0{}, T_{}, F_{}, F_{}, F_{}, SAFE_T{}); \
+        } \
+    }
+    GL_ATTN3_TILES(F_)
+    if constexpr (LAZY) {
+        // a denominator that is not a positive finite number: a tile overshot the lazy stabiliser by more than fp32 holds. The whole
+        // workgroup (its waves share the barriers of the tile loop) runs its tiles again with the exact per-tile maximum
+        const float c0 = ot[0][OB][ORR], c1 = ot[1][OB][ORR];
+        // (below 2^100: O^T = sum P v stays finite with it for any |v| < 2^27; a lazy pass that went well leaves l < 2^(LAZY_LOG2 + two tiles' growth))
+        const bool bad = overshoot || (g4 == OG && (!(c0 > 0.f && c0 < 1.0e30f) || !(c1 > 0.f && c1 < 1.0e30f)));
+        // workgroup-wide OR through the first words of the (now idle) stage buffers -- not __syncthreads_or: its static LDS scratch would
+        // move the dynamic buffer off address 0, which the fragment reads assume
+        volatile unsigned* flags = reinterpret_cast<volatile unsigned*>(smem);
+        __builtin_amdgcn_s_barrier();                       // every wave is done reading the last stage
+        const unsigned wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0 ? 1u : 0u;     // (all lanes vote: outside the lane-0 branch)
+        if (lane == 0) flags[wave] = wave_bad;
+        __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): the flag is written
+        __builtin_amdgcn_s_barrier();
+        unsigned any_bad = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) any_bad |= flags[w];
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();                       // (the flags are read before the rerun's DMA overwrites them)
+        if (any_bad) {
+#pragma unroll
+            for (int qh = 0; qh < 2; ++qh)
+#pragma unroll
+                for (int i = 0; i < DB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ot[qh][i][r] = 0.f;
+            m_run = 0.f;
+            if (half == 1) qf[2][0] = f2bf(0.f);
+            issue_k(0, 0);
+            GL_ATTN3_TILES(T_)
         }
     }
+#undef GL_ATTN3_TILES
 
     // softmax denominator = O^T row d (the ones row of V^T): row block d / 16, local row d % 16 = register (d % 4) of the 16-lane row
     // (d % 16) / 4   (d = 40: block 2, lanes 32..47, register 0; d = 80: block 5, lanes 0..15, register 0)

@@ -253,7 +253,7 @@ def test_attn3_loop_puts_pv_on_16x16x32(attn_asm):
         elif o.startswith("v_"):
             run_v += 1; run_m = 0
         worst_v, worst_m = max(worst_v, run_v), max(worst_m, run_m)
-    assert worst_v <= 22 and worst_m <= 4, (worst_v, worst_m)
+    assert worst_v <= 22 and worst_m <= 8, (worst_v, worst_m)   # (round 6: no row maximum between the six MFMAs of the second P V half any more)
     # d = 80 (attn3_kernel<80, 96, false, 4>, the LATE_V form): the steady-state loop fits 256 registers without scratch traffic
     # (the once-only first / last iterations may spill a few accumulator tuples across their merges: bounded here)
     name80 = re.search(r"^(_ZN2gl12attn3_kernelILi80ELi96ELb0ELi4EE[^:\s]*):", attn_asm, re.M).group(1)

@@ -294,20 +294,26 @@ def test_splitk_is_deterministic(engine):
             assert torch.equal(engine.op_linear(x, wb, b, res), y0)
 
 
-@pytest.mark.parametrize("C", [320, 640])
-def test_attention_spike(engine, C):
+@pytest.mark.parametrize("C,gain", [(320, 6.0), (640, 6.0), (320, 2.5), (320, 40.0)])
+def test_attention_spike(engine, C, gain):
     """Force the online-softmax rescale: one key dominates a late tile (§ rule: data-dependent branch needs its own test). d = 40: the
-    stabiliser rides in Q column 40; d = 80: it is subtracted in front of the exps -- both rescale O^T across 16-lane rows in attn3_kernel."""
+    stabiliser rides in Q column 40; d = 80: it is subtracted in front of the exps -- both rescale O^T across 16-lane rows in attn3_kernel.
+    Round 6 (d = 40): the stabiliser follows the denominator two tiles late. gain 2.5: a jump of ~20 log2 units, absorbed without a
+    move; gain 6: ~55 units, the lazy move; gain 40: ~360 units -- exp2 overflows in the lazy pass, the denominator comes out
+    non-finite and the workgroup runs its tiles again with the exact per-tile maximum."""
     B, N, H = 1, 512, 8
     xq = bf(rnd(B, N, C, seed=1))
     xkv = xq.clone()
-    xkv[0, 400] = xq[0, 7] * 6  # key 400 (tile 6) spikes against query 7
+    xkv[0, 400] = xq[0, 7] * gain  # key 400 (tile 6) spikes against query 7
     wq = torch.eye(C).cuda()
     wk = torch.eye(C).cuda()
     wv = rnd(C, C, scale=C ** -0.5, seed=5)
     ref = attn_ref(xq, xkv, wq, wk, wv, H)
     y = engine.op_attention(xq, xkv, wq, wk, wv, H)
-    assert rel_err(y, ref) < 2.5e-2
+    assert torch.isfinite(y.float()).all()
+    # (gain 40: scores of ~530 log2 units, where the stabiliser that rides through the MFMA as a bf16 value has a step of 2: 2.8e-2 measured,
+    # the same with the exact per-tile maximum of rounds 3-5)
+    assert rel_err(y, ref) < (4e-2 if gain > 30 else 2.5e-2)
 
 
 # ---- LayerNorm folded into the GEMM behind it (gemm.h Epilogue::ln_stats): producer GEMM (+ residual) writing the residual
