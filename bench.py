@@ -20,8 +20,9 @@ data-path collective); value = all images / max-over-ranks time.
 
 Beside the contract's keys the line carries what makes a number comparable across boxes and rounds:
     box_calibration   float4-copy GB/s, global->LDS DMA TB/s, sustained bf16 MFMA TFLOP/s of THIS box (gl_box_calibrate)
-    ff_rows_ab        one-lane UNet evaluation ms with the row-local feed-forward kernel off / forced on / chosen by the engine's
-                      on-device timing (the default), and the timed table itself: the same-box A/B of that kernel
+    ff_rows_ab        one-lane UNet evaluation ms with the row-local kernels (feed-forward chains and, since round 6, the projection +
+                      LayerNorm + q,k,v^T launch) off / forced on / chosen by the engine's on-device timing (the default), and the timed
+                      table itself: the same-box A/B of those kernels
     train_step        one iteration of the reference's trainer step (forward + loss + backward + nothing else) of the shipped
                       topology at the same batch and latent, outside the timed region (rank 0, text / text+image / keypoint models)
 """
@@ -306,7 +307,7 @@ def main():
                          "carries that number too (value_one_lane)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true", help="skip the training-iteration line (train_step)")
-    ap.add_argument("--no-ff-ab", action="store_true", help="skip the same-box A/B of the row-local feed-forward kernel (ff_rows_ab)")
+    ap.add_argument("--no-ff-ab", action="store_true", help="skip the same-box A/B of the row-local kernels (ff_rows_ab)")
     ap.add_argument("--alpha-type", default=None,
                     help="gate schedule 'on,decay,off' (fractions of the steps), e.g. 0.3,0,0.7 as in the reference's demo prompts; default: "
                          "None = fusers on at every step, the configuration the metric is quoted on (and the one with the most work)")
