@@ -254,7 +254,12 @@ class Engine:
         B, _, h, w = z.shape
         f = 2 ** self.vae_cfg["n_up"]
         out = torch.empty((B, self.vae_cfg["out_ch"], h * f, w * f), device=dev, dtype=torch.float32)
-        check(self.lib.gl_vae_decode(self._ctx, int(B), int(h), int(w), _ptr(z), _ptr(out), _stream(self.device)))
+        # samples are independent: batches beyond 8 images at 64 x 64 go through in slices, so the arena (sized for the benchmark's
+        # batch) bounds the activations whatever the caller's batch is
+        n = max(1, (8 * 64 * 64) // (h * w))
+        for i in range(0, B, n):
+            m = min(n, B - i)
+            check(self.lib.gl_vae_decode(self._ctx, int(m), int(h), int(w), _ptr(z[i:i + m]), _ptr(out[i:i + m]), _stream(self.device)))
         return out
 
     def vae_encode(self, img: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
@@ -263,7 +268,11 @@ class Engine:
         img, noise = _f32(img, dev), _f32(noise, dev)
         B, _, H, W = img.shape
         out = torch.empty_like(noise)
-        check(self.lib.gl_vae_encode(self._ctx, int(B), int(H), int(W), _ptr(img), _ptr(noise), _ptr(out), _stream(self.device)))
+        n = max(1, (8 * 512 * 512) // (H * W))       # (slices of the batch, as in vae_decode)
+        for i in range(0, B, n):
+            m = min(n, B - i)
+            check(self.lib.gl_vae_encode(self._ctx, int(m), int(H), int(W), _ptr(img[i:i + m]), _ptr(noise[i:i + m]), _ptr(out[i:i + m]),
+                                         _stream(self.device)))
         return out
 
     def sample_plms(self, x: torch.Tensor, timesteps: np.ndarray, a_t: np.ndarray, a_prev: np.ndarray,

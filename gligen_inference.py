@@ -28,6 +28,9 @@ from ldm.models.diffusion.plms import PLMSSampler
 from ldm.util import instantiate_from_config
 
 device = "cuda"
+# run(): a per-GPU batch is split into two half-batches in flight (generate_lanes) from this many images on; below it one UNet
+# evaluation over the whole batch is faster than two half-size ones side by side (profiles/r6/batch_sweep.txt)
+SPLIT_BATCH_AT = 32
 
 
 def set_alpha_scale(model, alpha_scale):
@@ -573,11 +576,13 @@ def run(meta, config, starting_noise=None, models=None):
         grounding_input = {"tokens": batch["tokens"]}
     no_plms = bool(args.get("no_plms"))
     steps = int(args.get("steps") or (250 if no_plms else 50))
-    # batches of 8 and more run as two half-batches in flight (generate_lanes). Not for inpainting: its per-step q_sample noise
-    # comes from the device generator, whose draws would interleave differently
+    # batches of 32 and more run as two half-batches in flight (generate_lanes); below that one evaluation over the whole batch is the
+    # faster schedule (measured, profiles/r6/batch_sweep.txt: 8 images 6.69 images/s as one batch against 6.24 as two halves, 16 images
+    # 7.08 against 6.91, 32 images 7.11 against 7.19). Not for inpainting: its per-step q_sample noise comes from the device generator,
+    # whose draws would interleave differently
     lanes = args.get("lanes")
     lanes = 2 if lanes is None else max(1, int(lanes))      # (--lanes 0 and 1 both mean one batch at a time)
-    if mask is not None or (hi - lo) < 8:
+    if mask is not None or (hi - lo) < SPLIT_BATCH_AT:
         lanes = 1
     if lanes > 1 and starting_noise is None:   # x_T as the sampler would draw it (plms.py:71), before the batch is split
         starting_noise = torch.randn((hi - lo, model.in_channels, model.image_size, model.image_size), device=device)
@@ -702,7 +707,7 @@ def main(argv=None):
     parser.add_argument("--inpaint", action="store_true", help="with --synthetic text: the inpainting model (9-channel first conv, encode + blend)")
     parser.add_argument("--ckpt", type=str, default=None, help="run only the meta_list entries whose checkpoint path contains this string")
     parser.add_argument("--seed", type=int, default=None, help="seed of x_T (one draw for the whole batch, sliced across ranks)")
-    parser.add_argument("--lanes", type=int, default=2, help="per-GPU batches of 8 and more run as this many sub-batches in flight (1 = off)")
+    parser.add_argument("--lanes", type=int, default=2, help="per-GPU batches of 32 and more run as this many sub-batches in flight (1 = off); with --repeat: whole batches in flight")
     parser.add_argument("--steps", type=int, default=None, help="override the sampler's step count (reference: 50 PLMS / 250 DDIM)")
     parser.add_argument("--repeat", type=int, default=1, help="batches of --batch_size per prompt (seed, seed + 1, ...): whole batches run --lanes at a time, as bench.py times them")
     parser.add_argument("--warmup", type=int, default=0, help="with --repeat: untimed rounds first (tile tuning, graph capture), so the printed images/s is the steady state")

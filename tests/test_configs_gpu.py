@@ -587,6 +587,7 @@ def test_run_two_lanes_equal_one(tmp_path, monkeypatch):
     dev = _dev()
     import gligen_inference as gi
     monkeypatch.setattr(gi, "device", dev)
+    monkeypatch.setattr(gi, "SPLIT_BATCH_AT", 8)     # (the product splits from 32 images on; the small model stands in for that)
     monkeypatch.chdir(tmp_path)
     B, hw = 8, 16
     cfg = gi.synthetic_config("text", inpaint=False, image_size=hw)

@@ -182,6 +182,21 @@ def test_vae_decode_vs_reference(name, dd):
         assert diff.mean() < 3.0
 
 
+def test_vae_decode_large_batch_goes_through_in_slices():
+    """A batch beyond the arena's sizing (8 images at 64 x 64 latents) is decoded in slices of the batch: image i of a batch of 10 is
+    image i of its slice bit for bit, and the tail slice (2 images: other tile choices) agrees within the decode tolerance with the
+    same latents decoded among 8."""
+    dev = _dev()
+    ae = build_product_vae(syn.VAE_DDCONFIG, device=dev)
+    z = (syn.make_latent(10, 4, 64, 64, seed=21) * 0.18215 * 4).to(dev)
+    img = ae.decode(z)
+    assert img.shape == (10, 3, 512, 512) and bool(torch.isfinite(img).all())
+    assert torch.equal(img[:8], ae.decode(z[:8])) and torch.equal(img[8:], ae.decode(z[8:]))
+    among8 = ae.decode(torch.cat([z[8:], z[:6]]))[:2]
+    assert mse(img[8:], among8) < 1e-4 * float(among8.var()), mse(img[8:], among8)
+    ae._drop_engine()
+
+
 @pytest.mark.parametrize("name,dd", [("vae_enc_small", "VAE_DDCONFIG_SMALL"), ("vae_enc_full", "VAE_DDCONFIG")])
 def test_vae_encode_vs_reference(name, dd, monkeypatch):
     """AutoencoderKL.encode (inpainting: once per prompt) on the device vs the reference's output for the same image, the
