@@ -294,17 +294,18 @@ def stub_main(args, cfg, gdist, rank, world, dist_world, dist_backend):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=6)       # (a multiple of the batches in flight: no lane idles through the last step)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS), help="BASELINE.json configuration (default: C2, the one the metric is quoted on)")
     ap.add_argument("--batch", type=int, default=4, help="images per GPU per step (BASELINE C2: 4; C3: 32 / 8 GPUs; C5: 16 / 4 GPUs)")
     ap.add_argument("--plms-steps", type=int, default=50)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--lanes", type=int, default=2,
+    ap.add_argument("--lanes", type=int, default=3,
                     help="batches in flight per GPU: consecutive steps are issued round-robin to this many execution contexts (engine "
                          "forks: ONE set of packed weights, own arena, hipGraph, HIP stream each), so one batch's kernel tails, launch "
                          "gaps and memory-bound kernels overlap the other's MFMA work. 1 = strictly one batch at a time; the line "
-                         "carries that number too (value_one_lane)")
+                         "carries that number too (value_one_lane). Default 3 (round 6, same box, the driver's step counts: 5.73 / 6.50 / "
+                         "6.64 / 6.38 images/s at 1 / 2 / 3 / 4, profiles/r6/lanes_sweep.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true", help="skip the training-iteration line (train_step)")
     ap.add_argument("--no-ff-ab", action="store_true", help="skip the same-box A/B of the row-local kernels (ff_rows_ab)")

@@ -581,13 +581,13 @@ def run(meta, config, starting_noise=None, models=None):
     # 7.08 against 6.91, 32 images 7.11 against 7.19). Not for inpainting: its per-step q_sample noise comes from the device generator,
     # whose draws would interleave differently
     lanes = args.get("lanes")
-    lanes = 2 if lanes is None else max(1, int(lanes))      # (--lanes 0 and 1 both mean one batch at a time)
+    lanes = 2 if lanes is None else min(2, max(1, int(lanes)))      # (--lanes 0 and 1 both mean one batch at a time; one batch is split in two at most)
     if mask is not None or (hi - lo) < SPLIT_BATCH_AT:
         lanes = 1
     if lanes > 1 and starting_noise is None:   # x_T as the sampler would draw it (plms.py:71), before the batch is split
         starting_noise = torch.randn((hi - lo, model.in_channels, model.image_size, model.image_size), device=device)
     repeat = max(1, int(args.get("repeat") or 1))
-    n_lanes_req = 2 if args.get("lanes") is None else max(1, int(args.get("lanes")))
+    n_lanes_req = 3 if args.get("lanes") is None else max(1, int(args.get("lanes")))    # whole batches in flight (--repeat): 3, as bench.py
     if repeat > 1 and mask is None and meta.get("alpha_type") in (None, [1, 0, 0], [1.0, 0.0, 0.0]):
         # `repeat` batches of this prompt (seed, seed + 1, ...): whole batches in flight on the lanes, as bench.py runs them
         gkw = dict(steps=steps, guidance_scale=args["guidance_scale"], alpha_type=meta.get("alpha_type"), no_plms=no_plms,
@@ -707,7 +707,7 @@ def main(argv=None):
     parser.add_argument("--inpaint", action="store_true", help="with --synthetic text: the inpainting model (9-channel first conv, encode + blend)")
     parser.add_argument("--ckpt", type=str, default=None, help="run only the meta_list entries whose checkpoint path contains this string")
     parser.add_argument("--seed", type=int, default=None, help="seed of x_T (one draw for the whole batch, sliced across ranks)")
-    parser.add_argument("--lanes", type=int, default=2, help="per-GPU batches of 32 and more run as this many sub-batches in flight (1 = off); with --repeat: whole batches in flight")
+    parser.add_argument("--lanes", type=int, default=None, help="with --repeat: whole batches in flight (default 3, the bench's schedule); without: per-GPU batches of 32 and more run as two half-batches in flight unless this is 1")
     parser.add_argument("--steps", type=int, default=None, help="override the sampler's step count (reference: 50 PLMS / 250 DDIM)")
     parser.add_argument("--repeat", type=int, default=1, help="batches of --batch_size per prompt (seed, seed + 1, ...): whole batches run --lanes at a time, as bench.py times them")
     parser.add_argument("--warmup", type=int, default=0, help="with --repeat: untimed rounds first (tile tuning, graph capture), so the printed images/s is the steady state")

@@ -38,8 +38,8 @@ while [ $# -gt 0 ]; do
     bench) nodev; ( timeout 900 python bench.py $BENCH_ARGS > $O/bench_default.json 2> $O/bench_default.err ); cut -c1-600 $O/bench_default.json; tail -2 $O/bench_default.err | cut -c1-200 ;;
     driver) nodev; ( timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err ); cut -c1-400 $O/bench.json; tail -2 $O/bench.err | cut -c1-200 ;;
     configs) nodev
-           for c in C3 C4 C5; do timeout 500 python bench.py --config $c --steps 2 --no-cpu-baseline --no-train-step > $O/bench_$c.json 2> $O/bench_$c.err; cut -c1-140 $O/bench_$c.json; done
-           timeout 500 python bench.py --alpha-type 0.3,0,0.7 --steps 2 --no-cpu-baseline --no-train-step > $O/bench_alpha.json 2> $O/bench_alpha.err; cut -c1-140 $O/bench_alpha.json
+           for c in C3 C4 C5; do timeout 500 python bench.py --config $c --steps 3 --no-cpu-baseline --no-train-step > $O/bench_$c.json 2> $O/bench_$c.err; cut -c1-140 $O/bench_$c.json; done
+           timeout 500 python bench.py --alpha-type 0.3,0,0.7 --steps 3 --no-cpu-baseline --no-train-step > $O/bench_alpha.json 2> $O/bench_alpha.err; cut -c1-140 $O/bench_alpha.json
            timeout 500 python bench.py --lanes 1 --steps 2 --no-cpu-baseline --no-train-step > $O/bench_l1.json 2> $O/bench_l1.err; cut -c1-140 $O/bench_l1.json ;;
     kbench) dev; f=$1; shift; n=5; case "$1" in ''|*[!0-9]*) ;; *) n=$1; shift ;; esac
            b=$(basename $f .shapes); timeout 400 $K $f $n - check > $O/kbench_$b.txt 2>&1; grep -E "^TOTAL|CHECK|MISMATCH|^FFN|^ATT" $O/kbench_$b.txt | cut -c1-200 | tail -40 ;;
@@ -57,15 +57,15 @@ while [ $# -gt 0 ]; do
     ab) dev; var=$1; a=$2; b=$3; shift 3; n=2; case "$1" in ''|*[!0-9]*) ;; *) n=$1; shift ;; esac
            : > $O/ab_$var.txt
            for i in $(seq $n); do for v in $a $b; do
-             ( export $var=$v; timeout 500 python bench.py --steps 4 --no-cpu-baseline --no-train-step --no-ff-ab 2>/dev/null ) | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$var=$v value %.3f one_lane %.3f unet_step_ms %.3f eager_sum %.3f' % (d['value'], d['value_one_lane'], d['unet_step_ms'], d['roofline']['eager_sum_ms']))" | tee -a $O/ab_$var.txt
+             ( export $var=$v; timeout 500 python bench.py --steps 6 --no-cpu-baseline --no-train-step --no-ff-ab 2>/dev/null ) | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$var=$v value %.3f one_lane %.3f unet_step_ms %.3f eager_sum %.3f' % (d['value'], d['value_one_lane'], d['unet_step_ms'], d['roofline']['eager_sum_ms']))" | tee -a $O/ab_$var.txt
            done; done ;;
     abn) dev; var=$1; n=$2; shift 2; vals=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do vals+=("$1"); shift; done; [ "$1" = "--" ] && shift
            : > $O/ab_$var.txt
            for i in $(seq $n); do for v in "${vals[@]}"; do
-             ( export $var=$v; timeout 500 python bench.py --steps 4 --no-cpu-baseline --no-train-step --no-ff-ab 2>/dev/null ) | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$var=$v value %.3f one_lane %.3f unet_step_ms %.3f eager_sum %.3f' % (d['value'], d['value_one_lane'], d['unet_step_ms'], d['roofline']['eager_sum_ms']))" | tee -a $O/ab_$var.txt
+             ( export $var=$v; timeout 500 python bench.py --steps 6 --no-cpu-baseline --no-train-step --no-ff-ab 2>/dev/null ) | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$var=$v value %.3f one_lane %.3f unet_step_ms %.3f eager_sum %.3f' % (d['value'], d['value_one_lane'], d['unet_step_ms'], d['roofline']['eager_sum_ms']))" | tee -a $O/ab_$var.txt
            done; done ;;
     tune) dev; name=$1; shift; envs=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do envs+=("$1"); shift; done; [ "$1" = "--" ] && shift
-           ( export GL_GEMM_NO_TABLE=1 GL_GEMM_TUNE_LOG=1 GL_GEMM_TUNE_REPS=${TUNE_REPS:-10} "${envs[@]}"; timeout 800 python bench.py --steps 4 --no-cpu-baseline --no-train-step --no-ff-ab 2> $O/tune_$name.log ) | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('tune $name value %.3f one_lane %.3f unet_step_ms %.3f eager_sum %.3f' % (d['value'], d['value_one_lane'], d['unet_step_ms'], d['roofline']['eager_sum_ms']))" | tee -a $O/tune_summary.txt
+           ( export GL_GEMM_NO_TABLE=1 GL_GEMM_TUNE_LOG=1 GL_GEMM_TUNE_REPS=${TUNE_REPS:-10} "${envs[@]}"; timeout 800 python bench.py --steps 6 --no-cpu-baseline --no-train-step --no-ff-ab 2> $O/tune_$name.log ) | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('tune $name value %.3f one_lane %.3f unet_step_ms %.3f eager_sum %.3f' % (d['value'], d['value_one_lane'], d['unet_step_ms'], d['roofline']['eager_sum_ms']))" | tee -a $O/tune_summary.txt
            grep -c "gemm autotune" $O/tune_$name.log ;;
     calib) dev; ( PYTHONPATH=. timeout 300 python tools/calib_mfma.py ${CALIB_MS:-40} ) > $O/calib_mfma.txt 2> $O/calib_mfma.err; cat $O/calib_mfma.txt | cut -c1-200; tail -2 $O/calib_mfma.err | cut -c1-200 ;;
     lib) d=$1; shift; cp $d/libgligen_amd.so gligen_amd/libgligen_amd.so; [ -f $d/kbench ] && cp $d/kbench $K; echo "library <- $d" ;;

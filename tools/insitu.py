@@ -11,7 +11,7 @@ from gligen_amd import synthetic as syn
 
 dev = torch.device("cuda", 0)
 gi.device = dev
-B = 4
+B = int(os.environ.get("INSITU_B", "4"))      # images per batch (the benchmark: 4 = 8 samples per evaluation)
 model, ae, diffusion, cfg = gi.load_synthetic("text", seed=1234, fast=True)
 model.grounding_tokenizer_input = gi.instantiate_from_config(cfg["grounding_tokenizer_input"])
 batch = {k: v.to(dev) for k, v in syn.make_batch("text", B, n_valid=8, seed=0).items()}
@@ -31,6 +31,6 @@ for r in range(R + 1):
         a[1] += p["ms"] / R
 tot = sum(a[1] for a in acc.values())
 print(f"in-situ total {tot:.3f} ms (event-timed eager launches, mean of {R})")
-for name, (calls, ms, flops) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:70]:
+for name, (calls, ms, flops) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get("INSITU_ROWS", "70"))]:
     tf = f"{flops / (ms * 1e-3) / 1e12:7.1f} TF/s" if flops > 0 else ""
     print(f"{name:78s} {calls:4d} x {ms / calls * 1e3:8.1f} us = {ms:7.3f} ms {tf}")
