@@ -484,7 +484,7 @@ def main():
             box = eng0.box_calibrate()     # (after the memory numbers above: it borrows 1 GiB of lane 0's arena)
         except Exception as e:
             box = {"error": str(e)[:200]}
-        if not args.no_train_step and not cfg["inpaint"] and alpha_type is None:
+        if not args.no_train_step and not cfg["inpaint"] and alpha_type is None and world == 1:
             train = train_step_line(lanes[0][0], kind, B, dev)
 
     if rank == 0:
@@ -538,7 +538,7 @@ def main():
             "gpu_clocks": clk,
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline:   # rank 0's host cores, whatever the world size
+        if not args.no_cpu_baseline and world == 1:   # rank 0's host cores, the 1-GPU run only (the N > 1 runs of a scaling sweep repeat nothing)
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)
     gdist.shutdown()
