@@ -344,12 +344,15 @@ def main():
     L = max(1, min(args.lanes, args.steps))
     model, autoencoder, diffusion, mcfg = gi.load_synthetic(kind, inpaint=cfg["inpaint"], seed=1234, fast=True)
     model.grounding_tokenizer_input = gi.instantiate_from_config(mcfg["grounding_tokenizer_input"])
-    lanes = [(model, autoencoder, diffusion, torch.cuda.Stream(device=dev))]
-    for _ in range(1, L):    # further lanes: forks of the first lane's engines (shared packed weights, gl_ctx_fork), own tokenizer-input state
+    # (developer A/B: GL_LANE_PRIO="-1,0,0" gives the lanes' streams HIP priorities; measured neutral-to-worse, profiles/r6/lanes_sweep.txt)
+    prio = [int(v) for v in os.environ.get("GL_LANE_PRIO", "").split(",") if v.strip()] if os.environ.get("GL_DEV_SWITCHES") else []
+    lane_stream = lambda i: torch.cuda.Stream(device=dev, priority=prio[i]) if i < len(prio) else torch.cuda.Stream(device=dev)
+    lanes = [(model, autoencoder, diffusion, lane_stream(0))]
+    for i in range(1, L):    # further lanes: forks of the first lane's engines (shared packed weights, gl_ctx_fork), own tokenizer-input state
         import copy
         m, ae = gi._lane_clone(model), gi._lane_clone(autoencoder)
         m.grounding_tokenizer_input = copy.copy(model.grounding_tokenizer_input)
-        lanes.append((m, ae, diffusion, torch.cuda.Stream(device=dev)))
+        lanes.append((m, ae, diffusion, lane_stream(i)))
     lo, hi = gdist.shard_range(B * world, rank, world)
     batch = {k: v[lo:hi].to(dev) for k, v in syn.make_batch(kind, B * world, n_valid=8, seed=0).items()}
     context = syn.make_context(B * world, seed=0)[lo:hi].to(dev)
