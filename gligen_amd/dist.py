@@ -114,9 +114,11 @@ class GradBuckets:
         for b in self.buckets:
             b.zero_()
 
-    def all_reduce_bucket(self, i: int, average: bool = True) -> int:
-        """Sum (or mean) of bucket i over the ranks, in place, on the current stream. Returns the number of collectives issued."""
-        if not dist.is_initialized() or self.world == 1:
+    def all_reduce_bucket(self, i: int, average: bool = True, even_alone: bool = False) -> int:
+        """Sum (or mean) of bucket i over the ranks, in place, on the current stream. Returns the number of collectives issued.
+        A single rank has nothing to exchange and issues none, unless `even_alone` asks for the collectives anyway (the one-GPU
+        test of the RCCL branch: a world of one runs the same reduce-scatter + all-gather pair and must leave the bucket as it was)."""
+        if not dist.is_initialized() or (self.world == 1 and not even_alone):
             return 0
         buf = self.buckets[i]
         if dist.get_backend() == "nccl":

@@ -827,3 +827,51 @@ def test_ff_chain_with_to_q(engine, B, N):
     # the plain chained launch gives the same y
     y0 = engine.op_ff_chain(x.view(B * N, C), pre_w, pre_b, pre_res.view(B * N, C), gamma, beta, w1, b1, w2, b2, pre_gate=g1, gate=g2)
     assert torch.equal(y.view(B * N, C), y0)
+
+
+_RCCL_WORLD_OF_ONE = r"""
+import os, socket, sys, torch
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from gligen_amd.dist import GradBuckets
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+assert dist.get_backend() == "nccl"
+shapes = {"fuser.linear.weight": (1280, 768), "position_net.linears.0.weight": (512, 1792), "fuser.alpha_attn": (1,), "fuser.ff.net.2.bias": (321,)}
+gb = GradBuckets(shapes, bucket_mb=3.0, world=1, device="cuda")
+assert len(gb.buckets) >= 2
+g = torch.Generator(device="cuda").manual_seed(5)
+for b in gb.buckets:
+    b.copy_(torch.randn(b.shape, generator=g, device="cuda"))
+before = [b.clone() for b in gb.buckets]
+comm = torch.cuda.Stream()
+comm.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(comm):                       # the trainer issues the exchange on its communication stream (train.py)
+    n = sum(gb.all_reduce_bucket(i, average=True, even_alone=True) for i in range(len(gb.buckets)))
+torch.cuda.current_stream().wait_stream(comm)
+torch.cuda.synchronize()
+assert n == 2 * len(gb.buckets), n                  # a reduce-scatter + all-gather pair per bucket went to RCCL
+assert all(torch.equal(a, b) for a, b in zip(before, gb.buckets))
+assert gb.all_reduce() == 0                         # (a lone rank issues nothing unless asked)
+dist.barrier(); dist.destroy_process_group()
+print("rccl world of one ok", n)
+"""
+
+
+def test_gradient_exchange_branch_runs_on_rccl(tmp_path):
+    """The RCCL branch of the training path's gradient exchange (gligen_amd/dist.py: reduce-scatter + all-gather per flat bucket; reference
+    trainer.py:321-322, DDP) executed on RCCL itself: a world of ONE rank on this GPU -- all a one-GPU box can offer; the two-rank
+    semantics are the gloo tests of tests/test_dist_cpu.py -- must issue both collectives per bucket on the communication stream and
+    leave every bucket bit for bit as it was (mean over one rank)."""
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_one.py"
+    script.write_text(_RCCL_WORLD_OF_ONE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "rccl world of one ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
