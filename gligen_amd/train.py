@@ -94,8 +94,11 @@ class TrainStep:
     def __init__(self, engine, cfg: Mapping, state_dict: Mapping[str, torch.Tensor], lr: Union[float, Callable[[int], float]] = 5e-5,
                  weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8, bucket_mb: float = 128.0, world: Optional[int] = None,
                  checkpoint: bool = True, drop_prob: float = 0.0, rng: Optional[random.Random] = None, broadcast: bool = True, overlap: bool = True,
-                 cache_frozen: bool = True):
+                 cache_frozen: bool = True, exchange_even_alone: bool = False):
         self.engine, self.cfg = engine, dict(cfg)
+        # (a world of one rank issues no collective; True sends the buckets through the collectives anyway -- the one-GPU test of the
+        # overlapped schedule with RCCL's kernels on the communication stream, tests/test_ops_gpu.py)
+        self.exchange_even_alone = bool(exchange_even_alone)
         dev = engine.device
         self.lr = lr if callable(lr) else float(lr)
         self.wd, self.betas, self.eps = float(weight_decay), tuple(betas), float(eps)
@@ -156,21 +159,23 @@ class TrainStep:
         upd = lambda i: self.engine.op_adamw_step(self.pbuf.buckets[i], self.gbuf.buckets[i], self.m[i], self.v[i], self.steps, lr=lr, betas=self.betas,
                                                   eps=self.eps, weight_decay=self.wd)
         nb = len(self.gbuf.buckets)
+        alone = self.exchange_even_alone
         if not self.overlap:                        # backward, every collective, every update: one stream
-            self.gbuf.all_reduce(average=True)
+            for i in range(nb):
+                self.gbuf.all_reduce_bucket(i, average=True, even_alone=alone)
             for i in range(nb):
                 upd(i)
         elif self._comm is None:                    # (a host-side engine: the same per-bucket order without streams)
             for i in range(nb):
                 self.engine.train_wait_grads(self.bucket_ready[i], None)
-                self.gbuf.all_reduce_bucket(i, average=True)
+                self.gbuf.all_reduce_bucket(i, average=True, even_alone=alone)
                 upd(i)
         else:
             main = torch.cuda.current_stream(self.engine.device)
             for i in range(nb):                     # bucket i: wait for its last gradient only, exchange, update -- all behind the backward
                 self.engine.train_wait_grads(self.bucket_ready[i], self._comm)
                 with torch.cuda.stream(self._comm):
-                    self.gbuf.all_reduce_bucket(i, average=True)
+                    self.gbuf.all_reduce_bucket(i, average=True, even_alone=alone)
                     upd(i)
             main.wait_stream(self._comm)            # the next forward reads the updated parameters
         return loss, eps

@@ -855,6 +855,45 @@ torch.cuda.synchronize()
 assert n == 2 * len(gb.buckets), n                  # a reduce-scatter + all-gather pair per bucket went to RCCL
 assert all(torch.equal(a, b) for a, b in zip(before, gb.buckets))
 assert gb.all_reduce() == 0                         # (a lone rank issues nothing unless asked)
+
+# the trainer's overlapped schedule with RCCL's kernels really on the communication stream, under the backward of the earlier blocks:
+# two iterations of TrainStep on the small UNet, every bucket through reduce-scatter + all-gather, against the same two iterations
+# without an exchange and against the one-stream schedule with it -- the same parameters bit for bit (a mean over one rank)
+sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from gligen_amd import synthetic as syn
+from gligen_amd.engine import Engine
+from gligen_amd.train import TrainStep
+from helpers import golden_shapes, load_golden
+meta = load_golden("unet_small_train_2steps")["meta"]
+B, hw = meta["B"], meta["hw"]
+sd = syn.seeded_state_dict(golden_shapes("unet_small_train_step"), meta["weight_seed"])
+b = syn.make_batch("text", B, n_valid=meta["n_valid"], seed=5)
+batch = dict(x=syn.make_latent(B, 4, hw, hw, seed=6), timesteps=torch.tensor([981, 441][:B]).float(), context=syn.make_context(B, seed=6),
+             boxes=b["boxes"], masks=b["masks"], positive_embeddings=b["text_embeddings"], target=syn.make_latent(B, 4, hw, hw, seed=7))
+eng = Engine(0, arena_gb=8.0)
+calls = []
+real = GradBuckets.all_reduce_bucket
+def counted(self, i, average=True, even_alone=False):
+    n = real(self, i, average, even_alone)
+    calls.append((n, torch.cuda.current_stream().cuda_stream))
+    return n
+GradBuckets.all_reduce_bucket = counted
+out = {}
+for name, kw in (("none", {}), ("rccl_overlapped", dict(exchange_even_alone=True)), ("rccl_one_stream", dict(exchange_even_alone=True, overlap=False))):
+    calls.clear()
+    ts = TrainStep(eng, meta["cfg"], sd, lr=meta["lr"], weight_decay=0.0, bucket_mb=32.0, world=1, **kw)
+    losses = [float(ts.step(batch)[0]) for _ in range(2)]
+    torch.cuda.synchronize()
+    out[name] = (losses, ts.state_dict())
+    nb = len(ts.gbuf.buckets)
+    assert nb >= 4 and len(calls) == 2 * nb
+    assert sum(c[0] for c in calls) == (0 if name == "none" else 2 * 2 * nb), (name, calls)
+    if name == "rccl_overlapped":                   # issued on the communication stream, not on the compute stream
+        assert ts._comm is not None and all(c[1] == ts._comm.cuda_stream for c in calls)
+for name in ("rccl_overlapped", "rccl_one_stream"):
+    assert out[name][0] == out["none"][0], (name, out[name][0], out["none"][0])
+    bad = [k for k in out["none"][1] if not torch.equal(out["none"][1][k], out[name][1][k])]
+    assert not bad, (name, bad[:5])
 dist.barrier(); dist.destroy_process_group()
 print("rccl world of one ok", n)
 """
@@ -864,7 +903,9 @@ def test_gradient_exchange_branch_runs_on_rccl(tmp_path):
     """The RCCL branch of the training path's gradient exchange (gligen_amd/dist.py: reduce-scatter + all-gather per flat bucket; reference
     trainer.py:321-322, DDP) executed on RCCL itself: a world of ONE rank on this GPU -- all a one-GPU box can offer; the two-rank
     semantics are the gloo tests of tests/test_dist_cpu.py -- must issue both collectives per bucket on the communication stream and
-    leave every bucket bit for bit as it was (mean over one rank)."""
+    leave every bucket bit for bit as it was (mean over one rank); then two TrainStep iterations on the small UNet with every bucket going
+    through RCCL on the communication stream under the backward (the overlapped schedule) give the parameters of the run without an
+    exchange and of the one-stream schedule, bit for bit."""
     import subprocess
     import sys
     if not torch.cuda.is_available():
